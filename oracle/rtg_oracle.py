@@ -1,0 +1,499 @@
+"""CPU oracle for the RetuneGAN train-step hot path.  *** TEST INFRASTRUCTURE — NOT PRODUCT CODE. ***
+
+A from-scratch restatement, in stock PyTorch fp32 CPU ops, of what the reference computes on this path
+(all citations are relative to /root/reference):
+
+  * UNet-G  `Generator_RefineGAN_small`      retunegan/models/generator.py:670-796
+  * `ResidualStack` / `ResBlock3` / noise    retunegan/models/generator.py:33-77, 133-155, 19-30
+  * MSD / MPD / MTD                          retunegan/models/discrminator.py:17-129, 132-244, 247-330
+  * `get_stft_torch`                         retunegan/audio.py:150-170
+  * losses                                   retunegan/models/loss.py:22-156
+  * the D x n + G update                     retunegan/train.py:121-193
+  * old-style weight norm  w = g * v / ||v|| (torch.nn.utils.weight_norm, dim=0; call sites generator.py:682-722)
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this file; the product package
+(transtacos-retunegan_amd/) never does.  Parity status: PINNED — every function here is checked in
+tests/test_oracle_golden.py against fixtures under tests/golden/ that oracle/gen_golden.py produced by importing and
+running the reference itself in the build container.  The mel filterbank is the published librosa-0.8.1 Slaney
+formula (librosa is a third-party dependency absent from /root/reference: requirements.txt:1); no reference test pins
+it, so mel-basis parity rests on that published formula (the same restatement feeds the reference when goldens are made).
+"""
+import math
+import zlib
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+LRELU_SLOPE = 0.15            # retunegan/utils.py:11
+PI = 3.14159265358979         # retunegan/utils.py:12
+SAMPLE_RATE = 22050           # retunegan/hparam.py:4
+N_MEL, FMIN, FMAX = 80, 125, 7600                      # hparam.py:8,14,15
+STFT_PARAMS = [(2048, 1024, 240), (1024, 512, 120), (512, 256, 60)]   # hparam.py:72-81
+MPD_PERIODS = [3, 5, 7, 11]   # hparam.py:71
+MSD_LAYERS = 3                # hparam.py:70
+POOL_K = 160                  # hparam.py:90 envelope_pool_k
+W_FM, W_MSTFT, W_ENV, W_DYN, W_SM = 2, 8, 4, 4, 0.01    # hparam.py:110-114
+LR_D, LR_G, B1, B2 = 2e-4, 1.8e-4, 0.8, 0.99             # hparam.py:103-107
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# weight-normed conv primitive
+# ---------------------------------------------------------------------------------------------------------------
+class WNConv(nn.Module):
+    """Conv1d / ConvTranspose1d / Conv2d whose weight is g * v / ||v|| with the norm over every dim but 0
+    (torch.nn.utils.weight_norm default).  Parameters are named weight_g / weight_v / bias like the reference's."""
+
+    def __init__(self, kind, cin, cout, k, stride=1, padding=0, dilation=1, groups=1, output_padding=0):
+        super().__init__()
+        self.kind, self.stride, self.padding, self.dilation, self.groups = kind, stride, padding, dilation, groups
+        self.output_padding = output_padding
+        ks = tuple(k) if isinstance(k, (tuple, list)) else (k,)
+        if kind == 'convT1d':
+            shape = (cin, cout // groups) + ks
+        else:
+            shape = (cout, cin // groups) + ks
+        v = torch.empty(shape)
+        nn.init.kaiming_uniform_(v, a=math.sqrt(5))          # torch Conv default init (reset_parameters)
+        fan_in = shape[1] * int(np.prod(ks))
+        bound = 1.0 / math.sqrt(fan_in)
+        b = torch.empty(cout).uniform_(-bound, bound)
+        self.weight_g = nn.Parameter(v.flatten(1).norm(dim=1).reshape((shape[0],) + (1,) * (len(shape) - 1)))
+        self.weight_v = nn.Parameter(v)
+        self.bias = nn.Parameter(b)
+
+    def burn_init_rng(self):
+        """`init_weights` (utils.py:26-29) run after weight_norm only overwrites the derived .weight, which the
+        forward pre-hook recomputes: a no-op on parameters that still draws numel(weight) normals from the RNG."""
+        torch.empty(self.weight_v.shape).normal_(0, 1.0)
+
+    def weight(self):
+        v = self.weight_v
+        n = v.flatten(1).norm(dim=1).reshape(self.weight_g.shape)
+        return v * (self.weight_g / n)
+
+    def forward(self, x):
+        w = self.weight()
+        if self.kind == 'conv1d':
+            return F.conv1d(x, w, self.bias, self.stride, self.padding, self.dilation, self.groups)
+        if self.kind == 'convT1d':
+            return F.conv_transpose1d(x, w, self.bias, self.stride, self.padding, self.output_padding, self.groups)
+        return F.conv2d(x, w, self.bias, self.stride, self.padding, self.dilation, self.groups)
+
+
+class _Seq(nn.Module):
+    """Container that reproduces nn.Sequential's integer child names at chosen indices (res_1.1, res_1.3 ...)."""
+
+    def __init__(self, named):
+        super().__init__()
+        for name, m in named:
+            self.add_module(str(name), m)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# generator
+# ---------------------------------------------------------------------------------------------------------------
+class ResidualStack(nn.Module):
+    """generator.py:33-77: x += conv_d1(lrelu.01(conv_dil(lrelu.01(x)))) for dil in 1, 3, 9 (k=3)."""
+
+    def __init__(self, ch):
+        super().__init__()
+        for name, d in (('res_1', 1), ('res_2', 3), ('res_3', 9)):
+            self.add_module(name, _Seq([(1, WNConv('conv1d', ch, ch, 3, padding=d, dilation=d)),
+                                        (3, WNConv('conv1d', ch, ch, 3, padding=1))]))
+
+    def forward(self, x):
+        for blk in (self.res_1, self.res_2, self.res_3):
+            r = getattr(blk, '1')(F.leaky_relu(x, 0.01))
+            r = getattr(blk, '3')(F.leaky_relu(r, 0.01))
+            x = x + r
+        return x
+
+
+class ResBlock3(nn.Module):
+    """generator.py:133-155 with dilations [9, 3, 1] (generator.py:709-711)."""
+
+    def __init__(self, ch, k, dils=(9, 3, 1)):
+        super().__init__()
+        self.convs = nn.ModuleList([WNConv('conv1d', ch, ch, k, padding=(k * d - d) // 2, dilation=d) for d in dils])
+        for c in self.convs:
+            c.burn_init_rng()
+
+    def forward(self, x):
+        for c in self.convs:
+            x = c(F.leaky_relu(x, LRELU_SLOPE)) + x
+        return x
+
+
+class Generator(nn.Module):
+    """generator.py:670-796 (UNet-G = Generator_RefineGAN_small)."""
+
+    def __init__(self):
+        super().__init__()
+        rates, ks = [8, 8, 4], [15, 15, 7]                         # hparam.py:61-62
+        self.conv_pre = WNConv('conv1d', 1, 16, 7, padding=3)
+        self.downs = nn.ModuleList([WNConv('conv1d', 16 * 2 ** i, 32 * 2 ** i, k, u, padding=k // 2)
+                                    for i, (u, k) in enumerate(zip(rates[::-1], ks[::-1]))])
+        self.resblock = nn.ModuleList([ResidualStack(32 * 2 ** i) for i in range(3)])
+        self.conv_fuse = WNConv('conv1d', N_MEL + 128, 256, 7, padding=3)
+        self.ups = nn.ModuleList([WNConv('convT1d', 256 // 2 ** i, 128 // 2 ** i, k, u, padding=k // 2,
+                                         output_padding=u - 1) for i, (u, k) in enumerate(zip(rates, ks))])
+        self.resblocks = nn.ModuleList([ResBlock3(ch, k) for ch in (128, 64, 32) for k in (3, 5, 7)])
+        self.merge = nn.ModuleList([WNConv('conv1d', 192, 128, 7, padding=3), WNConv('conv1d', 96, 64, 7, padding=3),
+                                    WNConv('conv1d', 48, 32, 7, padding=3)])
+        self.conv_post = WNConv('conv1d', 32, 1, 7, padding=3)
+        self.noise = _Noise()
+        for m in [self.conv_pre, self.conv_fuse, self.conv_post, *self.downs, *self.merge, *self.ups]:
+            m.burn_init_rng()                                      # generator.py:727-732
+
+    def forward(self, x, y, noise_list=None):
+        """x: mel [B,80,T/256]; y: reference wav [B,1,T].  noise_list: optional 6 pre-drawn uniform tensors."""
+        skips = []
+        y = self.conv_pre(y)
+        for i in range(3):
+            y = F.leaky_relu(y, LRELU_SLOPE)
+            skips.append(y)
+            y = self.resblock[i](self.downs[i](y))
+        y = F.leaky_relu(y, LRELU_SLOPE)
+        z = self.conv_fuse(torch.cat([x, y], dim=1))
+        for i in range(3):
+            z = self.ups[i](F.leaky_relu(z, LRELU_SLOPE))
+            z = self.merge[i](torch.cat([z, skips[2 - i]], dim=1))
+            z = self.noise(z, None if noise_list is None else noise_list[2 * i])
+            z = sum(self.resblocks[3 * i + j](z) for j in range(3)) / 3
+            z = self.noise(z, None if noise_list is None else noise_list[2 * i + 1])
+        return torch.tanh(self.conv_post(F.leaky_relu(z, LRELU_SLOPE)))
+
+
+class _Noise(nn.Module):
+    """generator.py:19-30: x + U[0,1) * w, then leaky_relu(0.15).  One shared scalar w = 1e-6."""
+
+    def __init__(self):
+        super().__init__()
+        self.w = nn.Parameter(torch.tensor([1e-6]))
+
+    def forward(self, x, n=None):
+        if n is None:
+            n = torch.rand_like(x)
+        return F.leaky_relu(x + n * self.w, LRELU_SLOPE)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# discriminators
+# ---------------------------------------------------------------------------------------------------------------
+class _DiscBase(nn.Module):
+    def run(self, x):
+        fmap = []
+        for c in self.convs:
+            x = c(x)
+            fmap.append(x)                       # feature map is taken BEFORE the activation (discrminator.py:93-96)
+            x = F.leaky_relu(x, LRELU_SLOPE)
+        return torch.flatten(self.conv_post(x), 1, -1), fmap
+
+
+class DiscS(_DiscBase):
+    """discrminator.py:36-45 ('MelGAN_small')."""
+
+    def __init__(self):
+        super().__init__()
+        spec = [(1, 32, 15, 1, 7, 1), (32, 64, 41, 2, 20, 4), (64, 128, 41, 2, 20, 8), (128, 512, 41, 4, 20, 32),
+                (512, 512, 41, 4, 20, 64), (512, 512, 5, 1, 2, 1)]
+        self.convs = nn.ModuleList([WNConv('conv1d', ci, co, k, s, p, groups=g) for ci, co, k, s, p, g in spec])
+        self.conv_post = WNConv('conv1d', 512, 1, 3, 1, 1)
+
+    def forward(self, x):
+        return self.run(x)
+
+
+class DiscP(_DiscBase):
+    """discrminator.py:155-163 ('HiFiGAN_small') + the reflect-pad / fold at :203-210."""
+
+    def __init__(self, period):
+        super().__init__()
+        self.period = period
+        chans = [1, 32, 128, 256, 512]
+        self.convs = nn.ModuleList([WNConv('conv2d', chans[i], chans[i + 1], (5, 1), (3, 1), (2, 0)) for i in range(4)]
+                                   + [WNConv('conv2d', 512, 512, (5, 1), 1, (2, 0))])
+        self.conv_post = WNConv('conv2d', 512, 1, (3, 1), 1, (1, 0))
+
+    def forward(self, x):
+        b, c, t = x.shape
+        if t % self.period:
+            n_pad = self.period - t % self.period
+            x = F.pad(x, (0, n_pad), 'reflect')
+            t += n_pad
+        return self.run(x.view(b, c, t // self.period, self.period))
+
+
+class DiscT(_DiscBase):
+    """discrminator.py:247-308."""
+
+    def __init__(self):
+        super().__init__()
+        spec = [(2, 32, (3, 3), (2, 1), (1, 1)), (32, 64, (3, 3), (2, 2), (1, 1)), (64, 256, (5, 3), (3, 2), (2, 1)),
+                (256, 512, (5, 3), (3, 2), (2, 1)), (512, 512, (3, 3), 1, 1)]
+        self.convs = nn.ModuleList([WNConv('conv2d', *s) for s in spec])
+        self.conv_post = WNConv('conv2d', 512, 1, (3, 3), 1, 1)
+        for c in [*self.convs, self.conv_post]:
+            c.burn_init_rng()                                       # discrminator.py:264-265
+
+    def forward(self, x):
+        return self.run(x)
+
+
+class _Multi(nn.Module):
+    def pair(self, d, a, b):
+        return d(a), d(b)
+
+
+class MSD(_Multi):
+    """discrminator.py:104-129: three DiscS on y, AvgPool1d(4,2,1)(y), AvgPool1d^2(y)."""
+
+    def __init__(self):
+        super().__init__()
+        self.discriminators = nn.ModuleList([DiscS() for _ in range(MSD_LAYERS)])
+
+    def forward(self, y, y_hat):
+        out = ([], [], [], [])
+        for i, d in enumerate(self.discriminators):
+            (lr, fr), (lg, fg) = self.pair(d, y, y_hat)
+            for o, v in zip(out, (lr, lg, fr, fg)):
+                o.append(v)
+            if i != len(self.discriminators) - 1:
+                y, y_hat = F.avg_pool1d(y, 4, 2, 1), F.avg_pool1d(y_hat, 4, 2, 1)
+        return out
+
+
+class MPD(_Multi):
+    """discrminator.py:225-244."""
+
+    def __init__(self):
+        super().__init__()
+        self.discriminators = nn.ModuleList([DiscP(p) for p in MPD_PERIODS])
+
+    def forward(self, y, y_hat):
+        out = ([], [], [], [])
+        for d in self.discriminators:
+            (lr, fr), (lg, fg) = self.pair(d, y, y_hat)
+            for o, v in zip(out, (lr, lg, fr, fg)):
+                o.append(v)
+        return out
+
+
+class MTD(_Multi):
+    """discrminator.py:311-330: one DiscT per STFT resolution, zipped with the spec lists."""
+
+    def __init__(self):
+        super().__init__()
+        self.discriminators = nn.ModuleList([DiscT() for _ in STFT_PARAMS])
+
+    def forward(self, specs, specs_hat):
+        out = ([], [], [], [])
+        for d, a, b in zip(self.discriminators, specs, specs_hat):
+            (lr, fr), (lg, fg) = self.pair(d, a, b)
+            for o, v in zip(out, (lr, lg, fr, fg)):
+                o.append(v)
+        return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# STFT / mel
+# ---------------------------------------------------------------------------------------------------------------
+def mel_filterbank(n_fft, sr=SAMPLE_RATE, n_mels=N_MEL, fmin=FMIN, fmax=FMAX):
+    """librosa 0.8.1 filters.mel, Slaney scale + area norm (called at audio.py:158); float32 [n_mels, n_fft/2+1]."""
+    f_sp, min_log_hz = 200.0 / 3, 1000.0
+    min_log_mel, logstep = min_log_hz / f_sp, math.log(6.4) / 27.0
+
+    def hz2mel(f):
+        return f / f_sp if f < min_log_hz else min_log_mel + math.log(f / min_log_hz) / logstep
+
+    mels = np.linspace(hz2mel(fmin), hz2mel(fmax), n_mels + 2)
+    edges = np.where(mels >= min_log_mel, min_log_hz * np.exp(logstep * (mels - min_log_mel)), f_sp * mels)
+    bins = np.linspace(0.0, sr / 2.0, n_fft // 2 + 1)
+    up = (bins[None, :] - edges[:-2, None]) / (edges[1:-1] - edges[:-2])[:, None]
+    down = (edges[2:, None] - bins[None, :]) / (edges[2:] - edges[1:-1])[:, None]
+    fb = np.maximum(0.0, np.minimum(up, down)).astype(np.float32)
+    fb *= (2.0 / (edges[2:] - edges[:-2]))[:, None].astype(np.float64)
+    return fb.astype(np.float32)
+
+
+_MEL_CACHE = {}
+
+
+def stft_mag_mel_phase(y, n_fft, win_length, hop):
+    """audio.py:150-170 without torch.stft: reflect-pad n_fft/2, frame i = samples [i*hop, i*hop+n_fft), periodic hann
+    of win_length zero-padded centred to n_fft, rFFT; S = |D + 1e-9| (1e-9 joins the real part), M = mel @ S, P = angle."""
+    if n_fft not in _MEL_CACHE:
+        _MEL_CACHE[n_fft] = torch.from_numpy(mel_filterbank(n_fft))
+    win = torch.zeros(n_fft)
+    lpad = (n_fft - win_length) // 2
+    win[lpad:lpad + win_length] = torch.hann_window(win_length, periodic=True)
+    yp = F.pad(y.unsqueeze(1), (n_fft // 2, n_fft // 2), mode='reflect').squeeze(1)
+    frames = yp.unfold(-1, n_fft, hop)                       # [B, n_frames, n_fft]
+    D = torch.fft.rfft(frames * win, dim=-1).transpose(1, 2)  # [B, F, n_frames]
+    S = torch.abs(D + 1e-9)
+    M = torch.matmul(_MEL_CACHE[n_fft].to(S.device), S)
+    P = torch.angle(D)
+    return S, M, P
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# losses
+# ---------------------------------------------------------------------------------------------------------------
+def multi_stft_loss(y, y_g, ret_loss=False, ret_specs=False):
+    """loss.py:22-62 (phd_input == 'stft')."""
+    if y.dim() == 3:
+        y, y_g = y.squeeze(1), y_g.squeeze(1)
+    loss, sr, sg = 0, [], []
+    for n_fft, win, hop in STFT_PARAMS:
+        S, M, P = stft_mag_mel_phase(y, n_fft, win, hop)
+        Sg, Mg, Pg = stft_mag_mel_phase(y_g, n_fft, win, hop)
+        if ret_specs:
+            sr.append(torch.stack([torch.log(S), P / PI], dim=1))
+            sg.append(torch.stack([torch.log(Sg), Pg / PI], dim=1))
+        loss = loss + F.l1_loss(M, Mg) + F.l1_loss(torch.log(M), torch.log(Mg))
+    loss = loss / len(STFT_PARAMS)
+    if ret_loss and ret_specs:
+        return loss, (sr, sg)
+    if ret_loss:
+        return loss
+    if ret_specs:
+        return sr, sg
+    raise ValueError
+
+
+def _pool(x):
+    return F.max_pool1d(x, POOL_K)
+
+
+def envelope_loss(y, y_g):          # loss.py:66-72
+    return torch.mean(torch.abs(_pool(y) - _pool(y_g))) + torch.mean(torch.abs(_pool(-y) - _pool(-y_g)))
+
+
+def dynamic_loss(y, y_g):           # loss.py:76-82
+    return torch.mean(torch.abs(torch.abs(_pool(y) + _pool(-y)) - torch.abs(_pool(y_g) + _pool(-y_g))))
+
+
+def strip_mirror_loss(y):           # loss.py:86-98
+    if y.shape[-1] % 2:
+        y = y[:, :, :-1]
+    even, odd = y[:, :, ::2], y[:, :, 1::2]
+    even, odd = even - even.mean(), odd - odd.mean()
+    return torch.mean(-torch.log(torch.clamp_max(torch.abs(even - odd) + 1e-9, max=1.0)))
+
+
+def discriminator_loss(disc_r, disc_g):   # loss.py:102-125, non-relative branch
+    return sum(torch.mean(torch.mean((1 - dr) ** 2, dim=-1)) + torch.mean(torch.mean(dg ** 2, dim=-1))
+               for dr, dg in zip(disc_r, disc_g))
+
+
+def generator_loss(disc_g, disc_r=None):  # loss.py:129-145, non-relative branch
+    return sum(torch.mean(torch.mean((1 - dg) ** 2, dim=-1)) for dg in disc_g)
+
+
+def feature_loss(fmap_r, fmap_g):         # loss.py:149-156
+    return sum(F.l1_loss(r, g) for dr, dg in zip(fmap_r, fmap_g) for r, g in zip(dr, dg))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# train step (train.py:121-193) with AdamW (train.py:80-81)
+# ---------------------------------------------------------------------------------------------------------------
+def make_optimizers(gen, discs):
+    pd = [p for d in discs for p in d.parameters()]
+    og = torch.optim.AdamW(gen.parameters(), LR_G, betas=(B1, B2))
+    od = torch.optim.AdamW(pd, LR_D, betas=(B1, B2))
+    return og, od
+
+
+def d_losses(y, y_hat_detached, msd=None, mpd=None, mtd=None):
+    """train.py:139-157. Any of the three discriminator stacks may be absent (BASELINE configs 1 and 2)."""
+    out = {}
+    if mtd is not None:
+        S, Sg = multi_stft_loss(y, y_hat_detached, ret_specs=True)
+        r, g, _, _ = mtd(S, Sg)
+        out['t'] = discriminator_loss(r, g)
+    if msd is not None:
+        r, g, _, _ = msd(y, y_hat_detached)
+        out['s'] = discriminator_loss(r, g)
+    if mpd is not None:
+        r, g, _, _ = mpd(y, y_hat_detached)
+        out['p'] = discriminator_loss(r, g)
+    return out
+
+
+def g_losses(y, y_hat, msd=None, mpd=None, mtd=None):
+    """train.py:165-190 (envelope / strip-mirror switched off as in hparam.py:87-89)."""
+    out = {}
+    out['mstft'], (S, Sg) = multi_stft_loss(y, y_hat, ret_loss=True, ret_specs=True)
+    out['dyn'] = dynamic_loss(y, y_hat)
+    total = W_MSTFT * out['mstft'] + W_DYN * out['dyn']
+    for tag, d, a, b in (('s', msd, y, y_hat), ('p', mpd, y, y_hat), ('t', mtd, S, Sg)):
+        if d is None:
+            continue
+        r, g, fr, fg = d(a, b)
+        out['gen_' + tag] = generator_loss(g, r)
+        out['fm_' + tag] = feature_loss(fr, fg)
+        total = total + out['gen_' + tag] + W_FM * out['fm_' + tag]
+    out['total'] = total
+    return out
+
+
+def train_step(gen, og, od, x, y_tmpl, y, msd=None, mpd=None, mtd=None, d_train_times=2, noise_list=None):
+    """One iteration of train.py:121-193.  Returns the loss dicts of the last D update and of the G update."""
+    y_hat = gen(x, y_tmpl, noise_list)
+    y_det = y_hat.detach()
+    dl = {}
+    for _ in range(d_train_times):
+        od.zero_grad()
+        dl = d_losses(y, y_det, msd, mpd, mtd)
+        tot = sum(dl.values())
+        if not torch.isnan(tot):
+            tot.backward()
+        od.step()
+    og.zero_grad()
+    gl = g_losses(y, y_hat, msd, mpd, mtd)
+    if not torch.isnan(gl['total']):
+        gl['total'].backward()
+    og.step()
+    return dl, gl
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# deterministic fixtures shared by gen_golden.py (applied to the REFERENCE modules) and the tests
+# ---------------------------------------------------------------------------------------------------------------
+def det_fill(module):
+    """Name-keyed deterministic parameter fill: identical on reference and build modules
+    because their state-dict keys are identical."""
+    for name, p in sorted(module.named_parameters(), key=lambda kv: kv[0]):
+        g = torch.Generator().manual_seed(zlib.crc32(name.encode()))
+        u = torch.rand(p.shape, generator=g, dtype=torch.float32) * 2 - 1
+        if name.endswith('weight_v'):
+            v = u
+        elif name.endswith('weight_g'):
+            v = 1.0 + 0.1 * u
+        elif name.endswith('bias'):
+            v = 0.1 * u
+        elif name == 'noise.w':
+            v = torch.zeros_like(u)
+        else:
+            raise KeyError(name)
+        p.data.copy_(v.to(p.device))
+
+
+def golden_inputs(batch=2, T=8192, seed=0):
+    torch.manual_seed(seed)
+    x = torch.randn(batch, 80, T // 256)
+    y_tmpl = torch.rand(batch, 1, T) * 2 - 1
+    y = torch.rand(batch, 1, T) * 2 - 1
+    return x, y_tmpl, y
+
+
+def synthetic_batch(batch, T, seed):
+    """bench.py's synthetic clips: x = mel_2048 @ |N(0,1)| linear spec, y_tmpl, y ~ U(-1,1)."""
+    g = torch.Generator().manual_seed(seed)
+    spec = torch.randn(batch, 1025, T // 256, generator=g).abs()
+    x = torch.matmul(torch.from_numpy(mel_filterbank(2048)), spec)
+    y_tmpl = torch.rand(batch, 1, T, generator=g) * 2 - 1
+    y = torch.rand(batch, 1, T, generator=g) * 2 - 1
+    return x, y_tmpl, y

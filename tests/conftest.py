@@ -1,0 +1,31 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(REPO, 'transtacos-retunegan_amd')
+for p in (REPO, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+@pytest.fixture(scope='session')
+def gold():
+    return dict(np.load(os.path.join(REPO, 'tests', 'golden', 'retunegan_b2_t8192.npz'), allow_pickle=False))
+
+
+@pytest.fixture(scope='session')
+def oracle():
+    """The CPU oracle (test infrastructure; see oracle/rtg_oracle.py header)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('rtg_oracle', os.path.join(REPO, 'oracle', 'rtg_oracle.py'))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules['rtg_oracle'] = mod
+    spec.loader.exec_module(mod)
+    return mod
