@@ -1,0 +1,224 @@
+/* rtg.h — C ABI of librtg.so: the MI355X (gfx950) kernels behind the RetuneGAN train-step hot path.
+ *
+ * The reference (Kahsolt/TransTacoS-RetuneGAN) is 100 % Python and has no FFI: its "operator interface" for this
+ * path is the set of torch library calls made by retunegan/models/{generator,discrminator,loss}.py, retunegan/audio.py and retunegan/train.py.
+ * Each entry point below names the reference call sites it replaces (paths relative to /root/reference).
+ * INTEGRATION.md shows the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain C: raw device pointers (float32 unless said otherwise), ints, floats; no torch / C++ types.
+ *   - every buffer (inputs, outputs, workspaces) is allocated and owned by the caller; kernels never allocate.
+ *   - asynchronous launch on the caller's `stream` (a hipStream_t passed as void*); no host synchronisation,
+ *     no global mutable state: safe under hipGraph capture and from several host threads on distinct streams.
+ *   - return 0 on success, a negative RTG_E* code on bad arguments, or -(1000 + hipError_t) on a launch failure.
+ *   - tensors are contiguous NCW: [batch][channel][time].
+ */
+#ifndef RTG_H
+#define RTG_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTG_ABI_VERSION 1
+
+#define RTG_OK 0
+#define RTG_EINVAL (-1)   /* inconsistent descriptor               */
+#define RTG_ERANGE (-2)   /* shape outside what the kernels tile   */
+#define RTG_ENULL  (-3)   /* required pointer is NULL              */
+
+/* input transform applied while a tile is staged into LDS */
+enum { RTG_PRE_NONE = 0, RTG_PRE_LRELU = 1, RTG_PRE_MUL_DLRELU = 2, RTG_PRE_MUL_DTANH = 3 };
+/* output activation */
+enum { RTG_ACT_NONE = 0, RTG_ACT_LRELU = 1, RTG_ACT_TANH = 2 };
+/* packed-weight layouts produced by rtg_weights_pack (see RtgPackJob.mode) */
+enum { RTG_PACK_FWD = 0, RTG_PACK_DGRAD_S1 = 1, RTG_PACK_DGRAD_POLY = 2, RTG_PACK_CONVT_POLY = 3 };
+
+/* ------------------------------------------------------------------------------------------------------------
+ * rtg_conv1d — implicit-GEMM 1-D convolution on the fp32 matrix cores (v_mfma_f32_32x32x2_f32 / 16x16x4_f32).
+ *
+ *   acc[b, g*Mg+m, q] = sum_{c<Cg, j<K} W[g][m][c][j] * pre( xcat[b, g*Cg+c, q*stride - pad + j*dil] )
+ *   out               = act( ((acc + bias[m']) * dmask + res) * out_scale )
+ *
+ * Replaces: F.conv1d / nn.Conv1d forward (generator.py:41-56,139-141,682-722; discrminator.py:37-45), the
+ * (k,1) Conv2d of DiscriminatorP with the period folded into the batch (discrminator.py:156-163), and - through
+ * repacked weights (rtg_weights_pack) - ConvTranspose1d forward (generator.py:697-700, polyphase: M = C_out*S rows,
+ * ceil(K/S) taps, "shuffle" store) and every convolution_backward w.r.t. the input (same kernel, RTG_PACK_DGRAD_*).
+ *
+ * xcat is the virtual concatenation along channels of x1 [B,C1,L_in] and x2 [B,C2,L_in] (torch.cat at
+ * generator.py:755,769); x2 may be NULL with C2 = 0.
+ * pre(): RTG_PRE_LRELU -> leaky_relu(x, pre_slope) (F.leaky_relu / nn.LeakyReLU call sites generator.py:40,147,745..);
+ *        RTG_PRE_MUL_DLRELU -> x * (aux > 0 ? 1 : pre_slope); RTG_PRE_MUL_DTANH -> x * (1 - aux^2)  (aux shaped like x1).
+ * dmask (optional, `mask` != NULL): (mask > 0 ? 1 : mask_slope), mask shaped like out (leaky-relu backward).
+ * Shuffle store (shuf_S > 1): row m' = g*Mg+m writes channel m'/shuf_S at time q*shuf_S + m'%shuf_S - shuf_P;
+ *        bias is then indexed by the channel m'/shuf_S.
+ * `wp` is the packed weight buffer of this layer (RtgPackJob).  tile_m selects the MFMA shape (32 or 16 rows).
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct RtgConv1dDesc {
+  int B, C1, C2, L_in;         /* input: C_in = C1 + C2                                                      */
+  int groups, Cg, Mg;          /* channels per group (in), logical output rows per group                    */
+  int K, stride, dil, pad;     /* taps, stride, dilation, left padding                                       */
+  int Q;                       /* number of output positions computed                                        */
+  int out_C, out_L;            /* shape of the stored tensor [B, out_C, out_L]                               */
+  int shuf_S, shuf_P;          /* 1, 0 for a normal store                                                    */
+  int pre_mode; float pre_slope;
+  float mask_slope;
+  float out_scale;
+  int act; float act_slope;
+  int accumulate;              /* out += result instead of out = result                                      */
+  int tile_m;                  /* 32 or 16                                                                   */
+} RtgConv1dDesc;
+
+int rtg_conv1d(const RtgConv1dDesc* d, const float* x1, const float* x2, const float* aux, const float* wp,
+               const float* bias, const float* mask, const float* res, float* out, void* stream);
+
+/* number of floats of the packed weight buffer for a layer with the given logical shape */
+long long rtg_packed_size(int groups, int Mg, int Cg, int K, int tile_m);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * rtg_conv1d_wgrad — convolution_backward w.r.t. weight and bias (train.py:158,191 -> autograd of every conv above).
+ *
+ *   dW[g*Mg+m][c][j] = sum_{b,q} gy(b, g*Mg+m, q) * pre( xcat[b, g*Cg+c, q*stride - pad + j*dil] )
+ *   db[g*Mg+m]       = sum_{b,q} gy(b, g*Mg+m, q)
+ *   gy = dy * (gy_aux given ? dact(gy_aux) : 1)        (gy_mode: RTG_PRE_NONE / MUL_DLRELU / MUL_DTANH, slope gy_slope)
+ *
+ * The (b,q) reduction is split `splits` ways; split s writes its partial to  part + s*part_stride  laid out as
+ * [rows = groups*Mg][Cg*K] followed (at part + s*part_stride + rows*Cg*K) by the `rows` bias partials.
+ * rtg_weightnorm_backward sums the partials in fixed order (bitwise reproducible).
+ * For ConvTranspose1d the caller swaps the roles (x := dy, dy := x) and gets dW in the [C_in][C_out][K] layout.
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct RtgWgradDesc {
+  int B, C1, C2, L_in;
+  int groups, Cg, Mg;
+  int K, stride, dil, pad;
+  int Q;                       /* positions of dy used (dy is [B, groups*Mg, dy_L])                          */
+  int dy_L;
+  int pre_mode; float pre_slope;
+  int gy_mode; float gy_slope;
+  int splits; long long part_stride;
+} RtgWgradDesc;
+
+int rtg_conv1d_wgrad(const RtgWgradDesc* d, const float* x1, const float* x2, const float* dy, const float* gy_aux,
+                     float* part, void* stream);
+/* suggested number of splits for a problem (>= 1) */
+int rtg_wgrad_splits(const RtgWgradDesc* d);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Weight bank: old-style weight norm (torch.nn.utils.weight_norm, dim=0: every conv of the path, e.g.
+ * generator.py:682, discrminator.py:38) for ALL layers of a model in one launch each.
+ *   scale[r] = g[r] / ||v[r,:]||,  w[r,:] = v[r,:] * scale[r]
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct RtgNormJob {      /* one per weight-normed tensor                                              */
+  long long g_off, v_off;        /* offsets (floats) into the flat parameter buffer                           */
+  long long scale_off;           /* offset into the scale buffer (rows floats) ; inv-norm stored at +rows     */
+  int rows, inner;
+} RtgNormJob;
+
+typedef struct RtgPackJob {      /* one per packed layout of a layer                                           */
+  long long v_off;               /* source v in the flat parameter buffer                                      */
+  long long scale_off;           /* scale[] of the source tensor                                               */
+  long long dst_off;             /* destination offset in the packed buffer                                    */
+  long long dst_size;            /* = rtg_packed_size(groups, Mg, Cg, K, tile_m)                                */
+  int mode;                      /* RTG_PACK_*                                                                 */
+  int groups, Mg, Cg, K;         /* logical shape of the PACKED operator (rows per group, in-ch per group, taps) */
+  int src_K, src_inner_c;        /* source taps; source dim-1 size (channels per group of the source tensor)  */
+  int S;                         /* stride of the source conv (polyphase modes)                                */
+  int tile_m;
+} RtgPackJob;
+
+typedef struct RtgWnBwdJob {     /* one per weight-normed tensor                                               */
+  long long g_off, v_off, b_off; /* offsets into the flat parameter / gradient buffers (b_off < 0: no bias)    */
+  long long scale_off;
+  long long part_off;            /* offset into the partial buffer                                             */
+  long long part_stride;
+  int splits;
+  int rows, inner;
+} RtgWnBwdJob;
+
+int rtg_weightnorm_scales(const RtgNormJob* jobs_dev, int n_jobs, const float* params, float* scales, void* stream);
+int rtg_weights_pack(const RtgPackJob* jobs_dev, int n_jobs, long long max_dst_size, const float* params,
+                     const float* scales, float* packed, void* stream);
+/* grads[g_off..], grads[v_off..], grads[b_off..] += weight-norm backward of (sum of partials) */
+int rtg_weightnorm_backward(const RtgWnBwdJob* jobs_dev, int n_jobs, int max_rows, const float* params,
+                            const float* scales, const float* partials, float* grads, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * rtg_stft_* — framed rFFT of get_stft_torch (retunegan/audio.py:150-170) + the epilogues of multi_stft_loss
+ * (retunegan/models/loss.py:32-52): reflect pad n_fft/2, periodic hann(win) centred in n_fft, rFFT,
+ * S = |D + 1e-9|, mel = melW @ S, outputs logS = log S and phase/PI  (PI = 3.14159265358979, utils.py:12).
+ *   y [B,T] -> mel [B,n_mel,frames]; spec [B,2,F,frames] (channel 0 = log S, 1 = angle/PI) if spec != NULL;
+ *   re/im [B,F,frames] saved for the backward if not NULL.
+ * Backward: given dmel [B,n_mel,frames] (may be NULL) and dspec [B,2,F,frames] (may be NULL) -> dy [B,T] (+=).
+ * melW is passed as CSR-like band tables: for filter m the non-zero bins are [lo[m], lo[m]+len[m]) with weights
+ * at wts + woff[m].  twiddle: [n_fft/2] cos then [n_fft/2] sin of 2*pi*k/n_fft (fp64-rounded).  window: [win].
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct RtgStftDesc {
+  int B, T, n_fft, win, hop, frames, n_mel;
+} RtgStftDesc;
+
+int rtg_stft_forward(const RtgStftDesc* d, const float* y, const float* window, const float* twiddle,
+                     const int* mel_lo, const int* mel_len, const int* mel_woff, const float* mel_w,
+                     float* mel, float* spec, float* re, float* im, void* stream);
+int rtg_stft_backward(const RtgStftDesc* d, const float* re, const float* im, const float* dmel, const float* dspec,
+                      const float* window, const float* twiddle,
+                      const int* binmel_idx, const float* binmel_w,   /* per bin: 2 (filter, weight) pairs          */
+                      float* frame_ws,                                 /* workspace [B*frames*win]                   */
+                      float* dy, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Small fused element-wise / reduction kernels of the path
+ * ------------------------------------------------------------------------------------------------------------ */
+/* GaussianNoise (generator.py:19-30): out = leaky_relu(x + u*w, slope), u ~ U[0,1) from a counter-based generator
+ * keyed by (seed, element index).  If `u_in` != NULL the noise is read from it instead (parity tests). */
+int rtg_noise_lrelu_fwd(const float* x, const float* w, const float* u_in, float* out, long long n, float slope,
+                        unsigned long long seed, void* stream);
+/* dx = dy * lrelu'(x + u*w);  dw_part[block] = sum dy * lrelu' * u   (n_blocks partials, summed by the caller) */
+int rtg_noise_lrelu_bwd(const float* x, const float* w, const float* u_in, const float* dy, float* dx,
+                        float* dw_part, int n_blocks, long long n, float slope, unsigned long long seed, void* stream);
+
+/* out[i] (+)= alpha * a[i] + beta * b[i]   (b may be NULL) */
+int rtg_axpby(const float* a, const float* b, float* out, long long n, float alpha, float beta, int accumulate,
+              void* stream);
+/* dx = dy * (ref > 0 ? 1 : slope) */
+int rtg_lrelu_bwd(const float* dy, const float* ref, float* dx, long long n, float slope, void* stream);
+
+/* nn.AvgPool1d(4, 2, 1) (discrminator.py:113) forward / backward on [rows, L] -> [rows, L/2] */
+int rtg_avgpool4s2_fwd(const float* x, float* out, int rows, int L, void* stream);
+int rtg_avgpool4s2_bwd(const float* dy, float* dx, int rows, int L, void* stream);
+
+/* DiscriminatorP fold (discrminator.py:203-210): y [B,T] -> out [B*p, H] with out[b*p+w, h] = reflect_pad(y)[b, h*p+w] */
+int rtg_period_fold_fwd(const float* y, float* out, int B, int T, int p, int H, void* stream);
+int rtg_period_fold_bwd(const float* dout, float* dy, int B, int T, int p, int H, void* stream);
+
+/* Scalar losses.  Each writes ONE float (+= weight * value) into *loss_out; *_bwd kernels take the upstream
+ * gradient as a device scalar pointer `gscale` (may be NULL = 1) times the host factor `w`.
+ *   l1_mean      : mean |a - b|                                     (F.l1_loss, loss.py:51-52,154)
+ *   lsgan        : mean (target - d)^2   over all elements          (loss.py:121-122,142; equal-length rows)
+ *   dyn          : mean | |max_k(y)+max_k(-y)| - |max_k(g)+max_k(-g)| |, windows of k=160 (loss.py:76-82) */
+int rtg_l1_mean_fwd(const float* a, const float* b, long long n, float w, float* loss_out, void* stream);
+int rtg_l1_mean_bwd(const float* a, const float* b, long long n, float w, const float* gscale, float* da, float* db,
+                    void* stream);
+int rtg_l1log_mean_fwd(const float* a, const float* b, long long n, float w, float* loss_out, void* stream);
+int rtg_lsgan_fwd(const float* d, long long n, float target, float w, float* loss_out, void* stream);
+int rtg_lsgan_bwd(const float* d, long long n, float target, float w, const float* gscale, float* dd, void* stream);
+int rtg_dyn_loss_fwd(const float* y, const float* g, int rows, int L, int k, float w, float* loss_out, void* stream);
+int rtg_dyn_loss_bwd(const float* y, const float* g, int rows, int L, int k, float w, const float* gscale, float* dg,
+                     void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * rtg_adamw — torch.optim.AdamW step (train.py:80-81,160,193) over a flat fp32 parameter buffer:
+ * decoupled weight decay, bias correction from the device-resident step counter state[0] (float),
+ * skipped entirely (counter included) when *loss_flag is NaN (NaN guard of train.py:158,191 made device-side).
+ * ------------------------------------------------------------------------------------------------------------ */
+int rtg_adamw(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n, float* step_state,
+              const float* loss_flag, float lr, float beta1, float beta2, float eps, float weight_decay,
+              float grad_scale, void* stream);
+
+/* library self-description */
+int rtg_abi_version(void);
+const char* rtg_build_info(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTG_H */

@@ -1,0 +1,179 @@
+"""rtg_conv1d (HIP, fp32 MFMA) against torch CPU convolutions, through the C ABI.  GPU only."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import packref
+
+pytestmark = pytest.mark.gpu
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def run_conv(desc_kw, x1, wp, x2=None, aux=None, bias=None, mask=None, res=None, out_shape=None, out_init=None):
+    from rtg.lib import lib, Conv1dDesc, check
+    d = Conv1dDesc(**desc_kw)
+    dev = 'cuda'
+    t = {k: (v.to(dev).contiguous() if v is not None else None)
+         for k, v in dict(x1=x1, x2=x2, aux=aux, bias=bias, mask=mask, res=res).items()}
+    wp_d = torch.from_numpy(wp).to(dev)
+    out = torch.full(out_shape, float('nan'), device=dev) if out_init is None else out_init.to(dev).clone()
+    st = torch.cuda.current_stream().cuda_stream
+    check(lib.rtg_conv1d(C.byref(d), _ptr(t['x1']), _ptr(t['x2']), _ptr(t['aux']), _ptr(wp_d), _ptr(t['bias']),
+                         _ptr(t['mask']), _ptr(t['res']), _ptr(out), C.c_void_p(st)), 'rtg_conv1d')
+    torch.cuda.synchronize()
+    return out.cpu()
+
+
+def base_desc(B, C1, C2, L_in, groups, Cg, Mg, K, stride, dil, pad, Q, out_C, out_L, tile_m, **kw):
+    d = dict(B=B, C1=C1, C2=C2, L_in=L_in, groups=groups, Cg=Cg, Mg=Mg, K=K, stride=stride, dil=dil, pad=pad, Q=Q,
+             out_C=out_C, out_L=out_L, shuf_S=1, shuf_P=0, pre_mode=0, pre_slope=1.0, mask_slope=1.0, out_scale=1.0,
+             act=0, act_slope=1.0, accumulate=0, tile_m=tile_m)
+    d.update(kw)
+    return d
+
+
+FWD_CASES = [
+    # B, C_in, C_out, L, K, stride, dil, pad, groups, tile_m
+    (2, 32, 32, 1024, 3, 1, 1, 1, 1, 32),
+    (2, 32, 32, 1000, 7, 1, 9, 27, 1, 32),       # ResBlock3 k7 d9, ragged length
+    (2, 64, 64, 512, 5, 1, 3, 6, 1, 32),
+    (3, 128, 128, 256, 7, 1, 1, 3, 1, 32),
+    (2, 128, 128, 32, 3, 1, 9, 9, 1, 32),        # ResidualStack at T'=32 (dilation wider than the signal)
+    (2, 16, 32, 2048, 7, 4, 1, 3, 1, 32),        # downs.0
+    (2, 32, 64, 2048, 15, 8, 1, 7, 1, 32),       # downs.1
+    (2, 1, 16, 1024, 7, 1, 1, 3, 1, 32),         # conv_pre  (C_in = 1)
+    (2, 32, 1, 1024, 7, 1, 1, 3, 1, 16),         # conv_post (C_out = 1)
+    (2, 1, 32, 1024, 15, 1, 1, 7, 1, 32),        # MSD conv0
+    (2, 32, 64, 1024, 41, 2, 1, 20, 4, 16),      # MSD grouped k41 s2
+    (2, 128, 512, 512, 41, 4, 1, 20, 32, 16),    # MSD grouped k41 s4, 4 in-ch per group
+    (2, 512, 512, 128, 41, 4, 1, 20, 64, 16),    # MSD grouped, 8 rows per group
+    (2, 512, 512, 64, 5, 1, 1, 2, 1, 32),        # MSD conv5
+    (6, 32, 128, 911, 5, 3, 1, 2, 1, 32),        # MPD (5,1) stride 3 with the period folded into the batch
+    (6, 512, 1, 34, 3, 1, 1, 1, 1, 16),          # D conv_post
+    (1, 48, 32, 300, 7, 1, 1, 3, 1, 32),         # merge.2 shape, C_in not a multiple of 32
+]
+
+
+@pytest.mark.parametrize('case', FWD_CASES)
+def test_conv_forward_matches_torch(case):
+    B, Cin, Cout, L, K, s, d, p, g, TM = case
+    gen = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    x = torch.randn(B, Cin, L, generator=gen)
+    w = torch.randn(Cout, Cin // g, K, generator=gen) / np.sqrt(Cin // g * K)
+    bias = torch.randn(Cout, generator=gen)
+    ref = F.conv1d(F.leaky_relu(x, 0.15).double(), w.double(), bias.double(), s, p, d, g)
+    L_out = ref.shape[-1]
+    res = torch.randn(B, Cout, L_out, generator=gen)
+    ref = F.leaky_relu((ref + res.double()) * 0.5, 0.01).float()
+    wp = packref.pack_logical(packref.logical_fwd(w.numpy(), g), TM)
+    desc = base_desc(B, Cin, 0, L, g, Cin // g, Cout // g, K, s, d, p, L_out, Cout, L_out, TM,
+                     pre_mode=1, pre_slope=0.15, out_scale=0.5, act=1, act_slope=0.01)
+    out = run_conv(desc, x, wp, bias=bias, res=res, out_shape=(B, Cout, L_out))
+    np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=1e-4, atol=2e-5)
+
+
+def test_virtual_concat_and_accumulate():
+    gen = torch.Generator().manual_seed(5)
+    B, C1, C2, Cout, L, K = 2, 80, 128, 256, 32, 7
+    x1, x2 = torch.randn(B, C1, L, generator=gen), torch.randn(B, C2, L, generator=gen)
+    w = torch.randn(Cout, C1 + C2, K, generator=gen) / 30
+    ref = F.conv1d(torch.cat([x1, x2], 1).double(), w.double(), None, 1, 3).float()
+    wp = packref.pack_logical(packref.logical_fwd(w.numpy(), 1), 32)
+    desc = base_desc(B, C1, C2, L, 1, C1 + C2, Cout, K, 1, 1, 3, L, Cout, L, 32, accumulate=1)
+    init = torch.randn(B, Cout, L, generator=gen)
+    out = run_conv(desc, x1, wp, x2=x2, out_shape=(B, Cout, L), out_init=init)
+    np.testing.assert_allclose(out.numpy(), (ref + init).numpy(), rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize('case', [(2, 32, 32, 777, 7, 9, 27), (2, 64, 64, 256, 5, 3, 6), (2, 128, 128, 64, 3, 1, 1)])
+def test_dgrad_stride1(case):
+    """backward-data of a 'same' dilated conv = rtg_conv1d on RTG_PACK_DGRAD_S1 weights, with the leaky-relu
+    derivative mask and the residual gradient fused in the epilogue (ResBlock3: y = conv(lrelu(x)) + x)."""
+    B, Cin, Cout, L, K, d, p = case
+    gen = torch.Generator().manual_seed(11)
+    x = torch.randn(B, Cin, L, generator=gen, dtype=torch.float64, requires_grad=True)
+    w = (torch.randn(Cout, Cin, K, generator=gen) / np.sqrt(Cin * K))
+    y = F.conv1d(F.leaky_relu(x, 0.15), w.double(), None, 1, p, d) + x
+    dy = torch.randn(y.shape, generator=gen)
+    y.backward(dy.double())
+    wp = packref.pack_logical(packref.logical_dgrad_s1(w.numpy(), 1), 32)
+    desc = base_desc(B, Cout, 0, L, 1, Cout, Cin, K, 1, d, (K - 1) * d - p, L, Cin, L, 32, mask_slope=0.15)
+    out = run_conv(desc, dy, wp, mask=x.detach().float(), res=dy, out_shape=(B, Cin, L))
+    np.testing.assert_allclose(out.numpy(), x.grad.float().numpy(), rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize('case', [(2, 16, 32, 2048, 7, 4, 3, 1, 32), (2, 64, 128, 256, 15, 8, 7, 1, 32),
+                                  (6, 32, 128, 911, 5, 3, 2, 1, 32), (2, 32, 64, 1024, 41, 2, 20, 4, 16),
+                                  (2, 512, 512, 128, 41, 4, 20, 64, 16)])
+def test_dgrad_strided_polyphase(case):
+    B, Cin, Cout, L, K, s, p, g, TM = case
+    gen = torch.Generator().manual_seed(13)
+    x = torch.randn(B, Cin, L, generator=gen, dtype=torch.float64, requires_grad=True)
+    w = (torch.randn(Cout, Cin // g, K, generator=gen) / np.sqrt(Cin // g * K))
+    y = F.conv1d(x, w.double(), None, s, p, 1, g)
+    dy = torch.randn(y.shape, generator=gen)
+    y.backward(dy.double())
+    Lo = y.shape[-1]
+    nt = -(-K // s)
+    wp = packref.pack_logical(packref.logical_dgrad_poly(w.numpy(), g, s), TM)
+    NQ = (L - 1 + p) // s + 1
+    desc = base_desc(B, Cout, 0, Lo, g, Cout // g, (Cin // g) * s, nt, 1, 1, nt - 1, NQ, Cin, L, TM,
+                     shuf_S=s, shuf_P=p)
+    out = run_conv(desc, dy, wp, out_shape=(B, Cin, L))
+    np.testing.assert_allclose(out.numpy(), x.grad.float().numpy(), rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize('case', [(2, 256, 128, 32, 15, 8, 7, 7), (2, 128, 64, 256, 15, 8, 7, 7),
+                                  (2, 64, 32, 512, 7, 4, 3, 3)])
+def test_conv_transpose_forward_and_dgrad(case):
+    B, Cin, Cout, L, K, s, p, op = case
+    gen = torch.Generator().manual_seed(17)
+    x = torch.randn(B, Cin, L, generator=gen, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(Cin, Cout, K, generator=gen) / np.sqrt(Cin * K / s)
+    bias = torch.randn(Cout, generator=gen)
+    y = F.conv_transpose1d(F.leaky_relu(x, 0.15), w.double(), bias.double(), s, p, op)
+    Lo = y.shape[-1]
+    assert Lo == L * s
+    nt = -(-K // s)
+    wp = packref.pack_logical(packref.logical_convT_poly(w.numpy(), s), 32)
+    NQ = (Lo - 1 + p) // s + 1
+    desc = base_desc(B, Cin, 0, L, 1, Cin, Cout * s, nt, 1, 1, nt - 1, NQ, Cout, Lo, 32, shuf_S=s, shuf_P=p,
+                     pre_mode=1, pre_slope=0.15)
+    out = run_conv(desc, x.detach().float(), wp, bias=bias, out_shape=(B, Cout, Lo))
+    np.testing.assert_allclose(out.numpy(), y.detach().float().numpy(), rtol=1e-4, atol=2e-5)
+    # backward-data of the transposed conv = strided conv of dy, times lrelu'(x)
+    dy = torch.randn(y.shape, generator=gen)
+    y.backward(dy.double())
+    wp2 = packref.pack_logical(packref.logical_convT_dgrad(w.numpy()), 32)
+    desc2 = base_desc(B, Cout, 0, Lo, 1, Cout, Cin, K, s, 1, p, L, Cin, L, 32, mask_slope=0.15)
+    dx = run_conv(desc2, dy, wp2, mask=x.detach().float(), out_shape=(B, Cin, L))
+    np.testing.assert_allclose(dx.numpy(), x.grad.float().numpy(), rtol=1e-4, atol=2e-5)
+
+
+def test_pre_modes_on_dy():
+    """dy * lrelu'(out) and dy * (1 - out^2) applied while staging (post-activation layers' backward)."""
+    gen = torch.Generator().manual_seed(19)
+    B, Cc, L, K = 2, 32, 300, 3
+    dy, outp = torch.randn(B, Cc, L, generator=gen), torch.randn(B, Cc, L, generator=gen).tanh()
+    w = torch.randn(Cc, Cc, K, generator=gen) / 10
+    wp = packref.pack_logical(packref.logical_fwd(w.numpy(), 1), 32)
+    for mode, eff in ((2, dy * torch.where(outp > 0, 1.0, 0.15)), (3, dy * (1 - outp * outp))):
+        ref = F.conv1d(eff.double(), w.double(), None, 1, 1).float()
+        desc = base_desc(B, Cc, 0, L, 1, Cc, Cc, K, 1, 1, 1, L, Cc, L, 32, pre_mode=mode, pre_slope=0.15)
+        out = run_conv(desc, dy, wp, aux=outp, out_shape=(B, Cc, L))
+        np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=1e-4, atol=2e-5)
+
+
+def test_bad_descriptor_is_refused():
+    from rtg.lib import lib, Conv1dDesc
+    d = Conv1dDesc(**base_desc(1, 8, 0, 16, 1, 7, 8, 3, 1, 1, 1, 16, 8, 16, 32))   # C1 != groups*Cg
+    x = torch.zeros(1, 8, 16, device='cuda')
+    assert lib.rtg_conv1d(C.byref(d), _ptr(x), None, None, _ptr(x), None, None, None, _ptr(x), None) == -1
+    d = Conv1dDesc(**base_desc(1, 8, 0, 16, 1, 8, 8, 3, 1, 1, 1, 16, 8, 16, 32))
+    assert lib.rtg_conv1d(C.byref(d), None, None, None, _ptr(x), None, None, None, _ptr(x), None) == -3

@@ -1,0 +1,36 @@
+// rtg_common.h — shared device/host helpers for librtg.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/rtg.h"
+
+#define RTG_CK 16            // input channels staged per LDS chunk
+#define RTG_PW_MAX 576       // widest input patch (floats per channel row) a block stages
+#define RTG_THREADS 256      // 4 wavefronts of 64
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static inline int rtg_launch_status() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? RTG_OK : -(1000 + (int)e);
+}
+
+static inline int rtg_ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+__device__ __forceinline__ float rtg_lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
+
+// sum across the 64 lanes of a wavefront (result valid in every lane)
+__device__ __forceinline__ float rtg_wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+// block-wide sum for RTG_THREADS threads; `red` is a 4-float LDS scratch. Result valid in every thread.
+__device__ __forceinline__ float rtg_block_sum(float v, float* red) {
+  v = rtg_wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}

@@ -1,0 +1,121 @@
+"""ctypes loader for librtg.so (include/rtg.h).  Fails loudly when the library is missing: there is no fallback."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), 'librtg.so')
+
+
+class RtgError(RuntimeError):
+    pass
+
+
+class Conv1dDesc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ('B', 'C1', 'C2', 'L_in', 'groups', 'Cg', 'Mg', 'K', 'stride', 'dil', 'pad', 'Q',
+                                       'out_C', 'out_L', 'shuf_S', 'shuf_P', 'pre_mode')] + \
+               [('pre_slope', C.c_float), ('mask_slope', C.c_float), ('out_scale', C.c_float), ('act', C.c_int),
+                ('act_slope', C.c_float), ('accumulate', C.c_int), ('tile_m', C.c_int)]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ('B', 'C1', 'C2', 'L_in', 'groups', 'Cg', 'Mg', 'K', 'stride', 'dil', 'pad', 'Q',
+                                       'dy_L', 'pre_mode')] + \
+               [('pre_slope', C.c_float), ('gy_mode', C.c_int), ('gy_slope', C.c_float), ('splits', C.c_int),
+                ('part_stride', C.c_longlong)]
+
+
+class NormJob(C.Structure):
+    _fields_ = [('g_off', C.c_longlong), ('v_off', C.c_longlong), ('scale_off', C.c_longlong), ('rows', C.c_int),
+                ('inner', C.c_int)]
+
+
+class PackJob(C.Structure):
+    _fields_ = [('v_off', C.c_longlong), ('scale_off', C.c_longlong), ('dst_off', C.c_longlong),
+                ('dst_size', C.c_longlong)] + \
+               [(n, C.c_int) for n in ('mode', 'groups', 'Mg', 'Cg', 'K', 'src_K', 'src_inner_c', 'S', 'tile_m')]
+
+
+class WnBwdJob(C.Structure):
+    _fields_ = [('g_off', C.c_longlong), ('v_off', C.c_longlong), ('b_off', C.c_longlong), ('scale_off', C.c_longlong),
+                ('part_off', C.c_longlong), ('part_stride', C.c_longlong), ('splits', C.c_int), ('rows', C.c_int),
+                ('inner', C.c_int)]
+
+
+class StftDesc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ('B', 'T', 'n_fft', 'win', 'hop', 'frames', 'n_mel')]
+
+
+PRE_NONE, PRE_LRELU, PRE_MUL_DLRELU, PRE_MUL_DTANH = 0, 1, 2, 3
+ACT_NONE, ACT_LRELU, ACT_TANH = 0, 1, 2
+PACK_FWD, PACK_DGRAD_S1, PACK_DGRAD_POLY, PACK_CONVT_POLY = 0, 1, 2, 3
+CK = 16
+
+_P = C.c_void_p
+_I, _F, _LL, _ULL = C.c_int, C.c_float, C.c_longlong, C.c_ulonglong
+
+# name -> (restype, argtypes); must list every symbol include/rtg.h declares (checked by tests/test_abi.py)
+PROTOTYPES = {
+    'rtg_conv1d': (_I, [C.POINTER(Conv1dDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'rtg_packed_size': (_LL, [_I, _I, _I, _I, _I]),
+    'rtg_conv1d_wgrad': (_I, [C.POINTER(WgradDesc), _P, _P, _P, _P, _P, _P]),
+    'rtg_wgrad_splits': (_I, [C.POINTER(WgradDesc)]),
+    'rtg_weightnorm_scales': (_I, [_P, _I, _P, _P, _P]),
+    'rtg_weights_pack': (_I, [_P, _I, _LL, _P, _P, _P, _P]),
+    'rtg_weightnorm_backward': (_I, [_P, _I, _I, _P, _P, _P, _P, _P]),
+    'rtg_stft_forward': (_I, [C.POINTER(StftDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'rtg_stft_backward': (_I, [C.POINTER(StftDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'rtg_noise_lrelu_fwd': (_I, [_P, _P, _P, _P, _LL, _F, _ULL, _P]),
+    'rtg_noise_lrelu_bwd': (_I, [_P, _P, _P, _P, _P, _P, _I, _LL, _F, _ULL, _P]),
+    'rtg_axpby': (_I, [_P, _P, _P, _LL, _F, _F, _I, _P]),
+    'rtg_lrelu_bwd': (_I, [_P, _P, _P, _LL, _F, _P]),
+    'rtg_avgpool4s2_fwd': (_I, [_P, _P, _I, _I, _P]),
+    'rtg_avgpool4s2_bwd': (_I, [_P, _P, _I, _I, _P]),
+    'rtg_period_fold_fwd': (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    'rtg_period_fold_bwd': (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    'rtg_l1_mean_fwd': (_I, [_P, _P, _LL, _F, _P, _P]),
+    'rtg_l1_mean_bwd': (_I, [_P, _P, _LL, _F, _P, _P, _P, _P]),
+    'rtg_l1log_mean_fwd': (_I, [_P, _P, _LL, _F, _P, _P]),
+    'rtg_lsgan_fwd': (_I, [_P, _LL, _F, _F, _P, _P]),
+    'rtg_lsgan_bwd': (_I, [_P, _LL, _F, _F, _P, _P, _P]),
+    'rtg_dyn_loss_fwd': (_I, [_P, _P, _I, _I, _I, _F, _P, _P]),
+    'rtg_dyn_loss_bwd': (_I, [_P, _P, _I, _I, _I, _F, _P, _P, _P]),
+    'rtg_adamw': (_I, [_P, _P, _P, _P, _LL, _P, _P, _F, _F, _F, _F, _F, _F, _P]),
+    'rtg_abi_version': (_I, []),
+    'rtg_build_info': (C.c_char_p, []),
+}
+
+
+class _Lib:
+    """Lazy handle: importing the package works without the .so (CPU-only host logic and tests), calling any
+    kernel without it raises."""
+
+    def __init__(self):
+        self._dll = None
+
+    def load(self):
+        if self._dll is None:
+            if not os.path.exists(LIB_PATH):
+                raise RtgError(f'{LIB_PATH} is missing: run `python transtacos-retunegan_amd/build.py` '
+                               '(there is no non-HIP fallback for the RetuneGAN hot path)')
+            dll = C.CDLL(LIB_PATH)
+            for name, (res, args) in PROTOTYPES.items():
+                try:
+                    fn = getattr(dll, name)      # AttributeError if the symbol is not exported
+                except AttributeError:
+                    if os.environ.get('RTG_DEV_PARTIAL_LIB') == '1':   # bring-up only: kernels under construction
+                        continue
+                    raise
+                fn.restype, fn.argtypes = res, args
+            self._dll = dll
+        return self._dll
+
+    def __getattr__(self, name):
+        return getattr(self.load(), name)
+
+
+lib = _Lib()
+
+
+def check(status, what=''):
+    if status != 0:
+        raise RtgError(f'librtg call {what} failed with status {status}')
