@@ -67,10 +67,12 @@ typedef struct RtgConv1dDesc {
   int act; float act_slope;
   int accumulate;              /* out += result instead of out = result                                      */
   int tile_m;                  /* 32 or 16                                                                   */
+  int out_split;               /* 0, or: channels >= out_split are stored to `out2` ([B, out_C-out_split, out_L]);
+                                  either half may be skipped by passing NULL (backward of a torch.cat input pair) */
 } RtgConv1dDesc;
 
 int rtg_conv1d(const RtgConv1dDesc* d, const float* x1, const float* x2, const float* aux, const float* wp,
-               const float* bias, const float* mask, const float* res, float* out, void* stream);
+               const float* bias, const float* mask, const float* res, float* out, float* out2, void* stream);
 
 /* number of floats of the packed weight buffer for a layer with the given logical shape */
 long long rtg_packed_size(int groups, int Mg, int Cg, int K, int tile_m);
@@ -80,7 +82,9 @@ long long rtg_packed_size(int groups, int Mg, int Cg, int K, int tile_m);
  *
  *   dW[g*Mg+m][c][j] = sum_{b,q} gy(b, g*Mg+m, q) * pre( xcat[b, g*Cg+c, q*stride - pad + j*dil] )
  *   db[g*Mg+m]       = sum_{b,q} gy(b, g*Mg+m, q)
- *   gy = dy * (gy_aux given ? dact(gy_aux) : 1)        (gy_mode: RTG_PRE_NONE / MUL_DLRELU / MUL_DTANH, slope gy_slope)
+ *   gy = gy_scale * dy * dact(gy_aux)   (gy_mode RTG_PRE_MUL_DLRELU / MUL_DTANH, slope gy_slope),
+ *        gy_scale * leaky_relu(dy)       (gy_mode RTG_PRE_LRELU: the transposed-conv case where the roles are swapped),
+ *        gy_scale * dy                   (RTG_PRE_NONE)
  *
  * The (b,q) reduction is split `splits` ways; split s writes its partial to  part + s*part_stride  laid out as
  * [rows = groups*Mg][Cg*K] followed (at part + s*part_stride + rows*Cg*K) by the `rows` bias partials.
@@ -94,7 +98,7 @@ typedef struct RtgWgradDesc {
   int Q;                       /* positions of dy used (dy is [B, groups*Mg, dy_L])                          */
   int dy_L;
   int pre_mode; float pre_slope;
-  int gy_mode; float gy_slope;
+  int gy_mode; float gy_slope; float gy_scale;
   int splits; long long part_stride;
 } RtgWgradDesc;
 
@@ -135,11 +139,12 @@ typedef struct RtgWnBwdJob {     /* one per weight-normed tensor                
   int rows, inner;
 } RtgWnBwdJob;
 
-int rtg_weightnorm_scales(const RtgNormJob* jobs_dev, int n_jobs, const float* params, float* scales, void* stream);
+int rtg_weightnorm_scales(const RtgNormJob* jobs_dev, int n_jobs, int max_rows, const float* params, float* scales,
+                          void* stream);
 int rtg_weights_pack(const RtgPackJob* jobs_dev, int n_jobs, long long max_dst_size, const float* params,
                      const float* scales, float* packed, void* stream);
 /* grads[g_off..], grads[v_off..], grads[b_off..] += weight-norm backward of (sum of partials) */
-int rtg_weightnorm_backward(const RtgWnBwdJob* jobs_dev, int n_jobs, int max_rows, const float* params,
+int rtg_weightnorm_backward(const RtgWnBwdJob* jobs_dev, int n_jobs, int max_rows, int max_inner, const float* params,
                             const float* scales, const float* partials, float* grads, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
@@ -169,13 +174,18 @@ int rtg_stft_backward(const RtgStftDesc* d, const float* re, const float* im, co
  * Small fused element-wise / reduction kernels of the path
  * ------------------------------------------------------------------------------------------------------------ */
 /* GaussianNoise (generator.py:19-30): out = leaky_relu(x + u*w, slope), u ~ U[0,1) from a counter-based generator
- * keyed by (seed, element index).  If `u_in` != NULL the noise is read from it instead (parity tests). */
+ * keyed by (seed ^ f(*salt_dev), element index); salt_dev (optional) is a device word that changes every step (the
+ * optimizer's step counter) so that a captured hipGraph draws fresh noise at every replay.
+ * If `u_in` != NULL the noise is read from it instead (parity tests). */
 int rtg_noise_lrelu_fwd(const float* x, const float* w, const float* u_in, float* out, long long n, float slope,
-                        unsigned long long seed, void* stream);
+                        unsigned long long seed, const float* salt_dev, void* stream);
 /* dx = dy * lrelu'(x + u*w);  dw_part[block] = sum dy * lrelu' * u   (n_blocks partials, summed by the caller) */
 int rtg_noise_lrelu_bwd(const float* x, const float* w, const float* u_in, const float* dy, float* dx,
-                        float* dw_part, int n_blocks, long long n, float slope, unsigned long long seed, void* stream);
+                        float* dw_part, int n_blocks, long long n, float slope, unsigned long long seed,
+                        const float* salt_dev, void* stream);
 
+/* out[c] += sum_{b,t} x[b,c,t]   (bias gradient of ConvTranspose1d layers; x is [B, C, L]) */
+int rtg_channel_sum(const float* x, float* out, int B, int C, int L, void* stream);
 /* out[i] (+)= alpha * a[i] + beta * b[i]   (b may be NULL) */
 int rtg_axpby(const float* a, const float* b, float* out, long long n, float alpha, float beta, int accumulate,
               void* stream);
@@ -190,18 +200,25 @@ int rtg_avgpool4s2_bwd(const float* dy, float* dx, int rows, int L, void* stream
 int rtg_period_fold_fwd(const float* y, float* out, int B, int T, int p, int H, void* stream);
 int rtg_period_fold_bwd(const float* dout, float* dy, int B, int T, int p, int H, void* stream);
 
-/* Scalar losses.  Each writes ONE float (+= weight * value) into *loss_out; *_bwd kernels take the upstream
- * gradient as a device scalar pointer `gscale` (may be NULL = 1) times the host factor `w`.
- *   l1_mean      : mean |a - b|                                     (F.l1_loss, loss.py:51-52,154)
- *   lsgan        : mean (target - d)^2   over all elements          (loss.py:121-122,142; equal-length rows)
- *   dyn          : mean | |max_k(y)+max_k(-y)| - |max_k(g)+max_k(-g)| |, windows of k=160 (loss.py:76-82) */
-int rtg_l1_mean_fwd(const float* a, const float* b, long long n, float w, float* loss_out, void* stream);
-int rtg_l1_mean_bwd(const float* a, const float* b, long long n, float w, const float* gscale, float* da, float* db,
-                    void* stream);
-int rtg_l1log_mean_fwd(const float* a, const float* b, long long n, float w, float* loss_out, void* stream);
-int rtg_lsgan_fwd(const float* d, long long n, float target, float w, float* loss_out, void* stream);
-int rtg_lsgan_bwd(const float* d, long long n, float target, float w, const float* gscale, float* dd, void* stream);
-int rtg_dyn_loss_fwd(const float* y, const float* g, int rows, int L, int k, float w, float* loss_out, void* stream);
+/* Scalar losses, multi-tensor: ONE launch covers a whole list of (a, b) pairs (all feature maps of a discriminator
+ * stack, all logits, the three mel resolutions).   *loss_out += sum_j w_j * mean_j(term)   with
+ *   RTG_LOSS_L1         |a - b|                         F.l1_loss                    (loss.py:154)
+ *   RTG_LOSS_L1_L1LOG   |a - b| + |log a - log b|       mel + log-mel L1             (loss.py:51-52)
+ *   RTG_LOSS_MSE_TARGET (target - a)^2                  LSGAN terms, equal-length rows (loss.py:121-122,142)
+ * Partials are summed in fixed order (ws needs 64 * n_jobs floats).  The backward writes (not accumulates)
+ * d loss / d a into da and / or d loss / d b into db, scaled by w_j / n_j and by the device scalar *gscale (NULL = 1). */
+#define RTG_MAX_LOSS_JOBS 48
+enum { RTG_LOSS_L1 = 0, RTG_LOSS_L1_L1LOG = 1, RTG_LOSS_MSE_TARGET = 2 };
+typedef struct RtgLossJob {
+  const float* a; const float* b; float* da; float* db;
+  long long n; float w; float target;
+} RtgLossJob;
+int rtg_loss_fwd(int kind, const RtgLossJob* jobs_host, int n_jobs, float* ws, float* loss_out, void* stream);
+int rtg_loss_bwd(int kind, const RtgLossJob* jobs_host, int n_jobs, const float* gscale, void* stream);
+/* dynamic_loss (loss.py:76-82): mean | |max_k(y)+max_k(-y)| - |max_k(g)+max_k(-g)| | over windows of k (=160) samples,
+ * nn.MaxPool1d(k) semantics (stride k, tail dropped, first maximum wins).  ws: 256 floats.  Backward w.r.t. g. */
+int rtg_dyn_loss_fwd(const float* y, const float* g, int rows, int L, int k, float w, float* ws, float* loss_out,
+                     void* stream);
 int rtg_dyn_loss_bwd(const float* y, const float* g, int rows, int L, int k, float w, const float* gscale, float* dg,
                      void* stream);
 

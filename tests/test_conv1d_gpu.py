@@ -25,7 +25,7 @@ def run_conv(desc_kw, x1, wp, x2=None, aux=None, bias=None, mask=None, res=None,
     out = torch.full(out_shape, float('nan'), device=dev) if out_init is None else out_init.to(dev).clone()
     st = torch.cuda.current_stream().cuda_stream
     check(lib.rtg_conv1d(C.byref(d), _ptr(t['x1']), _ptr(t['x2']), _ptr(t['aux']), _ptr(wp_d), _ptr(t['bias']),
-                         _ptr(t['mask']), _ptr(t['res']), _ptr(out), C.c_void_p(st)), 'rtg_conv1d')
+                         _ptr(t['mask']), _ptr(t['res']), _ptr(out), None, C.c_void_p(st)), 'rtg_conv1d')
     torch.cuda.synchronize()
     return out.cpu()
 
@@ -33,7 +33,7 @@ def run_conv(desc_kw, x1, wp, x2=None, aux=None, bias=None, mask=None, res=None,
 def base_desc(B, C1, C2, L_in, groups, Cg, Mg, K, stride, dil, pad, Q, out_C, out_L, tile_m, **kw):
     d = dict(B=B, C1=C1, C2=C2, L_in=L_in, groups=groups, Cg=Cg, Mg=Mg, K=K, stride=stride, dil=dil, pad=pad, Q=Q,
              out_C=out_C, out_L=out_L, shuf_S=1, shuf_P=0, pre_mode=0, pre_slope=1.0, mask_slope=1.0, out_scale=1.0,
-             act=0, act_slope=1.0, accumulate=0, tile_m=tile_m)
+             act=0, act_slope=1.0, accumulate=0, tile_m=tile_m, out_split=0)
     d.update(kw)
     return d
 
@@ -130,7 +130,7 @@ def test_dgrad_strided_polyphase(case):
 
 
 @pytest.mark.parametrize('case', [(2, 256, 128, 32, 15, 8, 7, 7), (2, 128, 64, 256, 15, 8, 7, 7),
-                                  (2, 64, 32, 512, 7, 4, 3, 3)])
+                                  (2, 64, 32, 512, 7, 4, 3, 3), (2, 64, 32, 2048, 7, 4, 3, 3)])
 def test_conv_transpose_forward_and_dgrad(case):
     B, Cin, Cout, L, K, s, p, op = case
     gen = torch.Generator().manual_seed(17)
@@ -156,6 +156,30 @@ def test_conv_transpose_forward_and_dgrad(case):
     np.testing.assert_allclose(dx.numpy(), x.grad.float().numpy(), rtol=1e-4, atol=2e-5)
 
 
+@pytest.mark.parametrize('case', [(2, 32, 16, 32, 8192, 7), (2, 128, 64, 128, 256, 7), (2, 80, 128, 256, 32, 7)])
+def test_dgrad_split_store_for_concat_inputs(case):
+    """backward-data of conv(cat([x1, x2])) written straight into the two input gradients (out_split)."""
+    B, C1, C2, Cout, L, K = case
+    gen = torch.Generator().manual_seed(23)
+    x1 = torch.randn(B, C1, L, generator=gen, dtype=torch.float64, requires_grad=True)
+    x2 = torch.randn(B, C2, L, generator=gen, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(Cout, C1 + C2, K, generator=gen) / np.sqrt((C1 + C2) * K)
+    y = F.conv1d(torch.cat([x1, x2], 1), w.double(), None, 1, K // 2)
+    dy = torch.randn(y.shape, generator=gen)
+    y.backward(dy.double())
+    wp = packref.pack_logical(packref.logical_dgrad_s1(w.numpy(), 1), 32)
+    from rtg.lib import lib, Conv1dDesc, check
+    d = Conv1dDesc(**base_desc(B, Cout, 0, L, 1, Cout, C1 + C2, K, 1, 1, (K - 1) - K // 2, L, C1 + C2, L, 32,
+                               out_split=C1))
+    dyd, wpd = dy.cuda(), torch.from_numpy(wp).cuda()
+    o1 = torch.full((B, C1, L), float('nan'), device='cuda')
+    o2 = torch.full((B, C2, L), float('nan'), device='cuda')
+    check(lib.rtg_conv1d(C.byref(d), _ptr(dyd), None, None, _ptr(wpd), None, None, None, _ptr(o1), _ptr(o2), None))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(o1.cpu().numpy(), x1.grad.float().numpy(), rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(o2.cpu().numpy(), x2.grad.float().numpy(), rtol=1e-4, atol=2e-5)
+
+
 def test_pre_modes_on_dy():
     """dy * lrelu'(out) and dy * (1 - out^2) applied while staging (post-activation layers' backward)."""
     gen = torch.Generator().manual_seed(19)
@@ -174,6 +198,6 @@ def test_bad_descriptor_is_refused():
     from rtg.lib import lib, Conv1dDesc
     d = Conv1dDesc(**base_desc(1, 8, 0, 16, 1, 7, 8, 3, 1, 1, 1, 16, 8, 16, 32))   # C1 != groups*Cg
     x = torch.zeros(1, 8, 16, device='cuda')
-    assert lib.rtg_conv1d(C.byref(d), _ptr(x), None, None, _ptr(x), None, None, None, _ptr(x), None) == -1
+    assert lib.rtg_conv1d(C.byref(d), _ptr(x), None, None, _ptr(x), None, None, None, _ptr(x), None, None) == -1
     d = Conv1dDesc(**base_desc(1, 8, 0, 16, 1, 8, 8, 3, 1, 1, 1, 16, 8, 16, 32))
-    assert lib.rtg_conv1d(C.byref(d), None, None, None, _ptr(x), None, None, None, _ptr(x), None) == -3
+    assert lib.rtg_conv1d(C.byref(d), None, None, None, _ptr(x), None, None, None, _ptr(x), None, None) == -3

@@ -1,0 +1,228 @@
+"""Parity of the HIP hot path (through the reference-shaped Python API, i.e. through the C ABI) against the golden
+fixtures produced by the reference and against the CPU oracle on the same seeded inputs.  GPU only."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def stats(t):
+    t = t.detach().double().cpu()
+    return np.array([t.sum().item(), t.abs().mean().item()])
+
+
+def close_stats(a, b, numel, rtol=1e-3, atol=2e-5, sum_rel=2e-5):
+    """column 1 = mean |x| (relative check); column 0 = plain sum, which cancels: its tolerance is relative to the
+    sum of magnitudes numel * mean|x| (fp32 accumulation-order noise), not to the sum itself."""
+    a, b = np.asarray(a), np.asarray(b)
+    np.testing.assert_allclose(a[..., 1], b[..., 1], rtol=rtol, atol=atol)
+    bad = np.abs(a[..., 0] - b[..., 0]) > sum_rel * np.asarray(numel) * b[..., 1] + 1e-4
+    assert not bad.any(), (np.nonzero(bad), a[bad], b[bad])
+
+
+def numels(m):
+    return np.array([p.numel() for _, p in sorted(m.named_parameters())])
+
+
+@pytest.fixture(scope='module')
+def nets(oracle):
+    import hparam  # noqa: F401
+    from models import Generator_RefineGAN_small, MultiScaleDiscriminator, MultiPeriodDiscriminator
+    torch.manual_seed(7)
+    g, msd, mpd = Generator_RefineGAN_small(), MultiScaleDiscriminator(), MultiPeriodDiscriminator()
+    for m in (g, msd, mpd):
+        oracle.det_fill(m)
+        m.to(DEV).train()
+    return g, msd, mpd
+
+
+@pytest.fixture(scope='module')
+def onets(oracle):
+    torch.manual_seed(7)
+    g, msd, mpd = oracle.Generator(), oracle.MSD(), oracle.MPD()
+    for m in (g, msd, mpd):
+        oracle.det_fill(m)
+        m.train()
+    return g, msd, mpd
+
+
+def test_state_dict_roundtrip_and_flat_views(nets, oracle):
+    g = nets[0]
+    bank = g.bank()
+    assert bank.check_views()
+    sd = {k: v.clone() for k, v in g.state_dict().items()}
+    og = oracle.Generator()
+    og.load_state_dict({k: v.cpu() for k, v in sd.items()})       # the oracle has the reference's key set
+    g.load_state_dict(sd)
+    assert bank.check_views() and g.bank() is bank
+    assert bank.n_params == 2748371
+
+
+def test_pack_kernel_matches_host_packing(nets):
+    import packref
+    g = nets[0]
+    bank = g.bank()
+    g.token()
+    torch.cuda.synchronize()
+    packed = bank.packed.cpu().numpy()
+    for ly in bank.layers:
+        w = ly.module.effective_weight().detach().cpu().numpy()
+        w = w.reshape(w.shape[0], w.shape[1], -1)
+        s = ly.stride
+        if ly.kind == 'conv':
+            fwd = packref.logical_fwd(w, ly.groups)
+            bwd = packref.logical_dgrad_s1(w, ly.groups) if s == 1 else packref.logical_dgrad_poly(w, ly.groups, s)
+        else:
+            fwd, bwd = packref.logical_convT_poly(w, s), packref.logical_convT_dgrad(w)
+        for L, off, size, tm in ((fwd, ly.fwd_off, ly.fwd_size, ly.fwd_tm), (bwd, ly.bwd_off, ly.bwd_size, ly.bwd_tm)):
+            ref = packref.pack_logical(L, tm)
+            assert ref.size == size, ly.name
+            np.testing.assert_allclose(packed[off:off + size], ref, rtol=2e-6, atol=1e-7, err_msg=ly.name)
+
+
+def test_generator_forward_golden(nets, oracle, gold):
+    x, y_tmpl, _ = oracle.golden_inputs()
+    with torch.no_grad():
+        y_hat = nets[0](x.to(DEV), y_tmpl.to(DEV))
+    assert y_hat.shape == (2, 1, 8192)
+    np.testing.assert_allclose(y_hat.cpu().numpy(), gold['y_hat'], atol=1e-4, rtol=0)
+
+
+def test_generator_backward_golden(nets, oracle, gold):
+    g = nets[0]
+    x, y_tmpl, _ = oracle.golden_inputs()
+    g.zero_grad()
+    torch.manual_seed(4321)
+    noise = []
+    shapes = [(2, 128, 256), (2, 128, 256), (2, 64, 2048), (2, 64, 2048), (2, 32, 8192), (2, 32, 8192)]
+    for s in shapes:                       # the six rand_like draws of the reference forward, same order
+        noise.append(torch.rand(s).to(DEV))
+    y_hat = g(x.to(DEV), y_tmpl.to(DEV), noise_list=noise)
+    y_hat.backward(torch.from_numpy(gold['ggrad_yhat']).to(DEV))
+    torch.cuda.synchronize()
+    names = [n for n, _ in sorted(g.named_parameters())]
+    assert names == list(gold['ggrad_g_names'])
+    got = np.stack([stats(p.grad) for _, p in sorted(g.named_parameters())])
+    close_stats(got, gold['ggrad_g_stats'], numels(g), rtol=2e-3, atol=1e-5, sum_rel=2e-3)   # see the flip note below
+
+
+def test_generator_grads_elementwise_vs_oracle(nets, onets, oracle):
+    g, og = nets[0], onets[0]
+    x, y_tmpl, _ = oracle.golden_inputs(seed=3)
+    gen = torch.Generator().manual_seed(5)
+    dy = torch.randn(2, 1, 8192, generator=gen)
+    g.zero_grad(); og.zero_grad()
+    g(x.to(DEV), y_tmpl.to(DEV)).backward(dy.to(DEV))
+    og(x, y_tmpl).backward(dy)
+    torch.cuda.synchronize()
+    op = dict(og.named_parameters())
+    for n, p in g.named_parameters():
+        if n == 'noise.w':
+            continue
+        ref = op[n].grad
+        # leaky-relu's derivative jumps at 0: an activation that lands within fp32 rounding of 0 (|x| ~ 1e-7, seen on
+        # these inputs) takes a different branch on the GPU than on the CPU and perturbs every upstream gradient a
+        # little; the relative L2 error is robust to such isolated flips while any kernel bug is O(1)
+        err = (p.grad.cpu() - ref).norm().item() / (ref.norm().item() + 1e-20)
+        assert err <= 2e-3, (n, err)
+
+
+@pytest.mark.parametrize('which', ['msd', 'mpd'])
+def test_discriminator_forward_golden(nets, oracle, gold, which):
+    d = nets[1] if which == 'msd' else nets[2]
+    _, _, y = oracle.golden_inputs()
+    yd = torch.from_numpy(gold['y_hat'])
+    with torch.no_grad():
+        lr, lg, fr, fg = d(y.to(DEV), yd.to(DEV))
+    for i, (r, gg) in enumerate(zip(lr, lg)):
+        np.testing.assert_allclose(r.cpu().numpy(), gold[f'{which}_logit_r{i}'], rtol=1e-3, atol=2e-4)
+        np.testing.assert_allclose(gg.cpu().numpy(), gold[f'{which}_logit_g{i}'], rtol=1e-3, atol=2e-4)
+    shapes = np.array([list(f.shape) + [1] * (4 - f.dim()) for fl in fr for f in fl])
+    assert (shapes == gold[f'{which}_fmap_shapes']).all()
+    ne = np.array([f.numel() for fl in fr for f in fl])
+    close_stats(np.stack([stats(f) for fl in fr for f in fl]), gold[f'{which}_fmap_r_stats'], ne)
+    close_stats(np.stack([stats(f) for fl in fg for f in fl]), gold[f'{which}_fmap_g_stats'], ne)
+    from models import discriminator_loss, generator_loss, feature_loss
+    np.testing.assert_allclose(discriminator_loss(lr, lg).item(), gold[f'{which}_d_loss'], rtol=1e-4)
+    np.testing.assert_allclose(generator_loss(lg, lr).item(), gold[f'{which}_g_loss'], rtol=1e-4)
+    np.testing.assert_allclose(feature_loss(fr, fg).item(), gold[f'{which}_fm_loss'], rtol=1e-4)
+
+
+@pytest.mark.parametrize('which', ['msd', 'mpd'])
+def test_discriminator_backward_golden(nets, oracle, gold, which):
+    from models import discriminator_loss
+    d = nets[1] if which == 'msd' else nets[2]
+    _, _, y = oracle.golden_inputs()
+    yd = torch.from_numpy(gold['y_hat'])
+    d.zero_grad()
+    lr, lg, _, _ = d(y.to(DEV), yd.to(DEV))
+    discriminator_loss(lr, lg).backward()
+    torch.cuda.synchronize()
+    got = np.stack([stats(p.grad) for _, p in sorted(d.named_parameters())])
+    close_stats(got, gold[f'dgrad_{which}_stats'], numels(d), rtol=2e-3, atol=1e-6)
+
+
+@pytest.mark.parametrize('which', ['msd', 'mpd'])
+def test_generator_side_losses_through_frozen_discriminator(nets, onets, oracle, gold, which):
+    """G-update path: D frozen, gradient w.r.t. the generated wave through feature + adversarial losses."""
+    from models import generator_loss, feature_loss
+    d, od = (nets[1], onets[1]) if which == 'msd' else (nets[2], onets[2])
+    _, _, y = oracle.golden_inputs()
+    yd = torch.from_numpy(gold['y_hat'])
+    yh = yd.clone().to(DEV).requires_grad_(True)
+    for p in d.parameters():
+        p.requires_grad_(False)
+    try:
+        lr, lg, fr, fg = d(y.to(DEV), yh)
+        (generator_loss(lg, lr) + 2 * feature_loss(fr, fg)).backward()
+    finally:
+        for p in d.parameters():
+            p.requires_grad_(True)
+    yo = yd.clone().requires_grad_(True)
+    lr, lg, fr, fg = od(y, yo)
+    (oracle.generator_loss(lg, lr) + 2 * oracle.feature_loss(fr, fg)).backward()
+    ref = yo.grad
+    err = (yh.grad.cpu() - ref).abs().max().item()
+    assert err <= 2e-3 * ref.abs().max().item() + 1e-7, err
+
+
+def test_stft_mel_and_losses_golden(oracle, gold):
+    from audio import stft_mel_spec
+    from models import multi_stft_loss, dynamic_loss
+    _, _, y = oracle.golden_inputs()
+    yd = torch.from_numpy(gold['y_hat'])
+    for n_fft, win, hop in oracle.STFT_PARAMS:
+        mel, spec = stft_mel_spec(y.squeeze(1).to(DEV), n_fft, win, hop, True)
+        np.testing.assert_allclose(mel.cpu().numpy(), gold[f'stft{n_fft}_mel'], rtol=2e-4, atol=2e-6)
+        idx = gold[f'stft{n_fft}_idx']
+        logS = spec[:, 0].flatten().cpu().numpy()[idx]
+        P = spec[:, 1].flatten().cpu().numpy()[idx] * oracle.PI
+        Sg, Pg = gold[f'stft{n_fft}_S'], gold[f'stft{n_fft}_P']
+        np.testing.assert_allclose(np.exp(logS), Sg, rtol=2e-4, atol=2e-5)
+        dph = np.abs(P - Pg)
+        dph = np.minimum(dph, 2 * np.pi - dph)
+        assert np.all(dph[Sg > 1e-3] < 2e-3)
+    loss = multi_stft_loss(y.to(DEV), yd.to(DEV), ret_loss=True)
+    np.testing.assert_allclose(loss.item(), gold['loss_mstft'], rtol=1e-4)     # north-star tolerance: 1e-4 rel
+    np.testing.assert_allclose(dynamic_loss(y.to(DEV), yd.to(DEV)).item(), gold['loss_dyn'], rtol=1e-5)
+
+
+def test_stft_and_dyn_backward_golden(oracle, gold):
+    from models import multi_stft_loss, dynamic_loss
+    _, _, y = oracle.golden_inputs()
+    yd = torch.from_numpy(gold['y_hat'])
+    yh = yd.clone().to(DEV).requires_grad_(True)
+    multi_stft_loss(y.to(DEV), yh, ret_loss=True).backward()
+    ref = gold['grad_mstft_yhat']
+    np.testing.assert_allclose(yh.grad.cpu().numpy(), ref, rtol=2e-3, atol=2e-3 * np.abs(ref).max())
+    yh = yd.clone().to(DEV).requires_grad_(True)
+    dynamic_loss(y.to(DEV), yh).backward()
+    np.testing.assert_allclose(yh.grad.cpu().numpy(), gold['grad_dyn_yhat'], rtol=1e-5, atol=1e-9)
+
+
+def test_cpu_input_is_refused(nets):
+    from rtg.lib import RtgError
+    with pytest.raises(RtgError):
+        nets[0](torch.zeros(1, 80, 32), torch.zeros(1, 1, 8192))

@@ -22,7 +22,8 @@ namespace {
 
 struct ConvArgs {
   const float *x1, *x2, *aux, *wp, *bias, *mask, *res;
-  float* out;
+  float *out, *out2;
+  int out_split;
   int B, C1, C2, L_in, groups, Cg, Mg, K, stride, dil, pad, Q, out_C, out_L, shuf_S, shuf_P;
   int pre_mode;
   float pre_slope, mask_slope, out_scale;
@@ -210,7 +211,19 @@ __global__ __launch_bounds__(RTG_THREADS) void conv1d_mfma_kernel(const ConvArgs
           u = q * a.shuf_S + (mrow - ch * a.shuf_S) - a.shuf_P;
           if (u < 0 || u >= a.out_L) continue;
         }
-        const size_t idx = ((size_t)b * a.out_C + ch) * a.out_L + u;
+        float* dst = a.out;
+        size_t idx;
+        if (a.out_split > 0) {
+          if (ch >= a.out_split) {
+            dst = a.out2;
+            idx = ((size_t)b * (a.out_C - a.out_split) + (ch - a.out_split)) * a.out_L + u;
+          } else {
+            idx = ((size_t)b * a.out_split + ch) * a.out_L + u;
+          }
+          if (!dst) continue;
+        } else {
+          idx = ((size_t)b * a.out_C + ch) * a.out_L + u;
+        }
         float v = acc[i][j][r];
         if (a.bias) v += a.bias[ch];
         if (a.mask) v *= (a.mask[idx] > 0.f ? 1.f : a.mask_slope);
@@ -218,8 +231,8 @@ __global__ __launch_bounds__(RTG_THREADS) void conv1d_mfma_kernel(const ConvArgs
         v *= a.out_scale;
         if (a.act == RTG_ACT_LRELU) v = rtg_lrelu(v, a.act_slope);
         else if (a.act == RTG_ACT_TANH) v = tanhf(v);
-        if (a.accumulate) v += a.out[idx];
-        a.out[idx] = v;
+        if (a.accumulate) v += dst[idx];
+        dst[idx] = v;
       }
     }
   }
@@ -282,8 +295,12 @@ extern "C" long long rtg_packed_size(int groups, int Mg, int Cg, int K, int tile
 }
 
 extern "C" int rtg_conv1d(const RtgConv1dDesc* d, const float* x1, const float* x2, const float* aux, const float* wp,
-                          const float* bias, const float* mask, const float* res, float* out, void* stream) {
-  if (!d || !x1 || !wp || !out) return RTG_ENULL;
+                          const float* bias, const float* mask, const float* res, float* out, float* out2,
+                          void* stream) {
+  if (!d || !x1 || !wp) return RTG_ENULL;
+  if (d->out_split == 0 ? !out : (!out && !out2)) return RTG_ENULL;
+  if (d->out_split < 0 || d->out_split >= d->out_C) return RTG_EINVAL;
+  if (d->out_split > 0 && (mask || res)) return RTG_EINVAL;
   if (d->B < 1 || d->C1 < 1 || d->C2 < 0 || d->L_in < 1 || d->groups < 1 || d->Cg < 1 || d->Mg < 1 || d->K < 1 ||
       d->stride < 1 || d->dil < 1 || d->Q < 1 || d->out_C < 1 || d->out_L < 1 || d->shuf_S < 1)
     return RTG_EINVAL;
@@ -298,7 +315,7 @@ extern "C" int rtg_conv1d(const RtgConv1dDesc* d, const float* x1, const float* 
 
   ConvArgs a;
   a.x1 = x1; a.x2 = x2; a.aux = (d->pre_mode >= RTG_PRE_MUL_DLRELU) ? aux : nullptr; a.wp = wp; a.bias = bias;
-  a.mask = mask; a.res = res; a.out = out;
+  a.mask = mask; a.res = res; a.out = out; a.out2 = out2; a.out_split = d->out_split;
   a.B = d->B; a.C1 = d->C1; a.C2 = d->C2; a.L_in = d->L_in; a.groups = d->groups; a.Cg = d->Cg; a.Mg = d->Mg;
   a.K = d->K; a.stride = d->stride; a.dil = d->dil; a.pad = d->pad; a.Q = d->Q; a.out_C = d->out_C; a.out_L = d->out_L;
   a.shuf_S = d->shuf_S; a.shuf_P = d->shuf_P; a.pre_mode = d->pre_mode; a.pre_slope = d->pre_slope;

@@ -1,0 +1,444 @@
+// rtg_elem.hip — the HBM-bound element-wise / reduction kernels of the RetuneGAN train step (see include/rtg.h):
+// GaussianNoise, axpby, leaky-relu backward, AvgPool1d(4,2,1), DiscriminatorP fold, the scalar losses (multi-tensor,
+// one launch for a whole list of feature maps / logits) and the flat fused AdamW.
+#include "rtg_common.h"
+
+namespace {
+
+constexpr int MAX_GRID = 2048;
+
+inline int grid_for(long long n, int per_thread = 4) {
+  long long g = (n + (long long)RTG_THREADS * per_thread - 1) / ((long long)RTG_THREADS * per_thread);
+  if (g < 1) g = 1;
+  if (g > MAX_GRID) g = MAX_GRID;
+  return (int)g;
+}
+
+// counter-based uniform [0,1): splitmix64 finaliser of (seed, index); 24 mantissa bits
+__device__ __forceinline__ float uniform01(unsigned long long seed, unsigned long long idx) {
+  unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+__device__ __forceinline__ unsigned long long mix_salt(unsigned long long seed, const float* salt) {
+  if (!salt) return seed;
+  return seed ^ (0xD1B54A32D192ED03ull * (unsigned long long)(__float_as_uint(*salt) + 1u));
+}
+
+__global__ __launch_bounds__(RTG_THREADS) void noise_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                const float* __restrict__ u_in, float* __restrict__ out,
+                                                                long long n, float slope, unsigned long long seed,
+                                                                const float* salt) {
+  const float wv = *w;
+  const unsigned long long sd = mix_salt(seed, salt);
+  for (long long i = (long long)blockIdx.x * RTG_THREADS + threadIdx.x; i < n; i += (long long)gridDim.x * RTG_THREADS) {
+    const float u = u_in ? u_in[i] : uniform01(sd, (unsigned long long)i);
+    out[i] = rtg_lrelu(x[i] + u * wv, slope);
+  }
+}
+
+__global__ __launch_bounds__(RTG_THREADS) void noise_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                const float* __restrict__ u_in,
+                                                                const float* __restrict__ dy, float* __restrict__ dx,
+                                                                float* __restrict__ dw_part, long long n, float slope,
+                                                                unsigned long long seed, const float* salt) {
+  __shared__ float red[4];
+  const float wv = *w;
+  const unsigned long long sd = mix_salt(seed, salt);
+  float acc = 0.f;
+  for (long long i = (long long)blockIdx.x * RTG_THREADS + threadIdx.x; i < n; i += (long long)gridDim.x * RTG_THREADS) {
+    const float u = u_in ? u_in[i] : uniform01(sd, (unsigned long long)i);
+    const float pre = x[i] + u * wv;
+    const float g = dy[i] * (pre > 0.f ? 1.f : slope);
+    dx[i] = g;
+    acc += g * u;
+  }
+  acc = rtg_block_sum(acc, red);
+  if (threadIdx.x == 0) dw_part[blockIdx.x] = acc;
+}
+
+__global__ __launch_bounds__(RTG_THREADS) void axpby_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                            float* __restrict__ out, long long n, float alpha,
+                                                            float beta, int accumulate) {
+  for (long long i = (long long)blockIdx.x * RTG_THREADS + threadIdx.x; i < n; i += (long long)gridDim.x * RTG_THREADS) {
+    float v = alpha * a[i];
+    if (b) v += beta * b[i];
+    if (accumulate) v += out[i];
+    out[i] = v;
+  }
+}
+
+__global__ __launch_bounds__(RTG_THREADS) void channel_sum_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                                 int B, int C, int L) {
+  __shared__ float red[4];
+  const int c = blockIdx.x;
+  float acc = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float* xr = x + ((size_t)b * C + c) * L;
+    for (int i = threadIdx.x; i < L; i += RTG_THREADS) acc += xr[i];
+  }
+  acc = rtg_block_sum(acc, red);
+  if (threadIdx.x == 0) out[c] += acc;
+}
+
+__global__ __launch_bounds__(RTG_THREADS) void lrelu_bwd_kernel(const float* __restrict__ dy,
+                                                                const float* __restrict__ ref, float* __restrict__ dx,
+                                                                long long n, float slope) {
+  for (long long i = (long long)blockIdx.x * RTG_THREADS + threadIdx.x; i < n; i += (long long)gridDim.x * RTG_THREADS)
+    dx[i] = dy[i] * (ref[i] > 0.f ? 1.f : slope);
+}
+
+__global__ __launch_bounds__(RTG_THREADS) void avgpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                                  int rows, int L) {
+  const int Lo = L / 2;
+  const long long n = (long long)rows * Lo;
+  for (long long i = (long long)blockIdx.x * RTG_THREADS + threadIdx.x; i < n; i += (long long)gridDim.x * RTG_THREADS) {
+    const int r = (int)(i / Lo), o = (int)(i - (long long)r * Lo);
+    const float* xr = x + (size_t)r * L;
+    const int j = 2 * o - 1;
+    float s = xr[j + 1] + xr[j + 2];
+    if (j >= 0) s += xr[j];
+    if (j + 3 < L) s += xr[j + 3];
+    out[i] = 0.25f * s;                     // count_include_pad = True (nn.AvgPool1d default)
+  }
+}
+
+__global__ __launch_bounds__(RTG_THREADS) void avgpool_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx,
+                                                                  int rows, int L) {
+  const int Lo = L / 2;
+  const long long n = (long long)rows * L;
+  for (long long i = (long long)blockIdx.x * RTG_THREADS + threadIdx.x; i < n; i += (long long)gridDim.x * RTG_THREADS) {
+    const int r = (int)(i / L), j = (int)(i - (long long)r * L);
+    const float* g = dy + (size_t)r * Lo;
+    // outputs o with 2o-1 <= j <= 2o+2
+    const int o_hi = (j + 1) >> 1, o_lo = o_hi - 1;
+    float s = 0.f;
+    if (o_lo >= 0 && o_lo < Lo) s += g[o_lo];
+    if (o_hi < Lo) s += g[o_hi];
+    dx[i] = 0.25f * s;
+  }
+}
+
+__global__ __launch_bounds__(RTG_THREADS) void fold_fwd_kernel(const float* __restrict__ y, float* __restrict__ out,
+                                                               int B, int T, int p, int H) {
+  const long long n = (long long)B * p * H;
+  for (long long i = (long long)blockIdx.x * RTG_THREADS + threadIdx.x; i < n; i += (long long)gridDim.x * RTG_THREADS) {
+    const int h = (int)(i % H);
+    const long long bw = i / H;
+    const int w = (int)(bw % p), b = (int)(bw / p);
+    int t = h * p + w;
+    if (t >= T) t = 2 * (T - 1) - t;
+    out[i] = y[(size_t)b * T + t];
+  }
+}
+
+__global__ __launch_bounds__(RTG_THREADS) void fold_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dy,
+                                                               int B, int T, int p, int H) {
+  const long long n = (long long)B * T;
+  const int Tp = H * p;
+  for (long long i = (long long)blockIdx.x * RTG_THREADS + threadIdx.x; i < n; i += (long long)gridDim.x * RTG_THREADS) {
+    const int b = (int)(i / T), t = (int)(i - (long long)b * T);
+    const float* g = dout + (size_t)b * p * H;
+    float s = g[(size_t)(t % p) * H + t / p];
+    const int tr = 2 * (T - 1) - t;          // padded position that reflects onto t
+    if (tr >= T && tr < Tp) s += g[(size_t)(tr % p) * H + tr / p];
+    dy[i] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// multi-tensor scalar losses
+// ---------------------------------------------------------------------------------------------------------------
+struct LossJobs {
+  int n_jobs;
+  RtgLossJob job[RTG_MAX_LOSS_JOBS];
+};
+constexpr int LOSS_GX = 64;      // partial sums per job
+
+__device__ __forceinline__ float loss_term(int kind, float a, float b, float target) {
+  if (kind == RTG_LOSS_L1) return fabsf(a - b);
+  if (kind == RTG_LOSS_L1_L1LOG) return fabsf(a - b) + fabsf(logf(a) - logf(b));
+  const float e = target - a;      // RTG_LOSS_MSE_TARGET
+  return e * e;
+}
+
+__global__ __launch_bounds__(RTG_THREADS) void loss_fwd_kernel(int kind, const LossJobs jobs, float* __restrict__ ws) {
+  __shared__ float red[4];
+  const RtgLossJob j = jobs.job[blockIdx.y];
+  float acc = 0.f;
+  for (long long i = (long long)blockIdx.x * RTG_THREADS + threadIdx.x; i < j.n; i += (long long)LOSS_GX * RTG_THREADS)
+    acc += loss_term(kind, j.a[i], j.b ? j.b[i] : 0.f, j.target);
+  acc = rtg_block_sum(acc, red);
+  if (threadIdx.x == 0) ws[blockIdx.y * LOSS_GX + blockIdx.x] = acc * (j.w / (float)j.n);
+}
+
+__global__ __launch_bounds__(64) void loss_finish_kernel(int n_part, const float* __restrict__ ws,
+                                                         float* __restrict__ loss_out) {
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n_part; i += 64) acc += ws[i];
+  acc = rtg_wave_sum(acc);
+  if (threadIdx.x == 0) *loss_out += acc;
+}
+
+__global__ __launch_bounds__(RTG_THREADS) void loss_bwd_kernel(int kind, const LossJobs jobs,
+                                                               const float* __restrict__ gscale) {
+  const RtgLossJob j = jobs.job[blockIdx.y];
+  const float k = (gscale ? *gscale : 1.f) * j.w / (float)j.n;
+  for (long long i = (long long)blockIdx.x * RTG_THREADS + threadIdx.x; i < j.n; i += (long long)gridDim.x * RTG_THREADS) {
+    const float a = j.a[i], b = j.b ? j.b[i] : 0.f;
+    float ga, gb;
+    if (kind == RTG_LOSS_L1) {
+      const float s = (a > b) ? 1.f : ((a < b) ? -1.f : 0.f);
+      ga = s; gb = -s;
+    } else if (kind == RTG_LOSS_L1_L1LOG) {
+      const float s = (a > b) ? 1.f : ((a < b) ? -1.f : 0.f);
+      const float la = logf(a), lb = logf(b);
+      const float sl = (la > lb) ? 1.f : ((la < lb) ? -1.f : 0.f);
+      ga = s + sl / a; gb = -s - sl / b;
+    } else {
+      ga = -2.f * (j.target - a); gb = 0.f;
+    }
+    if (j.da) j.da[i] = k * ga;
+    if (j.db) j.db[i] = k * gb;
+  }
+}
+
+// dynamic loss: one wavefront per (row, window)
+__device__ __forceinline__ void wave_argmax(float& v, int& idx) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float ov = __shfl_xor(v, off, 64);
+    const int oi = __shfl_xor(idx, off, 64);
+    if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+  }
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(RTG_THREADS) void dyn_kernel(const float* __restrict__ y, const float* __restrict__ g,
+                                                          int rows, int L, int k, float scale,
+                                                          const float* __restrict__ gscale, float* __restrict__ ws,
+                                                          float* __restrict__ dg) {
+  const int W = L / k;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nwin = rows * W;
+  float total = 0.f;
+  for (int wi = blockIdx.x * 4 + wave; wi < nwin; wi += gridDim.x * 4) {
+    const int r = wi / W, w0 = (wi - r * W) * k;
+    const float* yr = y + (size_t)r * L + w0;
+    const float* gr = g + (size_t)r * L + w0;
+    float ymx = -INFINITY, ymn = -INFINITY, gmx = -INFINITY, gmn = -INFINITY;
+    int gimx = 1 << 30, gimn = 1 << 30, d0 = 0, d1 = 0;
+    for (int i = lane; i < k; i += 64) {
+      const float yv = yr[i], gv = gr[i];
+      if (yv > ymx) ymx = yv;
+      if (-yv > ymn) ymn = -yv;
+      if (gv > gmx) { gmx = gv; gimx = i; }
+      if (-gv > gmn) { gmn = -gv; gimn = i; }
+    }
+    wave_argmax(ymx, d0);
+    wave_argmax(ymn, d1);
+    wave_argmax(gmx, gimx);
+    wave_argmax(gmn, gimn);
+    const float dy_ = fabsf(ymx + ymn), sg = gmx + gmn, dgv = fabsf(sg);
+    if (!BWD) {
+      if (lane == 0) total += fabsf(dy_ - dgv);
+    } else {
+      // d/dg of |dy_ - |sg||: -sign(dy_ - dgv) * sign(sg) flows +1 to argmax(g) and -1 to argmax(-g)
+      const float s1 = (dy_ > dgv) ? 1.f : ((dy_ < dgv) ? -1.f : 0.f);
+      const float s2 = (sg > 0.f) ? 1.f : ((sg < 0.f) ? -1.f : 0.f);
+      const float c = -s1 * s2 * scale * (gscale ? *gscale : 1.f);
+      float* dr = dg + (size_t)r * L + w0;
+      for (int i = lane; i < k; i += 64) {
+        float v = 0.f;
+        if (i == gimx) v += c;
+        if (i == gimn) v -= c;
+        dr[i] = v;
+      }
+    }
+  }
+  if (!BWD) {
+    __shared__ float red[4];
+    total = rtg_block_sum(total, red);
+    if (threadIdx.x == 0) ws[blockIdx.x] = total * scale;
+  } else {
+    // tail samples beyond the last full window get no gradient
+    const int tail0 = W * k;
+    for (long long i = (long long)blockIdx.x * RTG_THREADS + threadIdx.x; i < (long long)rows * (L - tail0);
+         i += (long long)gridDim.x * RTG_THREADS) {
+      const int r = (int)(i / (L - tail0)), o = (int)(i - (long long)r * (L - tail0));
+      dg[(size_t)r * L + tail0 + o] = 0.f;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// AdamW over a flat buffer
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(RTG_THREADS) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                            float* __restrict__ m, float* __restrict__ v, long long n,
+                                                            const float* __restrict__ step_state,
+                                                            const float* __restrict__ loss_flag, float lr, float b1,
+                                                            float b2, float eps, float wd, float gscale) {
+  if (loss_flag && isnan(*loss_flag)) return;
+  const float t = step_state[0] + 1.f;
+  const float bc1 = 1.f - powf(b1, t), bc2 = 1.f - powf(b2, t);
+  const float step_size = lr / bc1, rs2 = 1.f / sqrtf(bc2), decay = 1.f - lr * wd;
+  for (long long i = (long long)blockIdx.x * RTG_THREADS + threadIdx.x; i < n; i += (long long)gridDim.x * RTG_THREADS) {
+    const float gi = g[i] * gscale;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] = p[i] * decay - step_size * (mi / (sqrtf(vi) * rs2 + eps));
+  }
+}
+
+__global__ void adamw_bump_kernel(float* step_state, const float* loss_flag) {
+  if (loss_flag && isnan(*loss_flag)) return;
+  step_state[0] += 1.f;
+}
+
+}  // namespace
+
+#define RTG_REQ(c) \
+  if (!(c)) return RTG_ENULL
+#define RTG_LAUNCH(k, g, b, sh, st, ...)                        \
+  hipLaunchKernelGGL(k, dim3(g), dim3(b), sh, (hipStream_t)st, __VA_ARGS__); \
+  return rtg_launch_status()
+
+extern "C" int rtg_noise_lrelu_fwd(const float* x, const float* w, const float* u_in, float* out, long long n,
+                                   float slope, unsigned long long seed, const float* salt_dev, void* stream) {
+  RTG_REQ(x && w && out);
+  if (n < 1) return RTG_EINVAL;
+  RTG_LAUNCH(noise_fwd_kernel, grid_for(n), RTG_THREADS, 0, stream, x, w, u_in, out, n, slope, seed, salt_dev);
+}
+
+extern "C" int rtg_noise_lrelu_bwd(const float* x, const float* w, const float* u_in, const float* dy, float* dx,
+                                   float* dw_part, int n_blocks, long long n, float slope, unsigned long long seed,
+                                   const float* salt_dev, void* stream) {
+  RTG_REQ(x && w && dy && dx && dw_part);
+  if (n < 1 || n_blocks < 1 || n_blocks > MAX_GRID) return RTG_EINVAL;
+  RTG_LAUNCH(noise_bwd_kernel, n_blocks, RTG_THREADS, 0, stream, x, w, u_in, dy, dx, dw_part, n, slope, seed, salt_dev);
+}
+
+extern "C" int rtg_axpby(const float* a, const float* b, float* out, long long n, float alpha, float beta,
+                         int accumulate, void* stream) {
+  RTG_REQ(a && out);
+  if (n < 1) return RTG_EINVAL;
+  RTG_LAUNCH(axpby_kernel, grid_for(n), RTG_THREADS, 0, stream, a, b, out, n, alpha, beta, accumulate);
+}
+
+extern "C" int rtg_channel_sum(const float* x, float* out, int B, int C, int L, void* stream) {
+  RTG_REQ(x && out);
+  if (B < 1 || C < 1 || L < 1 || C > 65535) return RTG_EINVAL;
+  RTG_LAUNCH(channel_sum_kernel, C, RTG_THREADS, 0, stream, x, out, B, C, L);
+}
+
+extern "C" int rtg_lrelu_bwd(const float* dy, const float* ref, float* dx, long long n, float slope, void* stream) {
+  RTG_REQ(dy && ref && dx);
+  if (n < 1) return RTG_EINVAL;
+  RTG_LAUNCH(lrelu_bwd_kernel, grid_for(n), RTG_THREADS, 0, stream, dy, ref, dx, n, slope);
+}
+
+extern "C" int rtg_avgpool4s2_fwd(const float* x, float* out, int rows, int L, void* stream) {
+  RTG_REQ(x && out);
+  if (rows < 1 || L < 4 || (L & 1)) return RTG_EINVAL;
+  RTG_LAUNCH(avgpool_fwd_kernel, grid_for((long long)rows * (L / 2)), RTG_THREADS, 0, stream, x, out, rows, L);
+}
+
+extern "C" int rtg_avgpool4s2_bwd(const float* dy, float* dx, int rows, int L, void* stream) {
+  RTG_REQ(dy && dx);
+  if (rows < 1 || L < 4 || (L & 1)) return RTG_EINVAL;
+  RTG_LAUNCH(avgpool_bwd_kernel, grid_for((long long)rows * L), RTG_THREADS, 0, stream, dy, dx, rows, L);
+}
+
+extern "C" int rtg_period_fold_fwd(const float* y, float* out, int B, int T, int p, int H, void* stream) {
+  RTG_REQ(y && out);
+  if (B < 1 || T < 2 || p < 1 || H != (T + p - 1) / p || H * p - T >= T) return RTG_EINVAL;
+  RTG_LAUNCH(fold_fwd_kernel, grid_for((long long)B * p * H), RTG_THREADS, 0, stream, y, out, B, T, p, H);
+}
+
+extern "C" int rtg_period_fold_bwd(const float* dout, float* dy, int B, int T, int p, int H, void* stream) {
+  RTG_REQ(dout && dy);
+  if (B < 1 || T < 2 || p < 1 || H != (T + p - 1) / p || H * p - T >= T) return RTG_EINVAL;
+  RTG_LAUNCH(fold_bwd_kernel, grid_for((long long)B * T), RTG_THREADS, 0, stream, dout, dy, B, T, p, H);
+}
+
+static int fill_jobs(LossJobs* lj, int kind, const RtgLossJob* jobs, int n_jobs, bool bwd) {
+  if (!jobs) return RTG_ENULL;
+  if (n_jobs < 1 || n_jobs > RTG_MAX_LOSS_JOBS) return RTG_EINVAL;
+  if (kind != RTG_LOSS_L1 && kind != RTG_LOSS_L1_L1LOG && kind != RTG_LOSS_MSE_TARGET) return RTG_EINVAL;
+  lj->n_jobs = n_jobs;
+  for (int i = 0; i < n_jobs; ++i) {
+    if (!jobs[i].a || jobs[i].n < 1) return RTG_EINVAL;
+    if (kind != RTG_LOSS_MSE_TARGET && !jobs[i].b) return RTG_ENULL;
+    if (bwd && !jobs[i].da && !jobs[i].db) return RTG_ENULL;
+    lj->job[i] = jobs[i];
+  }
+  return RTG_OK;
+}
+
+extern "C" int rtg_loss_fwd(int kind, const RtgLossJob* jobs, int n_jobs, float* ws, float* loss_out, void* stream) {
+  RTG_REQ(ws && loss_out);
+  LossJobs lj;
+  int st = fill_jobs(&lj, kind, jobs, n_jobs, false);
+  if (st) return st;
+  hipLaunchKernelGGL(loss_fwd_kernel, dim3(LOSS_GX, n_jobs), dim3(RTG_THREADS), 0, (hipStream_t)stream, kind, lj, ws);
+  st = rtg_launch_status();
+  if (st) return st;
+  RTG_LAUNCH(loss_finish_kernel, 1, 64, 0, stream, n_jobs * LOSS_GX, ws, loss_out);
+}
+
+extern "C" int rtg_loss_bwd(int kind, const RtgLossJob* jobs, int n_jobs, const float* gscale, void* stream) {
+  LossJobs lj;
+  int st = fill_jobs(&lj, kind, jobs, n_jobs, true);
+  if (st) return st;
+  long long mx = 0;
+  for (int i = 0; i < n_jobs; ++i) mx = jobs[i].n > mx ? jobs[i].n : mx;
+  int gx = grid_for(mx);
+  if (gx > 512) gx = 512;
+  RTG_LAUNCH(loss_bwd_kernel, dim3(gx, n_jobs), RTG_THREADS, 0, stream, kind, lj, gscale);
+}
+
+extern "C" int rtg_dyn_loss_fwd(const float* y, const float* g, int rows, int L, int k, float w, float* ws,
+                                float* loss_out, void* stream) {
+  RTG_REQ(y && g && ws && loss_out);
+  if (rows < 1 || k < 1 || L < k) return RTG_EINVAL;
+  const int nwin = rows * (L / k);
+  int gx = (nwin + 3) / 4;
+  if (gx > 256) gx = 256;
+  hipLaunchKernelGGL(dyn_kernel<false>, dim3(gx), dim3(RTG_THREADS), 0, (hipStream_t)stream, y, g, rows, L, k,
+                     w / (float)nwin, (const float*)nullptr, ws, (float*)nullptr);
+  int st = rtg_launch_status();
+  if (st) return st;
+  RTG_LAUNCH(loss_finish_kernel, 1, 64, 0, stream, gx, ws, loss_out);
+}
+
+extern "C" int rtg_dyn_loss_bwd(const float* y, const float* g, int rows, int L, int k, float w, const float* gscale,
+                                float* dg, void* stream) {
+  RTG_REQ(y && g && dg);
+  if (rows < 1 || k < 1 || L < k) return RTG_EINVAL;
+  const int nwin = rows * (L / k);
+  int gx = (nwin + 3) / 4;
+  if (gx > 256) gx = 256;
+  RTG_LAUNCH(dyn_kernel<true>, gx, RTG_THREADS, 0, stream, y, g, rows, L, k, w / (float)nwin, gscale, (float*)nullptr,
+             dg);
+}
+
+extern "C" int rtg_adamw(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n,
+                         float* step_state, const float* loss_flag, float lr, float beta1, float beta2, float eps,
+                         float weight_decay, float grad_scale, void* stream) {
+  RTG_REQ(params && grads && exp_avg && exp_avg_sq && step_state);
+  if (n < 1) return RTG_EINVAL;
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(RTG_THREADS), 0, (hipStream_t)stream, params, grads, exp_avg,
+                     exp_avg_sq, n, step_state, loss_flag, lr, beta1, beta2, eps, weight_decay, grad_scale);
+  int st = rtg_launch_status();
+  if (st) return st;
+  RTG_LAUNCH(adamw_bump_kernel, 1, 1, 0, stream, step_state, loss_flag);
+}
+
+extern "C" int rtg_abi_version(void) { return RTG_ABI_VERSION; }
+extern "C" const char* rtg_build_info(void) { return "librtg gfx950 fp32-mfma " __DATE__ " " __TIME__; }

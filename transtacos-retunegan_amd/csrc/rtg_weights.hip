@@ -1,0 +1,140 @@
+// rtg_weights.hip — the weight bank: old-style weight norm (w = g * v / ||v||, norm over all dims but 0) for every
+// layer of a model in ONE launch per stage, instead of the reference's per-layer hook (torch.nn.utils.weight_norm;
+// 435 forward + 425 backward tiny launches per step).
+//   rtg_weightnorm_scales    scale[r] = g[r] / ||v[r,:]||  and 1/||v[r,:]||
+//   rtg_weights_pack         gathers v * scale into the MFMA-fragment layouts rtg_conv1d reads (forward, backward-data,
+//                            polyphase transposed): [g][m-tile][c-chunk][tap][k-step][kk][m], zero padded
+//   rtg_weightnorm_backward  sums the split partials of rtg_conv1d_wgrad in fixed order and applies the weight-norm
+//                            chain rule, accumulating into the flat gradient buffer
+#include "rtg_common.h"
+
+namespace {
+
+__global__ __launch_bounds__(RTG_THREADS) void wn_scales_kernel(const RtgNormJob* jobs, const float* params,
+                                                                 float* scales) {
+  __shared__ float red[4];
+  const RtgNormJob j = jobs[blockIdx.y];
+  for (int r = blockIdx.x; r < j.rows; r += gridDim.x) {
+    const float* v = params + j.v_off + (size_t)r * j.inner;
+    float ss = 0.f;
+    for (int i = threadIdx.x; i < j.inner; i += RTG_THREADS) ss += v[i] * v[i];
+    ss = rtg_block_sum(ss, red);
+    if (threadIdx.x == 0) {
+      const float n = sqrtf(ss);
+      scales[j.scale_off + r] = params[j.g_off + r] / n;
+      scales[j.scale_off + j.rows + r] = 1.f / n;
+    }
+  }
+}
+
+__global__ __launch_bounds__(RTG_THREADS) void pack_kernel(const RtgPackJob* jobs, const float* params,
+                                                           const float* scales, float* packed) {
+  const RtgPackJob j = jobs[blockIdx.y];
+  const int TM = j.tile_m, KK = 64 / TM, CPN = RTG_CK / KK;
+  const int n_mt = (j.Mg + TM - 1) / TM, n_cc = (j.Cg + RTG_CK - 1) / RTG_CK;
+  const int inner = j.src_inner_c * j.src_K;
+  for (long long e = (long long)blockIdx.x * RTG_THREADS + threadIdx.x; e < j.dst_size;
+       e += (long long)gridDim.x * RTG_THREADS) {
+    long long t = e;
+    const int m = (int)(t % TM); t /= TM;
+    const int kk = (int)(t % KK); t /= KK;
+    const int cp = (int)(t % CPN); t /= CPN;
+    const int tap = (int)(t % j.K); t /= j.K;
+    const int cc = (int)(t % n_cc); t /= n_cc;
+    const int mt = (int)(t % n_mt); t /= n_mt;
+    const int g = (int)t;
+    const int row = mt * TM + m, c = cc * RTG_CK + cp * KK + kk;
+    float val = 0.f;
+    if (row < j.Mg && c < j.Cg) {
+      long long srow = -1, sin = 0;
+      if (j.mode == RTG_PACK_FWD) {
+        srow = (long long)g * j.Mg + row;
+        sin = (long long)c * j.src_K + tap;
+      } else if (j.mode == RTG_PACK_DGRAD_S1) {
+        srow = (long long)g * j.Cg + c;
+        sin = (long long)row * j.src_K + (j.src_K - 1 - tap);
+      } else {
+        const int ch = row / j.S, r = row - ch * j.S;
+        const int jj = r + (j.K - 1 - tap) * j.S;
+        if (jj < j.src_K) {
+          if (j.mode == RTG_PACK_DGRAD_POLY) {
+            srow = (long long)g * j.Cg + c;
+            sin = (long long)ch * j.src_K + jj;
+          } else {   // RTG_PACK_CONVT_POLY (groups == 1): source [C_in][C_out][K]
+            srow = c;
+            sin = (long long)ch * j.src_K + jj;
+          }
+        }
+      }
+      if (srow >= 0) val = params[j.v_off + srow * inner + sin] * scales[j.scale_off + srow];
+    }
+    packed[j.dst_off + e] = val;
+  }
+}
+
+__global__ __launch_bounds__(RTG_THREADS) void wn_bwd_kernel(const RtgWnBwdJob* jobs, const float* params,
+                                                              const float* scales, const float* partials,
+                                                              float* grads) {
+  extern __shared__ float dw[];
+  __shared__ float red[4];
+  const RtgWnBwdJob j = jobs[blockIdx.y];
+  for (int r = blockIdx.x; r < j.rows; r += gridDim.x) {
+    const float* v = params + j.v_off + (size_t)r * j.inner;
+    const float* p0 = partials + j.part_off + (size_t)r * j.inner;
+    float dot = 0.f;
+    for (int i = threadIdx.x; i < j.inner; i += RTG_THREADS) {
+      float s = 0.f;
+      for (int sp = 0; sp < j.splits; ++sp) s += p0[(size_t)sp * j.part_stride + i];
+      dw[i] = s;
+      dot += s * v[i];
+    }
+    dot = rtg_block_sum(dot, red);
+    const float scale = scales[j.scale_off + r], inv_n = scales[j.scale_off + j.rows + r];
+    const float k2 = scale * dot * inv_n * inv_n;
+    float* dv = grads + j.v_off + (size_t)r * j.inner;
+    for (int i = threadIdx.x; i < j.inner; i += RTG_THREADS) dv[i] += scale * dw[i] - k2 * v[i];
+    if (threadIdx.x == 0) {
+      grads[j.g_off + r] += dot * inv_n;
+      if (j.b_off >= 0) {
+        const float* pb = partials + j.part_off + (size_t)j.rows * j.inner + r;
+        float s = 0.f;
+        for (int sp = 0; sp < j.splits; ++sp) s += pb[(size_t)sp * j.part_stride];
+        grads[j.b_off + r] += s;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+extern "C" int rtg_weightnorm_scales(const RtgNormJob* jobs_dev, int n_jobs, int max_rows, const float* params,
+                                     float* scales, void* stream) {
+  if (!jobs_dev || !params || !scales) return RTG_ENULL;
+  if (n_jobs < 1 || n_jobs > 65535 || max_rows < 1) return RTG_EINVAL;
+  dim3 grid(max_rows > 1024 ? 1024 : max_rows, n_jobs);
+  hipLaunchKernelGGL(wn_scales_kernel, grid, dim3(RTG_THREADS), 0, (hipStream_t)stream, jobs_dev, params, scales);
+  return rtg_launch_status();
+}
+
+extern "C" int rtg_weights_pack(const RtgPackJob* jobs_dev, int n_jobs, long long max_dst_size, const float* params,
+                                const float* scales, float* packed, void* stream) {
+  if (!jobs_dev || !params || !scales || !packed) return RTG_ENULL;
+  if (n_jobs < 1 || n_jobs > 65535 || max_dst_size < 1) return RTG_EINVAL;
+  long long gx = (max_dst_size + RTG_THREADS * 4 - 1) / (RTG_THREADS * 4);
+  if (gx > 4096) gx = 4096;
+  dim3 grid((unsigned)gx, n_jobs);
+  hipLaunchKernelGGL(pack_kernel, grid, dim3(RTG_THREADS), 0, (hipStream_t)stream, jobs_dev, params, scales, packed);
+  return rtg_launch_status();
+}
+
+extern "C" int rtg_weightnorm_backward(const RtgWnBwdJob* jobs_dev, int n_jobs, int max_rows, int max_inner,
+                                       const float* params, const float* scales, const float* partials, float* grads,
+                                       void* stream) {
+  if (!jobs_dev || !params || !scales || !partials || !grads) return RTG_ENULL;
+  if (n_jobs < 1 || n_jobs > 65535 || max_rows < 1 || max_inner < 1 || max_inner > 16384) return RTG_EINVAL;
+  dim3 grid(max_rows > 1024 ? 1024 : max_rows, n_jobs);
+  hipLaunchKernelGGL(wn_bwd_kernel, grid, dim3(RTG_THREADS), (size_t)max_inner * sizeof(float), (hipStream_t)stream,
+                     jobs_dev, params, scales, partials, grads);
+  return rtg_launch_status();
+}

@@ -1,0 +1,213 @@
+"""MSD / MPD discriminator stacks (retunegan/models/discrminator.py — the reference's file name, typo included, is
+kept so that `from models.discrminator import ...` keeps working) on the MI355X kernels.
+
+Differences in execution, not in results:
+  * D(real) and D(fake) share weights (discrminator.py:120-121): when both need the same treatment they run as ONE
+    batch of 2B clips per layer; when the discriminator is frozen (generator update) the real half runs without
+    autograd bookkeeping.
+  * DiscriminatorP's [B,1,T/p,p] view + (k,1) Conv2d is executed as Conv1d over T/p with the period folded into the
+    batch ([B*p, C, T/p]); feature maps are handed back as [B,C,T/p,p] views, logits in the reference's order.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F  # noqa: F401
+
+import hparam as hp
+from utils import *  # noqa: F401,F403
+from utils import LRELU_SLOPE
+from rtg import ops
+from .layers import WNConv, BankedModel, conv
+
+PI = 3.14159265358979
+
+
+def _frozen(model):
+    return not (torch.is_grad_enabled() and any(p.requires_grad for p in model.parameters()))
+
+
+def _run_stack(tok, convs, conv_post, x):
+    """conv -> (feature map, before activation) -> lrelu(0.15) fused into the next conv's prologue."""
+    fmap = []
+    h = conv(tok, convs[0], x)
+    fmap.append(h)
+    for c in convs[1:]:
+        h = conv(tok, c, h, pre_slope=LRELU_SLOPE)
+        fmap.append(h)
+    return conv(tok, conv_post, h, pre_slope=LRELU_SLOPE), fmap
+
+
+class DiscriminatorS(nn.Module):
+    """discrminator.py:17-101, active branch 'MelGAN_small' (:36-45).  `use_sn` is ignored by the reference too."""
+
+    def __init__(self, use_sn=False):
+        super().__init__()
+        spec = [(1, 32, 15, 1, 7, 1), (32, 64, 41, 2, 20, 4), (64, 128, 41, 2, 20, 8), (128, 512, 41, 4, 20, 32),
+                (512, 512, 41, 4, 20, 64), (512, 512, 5, 1, 2, 1)]
+        self.convs = nn.ModuleList([WNConv('conv', ci, co, k, stride=s, pad=p, groups=g) for ci, co, k, s, p, g in spec])
+        self.conv_post = WNConv('conv', 512, 1, 3, pad=1)
+
+    def run(self, tok, x):
+        logit, fmap = _run_stack(tok, self.convs, self.conv_post, x)
+        return torch.flatten(logit, 1, -1), fmap
+
+
+class DiscriminatorP(nn.Module):
+    """discrminator.py:132-222, active branch 'HiFiGAN_small' (:155-163)."""
+
+    def __init__(self, period):
+        super().__init__()
+        self.period = period
+        ch = [1, 32, 128, 256, 512]
+        self.convs = nn.ModuleList([WNConv('conv', ch[i], ch[i + 1], 5, stride=3, pad=2, kdims=2) for i in range(4)]
+                                   + [WNConv('conv', 512, 512, 5, stride=1, pad=2, kdims=2)])
+        self.conv_post = WNConv('conv', 512, 1, 3, pad=1, kdims=2)
+
+    def run(self, tok, x):
+        """x [B,1,T] -> (logits [B, H'*p], feature maps as [B,C,H,p] views whose `_rtg_base` is the contiguous
+        [B*p,C,H] tensor the kernels produced)."""
+        p = self.period
+        B = x.shape[0]
+        xf = ops.PeriodFoldFn.apply(x, p)
+        logit, fmap = _run_stack(tok, self.convs, self.conv_post, xf)
+        views = []
+        for f in fmap:
+            v = f.view(B, p, f.shape[1], f.shape[2]).permute(0, 2, 3, 1)
+            v._rtg_base = f
+            views.append(v)
+        lg = logit.view(B, p, logit.shape[2]).permute(0, 2, 1).reshape(B, -1)
+        lg._rtg_base = logit
+        return lg, views
+
+
+def _split(t, B):
+    """[2B, ...] batch of (real, fake) -> two halves that remember their contiguous kernel-side storage."""
+    base = getattr(t, '_rtg_base', None)
+    r, g = t[:B], t[B:]
+    if base is not None:
+        n = base.shape[0] // 2
+        r._rtg_base, g._rtg_base = base[:n], base[n:]
+    return r, g
+
+
+class _MultiBase(BankedModel):
+    def _pairs(self, runner, y, y_hat):
+        """Run `runner(tok, x)` on real and fake.  Returns (logit_r, logit_g, fmap_r, fmap_g)."""
+        tok = self.token()
+        B = y.shape[0]
+        if _frozen(self) and not y.requires_grad:
+            with torch.no_grad():
+                lr, fr = runner(tok, y)
+            lg, fg = runner(tok, y_hat)
+            return lr, lg, fr, fg
+        l2, f2 = runner(tok, torch.cat([y, y_hat], dim=0))
+        lr, lg = _split(l2, B)
+        fs = [_split(f, B) for f in f2]
+        return lr, lg, [a for a, _ in fs], [b for _, b in fs]
+
+
+class MultiScaleDiscriminator(_MultiBase):
+    """discrminator.py:104-129."""
+
+    def __init__(self):
+        super().__init__()
+        self.discriminators = nn.ModuleList([DiscriminatorS(use_sn=i == 0) for i in range(hp.msd_layers)])
+        assert hp.downsample_pool_k == 4, 'rtg_avgpool4s2 implements AvgPool1d(4, 2, 1) (hparam.py:91)'
+
+    def forward(self, y, y_hat):
+        tok = self.token()
+        B = y.shape[0]
+        frozen = _frozen(self) and not y.requires_grad
+        y_d_rs, y_d_gs, fmap_rs, fmap_gs = [], [], [], []
+        xs = [y, y_hat] if frozen else [torch.cat([y, y_hat], dim=0)]
+        for i, d in enumerate(self.discriminators):
+            if frozen:
+                with torch.no_grad():
+                    lr, fr = d.run(tok, xs[0])
+                lg, fg = d.run(tok, xs[1])
+            else:
+                l2, f2 = d.run(tok, xs[0])
+                lr, lg = _split(l2, B)
+                fs = [_split(f, B) for f in f2]
+                fr, fg = [a for a, _ in fs], [b for _, b in fs]
+            y_d_rs.append(lr); fmap_rs.append(fr)
+            y_d_gs.append(lg); fmap_gs.append(fg)
+            if i != len(self.discriminators) - 1:
+                if frozen:
+                    with torch.no_grad():
+                        xs[0] = ops.AvgPoolFn.apply(xs[0])
+                    xs[1] = ops.AvgPoolFn.apply(xs[1])
+                else:
+                    xs[0] = ops.AvgPoolFn.apply(xs[0])
+        return y_d_rs, y_d_gs, fmap_rs, fmap_gs
+
+
+class MultiPeriodDiscriminator(_MultiBase):
+    """discrminator.py:225-244."""
+
+    def __init__(self):
+        super().__init__()
+        self.discriminators = nn.ModuleList([DiscriminatorP(p) for p in hp.mpd_periods])
+
+    def forward(self, y, y_hat):
+        tok = self.token()
+        B = y.shape[0]
+        frozen = _frozen(self) and not y.requires_grad
+        y_d_rs, y_d_gs, fmap_rs, fmap_gs = [], [], [], []
+        x2 = None if frozen else torch.cat([y, y_hat], dim=0)
+        for d in self.discriminators:
+            if frozen:
+                with torch.no_grad():
+                    lr, fr = d.run(tok, y)
+                lg, fg = d.run(tok, y_hat)
+            else:
+                l2, f2 = d.run(tok, x2)
+                lr, lg = _split(l2, B)
+                fs = [_split(f, B) for f in f2]
+                fr, fg = [a for a, _ in fs], [b for _, b in fs]
+            y_d_rs.append(lr); fmap_rs.append(fr)
+            y_d_gs.append(lg); fmap_gs.append(fg)
+        return y_d_rs, y_d_gs, fmap_rs, fmap_gs
+
+
+class StftDiscriminator(nn.Module):
+    """discrminator.py:247-308 — parameter holder (2-D convolutions over [log|D|, phase/PI]).  The 2-D MFMA conv
+    kernels are the next row of the coverage table; BASELINE config 2 (the benchmarked one) does
+    not use MTD."""
+
+    def __init__(self, i, ch=2):
+        super().__init__()
+        import math
+        spec = [(ch, 32, (3, 3)), (32, 64, (3, 3)), (64, 256, (5, 3)), (256, 512, (5, 3)), (512, 512, (3, 3))]
+        self.convs = nn.ModuleList([_Conv2dParams(ci, co, k) for ci, co, k in spec])
+        self.conv_post = _Conv2dParams(512, 1, (3, 3))
+        for c in [*self.convs, self.conv_post]:
+            c.burn_init_rng()
+
+
+class _Conv2dParams(nn.Module):
+    def __init__(self, cin, cout, k):
+        super().__init__()
+        import math
+        v = torch.empty(cout, cin, *k)
+        nn.init.kaiming_uniform_(v, a=math.sqrt(5))
+        bound = 1.0 / math.sqrt(cin * k[0] * k[1])
+        b = torch.empty(cout).uniform_(-bound, bound)
+        self.weight_g = nn.Parameter(v.flatten(1).norm(dim=1).reshape(cout, 1, 1, 1))
+        self.weight_v = nn.Parameter(v)
+        self.bias = nn.Parameter(b)
+
+    def burn_init_rng(self):
+        torch.empty(self.weight_v.shape).normal_(0, 1.0)
+
+
+class MultiStftDiscriminator(nn.Module):
+    """discrminator.py:311-330."""
+
+    def __init__(self):
+        super().__init__()
+        self.discriminators = nn.ModuleList([StftDiscriminator(i) for i in range(len(hp.multi_stft_params))])
+
+    def forward(self, phs, ph_hats):
+        from rtg.lib import RtgError
+        raise RtgError('MultiStftDiscriminator: the 2-D conv kernels are not built yet (SURVEY.md §8a-8, next row); '
+                       'no CPU or library fallback is provided on the hot path')

@@ -1,0 +1,163 @@
+"""UNet-G (`Generator_RefineGAN_small`, retunegan/models/generator.py:670-796) on the MI355X kernels.
+
+Same constructor signature, module tree and state-dict keys as the reference; the forward is re-expressed as a chain
+of fused conv launches (activation prologues/epilogues, residual adds and torch.cat fused into rtg_conv1d)."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F  # noqa: F401  (re-exported like the reference's star import does)
+
+import hparam as hp
+from utils import *  # noqa: F401,F403
+from utils import LRELU_SLOPE
+from rtg import ops
+from .layers import WNConv, BankedModel, conv, ACT_LRELU, ACT_TANH
+
+device = 'cuda' if torch.cuda.is_available() else 'cpu'
+
+
+class GaussianNoise(nn.Module):
+    """generator.py:19-30: x + U[0,1)*w followed by leaky_relu(0.15); one shared trainable scalar w = 1e-6."""
+
+    def __init__(self):
+        super().__init__()
+        self.w = nn.Parameter(torch.FloatTensor([1e-6]), requires_grad=True)
+        self.seed = hp.randseed
+        self.calls = 0
+        self.salt = None          # optional device word mixed into the seed (changes every optimizer step)
+
+    def forward(self, x, u=None):
+        self.calls += 1
+        return ops.NoiseFn.apply(x, self.w, u, LRELU_SLOPE, (self.seed * 0x9E3779B1 + self.calls) & (2 ** 63 - 1),
+                                 self.salt)
+
+
+class _Seq(nn.Module):
+    """nn.Sequential-compatible child naming for ResidualStack ('res_1.1', 'res_1.3': the convs sit at the odd
+    indices of the reference's Sequential(LeakyReLU, Conv1d, LeakyReLU, Conv1d), generator.py:39-56)."""
+
+    def __init__(self, c1, c3):
+        super().__init__()
+        self.add_module('1', c1)
+        self.add_module('3', c3)
+
+
+class ResidualStack(nn.Module):
+    """generator.py:33-77.  x <- x + conv_d1(lrelu_.01(conv_dil(lrelu_.01(x)))) for dil in (1, 3, 9)."""
+
+    def __init__(self, channels, k=3):
+        super().__init__()
+        self.channels = channels
+        for name, d in (('res_1', 1), ('res_2', 3), ('res_3', 9)):
+            self.add_module(name, _Seq(WNConv('conv', channels, channels, k, pad=get_same_padding(3, d), dil=d),
+                                       WNConv('conv', channels, channels, k, pad=get_same_padding(3))))
+
+    def run(self, tok, x, final_act_slope=None):
+        blocks = (self.res_1, self.res_2, self.res_3)
+        for i, blk in enumerate(blocks):
+            r = conv(tok, getattr(blk, '1'), x, pre_slope=0.01)
+            if i == len(blocks) - 1 and final_act_slope is not None:
+                x = conv(tok, getattr(blk, '3'), r, res=x, pre_slope=0.01, act=ACT_LRELU, act_slope=final_act_slope)
+            else:
+                x = conv(tok, getattr(blk, '3'), r, res=x, pre_slope=0.01)
+        return x
+
+
+class ResBlock3(nn.Module):
+    """generator.py:133-155: three times x <- conv_d(lrelu_.15(x)) + x."""
+
+    def __init__(self, channels, kernel_size=3, dilation=(1, 3, 5)):
+        super().__init__()
+        self.convs = nn.ModuleList([WNConv('conv', channels, channels, kernel_size, dil=d,
+                                           pad=get_padding(kernel_size, d)) for d in dilation])
+        for c in self.convs:
+            c.burn_init_rng()       # self.convs.apply(init_weights), generator.py:143
+
+    def run(self, tok, x):
+        for c in self.convs:
+            x = conv(tok, c, x, res=x, pre_slope=LRELU_SLOPE)
+        return x
+
+
+class _Mean3(torch.autograd.Function):
+    """(a + b + c) / 3 — the average of the three ResBlock3 branches (generator.py:776-778)."""
+
+    @staticmethod
+    def forward(ctx, a, b, c):
+        import ctypes as C
+        from rtg.lib import lib, check
+        out = torch.empty_like(a)
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        third = 1.0 / 3
+        check(lib.rtg_axpby(C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(out.data_ptr()), a.numel(),
+                            third, third, 0, st), 'mean3')
+        check(lib.rtg_axpby(C.c_void_p(c.data_ptr()), None, C.c_void_p(out.data_ptr()), a.numel(), third, 0.0, 1, st),
+              'mean3')
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        import ctypes as C
+        from rtg.lib import lib, check
+        dy = dy.contiguous()
+        g = torch.empty_like(dy)
+        check(lib.rtg_axpby(C.c_void_p(dy.data_ptr()), None, C.c_void_p(g.data_ptr()), dy.numel(), 1.0 / 3, 0.0, 0,
+                            C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'mean3 bwd')
+        return g, g, g
+
+
+class Generator_RefineGAN_small(BankedModel):
+    """Zero-argument constructor, `forward(mel[B,80,T/256], wav_tmpl[B,1,T]) -> wav[B,1,T]`
+    (retunegan/train.py:48,126)."""
+
+    def __init__(self):
+        super().__init__()
+        self.num_kernels = len(hp.resblock_kernel_sizes)
+        self.num_upsamples = len(hp.upsample_rates)
+        self.n_layer = self.num_upsamples
+        ch = 32
+        self.conv_pre = WNConv('conv', 1, ch // 2, 7, pad=3)
+        self.downs = nn.ModuleList([
+            WNConv('conv', ch * 2 ** i // 2, ch * 2 ** (i + 1) // 2, k, stride=u, pad=k // 2)
+            for i, (u, k) in enumerate(zip(hp.upsample_rates[::-1], hp.upsample_kernel_sizes[::-1]))])
+        self.resblock = nn.ModuleList([ResidualStack(ch * 2 ** i) for i in range(len(self.downs))])
+        uic = hp.upsample_initial_channel
+        self.conv_fuse = WNConv('conv', hp.n_mel + uic // 2, uic, 7, pad=3)
+        self.ups = nn.ModuleList([
+            WNConv('convT', uic // (2 ** i), uic // (2 ** (i + 1)), k, stride=u, pad=k // 2, out_pad=u - 1)
+            for i, (u, k) in enumerate(zip(hp.upsample_rates, hp.upsample_kernel_sizes))])
+        self.resblocks = nn.ModuleList([ResBlock3(c, k, [9, 3, 1]) for c in (128, 64, 32) for k in (3, 5, 7)])
+        self.merge = nn.ModuleList([WNConv('conv', 128 + 64, 128, 7, pad=3), WNConv('conv', 64 + 32, 64, 7, pad=3),
+                                    WNConv('conv', 32 + 16, 32, 7, pad=3)])
+        self.conv_post = WNConv('conv', ch, 1, 7, pad=3)
+        self.noise = GaussianNoise()
+        for m in [self.conv_pre, self.conv_fuse, self.conv_post, *self.downs, *self.merge, *self.ups]:
+            m.burn_init_rng()       # the .apply(init_weights) calls of generator.py:727-732
+        self._wn_removed = False
+
+    def _extra_bank_params(self):
+        return [('noise.w', self.noise.w)]
+
+    def forward(self, x, y, noise_list=None):
+        """noise_list: optional six pre-drawn U[0,1) tensors (parity tests); by default drawn on the device."""
+        tok = self.token()
+        nz = (lambda i: None) if noise_list is None else (lambda i: noise_list[i])
+        o = []
+        y = conv(tok, self.conv_pre, y, act=ACT_LRELU, act_slope=LRELU_SLOPE)     # lrelu(conv_pre(y)) = skip o[0]
+        for i in range(self.n_layer):
+            o.append(y)
+            y = conv(tok, self.downs[i], y)
+            y = self.resblock[i].run(tok, y, final_act_slope=LRELU_SLOPE)          # next skip / fuse input
+        z = conv(tok, self.conv_fuse, x, y)                                        # cat([mel, y]) fused
+        for i in range(self.n_layer):
+            z = conv(tok, self.ups[i], z, pre_slope=LRELU_SLOPE)
+            z = conv(tok, self.merge[i], z, o[self.n_layer - i - 1])               # cat([z, skip]) fused
+            z = self.noise(z, nz(2 * i))
+            nk = self.num_kernels
+            z = _Mean3.apply(*[self.resblocks[i * nk + j].run(tok, z) for j in range(nk)])
+            z = self.noise(z, nz(2 * i + 1))
+        return conv(tok, self.conv_post, z, pre_slope=LRELU_SLOPE, act=ACT_TANH)
+
+    def remove_weight_norm(self):
+        """generator.py:790-796 (inference, retunegan/server.py:81).  The kernels always consume g*v/||v||, so the
+        result of the forward is unchanged; kept for API compatibility."""
+        self._wn_removed = True

@@ -1,0 +1,85 @@
+"""Building blocks shared by the generator and the discriminators: the weight-normed conv parameter holder and the
+base class that keeps all of a model's parameters in one flat GPU buffer (rtg/bank.py)."""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from rtg import ops
+from rtg.bank import WeightBank
+from rtg.lib import ACT_NONE, ACT_LRELU, ACT_TANH, RtgError  # noqa: F401
+
+
+class WNConv(nn.Module):
+    """Parameters of one weight-normed convolution, named like torch.nn.utils.weight_norm names them
+    (weight_g, weight_v, bias; call sites retunegan/models/generator.py:682-722, discrminator.py:37-45,156-163).
+    kind 'conv'  : Conv1d, or a (k,1)/(k,1)-strided Conv2d whose trailing kernel dim is 1 (v keeps the 4-D shape)
+    kind 'convT' : ConvTranspose1d (dim 0 of v is the INPUT channel axis, as in the reference's ups.N.weight_g)."""
+
+    def __init__(self, kind, cin, cout, k, stride=1, pad=0, dil=1, groups=1, out_pad=0, kdims=1):
+        super().__init__()
+        self.kind, self.cin, self.cout, self.k = kind, cin, cout, k
+        self.stride, self.pad, self.dil, self.groups, self.out_pad = stride, pad, dil, groups, out_pad
+        ks = (k,) if kdims == 1 else (k, 1)
+        shape = ((cin, cout // groups) if kind == 'convT' else (cout, cin // groups)) + ks
+        v = torch.empty(shape)
+        nn.init.kaiming_uniform_(v, a=math.sqrt(5))            # torch's default conv init (reset_parameters)
+        bound = 1.0 / math.sqrt(shape[1] * k)
+        b = torch.empty(cout).uniform_(-bound, bound)
+        self.weight_g = nn.Parameter(v.flatten(1).norm(dim=1).reshape((shape[0],) + (1,) * (len(shape) - 1)))
+        self.weight_v = nn.Parameter(v)
+        self.bias = nn.Parameter(b)
+        self._layer = None      # rtg.bank.ConvLayer, set when the owning model builds its bank
+
+    def burn_init_rng(self):
+        torch.empty(self.weight_v.shape).normal_(0, 1.0)
+
+    def effective_weight(self):
+        v = self.weight_v
+        return v * (self.weight_g / v.flatten(1).norm(dim=1).reshape(self.weight_g.shape))
+
+    def extra_repr(self):
+        return (f'{self.kind} {self.cin}->{self.cout} k={self.k} s={self.stride} p={self.pad} d={self.dil} '
+                f'g={self.groups}')
+
+
+class BankedModel(nn.Module):
+    """nn.Module whose WNConv children (and listed extra parameters) live in one WeightBank on the GPU."""
+
+    def __init__(self):
+        super().__init__()
+        self._bank = None
+
+    def _extra_bank_params(self):
+        return []
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        self._bank = None           # .to()/.cuda()/.float() re-materialise the parameters: rebuild the flat views
+        return r
+
+    def bank(self):
+        dev = next(self.parameters()).device
+        if dev.type != 'cuda':
+            raise RtgError(f'{type(self).__name__}: parameters are on {dev}; the RetuneGAN hot path runs on the HIP '
+                           'kernels only — call .to("cuda") (there is no CPU fallback)')
+        if self._bank is None or self._bank.device != dev or not self._bank.check_views():
+            layers = [(n, m) for n, m in self.named_modules() if isinstance(m, WNConv)]
+            self._bank = WeightBank(layers, self._extra_bank_params(), dev)
+            for ly in self._bank.layers:
+                ly.module._layer = ly
+        return self._bank
+
+    def token(self):
+        return self.bank().prepare()
+
+    def zero_grad(self, set_to_none=False):
+        if self._bank is not None:
+            self._bank.zero_grad()
+        else:
+            super().zero_grad(set_to_none=set_to_none)
+
+
+def conv(tok, m, x1, x2=None, res=None, pre_slope=1.0, act=ACT_NONE, act_slope=1.0, out_scale=1.0):
+    return ops.conv(tok, m._layer, x1, x2, res, pre_slope, act, act_slope, out_scale)

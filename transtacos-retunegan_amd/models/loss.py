@@ -1,0 +1,113 @@
+"""Loss functions of retunegan/models/loss.py on the MI355X kernels (same names, signatures and return values).
+
+multi_stft_loss runs the fused STFT kernel (mel, log-magnitude and phase/PI epilogues in one pass); all L1 / LSGAN
+reductions of a whole list of tensors are ONE multi-tensor launch each."""
+import torch
+import torch.nn as nn  # noqa: F401
+import torch.nn.functional as F  # noqa: F401
+
+import hparam as hp
+from audio import get_stft_torch, stft_mel_spec  # noqa: F401
+from utils import PI  # noqa: F401
+from rtg import ops
+from rtg.lib import LOSS_L1, LOSS_L1_L1LOG, LOSS_MSE_TARGET, RtgError
+
+_real_cache = {}
+
+
+class stft_cache:
+    """Context manager: inside it, the spectra of the REAL wave are computed once and reused by every
+    multi_stft_loss call (the reference recomputes them 3x per step: its own TODO at loss.py:32)."""
+
+    def __enter__(self):
+        _real_cache.clear()
+        _real_cache['on'] = True
+        return self
+
+    def __exit__(self, *a):
+        _real_cache.clear()
+
+
+def _real_specs(y, want_spec):
+    key = (y.data_ptr(), tuple(y.shape), y._version)
+    if _real_cache.get('on'):
+        hit = _real_cache.get(key)
+        if hit is not None and (not want_spec or hit[1][0] is not None):
+            return hit
+    with torch.no_grad():
+        mels, specs = [], []
+        for n_fft, win, hop in hp.multi_stft_params:
+            m, s = stft_mel_spec(y, n_fft, win, hop, want_spec)
+            mels.append(m); specs.append(s)
+    if _real_cache.get('on'):
+        _real_cache[key] = (mels, specs)
+    return mels, specs
+
+
+def multi_stft_loss(y, y_g, ret_loss=False, ret_specs=False):
+    """loss.py:22-62.  y, y_g: [B,1,T] or [B,T].  Returns loss, (stft_r, stft_g) per the two flags; spec tensors are
+    [B,2,F,frames] = stack([log S, P/PI], dim=1) (phd_input == 'stft', hparam.py:83)."""
+    if not (ret_loss or ret_specs):
+        raise ValueError('multi_stft_loss: nothing requested')
+    if hp.phd_input != 'stft':
+        raise RtgError("only phd_input == 'stft' (hparam.py:83) is on the path")
+    if y.dim() == 3:
+        y, y_g = y.squeeze(1), y_g.squeeze(1)
+    if y.requires_grad:
+        raise RtgError('multi_stft_loss: the real wave is treated as a constant (as in retunegan/train.py)')
+    mels_r, specs_r = _real_specs(y, ret_specs)
+    mels_g, specs_g = [], []
+    for n_fft, win, hop in hp.multi_stft_params:
+        m, s = stft_mel_spec(y_g, n_fft, win, hop, ret_specs)
+        mels_g.append(m); specs_g.append(s)
+    loss = None
+    if ret_loss:
+        n = len(hp.multi_stft_params)
+        loss = ops.multi_loss(LOSS_L1_L1LOG, mels_r, mels_g, [1.0 / n] * n)
+    if ret_loss and ret_specs:
+        return loss, (specs_r, specs_g)
+    if ret_loss:
+        return loss
+    return specs_r, specs_g
+
+
+def envelope_loss(y, y_g):
+    """loss.py:66-72 — switched off by hparam.py:88; not on the default hot path."""
+    raise RtgError('envelope_loss is disabled in hparam.py:88 and has no kernel yet (SURVEY.md §8 f4)')
+
+
+def dynamic_loss(y, y_g):
+    """loss.py:76-82."""
+    return ops.DynLossFn.apply(y, y_g, hp.envelope_pool_k)
+
+
+def strip_mirror_loss(y):
+    """loss.py:86-98 — switched off by hparam.py:87; not on the default hot path."""
+    raise RtgError('strip_mirror_loss is disabled in hparam.py:87 and has no kernel yet (SURVEY.md §8 f4)')
+
+
+def _base(t):
+    return getattr(t, '_rtg_base', t)
+
+
+def discriminator_loss(disc_r, disc_g):
+    """loss.py:102-125 (non-relative branch): sum_k mean((1 - dr_k)^2) + mean(dg_k^2)."""
+    if hp.relative_gan_loss:
+        raise RtgError('relative_gan_loss (hparam.py:86) is off on the path and has no kernel yet')
+    return (ops.multi_loss(LOSS_MSE_TARGET, [_base(d) for d in disc_r], target=1.0) +
+            ops.multi_loss(LOSS_MSE_TARGET, [_base(d) for d in disc_g], target=0.0))
+
+
+def generator_loss(disc_g, disc_r):
+    """loss.py:129-145 (non-relative branch): sum_k mean((1 - dg_k)^2)."""
+    if hp.relative_gan_loss:
+        raise RtgError('relative_gan_loss (hparam.py:86) is off on the path and has no kernel yet')
+    return ops.multi_loss(LOSS_MSE_TARGET, [_base(d) for d in disc_g], target=1.0)
+
+
+def feature_loss(fmap_r, fmap_g):
+    """loss.py:149-156: sum over every feature map of mean |r - g| (an element-order-invariant reduction, so the
+    kernel-side layout of MPD maps is used directly)."""
+    rs = [_base(r) for dr in fmap_r for r in dr]
+    gs = [_base(g) for dg in fmap_g for g in dg]
+    return ops.multi_loss(LOSS_L1, rs, gs)

@@ -1,0 +1,277 @@
+"""Weight bank: all weight-normed conv layers of one model share flat fp32 buffers on the GPU.
+
+  flat / gflat   parameters and gradients ([g | v | bias] per layer, then extras such as noise.w); every nn.Parameter
+                 of the model is a VIEW into `flat` and its .grad a view into `gflat`, so one fused AdamW launch and
+                 one RCCL all-reduce cover the whole model while state_dict() keeps the reference's keys
+                 (`conv_pre.weight_g`, `resblocks.7.convs.2.weight_v`, ... retunegan/train.py:263-273).
+  scales, packed effective weights g*v/||v|| in the MFMA fragment layouts of rtg_conv1d (forward and backward-data),
+                 refreshed by TWO launches per top-level forward (rtg_weightnorm_scales, rtg_weights_pack) instead of
+                 the reference's per-layer weight_norm hook (torch.nn.utils.weight_norm; generator.py:682 ...).
+  partials       split-K partial weight gradients written by rtg_conv1d_wgrad; one rtg_weightnorm_backward launch per
+                 backward reduces them in fixed order and accumulates d g, d v, d bias into gflat.
+
+Autograd coupling: `prepare()` returns a token produced by a custom Function; every conv consumes the token, so the
+token's backward runs after the last conv backward of that forward pass and flushes the partials.
+"""
+import ctypes as C
+
+import torch
+
+from . import lib as L
+from .lib import lib, check
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _table(structs, device):
+    """ctypes struct array -> device byte tensor"""
+    arr = (type(structs[0]) * len(structs))(*structs)
+    buf = bytes(memoryview(arr).cast('B'))
+    return torch.frombuffer(bytearray(buf), dtype=torch.uint8).to(device)
+
+
+class ConvLayer:
+    """Static description + bank bookkeeping of one weight-normed convolution."""
+
+    def __init__(self, name, module):
+        self.name, self.module = name, module
+        m = module
+        self.kind, self.cin, self.cout, self.k = m.kind, m.cin, m.cout, m.k
+        self.stride, self.pad, self.dil, self.groups, self.out_pad = m.stride, m.pad, m.dil, m.groups, m.out_pad
+        if self.kind == 'convT':
+            assert self.groups == 1 and self.dil == 1
+            self.rows, self.inner_c = self.cin, self.cout
+        else:
+            self.rows, self.inner_c = self.cout, self.cin // self.groups
+        self.inner = self.inner_c * self.k
+        s = self.stride
+        nt = -(-self.k // s)
+        self.nt = nt
+        # (mode, groups, Mg, Cg, K, S) of the packed forward / backward-data operators
+        if self.kind == 'conv':
+            cg, mg = self.cin // self.groups, self.cout // self.groups
+            self.fwd_op = (L.PACK_FWD, self.groups, mg, cg, self.k, 1)
+            if s == 1:
+                self.bwd_op = (L.PACK_DGRAD_S1, self.groups, cg, mg, self.k, 1)
+            else:
+                assert self.dil == 1
+                self.bwd_op = (L.PACK_DGRAD_POLY, self.groups, cg * s, mg, nt, s)
+        else:
+            self.fwd_op = (L.PACK_CONVT_POLY, 1, self.cout * s, self.cin, nt, s)
+            self.bwd_op = (L.PACK_FWD, 1, self.cin, self.cout, self.k, 1)
+        self.fwd_tm = 32 if self.fwd_op[2] >= 32 else 16
+        self.bwd_tm = 32 if self.bwd_op[2] >= 32 else 16
+        # filled by the bank
+        self.g_off = self.v_off = self.b_off = self.scale_off = 0
+        self.fwd_off = self.bwd_off = 0
+        self.part = None
+        self.splits = 0
+        self.lid = -1
+
+    def packed_sizes(self):
+        f = lib.rtg_packed_size(self.fwd_op[1], self.fwd_op[2], self.fwd_op[3], self.fwd_op[4], self.fwd_tm)
+        b = lib.rtg_packed_size(self.bwd_op[1], self.bwd_op[2], self.bwd_op[3], self.bwd_op[4], self.bwd_tm)
+        return f, b
+
+
+class _BankPrep(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, bank, tok_id):
+        ctx.set_materialize_grads(False)
+        ctx.bank, ctx.tok_id = bank, tok_id
+        bank._run_prep()
+        return torch.empty(1, device=bank.flat.device)
+
+    @staticmethod
+    def backward(ctx, _g):
+        ctx.bank._flush(ctx.tok_id)
+        return None, None, None
+
+
+class WeightBank:
+    def __init__(self, named_layers, extra_params, device):
+        """named_layers: [(name, WNConv module)] in construction order; extra_params: [(name, nn.Parameter)]."""
+        self.device = torch.device(device)
+        assert self.device.type == 'cuda', 'the RetuneGAN hot path runs on the HIP kernels only (no CPU fallback)'
+        lib.load()
+        self.layers = [ConvLayer(n, m) for n, m in named_layers]
+        off = 0
+        soff = 0
+        for i, ly in enumerate(self.layers):
+            ly.lid = i
+            ly.g_off = off; off += ly.rows
+            ly.v_off = off; off += ly.rows * ly.inner
+            ly.b_off = off; off += ly.cout
+            ly.scale_off = soff; soff += 2 * ly.rows
+        self.extra = []
+        for n, p in extra_params:
+            self.extra.append((n, p, off))
+            off += p.numel()
+        self.n_params = off
+        self.flat = torch.empty(off, device=self.device, dtype=torch.float32)
+        self.gflat = torch.zeros(off, device=self.device, dtype=torch.float32)
+        self.scales = torch.empty(soff, device=self.device, dtype=torch.float32)
+        poff = 0
+        for ly in self.layers:
+            f, b = ly.packed_sizes()
+            ly.fwd_off, ly.fwd_size = poff, f
+            poff += f
+            ly.bwd_off, ly.bwd_size = poff, b
+            poff += b
+        self.packed = torch.empty(poff, device=self.device, dtype=torch.float32)
+        self._bind_params()
+        self._build_tables()
+        self._anchor = torch.zeros(1, device=self.device, requires_grad=True)
+        self._tok_counter = 0
+        self._owner = [None] * len(self.layers)
+        self._wn_table = None
+        self._wn_dirty = True
+        self._keep = []          # tensors that must outlive the async kernels reading them within one flush
+
+    # ------------------------------------------------------------------ parameters as views of the flat buffers
+    def _bind_params(self):
+        self.params = []
+        for ly in self.layers:
+            m = ly.module
+            for p, o, n in ((m.weight_g, ly.g_off, ly.rows), (m.weight_v, ly.v_off, ly.rows * ly.inner),
+                            (m.bias, ly.b_off, ly.cout)):
+                view = self.flat[o:o + n].view(p.shape)
+                view.copy_(p.data)
+                p.data = view
+                p.grad = self.gflat[o:o + n].view(p.shape)
+                self.params.append(p)
+        for n, p, o in self.extra:
+            view = self.flat[o:o + p.numel()].view(p.shape)
+            view.copy_(p.data)
+            p.data = view
+            p.grad = self.gflat[o:o + p.numel()].view(p.shape)
+            self.params.append(p)
+
+    def check_views(self):
+        """True while every parameter still aliases the flat buffer (module.to()/load of foreign tensors break it)."""
+        base = self.flat.data_ptr()
+        for ly in self.layers:
+            if ly.module.weight_v.data_ptr() != base + 4 * ly.v_off:
+                return False
+        return True
+
+    def rebind_grads(self):
+        """zero_grad(set_to_none=True) detaches .grad; re-attach the views (the flat buffer is zeroed by the caller)."""
+        for ly in self.layers:
+            m = ly.module
+            for p, o, n in ((m.weight_g, ly.g_off, ly.rows), (m.weight_v, ly.v_off, ly.rows * ly.inner),
+                            (m.bias, ly.b_off, ly.cout)):
+                if p.grad is None or p.grad.data_ptr() != self.gflat.data_ptr() + 4 * o:
+                    p.grad = self.gflat[o:o + n].view(p.shape)
+        for n, p, o in self.extra:
+            if p.grad is None or p.grad.data_ptr() != self.gflat.data_ptr() + 4 * o:
+                p.grad = self.gflat[o:o + p.numel()].view(p.shape)
+
+    def grads_detached(self):
+        return any(p.grad is None for p in self.params)
+
+    # ------------------------------------------------------------------ device job tables
+    def _build_tables(self):
+        norm, pack = [], []
+        self.max_rows = max(ly.rows for ly in self.layers)
+        self.max_inner = max(ly.inner for ly in self.layers)
+        self.max_pack = 0
+        for ly in self.layers:
+            norm.append(L.NormJob(ly.g_off, ly.v_off, ly.scale_off, ly.rows, ly.inner))
+            for (mode, g, mg, cg, k, s), off, size, tm in ((ly.fwd_op, ly.fwd_off, ly.fwd_size, ly.fwd_tm),
+                                                           (ly.bwd_op, ly.bwd_off, ly.bwd_size, ly.bwd_tm)):
+                pack.append(L.PackJob(ly.v_off, ly.scale_off, off, size, mode, g, mg, cg, k, ly.k, ly.inner_c, s, tm))
+                self.max_pack = max(self.max_pack, size)
+        self.norm_table = _table(norm, self.device)
+        self.pack_table = _table(pack, self.device)
+        self.n_pack = len(pack)
+
+    # ------------------------------------------------------------------ forward-side refresh
+    def _run_prep(self):
+        st = _stream()
+        check(lib.rtg_weightnorm_scales(_p(self.norm_table), len(self.layers), self.max_rows, _p(self.flat),
+                                        _p(self.scales), st), 'weightnorm_scales')
+        check(lib.rtg_weights_pack(_p(self.pack_table), self.n_pack, self.max_pack, _p(self.flat), _p(self.scales),
+                                   _p(self.packed), st), 'weights_pack')
+
+    def prepare(self):
+        """Refresh the packed weights from the current parameters; returns the autograd token for this forward."""
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.params)
+        self._tok_counter += 1
+        tid = self._tok_counter
+        self._anchor.requires_grad_(need_grad)
+        tok = _BankPrep.apply(self._anchor, self, tid)
+        tok._rtg_id = tid
+        tok._rtg_bank = self
+        return tok
+
+    def fwd_ptr(self, ly):
+        return C.c_void_p(self.packed.data_ptr() + 4 * ly.fwd_off)
+
+    def bwd_ptr(self, ly):
+        return C.c_void_p(self.packed.data_ptr() + 4 * ly.bwd_off)
+
+    def bias_ptr(self, ly):
+        return C.c_void_p(self.flat.data_ptr() + 4 * ly.b_off)
+
+    # ------------------------------------------------------------------ backward-side: partial slots and the flush
+    def partial_slot(self, ly, splits, tok_id):
+        """Returns (tensor, stride, immediate): the split-partial buffer the wgrad of `ly` must write for this token.
+        immediate=True means the slot was busy (layer used by another pending forward): the caller must reduce it
+        right away with flush_one()."""
+        stride = ly.rows * (ly.inner + 1)
+        if self._owner[ly.lid] is not None and self._owner[ly.lid] != tok_id:
+            return torch.empty(splits * stride, device=self.device), stride, True
+        if self._owner[ly.lid] == tok_id:          # second use inside the same forward pass
+            return torch.empty(splits * stride, device=self.device), stride, True
+        if ly.part is None or ly.splits != splits:
+            ly.part = torch.empty(splits * stride, device=self.device)
+            ly.splits = splits
+            self._wn_dirty = True
+        self._owner[ly.lid] = tok_id
+        return ly.part, stride, False
+
+    def _job(self, ly, part, splits, base_ptr, with_bias=True):
+        stride = ly.rows * (ly.inner + 1)
+        has_bias = with_bias and ly.kind == 'conv'
+        return L.WnBwdJob(ly.g_off, ly.v_off, ly.b_off if has_bias else -1, ly.scale_off,
+                          (part.data_ptr() - base_ptr) // 4, stride, splits, ly.rows, ly.inner)
+
+    def flush_one(self, ly, part, splits):
+        tab = _table([self._job(ly, part, splits, self.flat.data_ptr())], self.device)
+        self._keep += [tab, part]
+        check(lib.rtg_weightnorm_backward(_p(tab), 1, ly.rows, ly.inner, _p(self.flat), _p(self.scales), _p(self.flat),
+                                          _p(self.gflat), _stream()), 'weightnorm_backward')
+
+    def _flush(self, tok_id):
+        owned = [ly for ly in self.layers if self._owner[ly.lid] == tok_id]
+        if not owned:
+            return
+        base = self.flat.data_ptr()
+        if len(owned) == len(self.layers):
+            if self._wn_dirty or self._wn_table is None:
+                self._wn_table = _table([self._job(ly, ly.part, ly.splits, base) for ly in self.layers], self.device)
+                self._wn_dirty = False
+            tab = self._wn_table
+        else:
+            tab = _table([self._job(ly, ly.part, ly.splits, base) for ly in owned], self.device)
+            self._keep.append(tab)
+        check(lib.rtg_weightnorm_backward(_p(tab), len(owned), self.max_rows, self.max_inner, _p(self.flat),
+                                          _p(self.scales), _p(self.flat), _p(self.gflat), _stream()),
+              'weightnorm_backward')
+        for ly in owned:
+            self._owner[ly.lid] = None
+        if len(self._keep) > 64:
+            self._keep = self._keep[-32:]
+
+    # ------------------------------------------------------------------ optimizer-facing helpers
+    def zero_grad(self):
+        self.gflat.zero_()
+        if self.grads_detached():
+            self.rebind_grads()

@@ -14,13 +14,14 @@ class Conv1dDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in ('B', 'C1', 'C2', 'L_in', 'groups', 'Cg', 'Mg', 'K', 'stride', 'dil', 'pad', 'Q',
                                        'out_C', 'out_L', 'shuf_S', 'shuf_P', 'pre_mode')] + \
                [('pre_slope', C.c_float), ('mask_slope', C.c_float), ('out_scale', C.c_float), ('act', C.c_int),
-                ('act_slope', C.c_float), ('accumulate', C.c_int), ('tile_m', C.c_int)]
+                ('act_slope', C.c_float), ('accumulate', C.c_int), ('tile_m', C.c_int), ('out_split', C.c_int)]
 
 
 class WgradDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in ('B', 'C1', 'C2', 'L_in', 'groups', 'Cg', 'Mg', 'K', 'stride', 'dil', 'pad', 'Q',
                                        'dy_L', 'pre_mode')] + \
-               [('pre_slope', C.c_float), ('gy_mode', C.c_int), ('gy_slope', C.c_float), ('splits', C.c_int),
+               [('pre_slope', C.c_float), ('gy_mode', C.c_int), ('gy_slope', C.c_float), ('gy_scale', C.c_float),
+                ('splits', C.c_int),
                 ('part_stride', C.c_longlong)]
 
 
@@ -41,6 +42,11 @@ class WnBwdJob(C.Structure):
                 ('inner', C.c_int)]
 
 
+class LossJob(C.Structure):
+    _fields_ = [('a', C.c_void_p), ('b', C.c_void_p), ('da', C.c_void_p), ('db', C.c_void_p), ('n', C.c_longlong),
+                ('w', C.c_float), ('target', C.c_float)]
+
+
 class StftDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in ('B', 'T', 'n_fft', 'win', 'hop', 'frames', 'n_mel')]
 
@@ -49,35 +55,35 @@ PRE_NONE, PRE_LRELU, PRE_MUL_DLRELU, PRE_MUL_DTANH = 0, 1, 2, 3
 ACT_NONE, ACT_LRELU, ACT_TANH = 0, 1, 2
 PACK_FWD, PACK_DGRAD_S1, PACK_DGRAD_POLY, PACK_CONVT_POLY = 0, 1, 2, 3
 CK = 16
+LOSS_L1, LOSS_L1_L1LOG, LOSS_MSE_TARGET = 0, 1, 2
+MAX_LOSS_JOBS = 48
 
 _P = C.c_void_p
 _I, _F, _LL, _ULL = C.c_int, C.c_float, C.c_longlong, C.c_ulonglong
 
 # name -> (restype, argtypes); must list every symbol include/rtg.h declares (checked by tests/test_abi.py)
 PROTOTYPES = {
-    'rtg_conv1d': (_I, [C.POINTER(Conv1dDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'rtg_conv1d': (_I, [C.POINTER(Conv1dDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'rtg_packed_size': (_LL, [_I, _I, _I, _I, _I]),
     'rtg_conv1d_wgrad': (_I, [C.POINTER(WgradDesc), _P, _P, _P, _P, _P, _P]),
     'rtg_wgrad_splits': (_I, [C.POINTER(WgradDesc)]),
-    'rtg_weightnorm_scales': (_I, [_P, _I, _P, _P, _P]),
+    'rtg_weightnorm_scales': (_I, [_P, _I, _I, _P, _P, _P]),
     'rtg_weights_pack': (_I, [_P, _I, _LL, _P, _P, _P, _P]),
-    'rtg_weightnorm_backward': (_I, [_P, _I, _I, _P, _P, _P, _P, _P]),
+    'rtg_weightnorm_backward': (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P]),
     'rtg_stft_forward': (_I, [C.POINTER(StftDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'rtg_stft_backward': (_I, [C.POINTER(StftDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
-    'rtg_noise_lrelu_fwd': (_I, [_P, _P, _P, _P, _LL, _F, _ULL, _P]),
-    'rtg_noise_lrelu_bwd': (_I, [_P, _P, _P, _P, _P, _P, _I, _LL, _F, _ULL, _P]),
+    'rtg_noise_lrelu_fwd': (_I, [_P, _P, _P, _P, _LL, _F, _ULL, _P, _P]),
+    'rtg_noise_lrelu_bwd': (_I, [_P, _P, _P, _P, _P, _P, _I, _LL, _F, _ULL, _P, _P]),
+    'rtg_channel_sum': (_I, [_P, _P, _I, _I, _I, _P]),
     'rtg_axpby': (_I, [_P, _P, _P, _LL, _F, _F, _I, _P]),
     'rtg_lrelu_bwd': (_I, [_P, _P, _P, _LL, _F, _P]),
     'rtg_avgpool4s2_fwd': (_I, [_P, _P, _I, _I, _P]),
     'rtg_avgpool4s2_bwd': (_I, [_P, _P, _I, _I, _P]),
     'rtg_period_fold_fwd': (_I, [_P, _P, _I, _I, _I, _I, _P]),
     'rtg_period_fold_bwd': (_I, [_P, _P, _I, _I, _I, _I, _P]),
-    'rtg_l1_mean_fwd': (_I, [_P, _P, _LL, _F, _P, _P]),
-    'rtg_l1_mean_bwd': (_I, [_P, _P, _LL, _F, _P, _P, _P, _P]),
-    'rtg_l1log_mean_fwd': (_I, [_P, _P, _LL, _F, _P, _P]),
-    'rtg_lsgan_fwd': (_I, [_P, _LL, _F, _F, _P, _P]),
-    'rtg_lsgan_bwd': (_I, [_P, _LL, _F, _F, _P, _P, _P]),
-    'rtg_dyn_loss_fwd': (_I, [_P, _P, _I, _I, _I, _F, _P, _P]),
+    'rtg_loss_fwd': (_I, [_I, _P, _I, _P, _P, _P]),
+    'rtg_loss_bwd': (_I, [_I, _P, _I, _P, _P]),
+    'rtg_dyn_loss_fwd': (_I, [_P, _P, _I, _I, _I, _F, _P, _P, _P]),
     'rtg_dyn_loss_bwd': (_I, [_P, _P, _I, _I, _I, _F, _P, _P, _P]),
     'rtg_adamw': (_I, [_P, _P, _P, _P, _LL, _P, _P, _F, _F, _F, _F, _F, _F, _P]),
     'rtg_abi_version': (_I, []),

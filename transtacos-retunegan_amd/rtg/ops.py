@@ -1,0 +1,400 @@
+"""Autograd wrappers over the C ABI of librtg.so (include/rtg.h).  Every function here launches hand-written HIP
+kernels on the current torch stream; PyTorch only owns the memory and the autograd graph.  CPU tensors are refused."""
+import ctypes as C
+
+import torch
+
+from . import lib as L
+from .lib import lib, check
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise L.RtgError('RetuneGAN hot-path ops run on the MI355X HIP kernels only: got a CPU tensor '
+                             '(move the model and its inputs to cuda; there is no CPU fallback)')
+
+
+def _c(t):
+    return t if t is None or t.is_contiguous() else t.contiguous()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# convolution (Conv1d / ConvTranspose1d, weight-normed, banked)
+# ---------------------------------------------------------------------------------------------------------------
+def _conv_out_len(ly, L_in):
+    if ly.kind == 'conv':
+        return (L_in + 2 * ly.pad - ly.dil * (ly.k - 1) - 1) // ly.stride + 1
+    return (L_in - 1) * ly.stride - 2 * ly.pad + ly.k + ly.out_pad
+
+
+def _desc(**kw):
+    base = dict(B=1, C1=1, C2=0, L_in=1, groups=1, Cg=1, Mg=1, K=1, stride=1, dil=1, pad=0, Q=1, out_C=1, out_L=1,
+                shuf_S=1, shuf_P=0, pre_mode=0, pre_slope=1.0, mask_slope=1.0, out_scale=1.0, act=0, act_slope=1.0,
+                accumulate=0, tile_m=32, out_split=0)
+    base.update(kw)
+    return L.Conv1dDesc(**base)
+
+
+class ConvFn(torch.autograd.Function):
+    """out = act(out_scale * (conv(pre(xcat)) + bias + res)), conv being the layer's Conv1d or ConvTranspose1d."""
+
+    @staticmethod
+    def forward(ctx, token, x1, x2, res, ly, pre_slope, act, act_slope, out_scale, res_is_input):
+        _need_cuda(x1, x2, res)
+        bank = token._rtg_bank
+        x1, x2, res = _c(x1), _c(x2), _c(res)
+        B, C1, L_in = x1.shape
+        C2 = x2.shape[1] if x2 is not None else 0
+        assert C1 + C2 == ly.cin, (ly.name, C1, C2, ly.cin)
+        L_out = _conv_out_len(ly, L_in)
+        out = torch.empty(B, ly.cout, L_out, device=x1.device, dtype=torch.float32)
+        mode, g, mg, cg, k, s = ly.fwd_op
+        pre_mode = L.PRE_LRELU if pre_slope != 1.0 else L.PRE_NONE
+        if ly.kind == 'conv':
+            d = _desc(B=B, C1=C1, C2=C2, L_in=L_in, groups=g, Cg=cg, Mg=mg, K=k, stride=ly.stride, dil=ly.dil,
+                      pad=ly.pad, Q=L_out, out_C=ly.cout, out_L=L_out, pre_mode=pre_mode, pre_slope=pre_slope,
+                      out_scale=out_scale, act=act, act_slope=act_slope, tile_m=ly.fwd_tm)
+        else:
+            nq = (L_out - 1 + ly.pad) // ly.stride + 1
+            d = _desc(B=B, C1=C1, C2=C2, L_in=L_in, groups=1, Cg=cg, Mg=mg, K=k, stride=1, dil=1, pad=k - 1, Q=nq,
+                      out_C=ly.cout, out_L=L_out, shuf_S=ly.stride, shuf_P=ly.pad, pre_mode=pre_mode,
+                      pre_slope=pre_slope, out_scale=out_scale, act=act, act_slope=act_slope, tile_m=ly.fwd_tm)
+        check(lib.rtg_conv1d(C.byref(d), _p(x1), _p(x2), None, bank.fwd_ptr(ly), bank.bias_ptr(ly), None, _p(res),
+                             _p(out), None, _stream()), f'conv1d fwd {ly.name}')
+        ctx.ly, ctx.bank, ctx.tok_id = ly, bank, token._rtg_id
+        ctx.cfg = (pre_slope, act, act_slope, out_scale, res_is_input, res is not None)
+        ctx.save_for_backward(x1, x2, out if act != L.ACT_NONE else None)
+        ctx.set_materialize_grads(False)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        ly, bank = ctx.ly, ctx.bank
+        x1, x2, out = ctx.saved_tensors
+        pre_slope, act, act_slope, out_scale, res_is_input, has_res = ctx.cfg
+        need_w, need_x1, need_x2, need_res = (ctx.needs_input_grad[0], ctx.needs_input_grad[1],
+                                              ctx.needs_input_grad[2], ctx.needs_input_grad[3])
+        if dy is None:
+            return (None,) * 10
+        dy = _c(dy)
+        B, C1, L_in = x1.shape
+        C2 = x2.shape[1] if x2 is not None else 0
+        L_out = dy.shape[-1]
+        st = _stream()
+        if act == L.ACT_LRELU:
+            gy_mode, gy_slope = L.PRE_MUL_DLRELU, act_slope
+        elif act == L.ACT_TANH:
+            gy_mode, gy_slope = L.PRE_MUL_DTANH, 1.0
+        else:
+            gy_mode, gy_slope = L.PRE_NONE, 1.0
+
+        # ---------------- gradient of the residual input (= effective output gradient)
+        dres = None
+        fuse_res = has_res and res_is_input and act == L.ACT_NONE and need_x1
+        if has_res and need_res and not fuse_res:
+            if act == L.ACT_NONE and out_scale == 1.0:
+                dres = dy
+            else:
+                dres = torch.empty_like(dy)
+                if act == L.ACT_LRELU:
+                    check(lib.rtg_lrelu_bwd(_p(dy), _p(out), _p(dres), dy.numel(), act_slope, st), 'lrelu_bwd')
+                    if out_scale != 1.0:
+                        check(lib.rtg_axpby(_p(dres), None, _p(dres), dres.numel(), out_scale, 0.0, 0, st), 'axpby')
+                elif act == L.ACT_NONE:
+                    check(lib.rtg_axpby(_p(dy), None, _p(dres), dy.numel(), out_scale, 0.0, 0, st), 'axpby')
+                else:
+                    raise L.RtgError('residual + tanh epilogue has no backward kernel')
+
+        # ---------------- backward-data
+        dx1 = dx2 = None
+        if need_x1 or need_x2:
+            mode, g, mg, cg, k, s = ly.bwd_op
+            split = C1 if C2 > 0 else 0
+            if C2 > 0:
+                assert pre_slope == 1.0, 'input activation on a concatenated pair is not used by the path'
+            if need_x1 or C2 == 0:
+                dx1 = torch.empty_like(x1)
+            if C2 > 0 and need_x2:
+                dx2 = torch.empty_like(x2)
+            mask = x1 if pre_slope != 1.0 else None
+            resg = dy if fuse_res else None
+            # (acc * mask + res) * out_scale: the residual branch and the conv branch share the factor out_scale
+            if ly.kind == 'conv' and ly.stride == 1:
+                d = _desc(B=B, C1=ly.cout, L_in=L_out, groups=g, Cg=cg, Mg=mg, K=k, stride=1, dil=ly.dil,
+                          pad=(ly.k - 1) * ly.dil - ly.pad, Q=L_in, out_C=ly.cin, out_L=L_in, pre_mode=gy_mode,
+                          pre_slope=gy_slope, mask_slope=pre_slope, out_scale=out_scale, tile_m=ly.bwd_tm,
+                          out_split=split)
+            elif ly.kind == 'conv':
+                nq = (L_in - 1 + ly.pad) // ly.stride + 1
+                d = _desc(B=B, C1=ly.cout, L_in=L_out, groups=g, Cg=cg, Mg=mg, K=k, stride=1, dil=1, pad=k - 1, Q=nq,
+                          out_C=ly.cin, out_L=L_in, shuf_S=ly.stride, shuf_P=ly.pad, pre_mode=gy_mode,
+                          pre_slope=gy_slope, mask_slope=pre_slope, out_scale=out_scale, tile_m=ly.bwd_tm,
+                          out_split=split)
+            else:   # transposed conv: backward-data is the strided conv of dy
+                d = _desc(B=B, C1=ly.cout, L_in=L_out, groups=1, Cg=cg, Mg=mg, K=k, stride=ly.stride, dil=1,
+                          pad=ly.pad, Q=L_in, out_C=ly.cin, out_L=L_in, pre_mode=gy_mode, pre_slope=gy_slope,
+                          mask_slope=pre_slope, out_scale=out_scale, tile_m=ly.bwd_tm, out_split=split)
+            check(lib.rtg_conv1d(C.byref(d), _p(dy), None, _p(out), bank.bwd_ptr(ly), None, _p(mask), _p(resg),
+                                 _p(dx1), _p(dx2), st), f'conv1d bwd-data {ly.name}')
+            if not need_x1:
+                dx1 = None
+
+        # ---------------- backward-weight into the bank's partial slot (flushed by the token's backward)
+        if need_w:
+            pre_mode = L.PRE_LRELU if pre_slope != 1.0 else L.PRE_NONE
+            if ly.kind == 'conv':
+                wd = L.WgradDesc(B=B, C1=C1, C2=C2, L_in=L_in, groups=ly.groups, Cg=ly.cin // ly.groups,
+                                 Mg=ly.cout // ly.groups, K=ly.k, stride=ly.stride, dil=ly.dil, pad=ly.pad, Q=L_out,
+                                 dy_L=L_out, pre_mode=pre_mode, pre_slope=pre_slope, gy_mode=gy_mode,
+                                 gy_slope=gy_slope, gy_scale=out_scale, splits=1, part_stride=0)
+                a1, a2, gyt, aux = x1, x2, dy, out
+            else:
+                # roles swapped: "input" = effective dy [B,C_out,L_out], "output gradient" = lrelu(x) [B,C_in,L_in]
+                assert act == L.ACT_NONE and C2 == 0
+                wd = L.WgradDesc(B=B, C1=ly.cout, C2=0, L_in=L_out, groups=1, Cg=ly.cout, Mg=ly.cin, K=ly.k,
+                                 stride=ly.stride, dil=1, pad=ly.pad, Q=L_in, dy_L=L_in, pre_mode=L.PRE_NONE,
+                                 pre_slope=1.0, gy_mode=pre_mode, gy_slope=pre_slope, gy_scale=out_scale, splits=1,
+                                 part_stride=0)
+                a1, a2, gyt, aux = dy, None, x1, None
+            splits = lib.rtg_wgrad_splits(C.byref(wd))
+            if splits < 1:
+                raise L.RtgError(f'wgrad geometry refused for {ly.name}: {splits}')
+            part, stride, immediate = bank.partial_slot(ly, splits, ctx.tok_id)
+            wd.splits, wd.part_stride = splits, stride
+            check(lib.rtg_conv1d_wgrad(C.byref(wd), _p(a1), _p(a2), _p(gyt), _p(aux), _p(part), st),
+                  f'conv1d wgrad {ly.name}')
+            if ly.kind == 'convT':   # bias gradient of a transposed conv: plain channel sum of dy
+                check(lib.rtg_channel_sum(_p(dy), C.c_void_p(bank.gflat.data_ptr() + 4 * ly.b_off), B, ly.cout, L_out,
+                                          st), 'channel_sum')
+            if immediate:
+                bank.flush_one(ly, part, splits)
+        return None, dx1, dx2, dres, None, None, None, None, None, None
+
+
+def conv(token, ly, x1, x2=None, res=None, pre_slope=1.0, act=L.ACT_NONE, act_slope=1.0, out_scale=1.0):
+    res_is_input = res is not None and res is x1
+    return ConvFn.apply(token, x1, x2, res, ly, float(pre_slope), int(act), float(act_slope), float(out_scale),
+                        res_is_input)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# GaussianNoise
+# ---------------------------------------------------------------------------------------------------------------
+class NoiseFn(torch.autograd.Function):
+    N_BLOCKS = 256
+
+    @staticmethod
+    def forward(ctx, x, w, u_in, slope, seed, salt):
+        _need_cuda(x, w, u_in)
+        x = _c(x)
+        out = torch.empty_like(x)
+        check(lib.rtg_noise_lrelu_fwd(_p(x), _p(w), _p(u_in), _p(out), x.numel(), slope, C.c_ulonglong(seed),
+                                      _p(salt), _stream()), 'noise fwd')
+        ctx.save_for_backward(x, w, u_in, salt)
+        ctx.cfg = (slope, seed)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, u_in, salt = ctx.saved_tensors
+        slope, seed = ctx.cfg
+        dy = _c(dy)
+        dx = torch.empty_like(x)
+        part = torch.empty(NoiseFn.N_BLOCKS, device=x.device)
+        check(lib.rtg_noise_lrelu_bwd(_p(x), _p(w), _p(u_in), _p(dy), _p(dx), _p(part), NoiseFn.N_BLOCKS, x.numel(),
+                                      slope, C.c_ulonglong(seed), _p(salt), _stream()), 'noise bwd')
+        dw = part.sum().reshape(w.shape) if ctx.needs_input_grad[1] else None
+        return dx, dw, None, None, None, None
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# small layers
+# ---------------------------------------------------------------------------------------------------------------
+class AvgPoolFn(torch.autograd.Function):
+    """nn.AvgPool1d(4, 2, 1) (retunegan/models/discrminator.py:113)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _need_cuda(x)
+        x = _c(x)
+        B, Cc, Lx = x.shape
+        out = torch.empty(B, Cc, Lx // 2, device=x.device)
+        check(lib.rtg_avgpool4s2_fwd(_p(x), _p(out), B * Cc, Lx, _stream()), 'avgpool fwd')
+        ctx.shape = (B, Cc, Lx)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, Cc, Lx = ctx.shape
+        dy = _c(dy)
+        dx = torch.empty(B, Cc, Lx, device=dy.device)
+        check(lib.rtg_avgpool4s2_bwd(_p(dy), _p(dx), B * Cc, Lx, _stream()), 'avgpool bwd')
+        return dx
+
+
+class PeriodFoldFn(torch.autograd.Function):
+    """y [B,1,T] -> [B*p, 1, H]: reflect-pad the tail to a multiple of p and put the period axis into the batch
+    (retunegan/models/discrminator.py:203-210 builds [B,1,H,p]; the (k,1) convs then act along H only)."""
+
+    @staticmethod
+    def forward(ctx, y, p):
+        _need_cuda(y)
+        y = _c(y)
+        B, _, T = y.shape
+        H = (T + p - 1) // p
+        out = torch.empty(B * p, 1, H, device=y.device)
+        check(lib.rtg_period_fold_fwd(_p(y), _p(out), B, T, p, H, _stream()), 'fold fwd')
+        ctx.cfg = (B, T, p, H)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, T, p, H = ctx.cfg
+        dout = _c(dout)
+        dy = torch.empty(B, 1, T, device=dout.device)
+        check(lib.rtg_period_fold_bwd(_p(dout), _p(dy), B, T, p, H, _stream()), 'fold bwd')
+        return dy, None
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# losses (multi-tensor)
+# ---------------------------------------------------------------------------------------------------------------
+def _jobs(entries):
+    arr = (L.LossJob * len(entries))()
+    for i, (a, b, da, db, w, target) in enumerate(entries):
+        arr[i] = L.LossJob(a.data_ptr(), b.data_ptr() if b is not None else None,
+                           da.data_ptr() if da is not None else None, db.data_ptr() if db is not None else None,
+                           a.numel(), w, target)
+    return arr
+
+
+class MultiLossFn(torch.autograd.Function):
+    """sum_j w_j * mean(term(a_j, b_j)) over a list of tensor pairs, one launch per <= 48 pairs.
+    Inputs are passed flat: a_0..a_{n-1}, b_0..b_{n-1}."""
+
+    @staticmethod
+    def forward(ctx, kind, weights, target, n, *tensors):
+        a_list = [_c(t) for t in tensors[:n]]
+        b_list = [_c(t) if t is not None else None for t in tensors[n:]]
+        _need_cuda(*a_list)
+        dev = a_list[0].device
+        loss = torch.zeros(1, device=dev)
+        ws = torch.empty(64 * L.MAX_LOSS_JOBS, device=dev)
+        st = _stream()
+        for s in range(0, n, L.MAX_LOSS_JOBS):
+            ent = [(a_list[i], b_list[i], None, None, weights[i], target) for i in range(s, min(n, s + L.MAX_LOSS_JOBS))]
+            check(lib.rtg_loss_fwd(kind, _jobs(ent), len(ent), _p(ws), _p(loss), st), 'loss fwd')
+        ctx.cfg = (kind, weights, target, n)
+        ctx.save_for_backward(*a_list, *[b for b in b_list if b is not None])
+        ctx.has_b = [b is not None for b in b_list]
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        kind, weights, target, n = ctx.cfg
+        saved = list(ctx.saved_tensors)
+        a_list = saved[:n]
+        rest = saved[n:]
+        b_list = []
+        for hb in ctx.has_b:
+            b_list.append(rest.pop(0) if hb else None)
+        g = _c(g).reshape(1)
+        st = _stream()
+        da = [torch.empty_like(a) if ctx.needs_input_grad[4 + i] else None for i, a in enumerate(a_list)]
+        db = [torch.empty_like(b) if (b is not None and ctx.needs_input_grad[4 + n + i]) else None
+              for i, b in enumerate(b_list)]
+        idx = [i for i in range(n) if da[i] is not None or db[i] is not None]
+        for s in range(0, len(idx), L.MAX_LOSS_JOBS):
+            ent = [(a_list[i], b_list[i], da[i], db[i], weights[i], target) for i in idx[s:s + L.MAX_LOSS_JOBS]]
+            check(lib.rtg_loss_bwd(kind, _jobs(ent), len(ent), _p(g), st), 'loss bwd')
+        return (None, None, None, None, *da, *db)
+
+
+def multi_loss(kind, a_list, b_list=None, weights=None, target=0.0):
+    n = len(a_list)
+    if b_list is None:
+        b_list = [None] * n
+    if weights is None:
+        weights = [1.0] * n
+    return MultiLossFn.apply(kind, [float(w) for w in weights], float(target), n, *a_list, *b_list)
+
+
+class DynLossFn(torch.autograd.Function):
+    """dynamic_loss (retunegan/models/loss.py:76-82); gradient w.r.t. the generated wave only."""
+
+    @staticmethod
+    def forward(ctx, y, g, k):
+        _need_cuda(y, g)
+        y, g = _c(y), _c(g)
+        rows, Lx = y.numel() // y.shape[-1], y.shape[-1]
+        loss = torch.zeros(1, device=y.device)
+        ws = torch.empty(256, device=y.device)
+        check(lib.rtg_dyn_loss_fwd(_p(y), _p(g), rows, Lx, k, 1.0, _p(ws), _p(loss), _stream()), 'dyn fwd')
+        ctx.save_for_backward(y, g)
+        ctx.cfg = (rows, Lx, k)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        y, g = ctx.saved_tensors
+        rows, Lx, k = ctx.cfg
+        dg = torch.empty_like(g)
+        check(lib.rtg_dyn_loss_bwd(_p(y), _p(g), rows, Lx, k, 1.0, _p(_c(gout).reshape(1)), _p(dg), _stream()),
+              'dyn bwd')
+        return None, dg, None
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# STFT
+# ---------------------------------------------------------------------------------------------------------------
+class StftFn(torch.autograd.Function):
+    """y [B,T] -> (mel [B,n_mel,frames], spec [B,2,F,frames] or None) for one resolution (see rtg_stft_forward)."""
+
+    @staticmethod
+    def forward(ctx, y, plan, want_spec):
+        _need_cuda(y)
+        y = _c(y)
+        B, T = y.shape
+        frames = 1 + T // plan.hop
+        F = plan.n_fft // 2 + 1
+        dev = y.device
+        t = plan.tensors(dev)
+        need_bwd = ctx.needs_input_grad[0]
+        mel = torch.empty(B, plan.n_mel, frames, device=dev)
+        spec = torch.empty(B, 2, F, frames, device=dev) if want_spec else None
+        re = torch.empty(B, frames, F, device=dev) if need_bwd else None
+        im = torch.empty(B, frames, F, device=dev) if need_bwd else None
+        d = L.StftDesc(B, T, plan.n_fft, plan.win, plan.hop, frames, plan.n_mel)
+        check(lib.rtg_stft_forward(C.byref(d), _p(y), _p(t['window']), _p(t['twiddle']), _p(t['mel_lo']),
+                                   _p(t['mel_len']), _p(t['mel_woff']), _p(t['mel_w']), _p(mel), _p(spec), _p(re),
+                                   _p(im), _stream()), 'stft fwd')
+        ctx.plan, ctx.shape = plan, (B, T, frames)
+        ctx.save_for_backward(re, im)
+        ctx.set_materialize_grads(False)
+        return mel, spec
+
+    @staticmethod
+    def backward(ctx, dmel, dspec):
+        re, im = ctx.saved_tensors
+        plan = ctx.plan
+        B, T, frames = ctx.shape
+        if dmel is None and dspec is None:
+            return None, None, None
+        dev = re.device
+        t = plan.tensors(dev)
+        dy = torch.zeros(B, T, device=dev)
+        ws = torch.empty(B * frames * plan.win, device=dev)
+        d = L.StftDesc(B, T, plan.n_fft, plan.win, plan.hop, frames, plan.n_mel)
+        check(lib.rtg_stft_backward(C.byref(d), _p(re), _p(im), _p(_c(dmel)), _p(_c(dspec)), _p(t['window']),
+                                    _p(t['twiddle']), _p(t['binmel_idx']), _p(t['binmel_w']), _p(ws), _p(dy),
+                                    _stream()), 'stft bwd')
+        return dy, None, None
