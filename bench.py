@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""bench.py — RetuneGAN train-step throughput on MI355X (metric of BASELINE.json).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload config2|config1|config4]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one iteration of retunegan/train.py:121-193 (1 G forward, d_train_times D updates, 1 G update) on a batch
+of synthetic clips already resident in HBM.  Default workload = BASELINE.json configs[1]: UNet-G + MSD + MPD,
+per-GPU batch 32, 8192-sample clips, multi-STFT loss, fp32.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(REPO, 'transtacos-retunegan_amd'))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_FP32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32, dense
+SAMPLE_RATE = 22050
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--workload', default='config2', choices=['config1', 'config2', 'config4'])
+    ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (default: the workload\'s)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    return ap.parse_args()
+
+
+WORKLOADS = {
+    # name: (description, use_mpd, use_mtd, d_train_times, per-GPU batch, T)
+    'config1': ('UNet-G + MSD, 1 D-step (BASELINE configs[0] shape on the GPU)', False, False, 1, 2, 8192),
+    'config2': ('UNet-G + MSD/MPD, multi-STFT loss, d_train_times=2 (BASELINE configs[1])', True, False, 2, 32, 8192),
+    'config4': ('UNet-G + MSD/MPD/MTD full stack (BASELINE configs[3])', True, True, 2, 32, 8192),
+}
+
+
+def synthetic_batch(batch, T, seed, device):
+    """x = mel_2048 @ |N(0,1)| linear spec (what the finetune path feeds), y_tmpl, y ~ U(-1,1)."""
+    import hparam as hp
+    from audio import mel_filterbank
+    g = torch.Generator().manual_seed(seed)
+    spec = torch.randn(batch, hp.n_freq, T // hp.hop_length, generator=g).abs()
+    mel = torch.from_numpy(mel_filterbank(hp.sample_rate, hp.n_fft, hp.n_mel, hp.fmin, hp.fmax))
+    x = torch.matmul(mel, spec)
+    y_tmpl = torch.rand(batch, 1, T, generator=g) * 2 - 1
+    y = torch.rand(batch, 1, T, generator=g) * 2 - 1
+    return x.to(device), y_tmpl.to(device), y.to(device)
+
+
+def cpu_baseline(budget_s=12.0):
+    """The CPU oracle (oracle/rtg_oracle.py, stock PyTorch fp32 CPU ops; the reference's own files cannot travel to the
+    GPU box) timed on this host: BASELINE configs[0] = UNet-G + MSD, batch 2, 8192-sample clips, 1 D-step + 1 G-step."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('rtg_oracle', os.path.join(REPO, 'oracle', 'rtg_oracle.py'))
+    O = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(O)
+    torch.manual_seed(0)
+    g, msd = O.Generator(), O.MSD()
+    og, od = O.make_optimizers(g, [msd])
+    x, y_tmpl, y = O.synthetic_batch(2, 8192, 1)
+    cores = torch.get_num_threads()
+    for _ in range(2):
+        O.train_step(g, og, od, x, y_tmpl, y, msd, None, None, 1)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        O.train_step(g, og, od, x, y_tmpl, y, msd, None, None, 1)
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or n >= 40:
+            break
+    return {'value': round(2 * 8192 / SAMPLE_RATE / (el / n), 4), 'unit': 'audio-s/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{n} steps of configs[0] (UNet-G + MSD, batch 2 x 8192 samples, 1 D-step + 1 G-step) '
+                      f'in {el:.1f} s on {cores} torch CPU threads; oracle/rtg_oracle.py'}
+
+
+def roofline(trainer, batch):
+    """Live per-kernel timing of ONE extra step: every conv launch bracketed by HIP events on its launch stream."""
+    from rtg import ops
+    ops.PROFILE = []
+    trainer.train_step(*batch)
+    torch.cuda.synchronize()
+    rec, ops.PROFILE = ops.PROFILE, None
+    agg = {}
+    for kernel, variant, flop, e0, e1 in rec:
+        k = (kernel, variant)
+        a = agg.setdefault(k, [0, 0.0, 0.0])
+        a[0] += 1
+        a[1] += e0.elapsed_time(e1) * 1e-3
+        a[2] += flop
+    (kernel, variant), (n, secs, flop) = max(agg.items(), key=lambda kv: kv[1][1])
+    name = (f'conv1d_mfma_kernel<{variant // 100},{variant // 10 % 10},{variant % 10}>' if kernel == 'conv1d'
+            else f'wgrad_kernel<{variant}>')
+    achieved = flop / secs / 1e12
+    out = {'bound': 'mfma', 'achieved': round(achieved, 3), 'peak': PEAK_FP32_MATRIX_TFLOPS, 'unit': 'TFLOP/s',
+           'frac': round(achieved / PEAK_FP32_MATRIX_TFLOPS, 4), 'traffic': None, 'kernel': name,
+           'launches_per_step': n, 'avg_launch_us': round(secs / n * 1e6, 2),
+           'algorithmic_gflop_per_launch': round(flop / n / 1e9, 4)}
+    total_flop = sum(a[2] for a in agg.values())
+    total_s = sum(a[1] for a in agg.values())
+    out['all_conv_kernels'] = {'tflops': round(total_flop / total_s / 1e12, 3), 'ms_per_step': round(total_s * 1e3, 3),
+                               'gflop_per_step': round(total_flop / 1e9, 2)}
+    out['by_kernel'] = {(f'{k[0]}:{k[1]}'): {'n': v[0], 'ms': round(v[1] * 1e3, 3),
+                                             'tflops': round(v[2] / v[1] / 1e12, 2)} for k, v in sorted(agg.items())}
+    return out
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.cuda.set_device(local)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: the hot path has no CPU fallback')
+    device = torch.device('cuda', local)
+    torch.cuda.set_device(device)
+
+    import hparam as hp
+    from train import Trainer
+    desc, use_mpd, use_mtd, d_times, batch, T = WORKLOADS[a.workload]
+    if a.batch:
+        batch = a.batch
+    torch.manual_seed(hp.randseed)          # identical initial weights on every rank (and broadcast from rank 0)
+    tr = Trainer(use_mpd=use_mpd, use_mtd=use_mtd, d_train_times=d_times, dev=device)
+    data = synthetic_batch(batch, T, hp.randseed + rank, device)
+
+    for _ in range(a.warmup):
+        tr.train_step(*data)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        dl, gl = tr.train_step(*data)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    loss_g = gl['gen_all'].item()
+    loss_d = dl['disc_all'].item()
+
+    roof = None
+    if not a.no_roofline and rank == 0:
+        roof = roofline(tr, data)
+    if world > 1:
+        dist.barrier()
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline()
+
+    if rank == 0:
+        ms = elapsed / a.steps * 1e3
+        value = world * batch * T / SAMPLE_RATE / (elapsed / a.steps)
+        out = {
+            'metric': 'G+D train-step audio-seconds/sec', 'value': round(value, 2), 'unit': 'audio-s/s',
+            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(ms, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'{a.workload}: {desc}', 'per_gpu_batch': batch, 'clip_samples': T,
+                       'global_batch': world * batch, 'd_train_times': d_times,
+                       'parallelism': f'dp{world}' if world > 1 else 'single'},
+            'roofline': roof, 'cpu_baseline': cpu,
+            'final_losses': {'gen_all': round(loss_g, 4), 'disc_all': round(loss_d, 4)},
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

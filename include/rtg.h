@@ -74,6 +74,10 @@ typedef struct RtgConv1dDesc {
 int rtg_conv1d(const RtgConv1dDesc* d, const float* x1, const float* x2, const float* aux, const float* wp,
                const float* bias, const float* mask, const float* res, float* out, float* out2, void* stream);
 
+/* which template instantiation rtg_conv1d would launch for this descriptor: tile_m*100 + MT*10 + NT (wave tile =
+ * MT x NT MFMA tiles), or a negative RTG_E* code.  Used by bench.py to attribute time per kernel. */
+int rtg_conv1d_variant(const RtgConv1dDesc* d);
+
 /* number of floats of the packed weight buffer for a layer with the given logical shape */
 long long rtg_packed_size(int groups, int Mg, int Cg, int K, int tile_m);
 

@@ -288,6 +288,16 @@ TileCfg pick_tiles(int TM, int n_mt, int Q, int B, int groups, int stride, int K
 
 }  // namespace
 
+extern "C" int rtg_conv1d_variant(const RtgConv1dDesc* d) {
+  if (!d) return RTG_ENULL;
+  if ((d->tile_m != 32 && d->tile_m != 16) || d->Mg < 1 || d->Q < 1 || d->B < 1 || d->groups < 1 || d->stride < 1 ||
+      d->K < 1 || d->dil < 1)
+    return RTG_EINVAL;
+  const TileCfg c = pick_tiles(d->tile_m, rtg_ceil_div(d->Mg, d->tile_m), d->Q, d->B, d->groups, d->stride, d->K, d->dil);
+  if (c.MT == 0) return RTG_ERANGE;
+  return d->tile_m * 100 + c.MT * 10 + c.NT;
+}
+
 extern "C" long long rtg_packed_size(int groups, int Mg, int Cg, int K, int tile_m) {
   if (groups < 1 || Mg < 1 || Cg < 1 || K < 1 || (tile_m != 32 && tile_m != 16)) return RTG_EINVAL;
   const long long n_mt = (Mg + tile_m - 1) / tile_m, n_cc = (Cg + RTG_CK - 1) / RTG_CK;

@@ -1,6 +1,7 @@
 """Building blocks shared by the generator and the discriminators: the weight-normed conv parameter holder and the
 base class that keeps all of a model's parameters in one flat GPU buffer (rtg/bank.py)."""
 import math
+import weakref
 
 import numpy as np
 import torch
@@ -47,9 +48,12 @@ class WNConv(nn.Module):
 class BankedModel(nn.Module):
     """nn.Module whose WNConv children (and listed extra parameters) live in one WeightBank on the GPU."""
 
+    _registry = weakref.WeakSet()      # lets train.AdamW(module.parameters(), ...) find the owning models
+
     def __init__(self):
         super().__init__()
         self._bank = None
+        BankedModel._registry.add(self)
 
     def _extra_bank_params(self):
         return []

@@ -133,6 +133,7 @@ class WeightBank:
         self._wn_table = None
         self._wn_dirty = True
         self._keep = []          # tensors that must outlive the async kernels reading them within one flush
+        self.on_flush = None     # optional callback(gflat) once a backward's weight gradients are complete (DP)
 
     # ------------------------------------------------------------------ parameters as views of the flat buffers
     def _bind_params(self):
@@ -267,6 +268,8 @@ class WeightBank:
               'weightnorm_backward')
         for ly in owned:
             self._owner[ly.lid] = None
+        if self.on_flush is not None:
+            self.on_flush(self.gflat)
         if len(self._keep) > 64:
             self._keep = self._keep[-32:]
 

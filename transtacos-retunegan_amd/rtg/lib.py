@@ -64,6 +64,7 @@ _I, _F, _LL, _ULL = C.c_int, C.c_float, C.c_longlong, C.c_ulonglong
 # name -> (restype, argtypes); must list every symbol include/rtg.h declares (checked by tests/test_abi.py)
 PROTOTYPES = {
     'rtg_conv1d': (_I, [C.POINTER(Conv1dDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'rtg_conv1d_variant': (_I, [C.POINTER(Conv1dDesc)]),
     'rtg_packed_size': (_LL, [_I, _I, _I, _I, _I]),
     'rtg_conv1d_wgrad': (_I, [C.POINTER(WgradDesc), _P, _P, _P, _P, _P, _P]),
     'rtg_wgrad_splits': (_I, [C.POINTER(WgradDesc)]),

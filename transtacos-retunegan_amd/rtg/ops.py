@@ -27,6 +27,27 @@ def _c(t):
     return t if t is None or t.is_contiguous() else t.contiguous()
 
 
+# bench.py's live per-kernel timing: when PROFILE is a list, every conv launch is bracketed by events on the stream it
+# is launched on and recorded as (kernel, variant, algorithmic flop, start event, end event)
+PROFILE = None
+
+
+def _timed(kernel, variant, flop, launch):
+    if PROFILE is None:
+        return launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    r = launch()
+    e1.record()
+    PROFILE.append((kernel, variant, flop, e0, e1))
+    return r
+
+
+def _conv_flop(ly, B, L_conv_out):
+    """algorithmic flop of one pass (forward, backward-data or backward-weight) of the layer's convolution"""
+    return 2.0 * B * L_conv_out * ly.cout * (ly.cin // ly.groups) * ly.k
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # convolution (Conv1d / ConvTranspose1d, weight-normed, banked)
 # ---------------------------------------------------------------------------------------------------------------
@@ -68,8 +89,10 @@ class ConvFn(torch.autograd.Function):
             d = _desc(B=B, C1=C1, C2=C2, L_in=L_in, groups=1, Cg=cg, Mg=mg, K=k, stride=1, dil=1, pad=k - 1, Q=nq,
                       out_C=ly.cout, out_L=L_out, shuf_S=ly.stride, shuf_P=ly.pad, pre_mode=pre_mode,
                       pre_slope=pre_slope, out_scale=out_scale, act=act, act_slope=act_slope, tile_m=ly.fwd_tm)
-        check(lib.rtg_conv1d(C.byref(d), _p(x1), _p(x2), None, bank.fwd_ptr(ly), bank.bias_ptr(ly), None, _p(res),
-                             _p(out), None, _stream()), f'conv1d fwd {ly.name}')
+        lc = L_out if ly.kind == 'conv' else L_in
+        check(_timed('conv1d', lib.rtg_conv1d_variant(C.byref(d)) if PROFILE is not None else 0, _conv_flop(ly, B, lc),
+                     lambda: lib.rtg_conv1d(C.byref(d), _p(x1), _p(x2), None, bank.fwd_ptr(ly), bank.bias_ptr(ly), None,
+                                            _p(res), _p(out), None, _stream())), f'conv1d fwd {ly.name}')
         ctx.ly, ctx.bank, ctx.tok_id = ly, bank, token._rtg_id
         ctx.cfg = (pre_slope, act, act_slope, out_scale, res_is_input, res is not None)
         ctx.save_for_backward(x1, x2, out if act != L.ACT_NONE else None)
@@ -143,8 +166,11 @@ class ConvFn(torch.autograd.Function):
                 d = _desc(B=B, C1=ly.cout, L_in=L_out, groups=1, Cg=cg, Mg=mg, K=k, stride=ly.stride, dil=1,
                           pad=ly.pad, Q=L_in, out_C=ly.cin, out_L=L_in, pre_mode=gy_mode, pre_slope=gy_slope,
                           mask_slope=pre_slope, out_scale=out_scale, tile_m=ly.bwd_tm, out_split=split)
-            check(lib.rtg_conv1d(C.byref(d), _p(dy), None, _p(out), bank.bwd_ptr(ly), None, _p(mask), _p(resg),
-                                 _p(dx1), _p(dx2), st), f'conv1d bwd-data {ly.name}')
+            lc = L_out if ly.kind == 'conv' else L_in
+            check(_timed('conv1d', lib.rtg_conv1d_variant(C.byref(d)) if PROFILE is not None else 0,
+                         _conv_flop(ly, B, lc),
+                         lambda: lib.rtg_conv1d(C.byref(d), _p(dy), None, _p(out), bank.bwd_ptr(ly), None, _p(mask),
+                                                _p(resg), _p(dx1), _p(dx2), st)), f'conv1d bwd-data {ly.name}')
             if not need_x1:
                 dx1 = None
 
@@ -170,7 +196,9 @@ class ConvFn(torch.autograd.Function):
                 raise L.RtgError(f'wgrad geometry refused for {ly.name}: {splits}')
             part, stride, immediate = bank.partial_slot(ly, splits, ctx.tok_id)
             wd.splits, wd.part_stride = splits, stride
-            check(lib.rtg_conv1d_wgrad(C.byref(wd), _p(a1), _p(a2), _p(gyt), _p(aux), _p(part), st),
+            lc = L_out if ly.kind == 'conv' else L_in
+            check(_timed('wgrad', 32 if wd.Mg >= 32 else 16, _conv_flop(ly, B, lc),
+                         lambda: lib.rtg_conv1d_wgrad(C.byref(wd), _p(a1), _p(a2), _p(gyt), _p(aux), _p(part), st)),
                   f'conv1d wgrad {ly.name}')
             if ly.kind == 'convT':   # bias gradient of a transposed conv: plain channel sum of dy
                 check(lib.rtg_channel_sum(_p(dy), C.c_void_p(bank.gflat.data_ptr() + 4 * ly.b_off), B, ly.cout, L_out,

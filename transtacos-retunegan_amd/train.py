@@ -1,0 +1,343 @@
+"""Train-step orchestration of retunegan/train.py:47-88,121-193 on the MI355X hot path.
+
+What is kept from the reference: model construction through `models` (zero-argument constructors looked up by
+`hp.generator_ver`, train.py:48-52), AdamW hyper-parameters (train.py:80-81), ExponentialLR per epoch (train.py:87-88),
+the D x d_train_times -> G update order with its detach semantics and loss weights (train.py:131-193), the NaN guard
+(train.py:158,191) and the checkpoint dict layout (train.py:263-273).
+
+What is new (absent from the reference): one flat fused AdamW launch per optimizer, device-side NaN guard (no host
+sync inside a step), the real wave's spectra computed once per step, and plain data parallelism over clips: one process
+per GPU, gradients of each model's flat buffer all-reduced with RCCL (torch.distributed backend "nccl") on a side stream
+as soon as that model's backward has been flushed, overlapping the rest of the backward.
+"""
+import ctypes as C
+import itertools  # noqa: F401
+import os
+import weakref
+
+import torch
+import torch.distributed as dist
+
+import hparam as hp
+import hparam as h  # noqa: F401  (train.py:17 imports it under both names)
+from models import *  # noqa: F401,F403
+from models import (multi_stft_loss, dynamic_loss, discriminator_loss, generator_loss, feature_loss,
+                    MultiScaleDiscriminator, MultiPeriodDiscriminator, MultiStftDiscriminator)
+from models.layers import BankedModel
+from models.loss import stft_cache
+from rtg.lib import lib, check, RtgError
+
+device = 'cuda' if torch.cuda.is_available() else 'cpu'
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# optimizer
+# ---------------------------------------------------------------------------------------------------------------
+class AdamW:
+    """torch.optim.AdamW semantics (decoupled weight decay 0.01, eps 1e-8, bias correction) over the flat parameter
+    buffers of one or more BankedModels: ONE kernel launch per model instead of 550 per-tensor updates per step
+    (SURVEY.md 2.1).  Constructible like the reference does it: AdamW(module.parameters(), lr, betas=[b1, b2])."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        params = list(params)
+        if params and isinstance(params[0], BankedModel):
+            models = params
+        else:
+            ids = {id(p) for p in params}
+            models = [m for m in BankedModel._registry if any(id(p) in ids for p in m.parameters())]
+            covered = sum(sum(1 for _ in m.parameters()) for m in models)
+            if covered != len(params):
+                raise RtgError('AdamW: parameters must cover whole RetuneGAN models (generator / msd / mpd / mtd)')
+        self.models = models
+        self.lr, self.betas, self.eps, self.weight_decay = float(lr), (float(betas[0]), float(betas[1])), eps, weight_decay
+        self.initial_lr = self.lr
+        self.state = {}
+        self.param_groups = [{'lr': self.lr, 'betas': self.betas, 'eps': eps, 'weight_decay': weight_decay,
+                              'initial_lr': self.lr}]
+        self.grad_scale = 1.0
+
+    def _st(self, m):
+        bank = m.bank()
+        s = self.state.get(id(m))
+        if s is None or s['bank'] is not bank:
+            dev = bank.flat.device
+            old = s
+            s = {'bank': bank, 'exp_avg': torch.zeros_like(bank.flat), 'exp_avg_sq': torch.zeros_like(bank.flat),
+                 'step': torch.zeros(1, device=dev)}
+            if old is not None:      # the model was moved: carry the moments over
+                s['exp_avg'].copy_(old['exp_avg']); s['exp_avg_sq'].copy_(old['exp_avg_sq']); s['step'].copy_(old['step'])
+            self.state[id(m)] = s
+        return s
+
+    def zero_grad(self, set_to_none=False):
+        for m in self.models:
+            m.bank().zero_grad()
+
+    def step(self, loss_flag=None):
+        """loss_flag: optional device scalar; if it is NaN the update (and the step counter) is skipped on the device
+        — the reference's `if not torch.isnan(loss): loss.backward()` guard without a host round trip."""
+        lr = self.param_groups[0]['lr']
+        for m in self.models:
+            s = self._st(m)
+            bank = s['bank']
+            check(lib.rtg_adamw(_p(bank.flat), _p(bank.gflat), _p(s['exp_avg']), _p(s['exp_avg_sq']), bank.n_params,
+                                _p(s['step']), _p(loss_flag), lr, self.betas[0], self.betas[1], self.eps,
+                                self.weight_decay, self.grad_scale, _stream()), 'adamw')
+
+    def step_tensor(self, m=None):
+        return self._st(m or self.models[0])['step']
+
+    # -- checkpoint format: per-parameter entries in parameter order, like torch.optim.AdamW.state_dict()
+    def state_dict(self):
+        state, idx = {}, 0
+        for m in self.models:
+            s = self._st(m)
+            bank = s['bank']
+            base = bank.flat.data_ptr()
+            for p in m.parameters():
+                off = (p.data_ptr() - base) // 4
+                state[idx] = {'step': s['step'].clone().reshape(()), 'exp_avg': s['exp_avg'][off:off + p.numel()].view(p.shape).clone(),
+                              'exp_avg_sq': s['exp_avg_sq'][off:off + p.numel()].view(p.shape).clone()}
+                idx += 1
+        g = dict(self.param_groups[0])
+        g['params'] = list(range(idx))
+        return {'state': state, 'param_groups': [g]}
+
+    def load_state_dict(self, sd):
+        idx = 0
+        for m in self.models:
+            s = self._st(m)
+            base = s['bank'].flat.data_ptr()
+            for p in m.parameters():
+                e = sd['state'].get(idx)
+                if e is not None:
+                    off = (p.data_ptr() - base) // 4
+                    s['exp_avg'][off:off + p.numel()].copy_(e['exp_avg'].reshape(-1))
+                    s['exp_avg_sq'][off:off + p.numel()].copy_(e['exp_avg_sq'].reshape(-1))
+                    s['step'].fill_(float(e['step']))
+                idx += 1
+        self.param_groups[0]['lr'] = sd['param_groups'][0]['lr']
+
+
+class ExponentialLR:
+    """torch.optim.lr_scheduler.ExponentialLR(optim, gamma, last_epoch) as used at train.py:87-88,326-327."""
+
+    def __init__(self, optimizer, gamma, last_epoch=-1):
+        self.optimizer, self.gamma = optimizer, gamma
+        self.last_epoch = max(last_epoch, 0)
+        self._apply()
+
+    def _apply(self):
+        self.optimizer.param_groups[0]['lr'] = self.optimizer.initial_lr * self.gamma ** self.last_epoch
+
+    def step(self):
+        self.last_epoch += 1
+        self._apply()
+
+    def get_last_lr(self):
+        return [self.optimizer.param_groups[0]['lr']]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# data parallel (one process per GPU, RCCL over xGMI)
+# ---------------------------------------------------------------------------------------------------------------
+class DataParallel:
+    """Plain data parallelism over utterance clips: identical replicas, per-rank batches, gradients
+    summed with all_reduce on each model's flat gradient buffer and averaged inside the AdamW kernel (grad_scale)."""
+
+    def __init__(self, models, process_group=None):
+        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if self.enabled else 1
+        self.models = [m for m in models if m is not None]
+        self.pending = []
+        self.comm_stream = None
+
+    def broadcast_parameters(self):
+        if not self.enabled:
+            return
+        for m in self.models:
+            dist.broadcast(m.bank().flat, src=0, group=self.group)
+
+    def reduce_async(self, flat_grad):
+        """all-reduce `flat_grad` on the communication stream once the kernels already queued on the current stream
+        (which produce it) have finished; returns immediately."""
+        if not self.enabled:
+            return
+        if flat_grad.is_cuda:
+            if self.comm_stream is None:
+                self.comm_stream = torch.cuda.Stream()
+            self.comm_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.comm_stream):
+                w = dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self.pending.append(w)
+        else:
+            self.pending.append(dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def wait(self):
+        for w in self.pending:
+            w.wait()
+        self.pending = []
+        if self.comm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+
+    def reduce_flag(self, flag):
+        """NaN guard made collective: a NaN on any rank makes every rank skip the update."""
+        if self.enabled:
+            dist.all_reduce(flag, op=dist.ReduceOp.SUM, group=self.group)
+        return flag
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the step
+# ---------------------------------------------------------------------------------------------------------------
+class Trainer:
+    """Owns the models and optimizers exactly as train.py:47-88 builds them and runs train.py:121-193 per batch."""
+
+    def __init__(self, generator=None, msd=None, mpd=None, mtd=None, use_mpd=True, use_mtd=True, d_train_times=None,
+                 dev=None, process_group=None):
+        dev = dev or device
+        Generator = globals().get(f'Generator_{hp.generator_ver}')
+        self.generator = (generator or Generator()).to(dev)
+        self.msd = (msd or MultiScaleDiscriminator()).to(dev)
+        self.mpd = (mpd or MultiPeriodDiscriminator()).to(dev) if use_mpd else None
+        self.mtd = (mtd or MultiStftDiscriminator()).to(dev) if use_mtd else None
+        self.discs = [d for d in (self.msd, self.mpd, self.mtd) if d is not None]
+        self.d_train_times = hp.d_train_times if d_train_times is None else d_train_times
+        self.optim_g = AdamW(self.generator.parameters(), hp.learning_rate_g, betas=[hp.adam_b1, hp.adam_b2])
+        self.optim_d = AdamW(itertools.chain(*[d.parameters() for d in self.discs]), hp.learning_rate_d,
+                             betas=[hp.adam_b1, hp.adam_b2])
+        self.scheduler_g = ExponentialLR(self.optim_g, gamma=hp.lr_decay)
+        self.scheduler_d = ExponentialLR(self.optim_d, gamma=hp.lr_decay)
+        self.dp = DataParallel([self.generator, *self.discs], process_group)
+        self.optim_g.grad_scale = self.optim_d.grad_scale = 1.0 / self.dp.world
+        self.dp.broadcast_parameters()
+        self.generator.noise.salt = None
+        self.steps = 0
+        for m in (self.generator, *self.discs):
+            m.train()
+        if self.dp.enabled:
+            for d in self.discs:
+                d.bank().on_flush = self.dp.reduce_async     # overlap each discriminator's all-reduce with backward
+
+    def _freeze(self, flag):
+        for d in self.discs:
+            for p in d.parameters():
+                p.requires_grad_(not flag)
+
+    def d_step(self, y, y_g_hat_detach):
+        """train.py:133-160."""
+        self.optim_d.zero_grad()
+        S = S_g = None
+        if self.mtd is not None:
+            S, S_g = multi_stft_loss(y, y_g_hat_detach, ret_specs=True)
+        losses = {}
+        r, g, _, _ = self.msd(y, y_g_hat_detach)
+        losses['disc_s'] = discriminator_loss(r, g)
+        if self.mpd is not None:
+            r, g, _, _ = self.mpd(y, y_g_hat_detach)
+            losses['disc_p'] = discriminator_loss(r, g)
+        if self.mtd is not None:
+            r, g, _, _ = self.mtd(S, S_g)
+            losses['disc_t'] = discriminator_loss(r, g)
+        total = sum(losses.values())
+        losses['disc_all'] = total
+        total.backward()
+        if self.dp.enabled:
+            for d in self.discs:
+                if getattr(d.bank(), 'on_flush', None) is None:
+                    self.dp.reduce_async(d.bank().gflat)
+            self.dp.wait()
+        self.optim_d.step(self.dp.reduce_flag(total.detach().clone().reshape(1)))
+        return losses
+
+    def g_step(self, y, y_g_hat):
+        """train.py:163-193."""
+        self.optim_g.zero_grad()
+        losses = {}
+        if self.mtd is not None:
+            losses['mstft'], (S, S_g_hat) = multi_stft_loss(y, y_g_hat, ret_loss=True, ret_specs=True)
+        else:
+            losses['mstft'] = multi_stft_loss(y, y_g_hat, ret_loss=True)
+        if hp.envelope_loss or hp.strip_mirror_loss:
+            raise RtgError('envelope / strip-mirror losses are off in hparam.py:87-88 and not on the hot path')
+        losses['dyn'] = dynamic_loss(y, y_g_hat) if hp.dynamic_loss else None
+        total = losses['mstft'] * hp.w_loss_mstft
+        if losses['dyn'] is not None:
+            total = total + losses['dyn'] * hp.w_loss_dyn
+        self._freeze(True)       # the reference lets D weight gradients accumulate and discards them at the next
+        try:                     # optim_d.zero_grad() (train.py:133): skipping them changes no result
+            for tag, d, a, b in (('s', self.msd, y, y_g_hat), ('p', self.mpd, y, y_g_hat),
+                                 ('t', self.mtd, None, None)):
+                if d is None:
+                    continue
+                if tag == 't':
+                    a, b = S, S_g_hat
+                r, g, fr, fg = d(a, b)
+                losses['gen_' + tag] = generator_loss(g, r)
+                losses['fm_' + tag] = feature_loss(fr, fg)
+                total = total + losses['gen_' + tag] + losses['fm_' + tag] * hp.w_loss_fm
+            losses['gen_all'] = total
+            total.backward()
+        finally:
+            self._freeze(False)
+        if self.dp.enabled:
+            self.dp.reduce_async(self.generator.bank().gflat)
+            self.dp.wait()
+        self.optim_g.step(self.dp.reduce_flag(total.detach().clone().reshape(1)))
+        return losses
+
+    def train_step(self, x, y_tmpl, y, noise_list=None):
+        """One iteration of the batch loop (train.py:121-193).  x [B,80,T/256], y_tmpl / y [B,1,T] on the GPU.
+        Returns (d_losses, g_losses) as device scalars — nothing here synchronises with the host."""
+        with stft_cache():
+            y_g_hat = self.generator(x, y_tmpl, noise_list) if noise_list is not None else self.generator(x, y_tmpl)
+            assert y.shape[-1] == y_g_hat.shape[-1]
+            y_det = y_g_hat.detach()
+            dl = {}
+            for _ in range(self.d_train_times):
+                dl = self.d_step(y, y_det)
+            gl = self.g_step(y, y_g_hat)
+        self.steps += 1
+        return dl, gl
+
+    def end_epoch(self):
+        self.scheduler_g.step()
+        self.scheduler_d.step()
+
+    # -- checkpoints in the reference's layout (train.py:263-273)
+    def checkpoint_dicts(self, epoch):
+        do = {'msd': self.msd.state_dict(), 'optim_g': self.optim_g.state_dict(), 'optim_d': self.optim_d.state_dict(),
+              'steps': self.steps, 'epoch': epoch}
+        if self.mpd is not None:
+            do['mpd'] = self.mpd.state_dict()
+        if self.mtd is not None:
+            do['mtd'] = self.mtd.state_dict()
+        return {'generator': self.generator.state_dict()}, do
+
+    def save(self, log_path, epoch):
+        g, do = self.checkpoint_dicts(epoch)
+        save_checkpoint(os.path.join(log_path, f'g_{self.steps:08d}'), g)        # noqa: F405
+        save_checkpoint(os.path.join(log_path, f'do_{self.steps:08d}'), do)      # noqa: F405
+
+    def resume(self, log_path):
+        cp_g, cp_do = scan_checkpoint(log_path, 'g_'), scan_checkpoint(log_path, 'do_')   # noqa: F405
+        if cp_g is None or cp_do is None:
+            return -1
+        self.generator.load_state_dict(load_checkpoint(cp_g, device)['generator'])         # noqa: F405
+        sd = load_checkpoint(cp_do, device)                                                # noqa: F405
+        for tag, m in (('msd', self.msd), ('mpd', self.mpd), ('mtd', self.mtd)):
+            if m is not None and tag in sd:
+                m.load_state_dict(sd[tag])
+        self.optim_g.load_state_dict(sd['optim_g'])
+        self.optim_d.load_state_dict(sd['optim_d'])
+        self.steps = sd['steps']
+        return sd['epoch']
