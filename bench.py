@@ -92,7 +92,7 @@ def roofline(trainer, batch):
     torch.cuda.synchronize()
     rec, ops.PROFILE = ops.PROFILE, None
     agg = {}
-    for kernel, variant, flop, e0, e1 in rec:
+    for kernel, variant, flop, e0, e1, _label in rec:
         k = (kernel, variant)
         a = agg.setdefault(k, [0, 0.0, 0.0])
         a[0] += 1

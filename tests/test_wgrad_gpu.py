@@ -1,0 +1,79 @@
+"""rtg_conv1d_wgrad + rtg_weightnorm_backward (HIP) against torch autograd on the CPU, through the C ABI.  GPU only."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+CASES = [
+    # B, C_in, C_out, L, K, stride, dil, pad, groups
+    (2, 32, 32, 1000, 7, 1, 9, 27, 1),
+    (3, 64, 64, 300, 3, 1, 3, 3, 1),
+    (2, 128, 128, 32, 3, 1, 9, 9, 1),        # dilation wider than the row
+    (2, 16, 32, 2048, 7, 4, 1, 3, 1),
+    (2, 64, 128, 256, 15, 8, 1, 7, 1),
+    (2, 1, 16, 1024, 7, 1, 1, 3, 1),
+    (2, 32, 1, 1024, 7, 1, 1, 3, 1),
+    (2, 1, 32, 1024, 15, 1, 1, 7, 1),
+    (2, 32, 64, 1024, 41, 2, 1, 20, 4),
+    (2, 128, 512, 512, 41, 4, 1, 20, 32),
+    (2, 512, 512, 128, 41, 4, 1, 20, 64),
+    (22, 512, 512, 10, 5, 1, 1, 2, 1),       # MPD tail: 10 positions per clip -> clips packed per tile
+    (14, 256, 512, 44, 5, 3, 1, 2, 1),       # MPD strided, short rows
+    (10, 512, 1, 21, 3, 1, 1, 1, 1),
+    (5, 48, 32, 300, 7, 1, 1, 3, 1),
+]
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_wgrad_and_weightnorm_backward(case):
+    from rtg.lib import lib, WgradDesc, WnBwdJob, NormJob, check
+    B, Cin, Cout, L, K, s, d, p, g = case
+    gen = torch.Generator().manual_seed(abs(hash(case)) % (2 ** 31))
+    x = torch.randn(B, Cin, L, generator=gen)
+    v = torch.randn(Cout, Cin // g, K, generator=gen, dtype=torch.float64, requires_grad=True)
+    gg = (1 + 0.1 * torch.randn(Cout, 1, 1, generator=gen, dtype=torch.float64)).requires_grad_(True)
+    bias = torch.zeros(Cout, dtype=torch.float64, requires_grad=True)
+    w = gg * v / v.flatten(1).norm(dim=1).reshape(-1, 1, 1)
+    y = F.leaky_relu(F.conv1d(F.leaky_relu(x.double(), 0.15), w, bias, s, p, d, g), 0.2)
+    dy = torch.randn(y.shape, generator=gen)
+    y.backward(dy.double())
+    Lo = y.shape[-1]
+
+    dev = 'cuda'
+    rows, inner = Cout, (Cin // g) * K
+    flat = torch.cat([gg.detach().flatten(), v.detach().flatten(), bias.detach()]).float().to(dev)
+    gflat = torch.zeros_like(flat)
+    scales = torch.empty(2 * rows, device=dev)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def table(job):
+        return torch.frombuffer(bytearray(bytes(memoryview((type(job) * 1)(job)).cast('B'))), dtype=torch.uint8).to(dev)
+
+    check(lib.rtg_weightnorm_scales(_ptr(table(NormJob(0, rows, 0, rows, inner))), 1, rows, _ptr(flat), _ptr(scales), st))
+    wd = WgradDesc(B=B, C1=Cin, C2=0, L_in=L, groups=g, Cg=Cin // g, Mg=Cout // g, K=K, stride=s, dil=d, pad=p, Q=Lo,
+                   dy_L=Lo, pre_mode=1, pre_slope=0.15, gy_mode=2, gy_slope=0.2, gy_scale=1.0, splits=1, part_stride=0)
+    splits = lib.rtg_wgrad_splits(C.byref(wd))
+    assert splits >= 1
+    stride = rows * (inner + 1)
+    part = torch.full((splits * stride,), float('nan'), device=dev)
+    wd.splits, wd.part_stride = splits, stride
+    xd, dyd, outd = x.to(dev), dy.to(dev), y.detach().float().to(dev)
+    check(lib.rtg_conv1d_wgrad(C.byref(wd), _ptr(xd), None, _ptr(dyd), _ptr(outd), _ptr(part), st))
+    job = WnBwdJob(0, rows, rows + rows * inner, 0, (part.data_ptr() - flat.data_ptr()) // 4, stride, splits, rows, inner)
+    check(lib.rtg_weightnorm_backward(_ptr(table(job)), 1, rows, inner, _ptr(flat), _ptr(scales), _ptr(flat),
+                                      _ptr(gflat), st))
+    torch.cuda.synchronize()
+    got = gflat.cpu().double()
+    for name, ref, sl in (('g', gg.grad.flatten(), slice(0, rows)), ('v', v.grad.flatten(), slice(rows, rows + rows * inner)),
+                          ('bias', bias.grad, slice(rows + rows * inner, None))):
+        err = (got[sl] - ref).abs().max().item()
+        assert err <= 2e-4 * ref.abs().max().item() + 1e-5, (name, err, ref.abs().max().item())

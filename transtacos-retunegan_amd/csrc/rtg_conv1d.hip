@@ -9,13 +9,18 @@
 //   workgroup   256 threads = 4 wavefronts arranged WM x WN; wave tile = MT x NT MFMA tiles of TM x TM
 //               (TM = 32: v_mfma_f32_32x32x2_f32, TM = 16: v_mfma_f32_16x16x4_f32 for 16-row groups).
 //   B operand   the input patch of 16 channels x (BN-1)*stride+(K-1)*dil+1 samples is staged ONCE per block into LDS
-//               (coalesced global loads, input activation fused at staging), double buffered across channel chunks;
-//               every tap / every output row re-reads it from LDS with ds_read_b32 at lane-consecutive addresses
-//               (strided convs de-interleave the patch by phase so that lanes stay bank-conflict free).
+//               (coalesced, branch-free global loads issued back to back; input activation fused at staging), double
+//               buffered across channel chunks; every tap / every output row re-reads it from LDS with ds_read_b32 at
+//               lane-consecutive addresses (strided convs de-interleave the patch by phase: bank-conflict free).
+//   short rows  when a clip's output row is much shorter than the block tile (MPD / MSD tails: 10..128 positions)
+//               several clips are packed side by side into one tile ("segments" of seg_len virtual positions), so the
+//               MFMA columns are not spent on padding.
 //   A operand   weights are pre-packed (rtg_weights_pack) so that one MFMA fragment is 64 consecutive floats:
 //               each wave loads its fragments straight from L2 with one coalesced 256-B load, prefetched one
 //               (chunk, tap) step ahead — no LDS traffic and no barrier for weights.
 //   epilogue    bias, leaky-relu-derivative mask, residual, scale, activation, optional polyphase "shuffle" store.
+#include <type_traits>
+
 #include "rtg_common.h"
 
 namespace {
@@ -31,6 +36,7 @@ struct ConvArgs {
   float act_slope;
   int accumulate;
   int n_cc, n_mt, WM, WN, PW, PH, ROW, m_blocks;
+  int seg_len, seg_pitch, seg_nb, seg_pw;   // segment packing (seg_len == 0: one clip per block column)
 };
 
 template <int TM>
@@ -54,6 +60,45 @@ struct Mfma<16> {
   static __device__ __forceinline__ int row(int lane, int r) { return (lane >> 4) * 4 + r; }
 };
 
+// Global -> register staging of RPW patch rows of channel chunk `cc` through buffer loads: out-of-range elements
+// (zero padding, channels past Cg, other clips' rows) get an offset beyond num_records, for which the hardware returns
+// 0 without touching memory — no branches, no clamping, all loads of a chunk issue back to back.
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+#define RTG_OOB 0x80000000u
+
+__device__ __forceinline__ float buf_load(rsrc_t r, unsigned off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+}
+
+template <bool AUX, int RPW, int MAXIT>
+__device__ __forceinline__ void stage_rows(const ConvArgs& a, rsrc_t r1, rsrc_t r2, rsrc_t raux,
+                                           float (&st)[RPW][MAXIT], const unsigned (&eb)[MAXIT],
+                                           const unsigned (&epos)[MAXIT], int cc, int wave, int g, float slope,
+                                           bool aux_tanh) {
+#pragma unroll
+  for (int i = 0; i < RPW; ++i) {
+    const int c = cc * RTG_CK + wave * RPW + i;
+    const int gc = g * a.Cg + c;
+    const bool in1 = gc < a.C1;
+    const rsrc_t r = in1 ? r1 : r2;
+    const unsigned cstride = (unsigned)(in1 ? a.C1 : a.C2) * (unsigned)a.L_in * 4u;   // bytes per clip
+    const unsigned rowoff = (unsigned)(in1 ? gc : gc - a.C1) * (unsigned)a.L_in * 4u;
+    const unsigned rowoob = (c < a.Cg) ? 0u : RTG_OOB;
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+      // valid byte offsets stay below 2^31 (host-checked); the OOB bit is OR-ed in, never added
+      const unsigned offs = (eb[it] * cstride + rowoff + (epos[it] & ~RTG_OOB)) | (epos[it] & RTG_OOB) | rowoob;
+      float v = buf_load(r, offs);
+      if (AUX) {
+        const float av = buf_load(raux, offs);
+        v *= aux_tanh ? (1.f - av * av) : (av > 0.f ? 1.f : slope);
+      }
+      st[i][it] = v;       // the leaky-relu of the plain path is applied when the tile is written to LDS, so that
+                           // nothing here waits for the loads: they stay in flight under the MFMA loop
+    }
+  }
+}
+
 template <int TM, int MT, int NT>
 __global__ __launch_bounds__(RTG_THREADS) void conv1d_mfma_kernel(const ConvArgs a) {
   using M = Mfma<TM>;
@@ -68,63 +113,62 @@ __global__ __launch_bounds__(RTG_THREADS) void conv1d_mfma_kernel(const ConvArgs
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / a.WN, wn = wave - wm * a.WN;
-  const int b = blockIdx.z;
   const int g = blockIdx.y / a.m_blocks, mb = blockIdx.y - g * a.m_blocks;
   const int mt0 = (mb * a.WM + wm) * MT;
   const int BN = a.WN * NT * TM;
-  const int q_blk = blockIdx.x * BN;
+  const bool packed = a.seg_len > 0;
+  const int b0 = packed ? blockIdx.z * a.seg_nb : blockIdx.z;   // first clip of this block
+  const int q_blk = packed ? 0 : blockIdx.x * BN;
   const int o_start = q_blk * a.stride - a.pad;
   const int bufsz = RTG_CK * a.ROW;
 
-  // ---- staging geometry (per thread, independent of the channel chunk)
+  // ---- staging geometry (per thread, independent of the channel chunk): LDS offset, clip index and byte position
+  // within the row (with the out-of-bounds bit set for zero padding / other clips)
   int loff[MAXIT];
+  unsigned epos[MAXIT], eb[MAXIT];
 #pragma unroll
   for (int it = 0; it < MAXIT; ++it) {
     const int o = lane + 64 * it;
     loff[it] = (a.stride == 1) ? o : (o % a.stride) * a.PH + o / a.stride;
+    int pos, bb;
+    bool ok = o < a.PW;
+    if (packed) {
+      const int seg = o / a.seg_pitch, w = o - seg * a.seg_pitch;
+      bb = b0 + seg;
+      pos = w - a.pad;
+      ok = ok && seg < a.seg_nb && bb < a.B && w < a.seg_pw;
+    } else {
+      bb = b0;
+      pos = o_start + o;
+    }
+    ok = ok && pos >= 0 && pos < a.L_in;
+    epos[it] = ok ? (unsigned)pos * 4u : RTG_OOB;
+    eb[it] = ok ? (unsigned)bb : 0u;
   }
   float st[RPW][MAXIT];
+  const bool aux_tanh = a.pre_mode == RTG_PRE_MUL_DTANH;
+  const float slope = (a.pre_mode == RTG_PRE_NONE) ? 1.f : a.pre_slope;
+  const float wslope = (a.pre_mode == RTG_PRE_LRELU) ? a.pre_slope : 1.f;   // applied at the LDS write
+  const rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.x1, 0, a.B * a.C1 * a.L_in * 4, 0x00020000);
+  const rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x2 ? a.x2 : a.x1), 0,
+                                                      a.x2 ? a.B * a.C2 * a.L_in * 4 : 0, 0x00020000);
+  const rsrc_t raux = __builtin_amdgcn_make_buffer_rsrc((void*)(a.aux ? a.aux : a.x1), 0,
+                                                        a.aux ? a.B * a.C1 * a.L_in * 4 : 0, 0x00020000);
 
-  auto gload = [&](int cc) {
-#pragma unroll
-    for (int i = 0; i < RPW; ++i) {
-      const int c = cc * RTG_CK + wave * RPW + i;
-      const int gc = g * a.Cg + c;
-      const bool cvalid = c < a.Cg;
-      const float* src;
-      const float* asrc = nullptr;
-      if (gc < a.C1) {
-        src = a.x1 + ((size_t)b * a.C1 + gc) * a.L_in;
-        if (a.aux) asrc = a.aux + ((size_t)b * a.C1 + gc) * a.L_in;
-      } else {
-        src = a.x2 + ((size_t)b * a.C2 + (gc - a.C1)) * a.L_in;
-      }
-#pragma unroll
-      for (int it = 0; it < MAXIT; ++it) {
-        const int o = lane + 64 * it;
-        const int pos = o_start + o;
-        const bool ok = cvalid && o < a.PW && pos >= 0 && pos < a.L_in;
-        float v = ok ? src[pos] : 0.f;
-        if (a.pre_mode == RTG_PRE_LRELU) {
-          v = rtg_lrelu(v, a.pre_slope);
-        } else if (a.pre_mode == RTG_PRE_MUL_DLRELU) {
-          const float av = ok ? asrc[pos] : 0.f;
-          v = v * (av > 0.f ? 1.f : a.pre_slope);
-        } else if (a.pre_mode == RTG_PRE_MUL_DTANH) {
-          const float av = ok ? asrc[pos] : 0.f;
-          v = v * (1.f - av * av);
-        }
-        st[i][it] = v;
-      }
-    }
+  auto stage = [&](int cc) __attribute__((always_inline)) {
+    if (a.aux) stage_rows<true, RPW, MAXIT>(a, r1, r2, raux, st, eb, epos, cc, wave, g, slope, aux_tanh);
+    else stage_rows<false, RPW, MAXIT>(a, r1, r2, raux, st, eb, epos, cc, wave, g, slope, aux_tanh);
   };
-  auto swrite = [&](float* buf) {
+  auto swrite = [&](float* buf) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
       float* rowp = buf + (wave * RPW + i) * a.ROW;
 #pragma unroll
       for (int it = 0; it < MAXIT; ++it)
-        if (lane + 64 * it < a.PW) rowp[loff[it]] = st[i][it];
+        if (lane + 64 * it < a.PW) {
+          const float v = st[i][it];
+          rowp[loff[it]] = v > 0.f ? v : v * wslope;
+        }
     }
   };
 
@@ -154,14 +198,14 @@ __global__ __launch_bounds__(RTG_THREADS) void conv1d_mfma_kernel(const ConvArgs
 #pragma unroll
     for (int cp = 0; cp < CPN; ++cp) acur[i][cp] = wptr[i][cp * 64];
 
-  gload(0);
+  stage(0);
   swrite(lds);
   __syncthreads();
 
   int step = 0;
   for (int cc = 0; cc < a.n_cc; ++cc) {
     const float* buf = lds + (cc & 1) * bufsz;
-    if (cc + 1 < a.n_cc) gload(cc + 1);
+    if (cc + 1 < a.n_cc) stage(cc + 1);
     for (int tap = 0; tap < a.K; ++tap, ++step) {
       // prefetch the next step's A fragments (64 consecutive floats per fragment, L2 resident)
       if (step + 1 < n_steps) {
@@ -198,7 +242,14 @@ __global__ __launch_bounds__(RTG_THREADS) void conv1d_mfma_kernel(const ConvArgs
     if (mt0 + i >= a.n_mt) continue;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      const int q = q_blk + (wn * NT + j) * TM + n_lane;
+      int q = q_blk + (wn * NT + j) * TM + n_lane;
+      int b = b0;
+      if (packed) {
+        const int seg = q / a.seg_len;
+        q -= seg * a.seg_len;
+        b = b0 + seg;
+        if (seg >= a.seg_nb || b >= a.B) continue;
+      }
       if (q >= a.Q) continue;
 #pragma unroll
       for (int r = 0; r < M::NREG; ++r) {
@@ -240,6 +291,7 @@ __global__ __launch_bounds__(RTG_THREADS) void conv1d_mfma_kernel(const ConvArgs
 
 struct TileCfg {
   int MT, NT, WM, WN;
+  int seg_len, seg_nb;   // > 0: clips packed per block
 };
 
 template <int TM, int MT, int NT>
@@ -256,25 +308,45 @@ int launch(const ConvArgs& a, dim3 grid, size_t lds_bytes, hipStream_t s) {
 // Patch width (floats per channel) for a block covering BN output positions.
 inline int patch_width(int BN, int stride, int K, int dil) { return (BN - 1) * stride + (K - 1) * dil + 1; }
 
+// virtual positions one clip occupies when clips are packed side by side: its Q outputs plus the gap that keeps the
+// next clip's input patch from overlapping (pitch = seg_len * stride >= (Q-1)*stride + (K-1)*dil + 1)
+inline int segment_len(int Q, int stride, int K, int dil) {
+  const int extra = (K - 1) * dil + 1 - stride;
+  return Q + (extra > 0 ? (extra + stride - 1) / stride : 0);
+}
+
 TileCfg pick_tiles(int TM, int n_mt, int Q, int B, int groups, int stride, int K, int dil) {
-  static const TileCfg c32[] = {{2, 2, 1, 4}, {2, 2, 2, 2}, {2, 2, 4, 1}, {1, 2, 1, 4}, {1, 2, 2, 2}, {1, 2, 4, 1},
-                                {1, 4, 1, 4}, {1, 4, 2, 2}, {2, 1, 1, 4}, {2, 1, 2, 2}, {2, 1, 4, 1}, {1, 1, 1, 4},
-                                {1, 1, 2, 2}, {1, 1, 4, 1}};
-  static const TileCfg c16[] = {{1, 4, 1, 4}, {1, 2, 1, 4}, {1, 1, 1, 4}, {1, 4, 2, 2}, {1, 2, 2, 2}, {1, 1, 2, 2},
-                                {1, 2, 4, 1}, {1, 1, 4, 1}};
-  const TileCfg* cs = TM == 32 ? c32 : c16;
-  const int n = TM == 32 ? (int)(sizeof(c32) / sizeof(TileCfg)) : (int)(sizeof(c16) / sizeof(TileCfg));
-  TileCfg best = {0, 0, 0, 0};
+  static const int c32[][4] = {{2, 2, 1, 4}, {2, 2, 2, 2}, {2, 2, 4, 1}, {1, 2, 1, 4}, {1, 2, 2, 2}, {1, 2, 4, 1},
+                               {1, 4, 1, 4}, {1, 4, 2, 2}, {2, 1, 1, 4}, {2, 1, 2, 2}, {2, 1, 4, 1}, {1, 1, 1, 4},
+                               {1, 1, 2, 2}, {1, 1, 4, 1}};
+  static const int c16[][4] = {{1, 4, 1, 4}, {1, 2, 1, 4}, {1, 1, 1, 4}, {1, 4, 2, 2}, {1, 2, 2, 2}, {1, 1, 2, 2},
+                               {1, 2, 4, 1}, {1, 1, 4, 1}};
+  const int(*cs)[4] = TM == 32 ? c32 : c16;
+  const int n = TM == 32 ? (int)(sizeof(c32) / sizeof(c32[0])) : (int)(sizeof(c16) / sizeof(c16[0]));
+  const int Lseg = segment_len(Q, stride, K, dil);
+  TileCfg best = {0, 0, 0, 0, 0, 0};
   double best_score = -1.0;
   for (int i = 0; i < n; ++i) {
-    const TileCfg c = cs[i];
+    TileCfg c = {cs[i][0], cs[i][1], cs[i][2], cs[i][3], 0, 0};
     const int BN = c.WN * c.NT * TM;
     if (patch_width(BN, stride, K, dil) > RTG_PW_MAX) continue;
     const int mrows = c.WM * c.MT;
     const int m_blocks = rtg_ceil_div(n_mt, mrows);
-    const int q_blocks = rtg_ceil_div(Q, BN);
-    const double eff = ((double)n_mt / (m_blocks * mrows)) * ((double)Q / ((double)q_blocks * BN));
-    const double blocks = (double)m_blocks * q_blocks * groups * B;
+    double eff_q, n_blocks_q;
+    const int nb = BN / Lseg;
+    if (nb >= 2 && B >= 2) {             // pack nb clips per block
+      c.seg_len = Lseg;
+      c.seg_nb = nb < B ? nb : B;
+      const int zb = rtg_ceil_div(B, c.seg_nb);
+      eff_q = ((double)B * Q) / ((double)zb * BN);
+      n_blocks_q = zb;
+    } else {
+      const int q_blocks = rtg_ceil_div(Q, BN);
+      eff_q = (double)Q / ((double)q_blocks * BN);
+      n_blocks_q = (double)q_blocks * B;
+    }
+    const double eff = ((double)n_mt / (m_blocks * mrows)) * eff_q;
+    const double blocks = (double)m_blocks * n_blocks_q * groups;
     const double fill = blocks >= 512.0 ? 1.0 : blocks / 512.0;
     const double reuse = (double)(c.MT * c.NT) / (c.MT + c.NT);   // MFMAs per operand fragment fetched
     const double score = eff * fill * (0.6 + 0.4 * (reuse > 1.0 ? 1.0 : reuse));
@@ -322,6 +394,7 @@ extern "C" int rtg_conv1d(const RtgConv1dDesc* d, const float* x1, const float* 
   if ((long long)d->groups * d->Mg != (long long)d->out_C * d->shuf_S) return RTG_EINVAL;
   if (d->shuf_S == 1 && d->Q > d->out_L) return RTG_EINVAL;
   if (d->B > 65535) return RTG_ERANGE;
+  if ((long long)d->B * (d->C1 > d->C2 ? d->C1 : d->C2) * d->L_in * 4 >= (1ll << 31)) return RTG_ERANGE;   // 32-bit buffer offsets
 
   ConvArgs a;
   a.x1 = x1; a.x2 = x2; a.aux = (d->pre_mode >= RTG_PRE_MUL_DLRELU) ? aux : nullptr; a.wp = wp; a.bias = bias;
@@ -340,6 +413,9 @@ extern "C" int rtg_conv1d(const RtgConv1dDesc* d, const float* x1, const float* 
   a.WM = c.WM; a.WN = c.WN;
   const int BN = c.WN * c.NT * TM;
   a.PW = patch_width(BN, d->stride, d->K, d->dil);
+  a.seg_len = c.seg_len; a.seg_nb = c.seg_nb;
+  a.seg_pitch = c.seg_len > 0 ? c.seg_len * d->stride : 1;
+  a.seg_pw = patch_width(d->Q, d->stride, d->K, d->dil);
   int row;
   if (d->stride == 1) {
     a.PH = a.PW;
@@ -352,7 +428,8 @@ extern "C" int rtg_conv1d(const RtgConv1dDesc* d, const float* x1, const float* 
   a.m_blocks = rtg_ceil_div(a.n_mt, c.WM * c.MT);
   const long long gy = (long long)d->groups * a.m_blocks;
   if (gy > 65535) return RTG_ERANGE;
-  dim3 grid(rtg_ceil_div(d->Q, BN), (unsigned)gy, d->B);
+  dim3 grid(c.seg_len > 0 ? 1 : rtg_ceil_div(d->Q, BN), (unsigned)gy,
+            c.seg_len > 0 ? rtg_ceil_div(d->B, c.seg_nb) : d->B);
   const size_t lds_bytes = (size_t)2 * RTG_CK * a.ROW * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
 

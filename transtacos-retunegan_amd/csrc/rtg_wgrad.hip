@@ -1,21 +1,32 @@
 // rtg_wgrad.hip — convolution backward w.r.t. weight and bias on the fp32 matrix cores (see include/rtg.h).
 //
 // GEMM view: rows = output channels m of one group, columns = (input channel c, tap j) pairs of a channel chunk
-// (+ one virtual "ones" column whose accumulator is the bias gradient), reduction over (batch, output position).
-//   A[m][t]   = gy[b, m, t]                      staged as an LDS tile [rows][TT] with an odd row pitch
-//   B[t][c,j] = pre(x[b, c, t*stride - pad + j*dil])   read from an LDS patch [channels][ROW]; the lane's (c,j) fixes a
-//               base address once per tile, the time loop only adds stride per step
-// A block owns (group, MB m-tiles, one channel chunk, one split of the reduction) and walks its share of the
-// (batch, time-tile) list with register-prefetched double buffering; its 4 waves share the staged tiles and each
-// owns up to TPW accumulator tiles.  Partials are stored per split (fixed-order reduction in rtg_weightnorm_backward).
+// (+ one virtual "ones" column whose accumulator is the bias gradient), reduction over (clip, output position).
+//   A[m][v]   = gy[b, m, t]                      staged as an LDS tile [rows][TT] with an odd row pitch
+//   B[v][c,j] = pre(x[b, c, t*stride - pad + j*dil])   read from an LDS patch [channels][ROW]; the lane's (c,j) fixes a
+//               base address once per tile, the reduction loop only adds stride per step
+// The reduction index v ("virtual position") walks tiles of TT = 64 positions.  Long rows: a tile is 64 consecutive
+// positions of one clip.  Short rows (MPD / MSD tails, 10..60 positions): several clips are packed side by side in one
+// tile (segments of seg_len positions, pitch seg_len*stride in the patch) so the MFMA reduction is not spent on padding.
+// A block owns (group, MB m-tiles, one channel chunk, one split of the reduction) and walks its share of the tile list
+// with register-prefetched double buffering (buffer loads with hardware bounds checking: branch-free, all in flight
+// under the MFMA loop); its 4 waves share the staged tiles and each owns up to TPW accumulator tiles.  Partials are
+// stored per split (fixed-order reduction in rtg_weightnorm_backward).
 #include "rtg_common.h"
 
 namespace {
 
-constexpr int TT = 64;          // reduction (time) steps per staged tile
+constexpr int TT = 64;          // reduction (virtual position) steps per staged tile
 constexpr int ROWD = 81;        // LDS pitch of the gy tile: odd, and 81^-1 = 17 (mod 32) keeps 16-row reads conflict free
 constexpr int TPW = 4;          // accumulator tiles per wave
 constexpr int MAXROWS = 64;     // gy rows staged per block
+
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+#define RTG_OOB 0x80000000u
+
+__device__ __forceinline__ float buf_load(rsrc_t r, unsigned off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+}
 
 struct WgArgs {
   const float *x1, *x2, *dy, *gy_aux;
@@ -27,7 +38,8 @@ struct WgArgs {
   float gy_slope, gy_scale;
   int splits;
   long long part_stride;
-  int CKW, n_cchunk, MB, m_blocks, NTB, n_ttiles, PW, ROW, ones_off;
+  int CKW, n_cchunk, MB, m_blocks, NTB, n_ttiles, n_tiles_total, PW, ROW, ones_off;
+  int seg_len, seg_pitch, seg_nb, seg_pw;   // seg_len == 0: one clip per tile
 };
 
 template <int TM>
@@ -74,6 +86,7 @@ __global__ __launch_bounds__(RTG_THREADS) void wgrad_kernel(const WgArgs a) {
   const int cw = min(a.CKW, a.Cg - c0);
   const int rows_blk = a.MB * TM;
   const int m0 = mb * rows_blk;                      // first row (within group) of this block
+  const bool packed = a.seg_len > 0;
 
   const int xbuf_sz = a.CKW * a.ROW;                 // floats
   const int dbuf_sz = rows_blk * ROWD;
@@ -97,52 +110,83 @@ __global__ __launch_bounds__(RTG_THREADS) void wgrad_kernel(const WgArgs a) {
     b_base[k] = (cl < a.CKW) ? (cl * a.ROW + j * a.dil + kk * a.stride) : (-(1 << 20) + kk * a.stride);
   }
 
-  float sx[XR][MAXIT], sd[DR];
+  // ---- static staging geometry
+  // x patch element o = lane + 64*it of a row: (segment, position within the clip's patch)
+  int xseg[MAXIT], xw[MAXIT];
+#pragma unroll
+  for (int it = 0; it < MAXIT; ++it) {
+    const int o = lane + 64 * it;
+    if (packed) {
+      xseg[it] = o / a.seg_pitch;
+      xw[it] = o - xseg[it] * a.seg_pitch;
+      if (xseg[it] >= a.seg_nb || xw[it] >= a.seg_pw || o >= a.PW) xw[it] = -(1 << 28);   // never valid
+    } else {
+      xseg[it] = 0;
+      xw[it] = (o < a.PW) ? o : -(1 << 28);
+    }
+  }
+  // gy tile column = lane: (segment, position within the clip)
+  const int dseg = packed ? lane / a.seg_len : 0;
+  const int dt = packed ? lane - dseg * a.seg_len : lane;
+  const bool dcol_ok = packed ? (dseg < a.seg_nb) : true;
 
-  auto gload = [&](int tl) {
-    const int b = tl / a.n_ttiles, tt = tl - b * a.n_ttiles;
-    const int t0 = tt * TT;
+  const rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.x1, 0, a.B * a.C1 * a.L_in * 4, 0x00020000);
+  const rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x2 ? a.x2 : a.x1), 0,
+                                                      a.x2 ? a.B * a.C2 * a.L_in * 4 : 0, 0x00020000);
+  const int dy_bytes = a.B * a.groups * a.Mg * a.dy_L * 4;
+  const rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, dy_bytes, 0x00020000);
+  const rsrc_t raux = __builtin_amdgcn_make_buffer_rsrc((void*)(a.gy_aux ? a.gy_aux : a.dy), 0,
+                                                        a.gy_aux ? dy_bytes : 0, 0x00020000);
+  const bool has_aux = a.gy_aux != nullptr && (a.gy_mode == RTG_PRE_MUL_DLRELU || a.gy_mode == RTG_PRE_MUL_DTANH);
+  const float xslope = (a.pre_mode == RTG_PRE_LRELU) ? a.pre_slope : 1.f;
+  const float gslope = (a.gy_mode == RTG_PRE_LRELU) ? a.gy_slope : 1.f;
+
+  float sx[XR][MAXIT], sd[DR], sa[DR];
+
+  auto gload = [&](int tl) __attribute__((always_inline)) {
+    int b0, t0;
+    if (packed) { b0 = tl * a.seg_nb; t0 = 0; }
+    else        { b0 = tl / a.n_ttiles; t0 = (tl - b0 * a.n_ttiles) * TT; }
     const int o_start = t0 * a.stride - a.pad;
     // input patch: rows c0 + wave*XR + i
 #pragma unroll
     for (int i = 0; i < XR; ++i) {
       const int cl = wave * XR + i;
-      const int gc = a.groups == 1 ? (c0 + cl) : (g * a.Cg + c0 + cl);
-      const bool cvalid = cl < cw;
-      const float* src = (gc < a.C1) ? a.x1 + ((size_t)b * a.C1 + gc) * a.L_in
-                                     : a.x2 + ((size_t)b * a.C2 + (gc - a.C1)) * a.L_in;
+      const int gc = g * a.Cg + c0 + cl;
+      const bool in1 = gc < a.C1;
+      const rsrc_t r = in1 ? r1 : r2;
+      const unsigned cstride = (unsigned)(in1 ? a.C1 : a.C2) * (unsigned)a.L_in * 4u;
+      const unsigned rowoff = (unsigned)(in1 ? gc : gc - a.C1) * (unsigned)a.L_in * 4u;
+      const unsigned rowoob = (cl < cw) ? 0u : RTG_OOB;
 #pragma unroll
       for (int it = 0; it < MAXIT; ++it) {
-        const int o = lane + 64 * it;
-        const int pos = o_start + o;
-        const bool ok = cvalid && o < a.PW && pos >= 0 && pos < a.L_in;
-        float v = ok ? src[pos] : 0.f;
-        if (a.pre_mode == RTG_PRE_LRELU) v = rtg_lrelu(v, a.pre_slope);
-        sx[i][it] = v;
+        const int pos = o_start + xw[it];
+        const int bb = b0 + xseg[it];
+        const bool ok = pos >= 0 && pos < a.L_in && bb < a.B;   // xw = -2^28 makes pos negative
+        const unsigned off = ok ? ((unsigned)bb * cstride + rowoff + (unsigned)pos * 4u) | rowoob : RTG_OOB;
+        sx[i][it] = buf_load(r, off);
       }
     }
     // gy tile: rows m0 + wave + 4*i, column = lane
+    {
+      const int bb = b0 + dseg;
+      const int t = t0 + dt;
+      const bool colok = dcol_ok && bb < a.B && t < a.Q;
+      const unsigned coloff = colok ? ((unsigned)bb * (unsigned)(a.groups * a.Mg) * (unsigned)a.dy_L + (unsigned)t) * 4u
+                                    : RTG_OOB;
 #pragma unroll
-    for (int i = 0; i < DR; ++i) {
-      const int rl = wave + 4 * i;
-      const int m = m0 + rl;
-      const int t = t0 + lane;
-      const bool ok = rl < rows_blk && m < a.Mg && t < a.Q;
-      const size_t idx = ((size_t)b * (a.groups * a.Mg) + g * a.Mg + m) * a.dy_L + t;
-      float v = ok ? a.dy[idx] : 0.f;
-      if (a.gy_mode == RTG_PRE_MUL_DLRELU) {
-        const float av = ok ? a.gy_aux[idx] : 0.f;
-        v *= (av > 0.f ? 1.f : a.gy_slope);
-      } else if (a.gy_mode == RTG_PRE_MUL_DTANH) {
-        const float av = ok ? a.gy_aux[idx] : 0.f;
-        v *= (1.f - av * av);
-      } else if (a.gy_mode == RTG_PRE_LRELU) {
-        v = rtg_lrelu(v, a.gy_slope);
+      for (int i = 0; i < DR; ++i) {
+        const int rl = wave + 4 * i;
+        const int m = m0 + rl;
+        const bool rok = rl < rows_blk && m < a.Mg;
+        const unsigned off = rok ? (coloff + (unsigned)(g * a.Mg + m) * (unsigned)a.dy_L * 4u) | (coloff & RTG_OOB)
+                                 : RTG_OOB;
+        sd[i] = buf_load(rdy, off);
+        if (has_aux) sa[i] = buf_load(raux, off);
       }
-      sd[i] = v * a.gy_scale;
     }
   };
-  auto swrite = [&](int which) {
+  auto swrite = [&](int which) __attribute__((always_inline)) {
     float* xb = lds + which * (xbuf_sz + dbuf_sz);
     float* db = xb + xbuf_sz;
 #pragma unroll
@@ -151,17 +195,29 @@ __global__ __launch_bounds__(RTG_THREADS) void wgrad_kernel(const WgArgs a) {
       if (cl < a.CKW) {
 #pragma unroll
         for (int it = 0; it < MAXIT; ++it)
-          if (lane + 64 * it < a.PW) xb[cl * a.ROW + lane + 64 * it] = sx[i][it];
+          if (lane + 64 * it < a.PW) {
+            const float v = sx[i][it];
+            xb[cl * a.ROW + lane + 64 * it] = v > 0.f ? v : v * xslope;
+          }
       }
     }
 #pragma unroll
     for (int i = 0; i < DR; ++i) {
       const int rl = wave + 4 * i;
-      if (rl < rows_blk) db[rl * ROWD + lane] = sd[i];
+      if (rl < rows_blk) {
+        float v = sd[i];
+        if (has_aux) {
+          const float av = sa[i];
+          v *= (a.gy_mode == RTG_PRE_MUL_DTANH) ? (1.f - av * av) : (av > 0.f ? 1.f : a.gy_slope);
+        } else {
+          v = v > 0.f ? v : v * gslope;
+        }
+        db[rl * ROWD + lane] = v * a.gy_scale;
+      }
     }
   };
 
-  const int total = a.B * a.n_ttiles;
+  const int total = a.n_tiles_total;
   int tl = split;
   int which = 0;
   if (tl < total) {
@@ -211,7 +267,8 @@ __global__ __launch_bounds__(RTG_THREADS) void wgrad_kernel(const WgArgs a) {
 }
 
 struct WgGeom {
-  int TM, CKW, MB, NTB, n_cchunk, m_blocks, n_ttiles, PW, ROW;
+  int TM, CKW, MB, NTB, n_cchunk, m_blocks, n_ttiles, n_tiles_total, PW, ROW;
+  int seg_len, seg_nb, seg_pw;
 };
 
 int geometry(const RtgWgradDesc* d, WgGeom* o) {
@@ -225,18 +282,30 @@ int geometry(const RtgWgradDesc* d, WgGeom* o) {
   int MB = (4 * TPW) / NTB;
   if (MB > n_mt) MB = n_mt;
   if (MB * TM > MAXROWS) MB = MAXROWS / TM;
-  // prefer balanced waves: do not take more m-tiles than keeps every wave at <= 2 tiles when the problem is small
   if (MB < 1) MB = 1;
   o->TM = TM; o->CKW = CKW; o->MB = MB; o->NTB = NTB;
   o->n_cchunk = rtg_ceil_div(d->Cg, CKW);
   o->m_blocks = rtg_ceil_div(n_mt, MB);
-  o->n_ttiles = rtg_ceil_div(d->Q, TT);
   o->PW = (TT - 1) * d->stride + (d->K - 1) * d->dil + 1;
   if (o->PW > RTG_PW_MAX) return RTG_ERANGE;
+  // segment packing for short rows
+  const int extra = (d->K - 1) * d->dil + 1 - d->stride;
+  const int Lseg = d->Q + (extra > 0 ? (extra + d->stride - 1) / d->stride : 0);
+  o->seg_pw = (d->Q - 1) * d->stride + (d->K - 1) * d->dil + 1;
+  if (2 * Lseg <= TT && d->B >= 2) {
+    o->seg_len = Lseg;
+    o->seg_nb = TT / Lseg < d->B ? TT / Lseg : d->B;
+    o->n_ttiles = 1;
+    o->n_tiles_total = rtg_ceil_div(d->B, o->seg_nb);
+  } else {
+    o->seg_len = 0;
+    o->seg_nb = 1;
+    o->n_ttiles = rtg_ceil_div(d->Q, TT);
+    o->n_tiles_total = d->B * o->n_ttiles;
+  }
   const int want = (d->K * d->dil) & 31;
   int row = o->PW;
   while ((row & 31) != want) ++row;
-  if ((row & 1) == 0) row += 0;   // even K*dil: conflicts accepted
   o->ROW = row;
   return RTG_OK;
 }
@@ -248,6 +317,9 @@ int validate(const RtgWgradDesc* d) {
   if (d->C1 + d->C2 != d->groups * d->Cg) return RTG_EINVAL;
   if (d->groups > 1 && d->C2 != 0) return RTG_EINVAL;
   if (d->stride > 8) return RTG_ERANGE;
+  // 32-bit buffer offsets
+  if ((long long)d->B * (d->C1 > d->C2 ? d->C1 : d->C2) * d->L_in * 4 >= (1ll << 31)) return RTG_ERANGE;
+  if ((long long)d->B * d->groups * d->Mg * d->dy_L * 4 >= (1ll << 31)) return RTG_ERANGE;
   return RTG_OK;
 }
 
@@ -261,10 +333,10 @@ extern "C" int rtg_wgrad_splits(const RtgWgradDesc* d) {
   st = geometry(d, &g);
   if (st) return st;
   const long long base = (long long)d->groups * g.m_blocks * g.n_cchunk;
-  const long long total = (long long)d->B * g.n_ttiles;
-  long long s = (1024 + base - 1) / base;        // aim at ~1024 blocks
+  const long long total = g.n_tiles_total;
+  long long s = (768 + base - 1) / base;         // aim at ~3 blocks per CU
   if (s > total) s = total;
-  if (s > 1024) s = 1024;
+  if (s > 512) s = 512;
   if (s < 1) s = 1;
   return (int)s;
 }
@@ -288,10 +360,13 @@ extern "C" int rtg_conv1d_wgrad(const RtgWgradDesc* d, const float* x1, const fl
   a.x1 = x1; a.x2 = x2; a.dy = dy; a.gy_aux = gy_aux; a.part = part;
   a.B = d->B; a.C1 = d->C1; a.C2 = d->C2; a.L_in = d->L_in; a.groups = d->groups; a.Cg = d->Cg; a.Mg = d->Mg;
   a.K = d->K; a.stride = d->stride; a.dil = d->dil; a.pad = d->pad; a.Q = d->Q; a.dy_L = d->dy_L;
-  a.pre_mode = d->pre_mode; a.pre_slope = d->pre_slope; a.gy_mode = d->gy_mode; a.gy_slope = d->gy_slope; a.gy_scale = d->gy_scale;
+  a.pre_mode = d->pre_mode; a.pre_slope = d->pre_slope; a.gy_mode = d->gy_mode; a.gy_slope = d->gy_slope;
+  a.gy_scale = d->gy_scale;
   a.splits = d->splits; a.part_stride = d->part_stride;
   a.CKW = g.CKW; a.n_cchunk = g.n_cchunk; a.MB = g.MB; a.m_blocks = g.m_blocks; a.NTB = g.NTB;
-  a.n_ttiles = g.n_ttiles; a.PW = g.PW; a.ROW = g.ROW;
+  a.n_ttiles = g.n_ttiles; a.n_tiles_total = g.n_tiles_total; a.PW = g.PW; a.ROW = g.ROW;
+  a.seg_len = g.seg_len; a.seg_nb = g.seg_nb; a.seg_pw = g.seg_pw;
+  a.seg_pitch = g.seg_len > 0 ? g.seg_len * d->stride : 1;
   const int buf = g.CKW * g.ROW + g.MB * g.TM * ROWD;
   a.ones_off = 2 * buf;
   const size_t lds_bytes = (size_t)(2 * buf + TT * d->stride + 8) * sizeof(float);

@@ -32,14 +32,14 @@ def _c(t):
 PROFILE = None
 
 
-def _timed(kernel, variant, flop, launch):
+def _timed(kernel, variant, flop, launch, label=''):
     if PROFILE is None:
         return launch()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     r = launch()
     e1.record()
-    PROFILE.append((kernel, variant, flop, e0, e1))
+    PROFILE.append((kernel, variant, flop, e0, e1, label))
     return r
 
 
@@ -92,7 +92,7 @@ class ConvFn(torch.autograd.Function):
         lc = L_out if ly.kind == 'conv' else L_in
         check(_timed('conv1d', lib.rtg_conv1d_variant(C.byref(d)) if PROFILE is not None else 0, _conv_flop(ly, B, lc),
                      lambda: lib.rtg_conv1d(C.byref(d), _p(x1), _p(x2), None, bank.fwd_ptr(ly), bank.bias_ptr(ly), None,
-                                            _p(res), _p(out), None, _stream())), f'conv1d fwd {ly.name}')
+                                            _p(res), _p(out), None, _stream()), f'fwd {ly.name} B{B} L{L_in}'), f'conv1d fwd {ly.name}')
         ctx.ly, ctx.bank, ctx.tok_id = ly, bank, token._rtg_id
         ctx.cfg = (pre_slope, act, act_slope, out_scale, res_is_input, res is not None)
         ctx.save_for_backward(x1, x2, out if act != L.ACT_NONE else None)
@@ -170,7 +170,7 @@ class ConvFn(torch.autograd.Function):
             check(_timed('conv1d', lib.rtg_conv1d_variant(C.byref(d)) if PROFILE is not None else 0,
                          _conv_flop(ly, B, lc),
                          lambda: lib.rtg_conv1d(C.byref(d), _p(dy), None, _p(out), bank.bwd_ptr(ly), None, _p(mask),
-                                                _p(resg), _p(dx1), _p(dx2), st)), f'conv1d bwd-data {ly.name}')
+                                                _p(resg), _p(dx1), _p(dx2), st), f'dgrad {ly.name} B{B} L{L_in}'), f'conv1d bwd-data {ly.name}')
             if not need_x1:
                 dx1 = None
 
@@ -198,7 +198,8 @@ class ConvFn(torch.autograd.Function):
             wd.splits, wd.part_stride = splits, stride
             lc = L_out if ly.kind == 'conv' else L_in
             check(_timed('wgrad', 32 if wd.Mg >= 32 else 16, _conv_flop(ly, B, lc),
-                         lambda: lib.rtg_conv1d_wgrad(C.byref(wd), _p(a1), _p(a2), _p(gyt), _p(aux), _p(part), st)),
+                         lambda: lib.rtg_conv1d_wgrad(C.byref(wd), _p(a1), _p(a2), _p(gyt), _p(aux), _p(part), st),
+                         f'wgrad {ly.name} B{B} L{L_in} splits{splits}'),
                   f'conv1d wgrad {ly.name}')
             if ly.kind == 'convT':   # bias gradient of a transposed conv: plain channel sum of dy
                 check(lib.rtg_channel_sum(_p(dy), C.c_void_p(bank.gflat.data_ptr() + 4 * ly.b_off), B, ly.cout, L_out,
