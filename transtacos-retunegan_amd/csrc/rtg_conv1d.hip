@@ -99,13 +99,12 @@ __device__ __forceinline__ void stage_rows(const ConvArgs& a, rsrc_t r1, rsrc_t 
   }
 }
 
-template <int TM, int MT, int NT>
+template <int TM, int MT, int NT, int MAXIT>   // MAXIT: 64-float pieces of a patch row each lane stages (>= PW / 64)
 __global__ __launch_bounds__(RTG_THREADS) void conv1d_mfma_kernel(const ConvArgs a) {
   using M = Mfma<TM>;
   using acc_t = typename M::acc_t;
   constexpr int KK = 64 / TM;           // K-values consumed per MFMA
   constexpr int CPN = RTG_CK / KK;      // MFMA k-steps per (chunk, tap)
-  constexpr int MAXIT = RTG_PW_MAX / 64;
   constexpr int RPW = RTG_CK / 4;       // patch rows staged per wave
 
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -166,7 +165,10 @@ __global__ __launch_bounds__(RTG_THREADS) void conv1d_mfma_kernel(const ConvArgs
 #pragma unroll
       for (int it = 0; it < MAXIT; ++it)
         if (lane + 64 * it < a.PW) {
-          const float v = st[i][it];
+          float v = st[i][it];
+          // keep the consumption of the prefetched values BELOW the MFMA loop: without this the compiler hoists the
+          // activation (and with it the s_waitcnt for the loads) above the loop and the prefetch hides nothing
+          asm volatile("" : "+v"(v) : : "memory");
           rowp[loff[it]] = v > 0.f ? v : v * wslope;
         }
     }
@@ -217,16 +219,22 @@ __global__ __launch_bounds__(RTG_THREADS) void conv1d_mfma_kernel(const ConvArgs
       const int td = tap * a.dil;
       const int tapoff = (a.stride == 1) ? td : (td % a.stride) * a.PH + td / a.stride;
       const float* bp = buf + bbase + tapoff;
+      // read phase: all B fragments of this (chunk, tap) into distinct registers, THEN the MFMA phase — the compiler
+      // otherwise recycles one register pair and serialises ds_read -> wait -> 2 MFMAs per k-step; with two waves
+      // per SIMD one wave's read phase overlaps the other's MFMA phase
+      float bf[CPN][NT];
 #pragma unroll
-      for (int cp = 0; cp < CPN; ++cp) {
-        float bf[NT];
+      for (int cp = 0; cp < CPN; ++cp)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) bf[j] = bp[cp * KK * a.ROW + j * TM];
+        for (int j = 0; j < NT; ++j) bf[cp][j] = bp[cp * KK * a.ROW + j * TM];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int cp = 0; cp < CPN; ++cp)
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
-          for (int j = 0; j < NT; ++j) acc[i][j] = M::run(acur[i][cp], bf[j], acc[i][j]);
-      }
+          for (int j = 0; j < NT; ++j) acc[i][j] = M::run(acur[i][cp], bf[cp][j], acc[i][j]);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -294,15 +302,22 @@ struct TileCfg {
   int seg_len, seg_nb;   // > 0: clips packed per block
 };
 
-template <int TM, int MT, int NT>
-int launch(const ConvArgs& a, dim3 grid, size_t lds_bytes, hipStream_t s) {
-  auto k = conv1d_mfma_kernel<TM, MT, NT>;
+template <int TM, int MT, int NT, int MAXIT>
+int launch_it(const ConvArgs& a, dim3 grid, size_t lds_bytes, hipStream_t s) {
+  auto k = conv1d_mfma_kernel<TM, MT, NT, MAXIT>;
   if (lds_bytes > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return -(1000 + (int)e);
   }
   hipLaunchKernelGGL(k, grid, dim3(RTG_THREADS), lds_bytes, s, a);
   return rtg_launch_status();
+}
+
+template <int TM, int MT, int NT>
+int launch(const ConvArgs& a, dim3 grid, size_t lds_bytes, hipStream_t s) {
+  if (a.PW <= 3 * 64) return launch_it<TM, MT, NT, 3>(a, grid, lds_bytes, s);
+  if (a.PW <= 5 * 64) return launch_it<TM, MT, NT, 5>(a, grid, lds_bytes, s);
+  return launch_it<TM, MT, NT, RTG_PW_MAX / 64>(a, grid, lds_bytes, s);
 }
 
 // Patch width (floats per channel) for a block covering BN output positions.

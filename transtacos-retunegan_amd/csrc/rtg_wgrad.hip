@@ -63,12 +63,11 @@ struct MfmaW<16> {
   static __device__ __forceinline__ int row(int lane, int r) { return (lane >> 4) * 4 + r; }
 };
 
-template <int TM>
+template <int TM, int MAXIT>   // MAXIT: 64-float pieces of a patch row each lane stages (>= PW / 64)
 __global__ __launch_bounds__(RTG_THREADS) void wgrad_kernel(const WgArgs a) {
   using M = MfmaW<TM>;
   using acc_t = typename M::acc_t;
   constexpr int KK = 64 / TM;
-  constexpr int MAXIT = RTG_PW_MAX / 64;
   constexpr int XR = RTG_CK / 4;         // patch rows per wave (CKW <= 16)
   constexpr int DR = MAXROWS / 4;        // gy rows per wave
 
@@ -196,7 +195,8 @@ __global__ __launch_bounds__(RTG_THREADS) void wgrad_kernel(const WgArgs a) {
 #pragma unroll
         for (int it = 0; it < MAXIT; ++it)
           if (lane + 64 * it < a.PW) {
-            const float v = sx[i][it];
+            float v = sx[i][it];
+            asm volatile("" : "+v"(v) : : "memory");   // consume the prefetched value here, below the MFMA loop
             xb[cl * a.ROW + lane + 64 * it] = v > 0.f ? v : v * xslope;
           }
       }
@@ -206,6 +206,7 @@ __global__ __launch_bounds__(RTG_THREADS) void wgrad_kernel(const WgArgs a) {
       const int rl = wave + 4 * i;
       if (rl < rows_blk) {
         float v = sd[i];
+        asm volatile("" : "+v"(v) : : "memory");
         if (has_aux) {
           const float av = sa[i];
           v *= (a.gy_mode == RTG_PRE_MUL_DTANH) ? (1.f - av * av) : (av > 0.f ? 1.f : a.gy_slope);
@@ -236,8 +237,22 @@ __global__ __launch_bounds__(RTG_THREADS) void wgrad_kernel(const WgArgs a) {
       const float* ap = db + a_base[k];
       const float* bp = (b_base[k] >= 0) ? xb + b_base[k] : ones + (b_base[k] + (1 << 20));
       acc_t c = acc[k];
-#pragma unroll 8
-      for (int t = 0; t < TT; t += KK) c = M::run(ap[t], bp[t * a.stride], c);
+      // read phase / MFMA phase in groups of 16 k-steps (distinct registers, so the reads are all in flight before
+      // the first MFMA; the other wave on the SIMD computes meanwhile)
+      constexpr int GRP = 16;
+#pragma unroll
+      for (int t0 = 0; t0 < TT; t0 += GRP * KK) {
+        float af[GRP], bf[GRP];
+#pragma unroll
+        for (int u = 0; u < GRP; ++u) {
+          af[u] = ap[t0 + u * KK];
+          bf[u] = bp[(t0 + u * KK) * a.stride];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < GRP; ++u) c = M::run(af[u], bf[u], c);
+        __builtin_amdgcn_sched_barrier(0);
+      }
       acc[k] = c;
     }
     if (more) swrite(which ^ 1);
@@ -374,14 +389,22 @@ extern "C" int rtg_conv1d_wgrad(const RtgWgradDesc* d, const float* x1, const fl
   if (gy > 65535) return RTG_ERANGE;
   dim3 grid(d->splits, (unsigned)gy, 1);
   hipStream_t s = (hipStream_t)stream;
-  if (g.TM == 32) {
-    auto k = wgrad_kernel<32>;
-    if (lds_bytes > 64 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    hipLaunchKernelGGL(k, grid, dim3(RTG_THREADS), lds_bytes, s, a);
-  } else {
-    auto k = wgrad_kernel<16>;
-    if (lds_bytes > 64 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    hipLaunchKernelGGL(k, grid, dim3(RTG_THREADS), lds_bytes, s, a);
+#define RTG_WG(tm, mi)                                                                                           \
+  {                                                                                                              \
+    auto k = wgrad_kernel<tm, mi>;                                                                               \
+    if (lds_bytes > 64 * 1024)                                                                                   \
+      hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);           \
+    hipLaunchKernelGGL(k, grid, dim3(RTG_THREADS), lds_bytes, s, a);                                             \
+    return rtg_launch_status();                                                                                  \
   }
-  return rtg_launch_status();
+  if (g.TM == 32) {
+    if (g.PW <= 2 * 64) RTG_WG(32, 2)
+    if (g.PW <= 4 * 64) RTG_WG(32, 4)
+    RTG_WG(32, RTG_PW_MAX / 64)
+  } else {
+    if (g.PW <= 2 * 64) RTG_WG(16, 2)
+    if (g.PW <= 4 * 64) RTG_WG(16, 4)
+    RTG_WG(16, RTG_PW_MAX / 64)
+  }
+#undef RTG_WG
 }
