@@ -8,18 +8,18 @@
 // The reduction index v ("virtual position") walks tiles of TT = 64 positions.  Long rows: a tile is 64 consecutive
 // positions of one clip.  Short rows (MPD / MSD tails, 10..60 positions): several clips are packed side by side in one
 // tile (segments of seg_len positions, pitch seg_len*stride in the patch) so the MFMA reduction is not spent on padding.
-// A block owns (group, MB m-tiles, one channel chunk, one split of the reduction) and walks its share of the tile list
-// with register-prefetched double buffering (buffer loads with hardware bounds checking: branch-free, all in flight
-// under the MFMA loop); its 4 waves share the staged tiles and each owns up to TPW accumulator tiles.  Partials are
-// stored per split (fixed-order reduction in rtg_weightnorm_backward).
+// A block owns (group, a band of output rows, one channel chunk, one split of the reduction).  Its 4 waves form a
+// WM x WN grid and each wave keeps an MTW x NTW register tile of MFMA accumulators, so one A fragment feeds NTW and one
+// B fragment feeds MTW MFMAs (the 2x2 form halves the LDS reads per MFMA).  The next tile's operands are fetched into
+// registers by bounds-checked buffer loads while the current tile is multiplied; LDS is single-buffered (two barriers
+// per tile) so that two workgroups fit a CU and cover each other's barrier phases.  Partials are stored per split
+// (fixed-order reduction in rtg_weightnorm_backward).
 #include "rtg_common.h"
 
 namespace {
 
 constexpr int TT = 64;          // reduction (virtual position) steps per staged tile
 constexpr int ROWD = 81;        // LDS pitch of the gy tile: odd, and 81^-1 = 17 (mod 32) keeps 16-row reads conflict free
-constexpr int TPW = 4;          // accumulator tiles per wave
-constexpr int MAXROWS = 64;     // gy rows staged per block
 
 using rsrc_t = __amdgpu_buffer_rsrc_t;
 #define RTG_OOB 0x80000000u
@@ -38,7 +38,7 @@ struct WgArgs {
   float gy_slope, gy_scale;
   int splits;
   long long part_stride;
-  int CKW, n_cchunk, MB, m_blocks, NTB, n_ttiles, n_tiles_total, PW, ROW, ones_off;
+  int CKW, n_cchunk, m_blocks, n_ttiles, n_tiles_total, PW, ROW, ones_off, xbuf_sz;
   int seg_len, seg_pitch, seg_nb, seg_pw;   // seg_len == 0: one clip per tile
 };
 
@@ -63,19 +63,23 @@ struct MfmaW<16> {
   static __device__ __forceinline__ int row(int lane, int r) { return (lane >> 4) * 4 + r; }
 };
 
-template <int TM, int MAXIT>   // MAXIT: 64-float pieces of a patch row each lane stages (>= PW / 64)
+// block shapes: wave grid WM x WN (WM*WN = 4), register tile MTW x NTW
+template <int TM, int MTW, int NTW, int WM, int MAXIT>
 __global__ __launch_bounds__(RTG_THREADS) void wgrad_kernel(const WgArgs a) {
   using M = MfmaW<TM>;
   using acc_t = typename M::acc_t;
+  constexpr int WN = 4 / WM;
   constexpr int KK = 64 / TM;
-  constexpr int XR = RTG_CK / 4;         // patch rows per wave (CKW <= 16)
-  constexpr int DR = MAXROWS / 4;        // gy rows per wave
+  constexpr int ROWS = WM * MTW * TM;          // gy rows of the block
+  constexpr int DR = ROWS / 4;                 // gy rows staged per wave
+  constexpr int XR = (MAXIT <= 4) ? 8 : 4;     // patch rows staged per wave (CKW <= 4*XR)
+  constexpr int GRP = 8;                       // k-steps per read phase
 
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave - wm * WN;
 
-  // block coordinates
   int by = blockIdx.y;
   const int cchunk = by % a.n_cchunk; by /= a.n_cchunk;
   const int mb = by % a.m_blocks;
@@ -83,34 +87,34 @@ __global__ __launch_bounds__(RTG_THREADS) void wgrad_kernel(const WgArgs a) {
   const int split = blockIdx.x;
   const int c0 = cchunk * a.CKW;
   const int cw = min(a.CKW, a.Cg - c0);
-  const int rows_blk = a.MB * TM;
-  const int m0 = mb * rows_blk;                      // first row (within group) of this block
+  const int m0 = mb * ROWS;                          // first row (within group) of this block
   const bool packed = a.seg_len > 0;
 
-  const int xbuf_sz = a.CKW * a.ROW;                 // floats
-  const int dbuf_sz = rows_blk * ROWD;
+  float* xb = lds;
+  float* db = lds + a.xbuf_sz;
   float* ones = lds + a.ones_off;
   for (int i = tid; i < TT * a.stride + 8; i += RTG_THREADS) ones[i] = 1.f;
 
-  // per-wave accumulator tiles
-  const int n_tiles = a.MB * a.NTB;
-  acc_t acc[TPW];
-  int a_base[TPW], b_base[TPW];
+  // ---- accumulators and LDS operand bases of this wave's register tile
+  acc_t acc[MTW][NTW];
+  int a_base[MTW], b_base[NTW];
   const int n_lane = lane & (TM - 1), kk = lane / TM;
 #pragma unroll
-  for (int k = 0; k < TPW; ++k) {
+  for (int i = 0; i < MTW; ++i) {
 #pragma unroll
-    for (int r = 0; r < M::NREG; ++r) acc[k][r] = 0.f;
-    const int tile = wave + 4 * k;
-    const int mt = tile / a.NTB, nt = tile - mt * a.NTB;
-    a_base[k] = (mt * TM + n_lane) * ROWD + kk;
-    const int n = nt * TM + n_lane;                  // column within the chunk
-    const int cl = n / a.K, j = n - cl * a.K;
-    b_base[k] = (cl < a.CKW) ? (cl * a.ROW + j * a.dil + kk * a.stride) : (-(1 << 20) + kk * a.stride);
+    for (int j = 0; j < NTW; ++j)
+#pragma unroll
+      for (int r = 0; r < M::NREG; ++r) acc[i][j][r] = 0.f;
+    a_base[i] = ((wm * MTW + i) * TM + n_lane) * ROWD + kk;
+  }
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) {
+    const int n = (wn * NTW + j) * TM + n_lane;      // column within the chunk
+    const int cl = n / a.K, jj = n - cl * a.K;
+    b_base[j] = (cl < a.CKW) ? (cl * a.ROW + jj * a.dil + kk * a.stride) : (-(1 << 20) + kk * a.stride);
   }
 
   // ---- static staging geometry
-  // x patch element o = lane + 64*it of a row: (segment, position within the clip's patch)
   int xseg[MAXIT], xw[MAXIT];
 #pragma unroll
   for (int it = 0; it < MAXIT; ++it) {
@@ -124,7 +128,6 @@ __global__ __launch_bounds__(RTG_THREADS) void wgrad_kernel(const WgArgs a) {
       xw[it] = (o < a.PW) ? o : -(1 << 28);
     }
   }
-  // gy tile column = lane: (segment, position within the clip)
   const int dseg = packed ? lane / a.seg_len : 0;
   const int dt = packed ? lane - dseg * a.seg_len : lane;
   const bool dcol_ok = packed ? (dseg < a.seg_nb) : true;
@@ -147,7 +150,6 @@ __global__ __launch_bounds__(RTG_THREADS) void wgrad_kernel(const WgArgs a) {
     if (packed) { b0 = tl * a.seg_nb; t0 = 0; }
     else        { b0 = tl / a.n_ttiles; t0 = (tl - b0 * a.n_ttiles) * TT; }
     const int o_start = t0 * a.stride - a.pad;
-    // input patch: rows c0 + wave*XR + i
 #pragma unroll
     for (int i = 0; i < XR; ++i) {
       const int cl = wave * XR + i;
@@ -166,7 +168,6 @@ __global__ __launch_bounds__(RTG_THREADS) void wgrad_kernel(const WgArgs a) {
         sx[i][it] = buf_load(r, off);
       }
     }
-    // gy tile: rows m0 + wave + 4*i, column = lane
     {
       const int bb = b0 + dseg;
       const int t = t0 + dt;
@@ -177,17 +178,14 @@ __global__ __launch_bounds__(RTG_THREADS) void wgrad_kernel(const WgArgs a) {
       for (int i = 0; i < DR; ++i) {
         const int rl = wave + 4 * i;
         const int m = m0 + rl;
-        const bool rok = rl < rows_blk && m < a.Mg;
-        const unsigned off = rok ? (coloff + (unsigned)(g * a.Mg + m) * (unsigned)a.dy_L * 4u) | (coloff & RTG_OOB)
-                                 : RTG_OOB;
+        const unsigned off = (m < a.Mg) ? (coloff + (unsigned)(g * a.Mg + m) * (unsigned)a.dy_L * 4u) | (coloff & RTG_OOB)
+                                        : RTG_OOB;
         sd[i] = buf_load(rdy, off);
         if (has_aux) sa[i] = buf_load(raux, off);
       }
     }
   };
-  auto swrite = [&](int which) __attribute__((always_inline)) {
-    float* xb = lds + which * (xbuf_sz + dbuf_sz);
-    float* db = xb + xbuf_sz;
+  auto swrite = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < XR; ++i) {
       const int cl = wave * XR + i;
@@ -204,105 +202,119 @@ __global__ __launch_bounds__(RTG_THREADS) void wgrad_kernel(const WgArgs a) {
 #pragma unroll
     for (int i = 0; i < DR; ++i) {
       const int rl = wave + 4 * i;
-      if (rl < rows_blk) {
-        float v = sd[i];
-        asm volatile("" : "+v"(v) : : "memory");
-        if (has_aux) {
-          const float av = sa[i];
-          v *= (a.gy_mode == RTG_PRE_MUL_DTANH) ? (1.f - av * av) : (av > 0.f ? 1.f : a.gy_slope);
-        } else {
-          v = v > 0.f ? v : v * gslope;
-        }
-        db[rl * ROWD + lane] = v * a.gy_scale;
+      float v = sd[i];
+      asm volatile("" : "+v"(v) : : "memory");
+      if (has_aux) {
+        const float av = sa[i];
+        v *= (a.gy_mode == RTG_PRE_MUL_DTANH) ? (1.f - av * av) : (av > 0.f ? 1.f : a.gy_slope);
+      } else {
+        v = v > 0.f ? v : v * gslope;
       }
+      db[rl * ROWD + lane] = v * a.gy_scale;
     }
   };
 
   const int total = a.n_tiles_total;
   int tl = split;
-  int which = 0;
   if (tl < total) {
     gload(tl);
-    swrite(0);
+    swrite();
   }
   __syncthreads();
   for (; tl < total; tl += a.splits) {
-    const float* xb = lds + which * (xbuf_sz + dbuf_sz);
-    const float* db = xb + xbuf_sz;
     const bool more = tl + a.splits < total;
     if (more) gload(tl + a.splits);
+    const float* ap[MTW];
+    const float* bp[NTW];
 #pragma unroll
-    for (int k = 0; k < TPW; ++k) {
-      if (wave + 4 * k >= n_tiles) continue;
-      const float* ap = db + a_base[k];
-      const float* bp = (b_base[k] >= 0) ? xb + b_base[k] : ones + (b_base[k] + (1 << 20));
-      acc_t c = acc[k];
-      // read phase / MFMA phase in groups of 16 k-steps (distinct registers, so the reads are all in flight before
-      // the first MFMA; the other wave on the SIMD computes meanwhile)
-      constexpr int GRP = 16;
+    for (int i = 0; i < MTW; ++i) ap[i] = db + a_base[i];
 #pragma unroll
-      for (int t0 = 0; t0 < TT; t0 += GRP * KK) {
-        float af[GRP], bf[GRP];
+    for (int j = 0; j < NTW; ++j) bp[j] = (b_base[j] >= 0) ? xb + b_base[j] : ones + (b_base[j] + (1 << 20));
 #pragma unroll
-        for (int u = 0; u < GRP; ++u) {
-          af[u] = ap[t0 + u * KK];
-          bf[u] = bp[(t0 + u * KK) * a.stride];
-        }
-        __builtin_amdgcn_sched_barrier(0);
+    for (int t0 = 0; t0 < TT; t0 += GRP * KK) {
+      float af[MTW][GRP], bf[NTW][GRP];
 #pragma unroll
-        for (int u = 0; u < GRP; ++u) c = M::run(af[u], bf[u], c);
-        __builtin_amdgcn_sched_barrier(0);
+      for (int u = 0; u < GRP; ++u) {
+#pragma unroll
+        for (int i = 0; i < MTW; ++i) af[i][u] = ap[i][t0 + u * KK];
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) bf[j][u] = bp[j][(t0 + u * KK) * a.stride];
       }
-      acc[k] = c;
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < GRP; ++u)
+#pragma unroll
+        for (int i = 0; i < MTW; ++i)
+#pragma unroll
+          for (int j = 0; j < NTW; ++j) acc[i][j] = M::run(af[i][u], bf[j][u], acc[i][j]);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    if (more) swrite(which ^ 1);
+    __syncthreads();                 // every wave is done reading the tile
+    if (more) swrite();
     __syncthreads();
-    which ^= 1;
   }
 
-  // store this split's partial
+  // ---- store this split's partial
   float* wpart = a.part + (size_t)split * a.part_stride;
   float* bpart = wpart + (size_t)a.groups * a.Mg * a.Cg * a.K;
   const int nb = a.CKW * a.K;                        // the "ones" column
 #pragma unroll
-  for (int k = 0; k < TPW; ++k) {
-    const int tile = wave + 4 * k;
-    if (tile >= n_tiles) continue;
-    const int mt = tile / a.NTB, nt = tile - mt * a.NTB;
-    const int n = nt * TM + n_lane;
+  for (int i = 0; i < MTW; ++i)
 #pragma unroll
-    for (int r = 0; r < M::NREG; ++r) {
-      const int m = m0 + mt * TM + M::row(lane, r);
-      if (m >= a.Mg) continue;
-      const size_t rowg = (size_t)g * a.Mg + m;
-      if (n < cw * a.K) wpart[rowg * (a.Cg * a.K) + (size_t)c0 * a.K + n] = acc[k][r];
-      else if (n == nb && cchunk == 0) bpart[rowg] = acc[k][r];
+    for (int j = 0; j < NTW; ++j) {
+      const int n = (wn * NTW + j) * TM + n_lane;
+#pragma unroll
+      for (int r = 0; r < M::NREG; ++r) {
+        const int m = m0 + (wm * MTW + i) * TM + M::row(lane, r);
+        if (m >= a.Mg) continue;
+        const size_t rowg = (size_t)g * a.Mg + m;
+        if (n < cw * a.K) wpart[rowg * (a.Cg * a.K) + (size_t)c0 * a.K + n] = acc[i][j][r];
+        else if (n == nb && cchunk == 0) bpart[rowg] = acc[i][j][r];
+      }
     }
-  }
 }
 
+struct Shape {
+  int MTW, NTW, WM;
+};
+// menu of block shapes (register tile, wave grid)
+constexpr Shape kShapes[] = {{2, 2, 2}, {2, 2, 1}, {1, 2, 1}, {1, 4, 1}, {1, 1, 1}, {1, 1, 4}};
+constexpr int kNumShapes = sizeof(kShapes) / sizeof(Shape);
+
 struct WgGeom {
-  int TM, CKW, MB, NTB, n_cchunk, m_blocks, n_ttiles, n_tiles_total, PW, ROW;
+  int TM, shape, CKW, n_cchunk, m_blocks, n_ttiles, n_tiles_total, PW, ROW, maxit;
   int seg_len, seg_nb, seg_pw;
 };
 
 int geometry(const RtgWgradDesc* d, WgGeom* o) {
   const int TM = d->Mg >= 32 ? 32 : 16;
   const int n_mt = rtg_ceil_div(d->Mg, TM);
-  int CKW = d->Cg < RTG_CK ? d->Cg : RTG_CK;
-  // shrink the channel chunk until the chunk's columns (+1 bias column) fit 4*TPW tiles with at least one m-tile
-  while (CKW > 1 && rtg_ceil_div(CKW * d->K + 1, TM) > 4 * TPW) CKW = (CKW + 1) / 2;
-  const int NTB = rtg_ceil_div(CKW * d->K + 1, TM);
-  if (NTB > 4 * TPW) return RTG_ERANGE;
-  int MB = (4 * TPW) / NTB;
-  if (MB > n_mt) MB = n_mt;
-  if (MB * TM > MAXROWS) MB = MAXROWS / TM;
-  if (MB < 1) MB = 1;
-  o->TM = TM; o->CKW = CKW; o->MB = MB; o->NTB = NTB;
-  o->n_cchunk = rtg_ceil_div(d->Cg, CKW);
-  o->m_blocks = rtg_ceil_div(n_mt, MB);
+  o->TM = TM;
   o->PW = (TT - 1) * d->stride + (d->K - 1) * d->dil + 1;
   if (o->PW > RTG_PW_MAX) return RTG_ERANGE;
+  o->maxit = o->PW <= 128 ? 2 : (o->PW <= 256 ? 4 : RTG_PW_MAX / 64);
+  const int ckw_cap = (o->maxit <= 4) ? 32 : 16;
+  double best = -1.0;
+  o->shape = -1;
+  for (int s = 0; s < kNumShapes; ++s) {
+    const Shape sh = kShapes[s];
+    const int bm = sh.WM * sh.MTW, bn = (4 / sh.WM) * sh.NTW;     // block tile in MFMA tiles
+    int ckw = (bn * TM - 1) / d->K;
+    if (ckw > d->Cg) ckw = d->Cg;
+    if (ckw > ckw_cap) ckw = ckw_cap;
+    if (ckw < 1) continue;
+    const int n_cchunk = rtg_ceil_div(d->Cg, ckw);
+    const int m_blocks = rtg_ceil_div(n_mt, bm);
+    const double eff_m = (double)d->Mg / ((double)m_blocks * bm * TM);
+    const double eff_n = ((double)d->Cg * d->K + 1.0) / ((double)n_cchunk * bn * TM);
+    const double reuse = (double)(sh.MTW * sh.NTW) / (sh.MTW + sh.NTW);
+    const double score = eff_m * eff_n * (0.55 + 0.45 * (reuse > 1.0 ? 1.0 : reuse));
+    if (score > best) {
+      best = score;
+      o->shape = s; o->CKW = ckw; o->n_cchunk = n_cchunk; o->m_blocks = m_blocks;
+    }
+  }
+  if (o->shape < 0) return RTG_ERANGE;
   // segment packing for short rows
   const int extra = (d->K - 1) * d->dil + 1 - d->stride;
   const int Lseg = d->Q + (extra > 0 ? (extra + d->stride - 1) / d->stride : 0);
@@ -338,6 +350,33 @@ int validate(const RtgWgradDesc* d) {
   return RTG_OK;
 }
 
+template <int TM, int MTW, int NTW, int WM, int MAXIT>
+int launch(const WgArgs& a, dim3 grid, size_t lds_bytes, hipStream_t s) {
+  auto k = wgrad_kernel<TM, MTW, NTW, WM, MAXIT>;
+  if (lds_bytes > 64 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  hipLaunchKernelGGL(k, grid, dim3(RTG_THREADS), lds_bytes, s, a);
+  return rtg_launch_status();
+}
+
+template <int TM, int MTW, int NTW, int WM>
+int launch_it(int maxit, const WgArgs& a, dim3 grid, size_t lds_bytes, hipStream_t s) {
+  if (maxit <= 2) return launch<TM, MTW, NTW, WM, 2>(a, grid, lds_bytes, s);
+  if (maxit <= 4) return launch<TM, MTW, NTW, WM, 4>(a, grid, lds_bytes, s);
+  return launch<TM, MTW, NTW, WM, RTG_PW_MAX / 64>(a, grid, lds_bytes, s);
+}
+
+template <int TM>
+int launch_shape(int shape, int maxit, const WgArgs& a, dim3 grid, size_t lds_bytes, hipStream_t s) {
+  switch (shape) {
+    case 0: return launch_it<TM, 2, 2, 2>(maxit, a, grid, lds_bytes, s);
+    case 1: return launch_it<TM, 2, 2, 1>(maxit, a, grid, lds_bytes, s);
+    case 2: return launch_it<TM, 1, 2, 1>(maxit, a, grid, lds_bytes, s);
+    case 3: return launch_it<TM, 1, 4, 1>(maxit, a, grid, lds_bytes, s);
+    case 4: return launch_it<TM, 1, 1, 1>(maxit, a, grid, lds_bytes, s);
+    default: return launch_it<TM, 1, 1, 4>(maxit, a, grid, lds_bytes, s);
+  }
+}
+
 }  // namespace
 
 extern "C" int rtg_wgrad_splits(const RtgWgradDesc* d) {
@@ -349,7 +388,7 @@ extern "C" int rtg_wgrad_splits(const RtgWgradDesc* d) {
   if (st) return st;
   const long long base = (long long)d->groups * g.m_blocks * g.n_cchunk;
   const long long total = g.n_tiles_total;
-  long long s = (768 + base - 1) / base;         // aim at ~3 blocks per CU
+  long long s = (640 + base - 1) / base;         // aim at ~2.5 blocks per CU
   if (s > total) s = total;
   if (s > 512) s = 512;
   if (s < 1) s = 1;
@@ -370,6 +409,7 @@ extern "C" int rtg_conv1d_wgrad(const RtgWgradDesc* d, const float* x1, const fl
   WgGeom g;
   st = geometry(d, &g);
   if (st) return st;
+  const Shape sh = kShapes[g.shape];
 
   WgArgs a;
   a.x1 = x1; a.x2 = x2; a.dy = dy; a.gy_aux = gy_aux; a.part = part;
@@ -378,33 +418,20 @@ extern "C" int rtg_conv1d_wgrad(const RtgWgradDesc* d, const float* x1, const fl
   a.pre_mode = d->pre_mode; a.pre_slope = d->pre_slope; a.gy_mode = d->gy_mode; a.gy_slope = d->gy_slope;
   a.gy_scale = d->gy_scale;
   a.splits = d->splits; a.part_stride = d->part_stride;
-  a.CKW = g.CKW; a.n_cchunk = g.n_cchunk; a.MB = g.MB; a.m_blocks = g.m_blocks; a.NTB = g.NTB;
+  a.CKW = g.CKW; a.n_cchunk = g.n_cchunk; a.m_blocks = g.m_blocks;
   a.n_ttiles = g.n_ttiles; a.n_tiles_total = g.n_tiles_total; a.PW = g.PW; a.ROW = g.ROW;
   a.seg_len = g.seg_len; a.seg_nb = g.seg_nb; a.seg_pw = g.seg_pw;
   a.seg_pitch = g.seg_len > 0 ? g.seg_len * d->stride : 1;
-  const int buf = g.CKW * g.ROW + g.MB * g.TM * ROWD;
-  a.ones_off = 2 * buf;
-  const size_t lds_bytes = (size_t)(2 * buf + TT * d->stride + 8) * sizeof(float);
+  const int rows = sh.WM * sh.MTW * g.TM;
+  const int xr_cap = (g.maxit <= 4) ? 32 : 16;
+  a.xbuf_sz = xr_cap * g.ROW;                       // patch rows up to the staging capacity (rows past CKW unused)
+  if (g.CKW < xr_cap) a.xbuf_sz = g.CKW * g.ROW;
+  a.ones_off = a.xbuf_sz + rows * ROWD;
+  const size_t lds_bytes = (size_t)(a.ones_off + TT * d->stride + 8) * sizeof(float);
   const long long gy = (long long)d->groups * g.m_blocks * g.n_cchunk;
   if (gy > 65535) return RTG_ERANGE;
   dim3 grid(d->splits, (unsigned)gy, 1);
   hipStream_t s = (hipStream_t)stream;
-#define RTG_WG(tm, mi)                                                                                           \
-  {                                                                                                              \
-    auto k = wgrad_kernel<tm, mi>;                                                                               \
-    if (lds_bytes > 64 * 1024)                                                                                   \
-      hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);           \
-    hipLaunchKernelGGL(k, grid, dim3(RTG_THREADS), lds_bytes, s, a);                                             \
-    return rtg_launch_status();                                                                                  \
-  }
-  if (g.TM == 32) {
-    if (g.PW <= 2 * 64) RTG_WG(32, 2)
-    if (g.PW <= 4 * 64) RTG_WG(32, 4)
-    RTG_WG(32, RTG_PW_MAX / 64)
-  } else {
-    if (g.PW <= 2 * 64) RTG_WG(16, 2)
-    if (g.PW <= 4 * 64) RTG_WG(16, 4)
-    RTG_WG(16, RTG_PW_MAX / 64)
-  }
-#undef RTG_WG
+  if (g.TM == 32) return launch_shape<32>(g.shape, g.maxit, a, grid, lds_bytes, s);
+  return launch_shape<16>(g.shape, g.maxit, a, grid, lds_bytes, s);
 }
