@@ -32,7 +32,7 @@ enum { RTG_PRE_NONE = 0, RTG_PRE_LRELU = 1, RTG_PRE_MUL_DLRELU = 2, RTG_PRE_MUL_
 /* output activation */
 enum { RTG_ACT_NONE = 0, RTG_ACT_LRELU = 1, RTG_ACT_TANH = 2 };
 /* packed-weight layouts produced by rtg_weights_pack (see RtgPackJob.mode) */
-enum { RTG_PACK_FWD = 0, RTG_PACK_DGRAD_S1 = 1, RTG_PACK_DGRAD_POLY = 2, RTG_PACK_CONVT_POLY = 3 };
+enum { RTG_PACK_FWD = 0, RTG_PACK_DGRAD_S1 = 1, RTG_PACK_DGRAD_POLY = 2, RTG_PACK_CONVT_POLY = 3, RTG_PACK_DGRAD_2D = 4 };
 
 /* ------------------------------------------------------------------------------------------------------------
  * rtg_conv1d — implicit-GEMM 1-D convolution on the fp32 matrix cores (v_mfma_f32_32x32x2_f32 / 16x16x4_f32).
@@ -69,6 +69,15 @@ typedef struct RtgConv1dDesc {
   int tile_m;                  /* 32 or 16                                                                   */
   int out_split;               /* 0, or: channels >= out_split are stored to `out2` ([B, out_C-out_split, out_L]);
                                   either half may be skipped by passing NULL (backward of a torch.cat input pair) */
+  /* Second dimension (Conv2d of StftDiscriminator, discrminator.py:255-262).  All zero (or h_k = h_n = 1) = 1-D.
+   * The 2-D convolution over [items, C, H, W] runs as this 1-D operator along W: a "clip" (index 0..B-1) is one
+   * (item, output row) pair, B = items * h_n; a "channel" (0..C1-1) is one (c, kernel row kh) pair, C1 = C * h_k;
+   * L_in = W.  The patch row of clip (item, r) and channel (c, kh) is input row
+   *     h_mode 0 (forward / weight gradient):  r * h_stride - h_pad + kh
+   *     h_mode 1 (backward-data over dy):      (r + h_pad - kh) / h_stride   when divisible, else a zero row
+   * of the [items, C, h_in, W] tensor; rows outside [0, h_in) are zero padding.  The output tensor is
+   * [items, out_C, h_n, out_L].  Requires groups == 1, C2 == 0, out_split == 0. */
+  int h_in, h_k, h_stride, h_pad, h_n, h_mode;
 } RtgConv1dDesc;
 
 int rtg_conv1d(const RtgConv1dDesc* d, const float* x1, const float* x2, const float* aux, const float* wp,
@@ -104,6 +113,9 @@ typedef struct RtgWgradDesc {
   int pre_mode; float pre_slope;
   int gy_mode; float gy_slope; float gy_scale;
   int splits; long long part_stride;
+  /* second dimension, as in RtgConv1dDesc (h_mode is always 0 here): x is [items, C1/h_k, h_in, L_in], dy is
+   * [items, groups*Mg, h_n, dy_L], B = items * h_n clips */
+  int h_in, h_k, h_stride, h_pad, h_n;
 } RtgWgradDesc;
 
 int rtg_conv1d_wgrad(const RtgWgradDesc* d, const float* x1, const float* x2, const float* dy, const float* gy_aux,
@@ -132,6 +144,8 @@ typedef struct RtgPackJob {      /* one per packed layout of a layer            
   int src_K, src_inner_c;        /* source taps; source dim-1 size (channels per group of the source tensor)  */
   int S;                         /* stride of the source conv (polyphase modes)                                */
   int tile_m;
+  int KH;                        /* RTG_PACK_DGRAD_2D: kernel rows of the source [C_out][C_in][KH][src_K] weight;
+                                    packed rows = (ci, phase), packed channels = (co, kh)                      */
 } RtgPackJob;
 
 typedef struct RtgWnBwdJob {     /* one per weight-normed tensor                                               */

@@ -326,14 +326,14 @@ def stft_mag_mel_phase(y, n_fft, win_length, hop):
     of win_length zero-padded centred to n_fft, rFFT; S = |D + 1e-9| (1e-9 joins the real part), M = mel @ S, P = angle."""
     if n_fft not in _MEL_CACHE:
         _MEL_CACHE[n_fft] = torch.from_numpy(mel_filterbank(n_fft))
-    win = torch.zeros(n_fft)
+    win = torch.zeros(n_fft, dtype=y.dtype)
     lpad = (n_fft - win_length) // 2
-    win[lpad:lpad + win_length] = torch.hann_window(win_length, periodic=True)
+    win[lpad:lpad + win_length] = torch.hann_window(win_length, periodic=True, dtype=y.dtype)
     yp = F.pad(y.unsqueeze(1), (n_fft // 2, n_fft // 2), mode='reflect').squeeze(1)
     frames = yp.unfold(-1, n_fft, hop)                       # [B, n_frames, n_fft]
     D = torch.fft.rfft(frames * win, dim=-1).transpose(1, 2)  # [B, F, n_frames]
     S = torch.abs(D + 1e-9)
-    M = torch.matmul(_MEL_CACHE[n_fft].to(S.device), S)
+    M = torch.matmul(_MEL_CACHE[n_fft].to(S.device, S.dtype), S)
     P = torch.angle(D)
     return S, M, P
 

@@ -1,0 +1,154 @@
+"""The 2-D mode of rtg_conv1d / rtg_conv1d_wgrad (StftDiscriminator layers) and the MTD stack against the CPU.  GPU only."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+CASES = [
+    # B, Cin, Cout, H, W, (kh,kw), (sh,sw), (ph,pw)
+    (2, 2, 32, 65, 35, (3, 3), (2, 1), (1, 1)),
+    (2, 32, 64, 33, 35, (3, 3), (2, 2), (1, 1)),
+    (2, 64, 256, 40, 18, (5, 3), (3, 2), (2, 1)),
+    (3, 256, 512, 22, 9, (5, 3), (3, 2), (2, 1)),
+    (2, 512, 512, 8, 5, (3, 3), (1, 1), (1, 1)),
+    (2, 512, 1, 8, 18, (3, 3), (1, 1), (1, 1)),
+]
+
+
+class _Net(nn.Module):
+    pass
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_conv2d_layer_forward_backward(case):
+    from models.layers import WNConv, BankedModel, conv
+    B, Cin, Cout, H, W, k, s, p = case
+
+    class Net(BankedModel):
+        def __init__(self):
+            super().__init__()
+            self.c = WNConv('conv2d', Cin, Cout, k, stride=s, pad=p)
+
+        def forward(self, x):
+            return conv(self.token(), self.c, x, pre_slope=0.15)
+
+    torch.manual_seed(3)
+    net = Net()
+    x = torch.randn(B, Cin, H, W)
+    dy_seed = torch.Generator().manual_seed(4)
+    # CPU reference in float64
+    v = net.c.weight_v.detach().double().requires_grad_(True)
+    g = net.c.weight_g.detach().double().requires_grad_(True)
+    bias = net.c.bias.detach().double().requires_grad_(True)
+    xr = x.double().requires_grad_(True)
+    w = g * v / v.flatten(1).norm(dim=1).reshape(-1, 1, 1, 1)
+    y = F.conv2d(F.leaky_relu(xr, 0.15), w, bias, s, p)
+    dy = torch.randn(y.shape, generator=dy_seed)
+    y.backward(dy.double())
+    net.to(DEV)
+    xg = x.to(DEV).requires_grad_(True)
+    out = net(xg)
+    out.backward(dy.to(DEV))
+    torch.cuda.synchronize()
+
+    def close(a, b, name):
+        err = (a.detach().cpu().double() - b).abs().max().item()
+        assert err <= 2e-4 * b.abs().max().item() + 1e-5, (name, err, b.abs().max().item())
+
+    close(out, y.detach(), 'out')
+    close(xg.grad, xr.grad, 'dx')
+    close(net.c.weight_v.grad, v.grad, 'dv')
+    close(net.c.weight_g.grad, g.grad, 'dg')
+    close(net.c.bias.grad, bias.grad, 'dbias')
+
+
+def _stats(t):
+    t = t.detach().double().cpu()
+    return np.array([t.sum().item(), t.abs().mean().item()])
+
+
+def _nets(oracle):
+    from models import MultiStftDiscriminator
+    torch.manual_seed(1)
+    mtd, omtd = MultiStftDiscriminator(), oracle.MTD()
+    oracle.det_fill(mtd)
+    oracle.det_fill(omtd)
+    mtd.to(DEV).train()
+    omtd.train()
+    return mtd, omtd
+
+
+def test_spec_tensors_match_reference_modulo_phase_wrap(oracle, gold):
+    """[log|D+1e-9|, angle(D)/PI] against the oracle.  Frame 0 of a centred, reflect-padded STFT is symmetric about its
+    centre, so its spectrum is real up to rounding: the REFERENCE's own angle() there is +pi or -pi by rounding noise
+    (float32 and float64 CPU runs disagree).  The phase is therefore compared modulo 2 (units of pi)."""
+    from models import multi_stft_loss
+    _, _, y = oracle.golden_inputs()
+    yd = torch.from_numpy(gold['y_hat'])
+    S, Sg = multi_stft_loss(y.to(DEV), yd.to(DEV), ret_specs=True)
+    oS, oSg = oracle.multi_stft_loss(y, yd, ret_specs=True)
+    for a, b in zip(S + Sg, oS + oSg):
+        a = a.cpu()
+        big = b[:, 0] > -5.0                                   # |D| > e^-5: phase well conditioned
+        np.testing.assert_allclose(a[:, 0][big].numpy(), b[:, 0][big].numpy(), rtol=0, atol=2e-4)
+        d = (a[:, 1] - b[:, 1]).abs()
+        d = torch.minimum(d, 2 - d)
+        assert d[big].max().item() < 2e-3
+        assert (d > 1e-2).float().mean().item() < 1e-4
+
+
+def test_mtd_stack_matches_oracle_on_the_same_spectra(oracle, gold):
+    """MTD forward, D-side and G-side backward against the CPU oracle fed with the SAME (GPU-produced) spectra."""
+    from models import multi_stft_loss, discriminator_loss, generator_loss, feature_loss
+    mtd, omtd = _nets(oracle)
+    _, _, y = oracle.golden_inputs()
+    yd = torch.from_numpy(gold['y_hat'])
+    S, Sg = multi_stft_loss(y.to(DEV), yd.to(DEV), ret_specs=True)
+    cS, cSg = [s.cpu() for s in S], [s.cpu().requires_grad_(True) for s in Sg]
+    gSg = [s.detach().clone().requires_grad_(True) for s in Sg]
+    lr, lg, fr, fg = mtd(S, gSg)
+    olr, olg, ofr, ofg = omtd(cS, cSg)
+    for a, b in zip(lr + lg, olr + olg):
+        np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().numpy(), rtol=1e-3, atol=2e-5)
+    shapes = np.array([list(f.shape) for fl in fr for f in fl])
+    assert (shapes == gold['mtd_fmap_shapes']).all()                     # discrminator.py:268-290
+    loss = discriminator_loss(lr, lg) + generator_loss(lg, lr) + 2 * feature_loss(fr, fg)
+    oloss = oracle.discriminator_loss(olr, olg) + oracle.generator_loss(olg, olr) + 2 * oracle.feature_loss(ofr, ofg)
+    np.testing.assert_allclose(loss.item(), oloss.item(), rtol=1e-5)
+    mtd.zero_grad(); omtd.zero_grad()
+    loss.backward(); oloss.backward()
+    torch.cuda.synchronize()
+    op = dict(omtd.named_parameters())
+    for n, p in mtd.named_parameters():
+        err = (p.grad.cpu() - op[n].grad).norm().item() / (op[n].grad.norm().item() + 1e-20)
+        assert err < 2e-3, (n, err)
+    for a, b in zip(gSg, cSg):
+        err = (a.grad.cpu() - b.grad).norm().item() / b.grad.norm().item()
+        assert err < 2e-3, err
+    # reference's own loss values: the phase of frame 0 is rounding noise in the reference (see the test above), which
+    # moves these sums by a few 1e-3 relative
+    np.testing.assert_allclose(discriminator_loss(lr, lg).item(), gold['mtd_d_loss'], rtol=2e-2)
+    np.testing.assert_allclose(feature_loss(fr, fg).item(), gold['mtd_fm_loss'], rtol=2e-2)
+
+
+def test_stft_backward_through_log_magnitude_and_phase(oracle, gold):
+    """d/dy of <cotangent, [log|D+1e-9|, angle(D)/PI]> and of the mel output against CPU autograd (float64)."""
+    from audio import stft_mel_spec
+    yd = torch.from_numpy(gold['y_hat']).squeeze(1)
+    gen = torch.Generator().manual_seed(9)
+    for n_fft, win, hop in oracle.STFT_PARAMS:
+        yh = yd.clone().to(DEV).requires_grad_(True)
+        mel, spec = stft_mel_spec(yh, n_fft, win, hop, True)
+        cs = torch.randn(spec.shape, generator=gen)
+        cm = torch.randn(mel.shape, generator=gen)
+        ((spec * cs.to(DEV)).sum() + (mel * cm.to(DEV)).sum()).backward()
+        y64 = yd.double().requires_grad_(True)
+        S, M, P = oracle.stft_mag_mel_phase(y64, n_fft, win, hop)
+        o = torch.stack([torch.log(S), P / oracle.PI], dim=1)
+        ((o * cs.double()).sum() + (M * cm.double()).sum()).backward()
+        err = (yh.grad.cpu().double() - y64.grad).norm().item() / y64.grad.norm().item()
+        assert err < 5e-3, (n_fft, err)      # fp32 vs float64: d angle / dD ~ 1/|D| amplifies rounding at weak bins

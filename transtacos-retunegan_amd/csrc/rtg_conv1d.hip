@@ -37,6 +37,10 @@ struct ConvArgs {
   int accumulate;
   int n_cc, n_mt, WM, WN, PW, PH, ROW, m_blocks;
   int seg_len, seg_pitch, seg_nb, seg_pw;   // segment packing (seg_len == 0: one clip per block column)
+  // 2-D mode (h_k > 1 or h_n > 1): a "clip" is one (batch item, output row) pair and a "channel" one (channel, kernel
+  // row) pair; the kernel row picks which input row of the [items, C, h_in, L_in] tensor the patch row comes from
+  int two_d, h_in, h_k, h_stride, h_pad, h_n, h_mode;
+  int x_bytes, aux_bytes;
 };
 
 template <int TM>
@@ -73,8 +77,38 @@ __device__ __forceinline__ float buf_load(rsrc_t r, unsigned off) {
 template <bool AUX, int RPW, int MAXIT>
 __device__ __forceinline__ void stage_rows(const ConvArgs& a, rsrc_t r1, rsrc_t r2, rsrc_t raux,
                                            float (&st)[RPW][MAXIT], const unsigned (&eb)[MAXIT],
-                                           const unsigned (&epos)[MAXIT], int cc, int wave, int g, float slope,
+                                           const unsigned (&epos)[MAXIT], const int (&ehq)[MAXIT],
+                                           const int (&ehr)[MAXIT], int cc, int wave, int g, float slope,
                                            bool aux_tanh) {
+  if (a.two_d) {
+    // 2-D: virtual channel c = (ci, kh); the patch row of clip (item, row) comes from input row hq +- kh/stride
+    const int cin = a.C1 / a.h_k;
+    const unsigned item_bytes = (unsigned)cin * (unsigned)a.h_in * (unsigned)a.L_in * 4u;
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      const int c = cc * RTG_CK + wave * RPW + i;
+      const int ci = c / a.h_k, kh = c - ci * a.h_k;
+      int khq, khr, sgn;
+      if (a.h_mode == 0) { khq = kh; khr = 0; sgn = 1; }                       // forward: row = ho*s - p + kh
+      else { khq = kh / a.h_stride; khr = kh - khq * a.h_stride; sgn = -1; }   // backward-data: (h + p - kh) / s
+      const unsigned rowoob = (c < a.Cg) ? 0u : RTG_OOB;
+#pragma unroll
+      for (int it = 0; it < MAXIT; ++it) {
+        const int hrow = ehq[it] + sgn * khq;
+        const bool hok = ehr[it] == khr && hrow >= 0 && hrow < a.h_in;
+        const unsigned offs = hok ? (eb[it] * item_bytes + (unsigned)(ci * a.h_in + hrow) * (unsigned)a.L_in * 4u +
+                                     (epos[it] & ~RTG_OOB)) | (epos[it] & RTG_OOB) | rowoob
+                                  : RTG_OOB;
+        float v = buf_load(r1, offs);
+        if (AUX) {
+          const float av = buf_load(raux, offs);
+          v *= aux_tanh ? (1.f - av * av) : (av > 0.f ? 1.f : slope);
+        }
+        st[i][it] = v;
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < RPW; ++i) {
     const int c = cc * RTG_CK + wave * RPW + i;
@@ -123,7 +157,7 @@ __global__ __launch_bounds__(RTG_THREADS) void conv1d_mfma_kernel(const ConvArgs
 
   // ---- staging geometry (per thread, independent of the channel chunk): LDS offset, clip index and byte position
   // within the row (with the out-of-bounds bit set for zero padding / other clips)
-  int loff[MAXIT];
+  int loff[MAXIT], ehq[MAXIT], ehr[MAXIT];
   unsigned epos[MAXIT], eb[MAXIT];
 #pragma unroll
   for (int it = 0; it < MAXIT; ++it) {
@@ -143,20 +177,31 @@ __global__ __launch_bounds__(RTG_THREADS) void conv1d_mfma_kernel(const ConvArgs
     ok = ok && pos >= 0 && pos < a.L_in;
     epos[it] = ok ? (unsigned)pos * 4u : RTG_OOB;
     eb[it] = ok ? (unsigned)bb : 0u;
+    ehq[it] = 0;
+    ehr[it] = 0;
+    if (a.two_d) {                       // clip -> (batch item, row); see stage_rows
+      const int item = (int)eb[it] / a.h_n, hh = (int)eb[it] - item * a.h_n;
+      eb[it] = (unsigned)item;
+      if (a.h_mode == 0) {
+        ehq[it] = hh * a.h_stride - a.h_pad;
+      } else {
+        ehq[it] = (hh + a.h_pad) / a.h_stride;
+        ehr[it] = (hh + a.h_pad) - ehq[it] * a.h_stride;
+      }
+    }
   }
   float st[RPW][MAXIT];
   const bool aux_tanh = a.pre_mode == RTG_PRE_MUL_DTANH;
   const float slope = (a.pre_mode == RTG_PRE_NONE) ? 1.f : a.pre_slope;
   const float wslope = (a.pre_mode == RTG_PRE_LRELU) ? a.pre_slope : 1.f;   // applied at the LDS write
-  const rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.x1, 0, a.B * a.C1 * a.L_in * 4, 0x00020000);
+  const rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.x1, 0, a.x_bytes, 0x00020000);
   const rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x2 ? a.x2 : a.x1), 0,
                                                       a.x2 ? a.B * a.C2 * a.L_in * 4 : 0, 0x00020000);
-  const rsrc_t raux = __builtin_amdgcn_make_buffer_rsrc((void*)(a.aux ? a.aux : a.x1), 0,
-                                                        a.aux ? a.B * a.C1 * a.L_in * 4 : 0, 0x00020000);
+  const rsrc_t raux = __builtin_amdgcn_make_buffer_rsrc((void*)(a.aux ? a.aux : a.x1), 0, a.aux_bytes, 0x00020000);
 
   auto stage = [&](int cc) __attribute__((always_inline)) {
-    if (a.aux) stage_rows<true, RPW, MAXIT>(a, r1, r2, raux, st, eb, epos, cc, wave, g, slope, aux_tanh);
-    else stage_rows<false, RPW, MAXIT>(a, r1, r2, raux, st, eb, epos, cc, wave, g, slope, aux_tanh);
+    if (a.aux) stage_rows<true, RPW, MAXIT>(a, r1, r2, raux, st, eb, epos, ehq, ehr, cc, wave, g, slope, aux_tanh);
+    else stage_rows<false, RPW, MAXIT>(a, r1, r2, raux, st, eb, epos, ehq, ehr, cc, wave, g, slope, aux_tanh);
   };
   auto swrite = [&](float* buf) __attribute__((always_inline)) {
 #pragma unroll
@@ -259,6 +304,12 @@ __global__ __launch_bounds__(RTG_THREADS) void conv1d_mfma_kernel(const ConvArgs
         if (seg >= a.seg_nb || b >= a.B) continue;
       }
       if (q >= a.Q) continue;
+      int hh = 0;
+      if (a.two_d) {                     // clip -> (batch item, output row)
+        const int item = b / a.h_n;
+        hh = b - item * a.h_n;
+        b = item;
+      }
 #pragma unroll
       for (int r = 0; r < M::NREG; ++r) {
         const int m = (mt0 + i) * TM + M::row(lane, r);
@@ -281,7 +332,7 @@ __global__ __launch_bounds__(RTG_THREADS) void conv1d_mfma_kernel(const ConvArgs
           }
           if (!dst) continue;
         } else {
-          idx = ((size_t)b * a.out_C + ch) * a.out_L + u;
+          idx = (((size_t)b * a.out_C + ch) * a.h_n + hh) * a.out_L + u;   // h_n == 1, hh == 0 in 1-D
         }
         float v = acc[i][j][r];
         if (a.bias) v += a.bias[ch];
@@ -408,8 +459,16 @@ extern "C" int rtg_conv1d(const RtgConv1dDesc* d, const float* x1, const float* 
   if (d->stride > 1 && d->dil != 1) return RTG_ERANGE;
   if ((long long)d->groups * d->Mg != (long long)d->out_C * d->shuf_S) return RTG_EINVAL;
   if (d->shuf_S == 1 && d->Q > d->out_L) return RTG_EINVAL;
-  if (d->B > 65535) return RTG_ERANGE;
-  if ((long long)d->B * (d->C1 > d->C2 ? d->C1 : d->C2) * d->L_in * 4 >= (1ll << 31)) return RTG_ERANGE;   // 32-bit buffer offsets
+  // second dimension (all zero / one = plain 1-D)
+  const bool two_d = d->h_k > 1 || d->h_n > 1;
+  if (two_d) {
+    if (d->h_in < 1 || d->h_k < 1 || d->h_stride < 1 || d->h_pad < 0 || d->h_n < 1 || (d->h_mode != 0 && d->h_mode != 1))
+      return RTG_EINVAL;
+    if (d->groups != 1 || d->C2 != 0 || d->out_split != 0 || d->C1 % d->h_k != 0 || d->B % d->h_n != 0) return RTG_EINVAL;
+  }
+  const long long x_bytes = two_d ? (long long)(d->B / d->h_n) * (d->C1 / d->h_k) * d->h_in * d->L_in * 4
+                                  : (long long)d->B * d->C1 * d->L_in * 4;
+  if (x_bytes >= (1ll << 31) || (long long)d->B * d->C2 * d->L_in * 4 >= (1ll << 31)) return RTG_ERANGE;   // 32-bit offsets
 
   ConvArgs a;
   a.x1 = x1; a.x2 = x2; a.aux = (d->pre_mode >= RTG_PRE_MUL_DLRELU) ? aux : nullptr; a.wp = wp; a.bias = bias;
@@ -419,6 +478,10 @@ extern "C" int rtg_conv1d(const RtgConv1dDesc* d, const float* x1, const float* 
   a.shuf_S = d->shuf_S; a.shuf_P = d->shuf_P; a.pre_mode = d->pre_mode; a.pre_slope = d->pre_slope;
   a.mask_slope = d->mask_slope; a.out_scale = d->out_scale; a.act = d->act; a.act_slope = d->act_slope;
   a.accumulate = d->accumulate;
+  a.two_d = two_d ? 1 : 0;
+  a.h_in = two_d ? d->h_in : 1; a.h_k = two_d ? d->h_k : 1; a.h_stride = two_d ? d->h_stride : 1;
+  a.h_pad = two_d ? d->h_pad : 0; a.h_n = two_d ? d->h_n : 1; a.h_mode = two_d ? d->h_mode : 0;
+  a.x_bytes = (int)x_bytes; a.aux_bytes = a.aux ? (int)x_bytes : 0;
   const int TM = d->tile_m;
   a.n_cc = rtg_ceil_div(d->Cg, RTG_CK);
   a.n_mt = rtg_ceil_div(d->Mg, TM);
@@ -443,8 +506,9 @@ extern "C" int rtg_conv1d(const RtgConv1dDesc* d, const float* x1, const float* 
   a.m_blocks = rtg_ceil_div(a.n_mt, c.WM * c.MT);
   const long long gy = (long long)d->groups * a.m_blocks;
   if (gy > 65535) return RTG_ERANGE;
-  dim3 grid(c.seg_len > 0 ? 1 : rtg_ceil_div(d->Q, BN), (unsigned)gy,
-            c.seg_len > 0 ? rtg_ceil_div(d->B, c.seg_nb) : d->B);
+  const int gz = c.seg_len > 0 ? rtg_ceil_div(d->B, c.seg_nb) : d->B;
+  if (gz > 65535) return RTG_ERANGE;
+  dim3 grid(c.seg_len > 0 ? 1 : rtg_ceil_div(d->Q, BN), (unsigned)gy, gz);
   const size_t lds_bytes = (size_t)2 * RTG_CK * a.ROW * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
 

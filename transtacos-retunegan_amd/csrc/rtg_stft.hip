@@ -78,7 +78,9 @@ __global__ __launch_bounds__(RTG_THREADS) void stft_fwd_kernel(RtgStftDesc d, co
 
   const size_t fo = ((size_t)b * d.frames + frame) * F;  // [B][frames][F] scratch layout for the backward
   for (int f = threadIdx.x; f < F; f += RTG_THREADS) {
-    const float re = X[f].x, im = X[f].y;
+    // DC and Nyquist of a real-input transform are exactly real: a real-to-complex FFT (torch.stft / pocketfft) returns
+    // imag = +0.0 there, so angle() is exactly 0 or +pi; rounding noise of a complex FFT would flip it to -pi at random
+    const float re = X[f].x, im = (f == 0 || f == N / 2) ? 0.f : X[f].y;
     const float rr = re + 1e-9f;
     const float mag = sqrtf(rr * rr + im * im);
     S[f] = mag;
@@ -153,6 +155,7 @@ __global__ __launch_bounds__(RTG_THREADS) void stft_bwd_frame_kernel(RtgStftDesc
         gr += dP * (-im / r2);
         gi += dP * (re / r2);
       }
+      if (f == 0 || f == N / 2) gi = 0.f;                 // structurally-zero imaginary parts carry no gradient
     }
     A[f].x = gr;                                          // conj(G): adjoint of the forward DFT = Re FFT(conj G)
     A[f].y = -gi;

@@ -53,6 +53,15 @@ __global__ __launch_bounds__(RTG_THREADS) void pack_kernel(const RtgPackJob* job
       } else if (j.mode == RTG_PACK_DGRAD_S1) {
         srow = (long long)g * j.Cg + c;
         sin = (long long)row * j.src_K + (j.src_K - 1 - tap);
+      } else if (j.mode == RTG_PACK_DGRAD_2D) {
+        // source [C_out][C_in][KH][src_K]; packed rows (ci, phase r), packed channels (co, kh), taps along W
+        const int ch = row / j.S, r = row - ch * j.S;
+        const int co = c / j.KH, kh = c - co * j.KH;
+        const int jj = r + (j.K - 1 - tap) * j.S;
+        if (jj < j.src_K) {
+          srow = co;
+          sin = ((long long)ch * j.KH + kh) * j.src_K + jj;
+        }
       } else {
         const int ch = row / j.S, r = row - ch * j.S;
         const int jj = r + (j.K - 1 - tap) * j.S;

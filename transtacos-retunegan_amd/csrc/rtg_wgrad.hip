@@ -40,6 +40,8 @@ struct WgArgs {
   long long part_stride;
   int CKW, n_cchunk, m_blocks, n_ttiles, n_tiles_total, PW, ROW, ones_off, xbuf_sz;
   int seg_len, seg_pitch, seg_nb, seg_pw;   // seg_len == 0: one clip per tile
+  int two_d, h_in, h_k, h_stride, h_pad, h_n;   // second dimension, see RtgConv1dDesc
+  int x_bytes, dy_bytes;
 };
 
 template <int TM>
@@ -132,10 +134,10 @@ __global__ __launch_bounds__(RTG_THREADS) void wgrad_kernel(const WgArgs a) {
   const int dt = packed ? lane - dseg * a.seg_len : lane;
   const bool dcol_ok = packed ? (dseg < a.seg_nb) : true;
 
-  const rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.x1, 0, a.B * a.C1 * a.L_in * 4, 0x00020000);
+  const rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.x1, 0, a.x_bytes, 0x00020000);
   const rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x2 ? a.x2 : a.x1), 0,
                                                       a.x2 ? a.B * a.C2 * a.L_in * 4 : 0, 0x00020000);
-  const int dy_bytes = a.B * a.groups * a.Mg * a.dy_L * 4;
+  const int dy_bytes = a.dy_bytes;
   const rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, dy_bytes, 0x00020000);
   const rsrc_t raux = __builtin_amdgcn_make_buffer_rsrc((void*)(a.gy_aux ? a.gy_aux : a.dy), 0,
                                                         a.gy_aux ? dy_bytes : 0, 0x00020000);
@@ -150,6 +152,29 @@ __global__ __launch_bounds__(RTG_THREADS) void wgrad_kernel(const WgArgs a) {
     if (packed) { b0 = tl * a.seg_nb; t0 = 0; }
     else        { b0 = tl / a.n_ttiles; t0 = (tl - b0 * a.n_ttiles) * TT; }
     const int o_start = t0 * a.stride - a.pad;
+    if (a.two_d) {
+      // channel (ci, kh) of clip (item, row r) reads input row r*h_stride - h_pad + kh of [items, C, h_in, L_in]
+      const int cin = a.C1 / a.h_k;
+      const unsigned item_bytes = (unsigned)cin * (unsigned)a.h_in * (unsigned)a.L_in * 4u;
+#pragma unroll
+      for (int i = 0; i < XR; ++i) {
+        const int cl = wave * XR + i;
+        const int c = c0 + cl;
+        const int ci = c / a.h_k, kh = c - ci * a.h_k;
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) {
+          const int pos = o_start + xw[it];
+          const int bb = b0 + xseg[it];
+          const int item = bb / a.h_n, hh = bb - item * a.h_n;
+          const int hrow = hh * a.h_stride - a.h_pad + kh;
+          const bool ok = cl < cw && pos >= 0 && pos < a.L_in && bb < a.B && hrow >= 0 && hrow < a.h_in;
+          const unsigned off = ok ? (unsigned)item * item_bytes +
+                                        ((unsigned)(ci * a.h_in + hrow) * (unsigned)a.L_in + (unsigned)pos) * 4u
+                                  : RTG_OOB;
+          sx[i][it] = buf_load(r1, off);
+        }
+      }
+    } else
 #pragma unroll
     for (int i = 0; i < XR; ++i) {
       const int cl = wave * XR + i;
@@ -172,13 +197,17 @@ __global__ __launch_bounds__(RTG_THREADS) void wgrad_kernel(const WgArgs a) {
       const int bb = b0 + dseg;
       const int t = t0 + dt;
       const bool colok = dcol_ok && bb < a.B && t < a.Q;
-      const unsigned coloff = colok ? ((unsigned)bb * (unsigned)(a.groups * a.Mg) * (unsigned)a.dy_L + (unsigned)t) * 4u
+      // dy is [items, rows, h_n, dy_L]: element (item, m, hh, t); h_n == 1 in 1-D
+      const int item = bb / a.h_n, hh = bb - item * a.h_n;
+      const unsigned rowpitch = (unsigned)a.h_n * (unsigned)a.dy_L * 4u;
+      const unsigned coloff = colok ? (unsigned)item * (unsigned)(a.groups * a.Mg) * rowpitch +
+                                          ((unsigned)hh * (unsigned)a.dy_L + (unsigned)t) * 4u
                                     : RTG_OOB;
 #pragma unroll
       for (int i = 0; i < DR; ++i) {
         const int rl = wave + 4 * i;
         const int m = m0 + rl;
-        const unsigned off = (m < a.Mg) ? (coloff + (unsigned)(g * a.Mg + m) * (unsigned)a.dy_L * 4u) | (coloff & RTG_OOB)
+        const unsigned off = (m < a.Mg) ? (coloff + (unsigned)(g * a.Mg + m) * rowpitch) | (coloff & RTG_OOB)
                                         : RTG_OOB;
         sd[i] = buf_load(rdy, off);
         if (has_aux) sa[i] = buf_load(raux, off);
@@ -344,8 +373,15 @@ int validate(const RtgWgradDesc* d) {
   if (d->C1 + d->C2 != d->groups * d->Cg) return RTG_EINVAL;
   if (d->groups > 1 && d->C2 != 0) return RTG_EINVAL;
   if (d->stride > 8) return RTG_ERANGE;
+  const bool two_d = d->h_k > 1 || d->h_n > 1;
+  if (two_d) {
+    if (d->h_in < 1 || d->h_k < 1 || d->h_stride < 1 || d->h_pad < 0 || d->h_n < 1) return RTG_EINVAL;
+    if (d->groups != 1 || d->C2 != 0 || d->C1 % d->h_k != 0 || d->B % d->h_n != 0) return RTG_EINVAL;
+  }
   // 32-bit buffer offsets
-  if ((long long)d->B * (d->C1 > d->C2 ? d->C1 : d->C2) * d->L_in * 4 >= (1ll << 31)) return RTG_ERANGE;
+  const long long xb = two_d ? (long long)(d->B / d->h_n) * (d->C1 / d->h_k) * d->h_in * d->L_in * 4
+                             : (long long)d->B * (d->C1 > d->C2 ? d->C1 : d->C2) * d->L_in * 4;
+  if (xb >= (1ll << 31)) return RTG_ERANGE;
   if ((long long)d->B * d->groups * d->Mg * d->dy_L * 4 >= (1ll << 31)) return RTG_ERANGE;
   return RTG_OK;
 }
@@ -422,6 +458,12 @@ extern "C" int rtg_conv1d_wgrad(const RtgWgradDesc* d, const float* x1, const fl
   a.n_ttiles = g.n_ttiles; a.n_tiles_total = g.n_tiles_total; a.PW = g.PW; a.ROW = g.ROW;
   a.seg_len = g.seg_len; a.seg_nb = g.seg_nb; a.seg_pw = g.seg_pw;
   a.seg_pitch = g.seg_len > 0 ? g.seg_len * d->stride : 1;
+  const bool two_d = d->h_k > 1 || d->h_n > 1;
+  a.two_d = two_d ? 1 : 0;
+  a.h_in = two_d ? d->h_in : 1; a.h_k = two_d ? d->h_k : 1; a.h_stride = two_d ? d->h_stride : 1;
+  a.h_pad = two_d ? d->h_pad : 0; a.h_n = two_d ? d->h_n : 1;
+  a.x_bytes = two_d ? (d->B / d->h_n) * (d->C1 / d->h_k) * d->h_in * d->L_in * 4 : d->B * d->C1 * d->L_in * 4;
+  a.dy_bytes = d->B * d->groups * d->Mg * d->dy_L * 4;
   const int rows = sh.WM * sh.MTW * g.TM;
   const int xr_cap = (g.maxit <= 4) ? 32 : 16;
   a.xbuf_sz = xr_cap * g.ROW;                       // patch rows up to the staging capacity (rows past CKW unused)

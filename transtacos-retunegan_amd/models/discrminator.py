@@ -90,19 +90,7 @@ def _split(t, B):
 
 
 class _MultiBase(BankedModel):
-    def _pairs(self, runner, y, y_hat):
-        """Run `runner(tok, x)` on real and fake.  Returns (logit_r, logit_g, fmap_r, fmap_g)."""
-        tok = self.token()
-        B = y.shape[0]
-        if _frozen(self) and not y.requires_grad:
-            with torch.no_grad():
-                lr, fr = runner(tok, y)
-            lg, fg = runner(tok, y_hat)
-            return lr, lg, fr, fg
-        l2, f2 = runner(tok, torch.cat([y, y_hat], dim=0))
-        lr, lg = _split(l2, B)
-        fs = [_split(f, B) for f in f2]
-        return lr, lg, [a for a, _ in fs], [b for _, b in fs]
+    pass
 
 
 class MultiScaleDiscriminator(_MultiBase):
@@ -170,44 +158,43 @@ class MultiPeriodDiscriminator(_MultiBase):
 
 
 class StftDiscriminator(nn.Module):
-    """discrminator.py:247-308 — parameter holder (2-D convolutions over [log|D|, phase/PI]).  The 2-D MFMA conv
-    kernels are the next row of the coverage table; BASELINE config 2 (the benchmarked one) does
-    not use MTD."""
+    """discrminator.py:247-308: five strided Conv2d layers + conv_post over [log|D|, phase/PI] ([B,2,F,frames])."""
 
     def __init__(self, i, ch=2):
         super().__init__()
-        import math
-        spec = [(ch, 32, (3, 3)), (32, 64, (3, 3)), (64, 256, (5, 3)), (256, 512, (5, 3)), (512, 512, (3, 3))]
-        self.convs = nn.ModuleList([_Conv2dParams(ci, co, k) for ci, co, k in spec])
-        self.conv_post = _Conv2dParams(512, 1, (3, 3))
+        spec = [(ch, 32, (3, 3), (2, 1), (1, 1)), (32, 64, (3, 3), (2, 2), (1, 1)), (64, 256, (5, 3), (3, 2), (2, 1)),
+                (256, 512, (5, 3), (3, 2), (2, 1)), (512, 512, (3, 3), (1, 1), (1, 1))]
+        self.convs = nn.ModuleList([WNConv('conv2d', ci, co, k, stride=s, pad=p) for ci, co, k, s, p in spec])
+        self.conv_post = WNConv('conv2d', 512, 1, (3, 3), stride=(1, 1), pad=(1, 1))
         for c in [*self.convs, self.conv_post]:
-            c.burn_init_rng()
+            c.burn_init_rng()       # self.convs.apply(init_weights); self.conv_post.apply(init_weights) (:264-265)
+
+    def run(self, tok, x):
+        logit, fmap = _run_stack(tok, self.convs, self.conv_post, x)
+        return torch.flatten(logit, 1, -1), fmap
 
 
-class _Conv2dParams(nn.Module):
-    def __init__(self, cin, cout, k):
-        super().__init__()
-        import math
-        v = torch.empty(cout, cin, *k)
-        nn.init.kaiming_uniform_(v, a=math.sqrt(5))
-        bound = 1.0 / math.sqrt(cin * k[0] * k[1])
-        b = torch.empty(cout).uniform_(-bound, bound)
-        self.weight_g = nn.Parameter(v.flatten(1).norm(dim=1).reshape(cout, 1, 1, 1))
-        self.weight_v = nn.Parameter(v)
-        self.bias = nn.Parameter(b)
-
-    def burn_init_rng(self):
-        torch.empty(self.weight_v.shape).normal_(0, 1.0)
-
-
-class MultiStftDiscriminator(nn.Module):
-    """discrminator.py:311-330."""
+class MultiStftDiscriminator(_MultiBase):
+    """discrminator.py:311-330: one StftDiscriminator per STFT resolution, zipped with the spec lists."""
 
     def __init__(self):
         super().__init__()
         self.discriminators = nn.ModuleList([StftDiscriminator(i) for i in range(len(hp.multi_stft_params))])
 
     def forward(self, phs, ph_hats):
-        from rtg.lib import RtgError
-        raise RtgError('MultiStftDiscriminator: the 2-D conv kernels are not built yet (SURVEY.md §8a-8, next row); '
-                       'no CPU or library fallback is provided on the hot path')
+        tok = self.token()
+        ph_d_rs, ph_d_gs, fmap_rs, fmap_gs = [], [], [], []
+        for d, ph, ph_hat in zip(self.discriminators, phs, ph_hats):
+            B = ph.shape[0]
+            if _frozen(self) and not ph.requires_grad:
+                with torch.no_grad():
+                    lr, fr = d.run(tok, ph)
+                lg, fg = d.run(tok, ph_hat)
+            else:
+                l2, f2 = d.run(tok, torch.cat([ph, ph_hat], dim=0))
+                lr, lg = _split(l2, B)
+                fs = [_split(f, B) for f in f2]
+                fr, fg = [a for a, _ in fs], [b for _, b in fs]
+            ph_d_rs.append(lr); fmap_rs.append(fr)
+            ph_d_gs.append(lg); fmap_gs.append(fg)
+        return ph_d_rs, ph_d_gs, fmap_rs, fmap_gs

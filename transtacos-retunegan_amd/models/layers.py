@@ -16,17 +16,22 @@ class WNConv(nn.Module):
     """Parameters of one weight-normed convolution, named like torch.nn.utils.weight_norm names them
     (weight_g, weight_v, bias; call sites retunegan/models/generator.py:682-722, discrminator.py:37-45,156-163).
     kind 'conv'  : Conv1d, or a (k,1)/(k,1)-strided Conv2d whose trailing kernel dim is 1 (v keeps the 4-D shape)
-    kind 'convT' : ConvTranspose1d (dim 0 of v is the INPUT channel axis, as in the reference's ups.N.weight_g)."""
+    kind 'convT' : ConvTranspose1d (dim 0 of v is the INPUT channel axis, as in the reference's ups.N.weight_g)
+    kind 'conv2d': Conv2d with (rows, cols) kernel / stride / padding pairs (StftDiscriminator, discrminator.py:255-262)."""
 
     def __init__(self, kind, cin, cout, k, stride=1, pad=0, dil=1, groups=1, out_pad=0, kdims=1):
         super().__init__()
         self.kind, self.cin, self.cout, self.k = kind, cin, cout, k
         self.stride, self.pad, self.dil, self.groups, self.out_pad = stride, pad, dil, groups, out_pad
-        ks = (k,) if kdims == 1 else (k, 1)
+        if kind == 'conv2d':                                   # k, stride, pad are (rows, cols) pairs
+            assert groups == 1 and dil == 1
+            ks = tuple(k)
+        else:
+            ks = (k,) if kdims == 1 else (k, 1)
         shape = ((cin, cout // groups) if kind == 'convT' else (cout, cin // groups)) + ks
         v = torch.empty(shape)
         nn.init.kaiming_uniform_(v, a=math.sqrt(5))            # torch's default conv init (reset_parameters)
-        bound = 1.0 / math.sqrt(shape[1] * k)
+        bound = 1.0 / math.sqrt(shape[1] * int(np.prod(ks)))
         b = torch.empty(cout).uniform_(-bound, bound)
         self.weight_g = nn.Parameter(v.flatten(1).norm(dim=1).reshape((shape[0],) + (1,) * (len(shape) - 1)))
         self.weight_v = nn.Parameter(v)

@@ -44,7 +44,12 @@ class ConvLayer:
         m = module
         self.kind, self.cin, self.cout, self.k = m.kind, m.cin, m.cout, m.k
         self.stride, self.pad, self.dil, self.groups, self.out_pad = m.stride, m.pad, m.dil, m.groups, m.out_pad
-        if self.kind == 'convT':
+        self.kh = 1
+        if self.kind == 'conv2d':
+            # runs as the 1-D operator along the last axis: channels = (c, kernel row), clips = (item, output row)
+            (self.kh, self.k), (self.sh, self.stride), (self.ph, self.pad) = m.k, m.stride, m.pad
+            self.rows, self.inner_c = self.cout, self.cin * self.kh
+        elif self.kind == 'convT':
             assert self.groups == 1 and self.dil == 1
             self.rows, self.inner_c = self.cin, self.cout
         else:
@@ -54,7 +59,10 @@ class ConvLayer:
         nt = -(-self.k // s)
         self.nt = nt
         # (mode, groups, Mg, Cg, K, S) of the packed forward / backward-data operators
-        if self.kind == 'conv':
+        if self.kind == 'conv2d':
+            self.fwd_op = (L.PACK_FWD, 1, self.cout, self.cin * self.kh, self.k, 1)
+            self.bwd_op = (L.PACK_DGRAD_2D, 1, self.cin * s, self.cout * self.kh, nt, s)
+        elif self.kind == 'conv':
             cg, mg = self.cin // self.groups, self.cout // self.groups
             self.fwd_op = (L.PACK_FWD, self.groups, mg, cg, self.k, 1)
             if s == 1:
@@ -187,7 +195,8 @@ class WeightBank:
             norm.append(L.NormJob(ly.g_off, ly.v_off, ly.scale_off, ly.rows, ly.inner))
             for (mode, g, mg, cg, k, s), off, size, tm in ((ly.fwd_op, ly.fwd_off, ly.fwd_size, ly.fwd_tm),
                                                            (ly.bwd_op, ly.bwd_off, ly.bwd_size, ly.bwd_tm)):
-                pack.append(L.PackJob(ly.v_off, ly.scale_off, off, size, mode, g, mg, cg, k, ly.k, ly.inner_c, s, tm))
+                pack.append(L.PackJob(ly.v_off, ly.scale_off, off, size, mode, g, mg, cg, k, ly.k, ly.inner_c, s, tm,
+                                      ly.kh))
                 self.max_pack = max(self.max_pack, size)
         self.norm_table = _table(norm, self.device)
         self.pack_table = _table(pack, self.device)
@@ -240,7 +249,7 @@ class WeightBank:
 
     def _job(self, ly, part, splits, base_ptr, with_bias=True):
         stride = ly.rows * (ly.inner + 1)
-        has_bias = with_bias and ly.kind == 'conv'
+        has_bias = with_bias and ly.kind != 'convT'
         return L.WnBwdJob(ly.g_off, ly.v_off, ly.b_off if has_bias else -1, ly.scale_off,
                           (part.data_ptr() - base_ptr) // 4, stride, splits, ly.rows, ly.inner)
 

@@ -14,7 +14,8 @@ class Conv1dDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in ('B', 'C1', 'C2', 'L_in', 'groups', 'Cg', 'Mg', 'K', 'stride', 'dil', 'pad', 'Q',
                                        'out_C', 'out_L', 'shuf_S', 'shuf_P', 'pre_mode')] + \
                [('pre_slope', C.c_float), ('mask_slope', C.c_float), ('out_scale', C.c_float), ('act', C.c_int),
-                ('act_slope', C.c_float), ('accumulate', C.c_int), ('tile_m', C.c_int), ('out_split', C.c_int)]
+                ('act_slope', C.c_float), ('accumulate', C.c_int), ('tile_m', C.c_int), ('out_split', C.c_int)] + \
+               [(n, C.c_int) for n in ('h_in', 'h_k', 'h_stride', 'h_pad', 'h_n', 'h_mode')]
 
 
 class WgradDesc(C.Structure):
@@ -22,7 +23,7 @@ class WgradDesc(C.Structure):
                                        'dy_L', 'pre_mode')] + \
                [('pre_slope', C.c_float), ('gy_mode', C.c_int), ('gy_slope', C.c_float), ('gy_scale', C.c_float),
                 ('splits', C.c_int),
-                ('part_stride', C.c_longlong)]
+                ('part_stride', C.c_longlong)] + [(n, C.c_int) for n in ('h_in', 'h_k', 'h_stride', 'h_pad', 'h_n')]
 
 
 class NormJob(C.Structure):
@@ -33,7 +34,7 @@ class NormJob(C.Structure):
 class PackJob(C.Structure):
     _fields_ = [('v_off', C.c_longlong), ('scale_off', C.c_longlong), ('dst_off', C.c_longlong),
                 ('dst_size', C.c_longlong)] + \
-               [(n, C.c_int) for n in ('mode', 'groups', 'Mg', 'Cg', 'K', 'src_K', 'src_inner_c', 'S', 'tile_m')]
+               [(n, C.c_int) for n in ('mode', 'groups', 'Mg', 'Cg', 'K', 'src_K', 'src_inner_c', 'S', 'tile_m', 'KH')]
 
 
 class WnBwdJob(C.Structure):
@@ -53,7 +54,7 @@ class StftDesc(C.Structure):
 
 PRE_NONE, PRE_LRELU, PRE_MUL_DLRELU, PRE_MUL_DTANH = 0, 1, 2, 3
 ACT_NONE, ACT_LRELU, ACT_TANH = 0, 1, 2
-PACK_FWD, PACK_DGRAD_S1, PACK_DGRAD_POLY, PACK_CONVT_POLY = 0, 1, 2, 3
+PACK_FWD, PACK_DGRAD_S1, PACK_DGRAD_POLY, PACK_CONVT_POLY, PACK_DGRAD_2D = 0, 1, 2, 3, 4
 CK = 16
 LOSS_L1, LOSS_L1_L1LOG, LOSS_MSE_TARGET = 0, 1, 2
 MAX_LOSS_JOBS = 48

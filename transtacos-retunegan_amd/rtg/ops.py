@@ -210,9 +210,87 @@ class ConvFn(torch.autograd.Function):
 
 
 def conv(token, ly, x1, x2=None, res=None, pre_slope=1.0, act=L.ACT_NONE, act_slope=1.0, out_scale=1.0):
+    if ly.kind == 'conv2d':
+        assert x2 is None and res is None and act == L.ACT_NONE and out_scale == 1.0
+        return Conv2dFn.apply(token, x1, ly, float(pre_slope))
     res_is_input = res is not None and res is x1
     return ConvFn.apply(token, x1, x2, res, ly, float(pre_slope), int(act), float(act_slope), float(out_scale),
                         res_is_input)
+
+
+class Conv2dFn(torch.autograd.Function):
+    """out = conv2d(leaky_relu(x, pre_slope)) + bias for the StftDiscriminator layers (discrminator.py:255-262),
+    executed by the 1-D MFMA kernels along the last axis: clips = (item, output row), channels = (c, kernel row)."""
+
+    @staticmethod
+    def forward(ctx, token, x, ly, pre_slope):
+        _need_cuda(x)
+        bank = token._rtg_bank
+        x = _c(x)
+        B, Cin, H, W = x.shape
+        assert Cin == ly.cin
+        Ho = (H + 2 * ly.ph - ly.kh) // ly.sh + 1
+        Wo = (W + 2 * ly.pad - ly.k) // ly.stride + 1
+        out = torch.empty(B, ly.cout, Ho, Wo, device=x.device, dtype=torch.float32)
+        pre_mode = L.PRE_LRELU if pre_slope != 1.0 else L.PRE_NONE
+        d = _desc(B=B * Ho, C1=Cin * ly.kh, L_in=W, groups=1, Cg=Cin * ly.kh, Mg=ly.cout, K=ly.k, stride=ly.stride,
+                  pad=ly.pad, Q=Wo, out_C=ly.cout, out_L=Wo, pre_mode=pre_mode, pre_slope=pre_slope, tile_m=ly.fwd_tm,
+                  h_in=H, h_k=ly.kh, h_stride=ly.sh, h_pad=ly.ph, h_n=Ho, h_mode=0)
+        flop = 2.0 * B * Ho * Wo * ly.cout * Cin * ly.kh * ly.k
+        check(_timed('conv1d', lib.rtg_conv1d_variant(C.byref(d)) if PROFILE is not None else 0, flop,
+                     lambda: lib.rtg_conv1d(C.byref(d), _p(x), None, None, bank.fwd_ptr(ly), bank.bias_ptr(ly), None,
+                                            None, _p(out), None, _stream()), f'fwd2d {ly.name} B{B} {H}x{W}'),
+              f'conv2d fwd {ly.name}')
+        ctx.ly, ctx.bank, ctx.tok_id, ctx.pre_slope = ly, bank, token._rtg_id, pre_slope
+        ctx.save_for_backward(x)
+        ctx.set_materialize_grads(False)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        ly, bank, pre_slope = ctx.ly, ctx.bank, ctx.pre_slope
+        (x,) = ctx.saved_tensors
+        if dy is None:
+            return None, None, None, None
+        dy = _c(dy)
+        B, Cin, H, W = x.shape
+        _, _, Ho, Wo = dy.shape
+        st = _stream()
+        flop = 2.0 * B * Ho * Wo * ly.cout * Cin * ly.kh * ly.k
+        dx = None
+        if ctx.needs_input_grad[1]:
+            dx = torch.empty_like(x)
+            mode, g, mg, cg, k, s = ly.bwd_op
+            mask = x if pre_slope != 1.0 else None
+            common = dict(B=B * H, C1=ly.cout * ly.kh, L_in=Wo, groups=1, Cg=cg, Mg=mg, K=k, out_C=Cin, out_L=W,
+                          mask_slope=pre_slope, tile_m=ly.bwd_tm, h_in=Ho, h_k=ly.kh, h_stride=ly.sh, h_pad=ly.ph,
+                          h_n=H, h_mode=1)
+            if ly.stride == 1:
+                d = _desc(stride=1, pad=(ly.k - 1) - ly.pad, Q=W, **common)
+            else:
+                d = _desc(stride=1, pad=k - 1, Q=(W - 1 + ly.pad) // ly.stride + 1, shuf_S=ly.stride, shuf_P=ly.pad,
+                          **common)
+            check(_timed('conv1d', lib.rtg_conv1d_variant(C.byref(d)) if PROFILE is not None else 0, flop,
+                         lambda: lib.rtg_conv1d(C.byref(d), _p(dy), None, None, bank.bwd_ptr(ly), None, _p(mask), None,
+                                                _p(dx), None, st), f'dgrad2d {ly.name} B{B} {H}x{W}'),
+                  f'conv2d bwd-data {ly.name}')
+        if ctx.needs_input_grad[0]:
+            pre_mode = L.PRE_LRELU if pre_slope != 1.0 else L.PRE_NONE
+            wd = L.WgradDesc(B=B * Ho, C1=Cin * ly.kh, C2=0, L_in=W, groups=1, Cg=Cin * ly.kh, Mg=ly.cout, K=ly.k,
+                             stride=ly.stride, dil=1, pad=ly.pad, Q=Wo, dy_L=Wo, pre_mode=pre_mode, pre_slope=pre_slope,
+                             gy_mode=L.PRE_NONE, gy_slope=1.0, gy_scale=1.0, splits=1, part_stride=0, h_in=H,
+                             h_k=ly.kh, h_stride=ly.sh, h_pad=ly.ph, h_n=Ho)
+            splits = lib.rtg_wgrad_splits(C.byref(wd))
+            if splits < 1:
+                raise L.RtgError(f'wgrad geometry refused for {ly.name}: {splits}')
+            part, stride, immediate = bank.partial_slot(ly, splits, ctx.tok_id)
+            wd.splits, wd.part_stride = splits, stride
+            check(_timed('wgrad', 32 if wd.Mg >= 32 else 16, flop,
+                         lambda: lib.rtg_conv1d_wgrad(C.byref(wd), _p(x), None, _p(dy), None, _p(part), st),
+                         f'wgrad2d {ly.name} B{B} {H}x{W} splits{splits}'), f'conv2d wgrad {ly.name}')
+            if immediate:
+                bank.flush_one(ly, part, splits)
+        return None, dx, None, None
 
 
 # ---------------------------------------------------------------------------------------------------------------
