@@ -1,0 +1,93 @@
+"""CPU checks of the C-ABI boundary: librtg.so loads without a GPU and exports every symbol include/rtg.h declares,
+the ctypes prototypes cover the header, struct layouts match the header's field order, argument validation works
+without touching a device.  (No compute calls: there is no GPU here.)"""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(REPO, 'include', 'rtg.h')
+
+
+@pytest.fixture(scope='module')
+def built():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('rtg_build', os.path.join(REPO, 'transtacos-retunegan_amd', 'build.py'))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    return b.build(verbose=False)
+
+
+def header_functions():
+    txt = open(HEADER).read()
+    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    return sorted(set(re.findall(r'\b(rtg_[a-z0-9_]+)\s*\(', txt)))
+
+
+def header_struct_fields(name):
+    txt = open(HEADER).read()
+    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    body = re.search(r'typedef struct %s \{(.*?)\} %s;' % (name, name), txt, flags=re.S).group(1)
+    fields = []
+    for decl in body.split(';'):
+        decl = decl.strip()
+        if not decl:
+            continue
+        decl = re.sub(r'^(const\s+)?(long long|int|float|float\*|const float\*)\s*', '', decl)
+        for f in decl.split(','):
+            fields.append(f.strip().lstrip('*').strip())
+    return fields
+
+
+def test_library_exports_every_declared_symbol(built):
+    from rtg.lib import PROTOTYPES
+    dll = C.CDLL(built)
+    declared = header_functions()
+    assert len(declared) >= 25
+    for name in declared:
+        assert hasattr(dll, name), f'{name} declared in include/rtg.h but not exported by librtg.so'
+        assert name in PROTOTYPES, f'{name} has no ctypes prototype in rtg/lib.py'
+    for name in PROTOTYPES:
+        assert name in declared, f'{name} bound in rtg/lib.py but not declared in include/rtg.h'
+
+
+def test_struct_layouts_follow_the_header():
+    from rtg import lib as L
+    for cname, cls in (('RtgConv1dDesc', L.Conv1dDesc), ('RtgWgradDesc', L.WgradDesc), ('RtgNormJob', L.NormJob),
+                       ('RtgPackJob', L.PackJob), ('RtgWnBwdJob', L.WnBwdJob), ('RtgStftDesc', L.StftDesc),
+                       ('RtgLossJob', L.LossJob)):
+        assert [f[0] for f in cls._fields_] == header_struct_fields(cname), cname
+
+
+def test_abi_version_and_host_side_queries(built):
+    from rtg.lib import lib, Conv1dDesc, WgradDesc
+    assert lib.rtg_abi_version() == 1
+    assert b'gfx950' in lib.rtg_build_info()
+    # packed sizes: [groups][m-tiles][c-chunks][taps][16 channels][tile_m rows]
+    assert lib.rtg_packed_size(1, 32, 32, 7, 32) == 1 * 1 * 2 * 7 * 16 * 32
+    assert lib.rtg_packed_size(4, 16, 8, 41, 16) == 4 * 1 * 1 * 41 * 16 * 16
+    assert lib.rtg_packed_size(1, 32, 32, 7, 24) == -1
+    d = Conv1dDesc(B=32, C1=32, C2=0, L_in=8192, groups=1, Cg=32, Mg=32, K=7, stride=1, dil=9, pad=27, Q=8192,
+                   out_C=32, out_L=8192, shuf_S=1, shuf_P=0, tile_m=32)
+    v = lib.rtg_conv1d_variant(C.byref(d))
+    assert v // 100 == 32 and v % 10 in (1, 2, 4)
+    assert lib.rtg_conv1d_variant(None) == -3
+    wd = WgradDesc(B=32, C1=32, C2=0, L_in=8192, groups=1, Cg=32, Mg=32, K=7, stride=1, dil=9, pad=27, Q=8192,
+                   dy_L=8192, splits=1)
+    assert 1 <= lib.rtg_wgrad_splits(C.byref(wd)) <= 512
+    wd.stride = 16
+    assert lib.rtg_wgrad_splits(C.byref(wd)) == -2          # RTG_ERANGE
+
+
+def test_null_and_inconsistent_arguments_are_refused_before_any_launch(built):
+    from rtg.lib import lib, Conv1dDesc, StftDesc
+    d = Conv1dDesc(B=1, C1=8, C2=0, L_in=16, groups=1, Cg=8, Mg=8, K=3, stride=1, dil=1, pad=1, Q=16, out_C=8, out_L=16,
+                   shuf_S=1, tile_m=32)
+    assert lib.rtg_conv1d(C.byref(d), None, None, None, None, None, None, None, None, None, None) == -3
+    assert lib.rtg_adamw(None, None, None, None, 10, None, None, 1e-3, 0.9, 0.99, 1e-8, 0.01, 1.0, None) == -3
+    sd = StftDesc(2, 8192, 2048, 1024, 240, 99, 80)          # wrong frame count
+    one = C.c_void_p(8)
+    assert lib.rtg_stft_forward(C.byref(sd), one, one, one, None, None, None, None, None, None, None, None, None) == -1
+    assert lib.rtg_axpby(one, None, one, 0, 1.0, 0.0, 0, None) == -1

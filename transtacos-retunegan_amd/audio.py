@@ -52,7 +52,7 @@ class StftPlan:
         F = n_fft // 2 + 1
         k = np.arange(n_fft // 2, dtype=np.float64)
         tw = np.concatenate([np.cos(2 * np.pi * k / n_fft), np.sin(2 * np.pi * k / n_fft)]).astype(np.float32)
-        window = (0.5 - 0.5 * np.cos(2 * np.pi * np.arange(win, dtype=np.float64) / win)).astype(np.float32)
+        window = getattr(torch, f'{hp.window_fn}_window')(win).numpy()      # exactly the tensor audio.py:155-156 builds
         fb = mel_filterbank(hp.sample_rate, n_fft, self.n_mel, hp.fmin, hp.fmax)
         self.fb = fb
         lo, ln, woff, wts = [], [], [], []
