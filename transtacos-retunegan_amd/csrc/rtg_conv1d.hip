@@ -19,6 +19,8 @@
 //               each wave loads its fragments straight from L2 with one coalesced 256-B load, prefetched one
 //               (chunk, tap) step ahead — no LDS traffic and no barrier for weights.
 //   epilogue    bias, leaky-relu-derivative mask, residual, scale, activation, optional polyphase "shuffle" store.
+#include <cstdio>
+#include <cstdlib>
 #include <type_traits>
 
 #include "rtg_common.h"
@@ -162,7 +164,8 @@ __global__ __launch_bounds__(RTG_THREADS) void conv1d_mfma_kernel(const ConvArgs
 #pragma unroll
   for (int it = 0; it < MAXIT; ++it) {
     const int o = lane + 64 * it;
-    loff[it] = (a.stride == 1) ? o : (o % a.stride) * a.PH + o / a.stride;
+    loff[it] = o;
+    if (a.stride != 1) loff[it] = (o % a.stride) * a.PH + o / a.stride;   // uniform branch: no division for stride 1
     int pos, bb;
     bool ok = o < a.PW;
     if (packed) {
@@ -239,57 +242,129 @@ __global__ __launch_bounds__(RTG_THREADS) void conv1d_mfma_kernel(const ConvArgs
     wptr[i] = a.wp + ((size_t)(g * a.n_mt + mt) * a.n_cc) * a.K * (RTG_CK * TM) + lane;
   }
   const int n_steps = a.n_cc * a.K;
-  float acur[MT][CPN], anext[MT][CPN];
+  // two named A-fragment register sets used alternately (no loop-carried copy: with a copy at the end of the tap the
+  // compiler waits for the JUST-issued prefetch in the middle of the MFMA phase, one exposed L2 latency per tap)
+  float a0[MT][CPN], a1[MT][CPN];
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
-    for (int cp = 0; cp < CPN; ++cp) acur[i][cp] = wptr[i][cp * 64];
+    for (int cp = 0; cp < CPN; ++cp) a0[i][cp] = wptr[i][cp * 64];
 
   stage(0);
   swrite(lds);
   __syncthreads();
 
-  int step = 0;
-  for (int cc = 0; cc < a.n_cc; ++cc) {
+  int cc = 0, tap = 0;
+  // one (chunk, tap) step: prefetch the next step's A fragments into `nxt`, multiply with `cur`
+  auto do_step = [&](int step, float (&cur)[MT][CPN], float (&nxt)[MT][CPN]) __attribute__((always_inline)) {
     const float* buf = lds + (cc & 1) * bufsz;
-    if (cc + 1 < a.n_cc) stage(cc + 1);
-    for (int tap = 0; tap < a.K; ++tap, ++step) {
-      // prefetch the next step's A fragments (64 consecutive floats per fragment, L2 resident)
-      if (step + 1 < n_steps) {
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-          for (int cp = 0; cp < CPN; ++cp) anext[i][cp] = wptr[i][(size_t)(step + 1) * (RTG_CK * TM) + cp * 64];
-      }
-      const int td = tap * a.dil;
-      const int tapoff = (a.stride == 1) ? td : (td % a.stride) * a.PH + td / a.stride;
-      const float* bp = buf + bbase + tapoff;
-      // read phase: all B fragments of this (chunk, tap) into distinct registers, THEN the MFMA phase — the compiler
-      // otherwise recycles one register pair and serialises ds_read -> wait -> 2 MFMAs per k-step; with two waves
-      // per SIMD one wave's read phase overlaps the other's MFMA phase
-      float bf[CPN][NT];
-#pragma unroll
-      for (int cp = 0; cp < CPN; ++cp)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) bf[cp][j] = bp[cp * KK * a.ROW + j * TM];
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int cp = 0; cp < CPN; ++cp)
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-          for (int j = 0; j < NT; ++j) acc[i][j] = M::run(acur[i][cp], bf[cp][j], acc[i][j]);
-      __builtin_amdgcn_sched_barrier(0);
+    if (step + 1 < n_steps) {
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int cp = 0; cp < CPN; ++cp) acur[i][cp] = anext[i][cp];
+        for (int cp = 0; cp < CPN; ++cp) nxt[i][cp] = wptr[i][(size_t)(step + 1) * (RTG_CK * TM) + cp * 64];
     }
-    if (cc + 1 < a.n_cc) swrite(lds + ((cc + 1) & 1) * bufsz);
-    __syncthreads();
+    // the next chunk's patch is requested AFTER the weight prefetch, on the chunk's first tap: vmcnt retires in order,
+    // so the wait for `nxt` one tap later does not include these loads, the wait two taps later finds them landed
+    if (tap == 0 && cc + 1 < a.n_cc) stage(cc + 1);
+    const int td = tap * a.dil;
+    const int tapoff = (a.stride == 1) ? td : (td % a.stride) * a.PH + td / a.stride;
+    const float* bp = buf + bbase + tapoff;
+    // read phase: all B fragments of this (chunk, tap) into distinct registers, THEN the MFMA phase — the compiler
+    // otherwise recycles one register pair and serialises ds_read -> wait -> 2 MFMAs per k-step; with two waves
+    // per SIMD one wave's read phase overlaps the other's MFMA phase
+    float bf[CPN][NT];
+#pragma unroll
+    for (int cp = 0; cp < CPN; ++cp)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) bf[cp][j] = bp[cp * KK * a.ROW + j * TM];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int cp = 0; cp < CPN; ++cp)
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = M::run(cur[i][cp], bf[cp][j], acc[i][j]);
+    __builtin_amdgcn_sched_barrier(0);
+    if (++tap == a.K) {
+      tap = 0;
+      if (cc + 1 < a.n_cc) swrite(lds + ((cc + 1) & 1) * bufsz);
+      __syncthreads();
+      ++cc;
+    }
+  };
+  int step = 0;
+  for (; step + 1 < n_steps; step += 2) {
+    do_step(step, a0, a1);
+    do_step(step + 1, a1, a0);
+  }
+  if (step < n_steps) do_step(step, a0, a1);
+
+  // ---- epilogue, fast path (plain store): 32-bit element offsets, every optional operand (bias, mask, residual,
+  // accumulate) read through a buffer descriptor that has ZERO records when the operand is absent (the load then
+  // returns 0 without touching memory), invalid rows / columns stored to an out-of-range offset (dropped by the
+  // hardware): no per-element branches, all loads of a tile in flight together, stores issue back to back
+  if (a.shuf_S == 1 && a.out_split == 0 && !a.two_d) {
+    const int out_bytes = a.B * a.out_C * a.out_L * 4;
+    const rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, out_bytes, 0x00020000);
+    const rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(a.bias ? a.bias : a.out), 0, a.bias ? a.out_C * 4 : 0,
+                                                        0x00020000);
+    const rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc((void*)(a.mask ? a.mask : a.out), 0, a.mask ? out_bytes : 0,
+                                                        0x00020000);
+    const rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)(a.res ? a.res : a.out), 0, a.res ? out_bytes : 0,
+                                                        0x00020000);
+    const rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, a.accumulate ? out_bytes : 0, 0x00020000);
+    const float mslope = a.mask ? a.mask_slope : 1.f;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      if (mt0 + i >= a.n_mt) continue;
+      const int mbase = (mt0 + i) * TM;
+      float bv[M::NREG];
+#pragma unroll
+      for (int r = 0; r < M::NREG; ++r) {
+        const int m = mbase + M::row(lane, r);
+        bv[r] = buf_load(rb, m < a.Mg ? (unsigned)(g * a.Mg + m) * 4u : RTG_OOB);
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        int q = q_blk + (wn * NT + j) * TM + n_lane;
+        int b = b0;
+        bool ok = true;
+        if (packed) {
+          const int seg = q / a.seg_len;
+          q -= seg * a.seg_len;
+          b = b0 + seg;
+          ok = seg < a.seg_nb && b < a.B;
+        }
+        ok = ok && q < a.Q;
+        const unsigned col = ok ? ((unsigned)(b * a.out_C + g * a.Mg + mbase) * (unsigned)a.out_L + (unsigned)q) * 4u
+                                : RTG_OOB;
+        unsigned off[M::NREG];
+        float mv[M::NREG], rv[M::NREG], av[M::NREG];
+#pragma unroll
+        for (int r = 0; r < M::NREG; ++r) {
+          const int row = M::row(lane, r);
+          off[r] = (mbase + row < a.Mg) ? (col + (unsigned)row * (unsigned)a.out_L * 4u) | (col & RTG_OOB) : RTG_OOB;
+          mv[r] = buf_load(rm, off[r]);
+          rv[r] = buf_load(rr, off[r]);
+          av[r] = buf_load(ra, off[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < M::NREG; ++r) {
+          float v = acc[i][j][r] + bv[r];
+          v *= (mv[r] > 0.f ? 1.f : mslope);
+          v = (v + rv[r]) * a.out_scale;
+          if (a.act == RTG_ACT_LRELU) v = rtg_lrelu(v, a.act_slope);
+          else if (a.act == RTG_ACT_TANH) v = tanhf(v);
+          v += av[r];
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ro, off[r], 0, 0);
+        }
+      }
+    }
+    return;
   }
 
-  // ---- epilogue
+  // ---- epilogue, general path (polyphase shuffle store, concat-split store, 2-D outputs)
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     if (mt0 + i >= a.n_mt) continue;
@@ -415,7 +490,11 @@ TileCfg pick_tiles(int TM, int n_mt, int Q, int B, int groups, int stride, int K
     const double blocks = (double)m_blocks * n_blocks_q * groups;
     const double fill = blocks >= 512.0 ? 1.0 : blocks / 512.0;
     const double reuse = (double)(c.MT * c.NT) / (c.MT + c.NT);   // MFMAs per operand fragment fetched
-    const double score = eff * fill * (0.6 + 0.4 * (reuse > 1.0 ? 1.0 : reuse));
+    double score = eff * fill * (0.6 + 0.4 * (reuse > 1.0 ? 1.0 : reuse));
+    if (const char* f = getenv("RTG_DEV_FORCE_TILE")) {      // tuning aid: "MT,NT,WM" pins the block shape
+      int fm = 0, fn = 0, fw = 0;
+      if (sscanf(f, "%d,%d,%d", &fm, &fn, &fw) == 3 && fm == c.MT && fn == c.NT && fw == c.WM) score += 100.0;
+    }
     if (score > best_score) {
       best_score = score;
       best = c;
@@ -469,6 +548,7 @@ extern "C" int rtg_conv1d(const RtgConv1dDesc* d, const float* x1, const float* 
   const long long x_bytes = two_d ? (long long)(d->B / d->h_n) * (d->C1 / d->h_k) * d->h_in * d->L_in * 4
                                   : (long long)d->B * d->C1 * d->L_in * 4;
   if (x_bytes >= (1ll << 31) || (long long)d->B * d->C2 * d->L_in * 4 >= (1ll << 31)) return RTG_ERANGE;   // 32-bit offsets
+  if ((long long)(two_d ? d->B / d->h_n : d->B) * d->out_C * (two_d ? d->h_n : 1) * d->out_L * 4 >= (1ll << 31)) return RTG_ERANGE;
 
   ConvArgs a;
   a.x1 = x1; a.x2 = x2; a.aux = (d->pre_mode >= RTG_PRE_MUL_DLRELU) ? aux : nullptr; a.wp = wp; a.bias = bias;

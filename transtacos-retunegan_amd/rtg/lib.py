@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), 'librtg.so')
+LIB_PATH = os.environ.get('RTG_DEV_LIB') or os.path.join(os.path.dirname(_HERE), 'librtg.so')   # RTG_DEV_LIB: tuning builds
 
 
 class RtgError(RuntimeError):
