@@ -78,6 +78,9 @@ typedef struct RtgConv1dDesc {
    * of the [items, C, h_in, W] tensor; rows outside [0, h_in) are zero padding.  The output tensor is
    * [items, out_C, h_n, out_L].  Requires groups == 1, C2 == 0, out_split == 0. */
   int h_in, h_k, h_stride, h_pad, h_n, h_mode;
+  int tap_major;               /* weights packed in the tap-major order (RtgPackJob.tap_major): for layers with few input
+                                  channels per group (C_in = 1 first layers, grouped MSD convs) the MFMA K dimension
+                                  walks (channel, 64/tile_m consecutive taps) instead of padding the channels to 16   */
 } RtgConv1dDesc;
 
 int rtg_conv1d(const RtgConv1dDesc* d, const float* x1, const float* x2, const float* aux, const float* wp,
@@ -89,6 +92,9 @@ int rtg_conv1d_variant(const RtgConv1dDesc* d);
 
 /* number of floats of the packed weight buffer for a layer with the given logical shape */
 long long rtg_packed_size(int groups, int Mg, int Cg, int K, int tile_m);
+/* the same for the tap-major order, and whether that order needs fewer MFMAs than the channel-major one (1 / 0) */
+long long rtg_packed_size_tapmajor(int groups, int Mg, int Cg, int K, int tile_m);
+int rtg_tapmajor_pays(int Cg, int K, int tile_m);
 
 /* ------------------------------------------------------------------------------------------------------------
  * rtg_conv1d_wgrad — convolution_backward w.r.t. weight and bias (train.py:158,191 -> autograd of every conv above).
@@ -146,6 +152,7 @@ typedef struct RtgPackJob {      /* one per packed layout of a layer            
   int tile_m;
   int KH;                        /* RTG_PACK_DGRAD_2D: kernel rows of the source [C_out][C_in][KH][src_K] weight;
                                     packed rows = (ci, phase), packed channels = (co, kh)                      */
+  int tap_major;                 /* 1: [g][m-tile][k-step group][k-step][kk][m] with k-step = (channel, tap group)  */
 } RtgPackJob;
 
 typedef struct RtgWnBwdJob {     /* one per weight-normed tensor                                               */

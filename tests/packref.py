@@ -17,6 +17,26 @@ def pack_logical(W, TM):
     return np.ascontiguousarray(P.transpose(0, 1, 3, 6, 4, 5, 2)).reshape(-1)
 
 
+def pack_logical_tapmajor(W, TM):
+    """tap-major K order: [g][mt][k-step group][cp][kk][m], k-step = (channel, group of KK consecutive taps)."""
+    G, Mg, Cg, K = W.shape
+    KK = 64 // TM
+    CPN = CK // KK
+    TG = -(-K // KK)
+    n_mt, n_grp = -(-Mg // TM), -(-(Cg * TG) // CPN)
+    P = np.zeros((G, n_mt, n_grp, CPN, KK, TM), dtype=np.float32)
+    for c in range(Cg):
+        for tg in range(TG):
+            ks = c * TG + tg
+            for kk in range(KK):
+                j = tg * KK + kk
+                if j < K:
+                    for mt in range(n_mt):
+                        rows = W[:, mt * TM:(mt + 1) * TM, c, j]
+                        P[:, mt, ks // CPN, ks % CPN, kk, :rows.shape[1]] = rows
+    return P.reshape(-1)
+
+
 def logical_fwd(w, groups):
     """torch Conv1d weight [C_out, Cg, K] -> [G, Mg, Cg, K]."""
     C_out, Cg, K = w.shape

@@ -60,13 +60,15 @@ def test_state_dict_roundtrip_and_flat_views(nets, oracle):
     assert bank.n_params == 2748371
 
 
-def test_pack_kernel_matches_host_packing(nets):
+@pytest.mark.parametrize('which', [0, 1, 2])
+def test_pack_kernel_matches_host_packing(nets, which):
     import packref
-    g = nets[0]
+    g = nets[which]
     bank = g.bank()
     g.token()
     torch.cuda.synchronize()
     packed = bank.packed.cpu().numpy()
+    assert which == 0 or any(ly.fwd_tap for ly in bank.layers)       # the discriminators use the tap-major order
     for ly in bank.layers:
         w = ly.module.effective_weight().detach().cpu().numpy()
         w = w.reshape(w.shape[0], w.shape[1], -1)
@@ -76,8 +78,9 @@ def test_pack_kernel_matches_host_packing(nets):
             bwd = packref.logical_dgrad_s1(w, ly.groups) if s == 1 else packref.logical_dgrad_poly(w, ly.groups, s)
         else:
             fwd, bwd = packref.logical_convT_poly(w, s), packref.logical_convT_dgrad(w)
-        for L, off, size, tm in ((fwd, ly.fwd_off, ly.fwd_size, ly.fwd_tm), (bwd, ly.bwd_off, ly.bwd_size, ly.bwd_tm)):
-            ref = packref.pack_logical(L, tm)
+        for L, off, size, tm, tap in ((fwd, ly.fwd_off, ly.fwd_size, ly.fwd_tm, ly.fwd_tap),
+                                      (bwd, ly.bwd_off, ly.bwd_size, ly.bwd_tm, ly.bwd_tap)):
+            ref = packref.pack_logical_tapmajor(L, tm) if tap else packref.pack_logical(L, tm)
             assert ref.size == size, ly.name
             np.testing.assert_allclose(packed[off:off + size], ref, rtol=2e-6, atol=1e-7, err_msg=ly.name)
 

@@ -43,6 +43,9 @@ struct ConvArgs {
   // row) pair; the kernel row picks which input row of the [items, C, h_in, L_in] tensor the patch row comes from
   int two_d, h_in, h_k, h_stride, h_pad, h_n, h_mode;
   int x_bytes, aux_bytes;
+  // tap-major K order (few input channels per group): the k-steps walk (channel, group of KK taps) instead of
+  // (tap, group of KK channels); `K` then counts groups of CPN k-steps, K_real the taps, tab_off the LDS offset table
+  int tapmajor, K_real, TG, tab_off;
 };
 
 template <int TM>
@@ -250,6 +253,20 @@ __global__ __launch_bounds__(RTG_THREADS) void conv1d_mfma_kernel(const ConvArgs
 #pragma unroll
     for (int cp = 0; cp < CPN; ++cp) a0[i][cp] = wptr[i][cp * 64];
 
+  int* tab = reinterpret_cast<int*>(lds + a.tab_off);
+  if (a.tapmajor) {
+    // LDS offset of every (k-step, kk): channel row + (phase-de-interleaved) tap offset; padding entries point at 0
+    for (int e = tid; e < a.K * CPN * KK; e += RTG_THREADS) {
+      const int ks = e / KK, k2 = e - ks * KK;
+      const int c = ks / a.TG, j = (ks - c * a.TG) * KK + k2;
+      int off = 0;
+      if (c < a.Cg && j < a.K_real) {
+        const int td = j * a.dil;
+        off = c * a.ROW + ((a.stride == 1) ? td : (td % a.stride) * a.PH + td / a.stride);
+      }
+      tab[e] = off;
+    }
+  }
   stage(0);
   swrite(lds);
   __syncthreads();
@@ -274,10 +291,21 @@ __global__ __launch_bounds__(RTG_THREADS) void conv1d_mfma_kernel(const ConvArgs
     // otherwise recycles one register pair and serialises ds_read -> wait -> 2 MFMAs per k-step; with two waves
     // per SIMD one wave's read phase overlaps the other's MFMA phase
     float bf[CPN][NT];
+    if (a.tapmajor) {
+      int boff[CPN];
 #pragma unroll
-    for (int cp = 0; cp < CPN; ++cp)
+      for (int cp = 0; cp < CPN; ++cp) boff[cp] = tab[(tap * CPN + cp) * KK + kk];
+      const float* b0p = buf + wn * NT * TM + n_lane;
 #pragma unroll
-      for (int j = 0; j < NT; ++j) bf[cp][j] = bp[cp * KK * a.ROW + j * TM];
+      for (int cp = 0; cp < CPN; ++cp)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bf[cp][j] = b0p[boff[cp] + j * TM];
+    } else {
+#pragma unroll
+      for (int cp = 0; cp < CPN; ++cp)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bf[cp][j] = bp[cp * KK * a.ROW + j * TM];
+    }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int cp = 0; cp < CPN; ++cp)
@@ -521,6 +549,24 @@ extern "C" long long rtg_packed_size(int groups, int Mg, int Cg, int K, int tile
   return (long long)groups * n_mt * n_cc * K * RTG_CK * tile_m;
 }
 
+// k-step groups of the tap-major order: Cg * ceil(K / KK) k-steps in groups of CPN
+static int tapmajor_groups(int Cg, int K, int tile_m) {
+  const int KK = 64 / tile_m, CPN = RTG_CK / KK;
+  return rtg_ceil_div(Cg * rtg_ceil_div(K, KK), CPN);
+}
+
+extern "C" int rtg_tapmajor_pays(int Cg, int K, int tile_m) {
+  if (Cg < 1 || K < 1 || (tile_m != 32 && tile_m != 16)) return RTG_EINVAL;
+  if (Cg > RTG_CK) return 0;
+  return tapmajor_groups(Cg, K, tile_m) < K ? 1 : 0;       // channel-major needs K groups of CPN k-steps per chunk
+}
+
+extern "C" long long rtg_packed_size_tapmajor(int groups, int Mg, int Cg, int K, int tile_m) {
+  if (groups < 1 || Mg < 1 || Cg < 1 || Cg > RTG_CK || K < 1 || (tile_m != 32 && tile_m != 16)) return RTG_EINVAL;
+  const long long n_mt = (Mg + tile_m - 1) / tile_m;
+  return (long long)groups * n_mt * tapmajor_groups(Cg, K, tile_m) * RTG_CK * tile_m;
+}
+
 extern "C" int rtg_conv1d(const RtgConv1dDesc* d, const float* x1, const float* x2, const float* aux, const float* wp,
                           const float* bias, const float* mask, const float* res, float* out, float* out2,
                           void* stream) {
@@ -565,6 +611,13 @@ extern "C" int rtg_conv1d(const RtgConv1dDesc* d, const float* x1, const float* 
   const int TM = d->tile_m;
   a.n_cc = rtg_ceil_div(d->Cg, RTG_CK);
   a.n_mt = rtg_ceil_div(d->Mg, TM);
+  a.tapmajor = d->tap_major ? 1 : 0;
+  a.K_real = d->K;
+  a.TG = rtg_ceil_div(d->K, 64 / TM);
+  if (a.tapmajor) {
+    if (d->Cg > RTG_CK) return RTG_EINVAL;
+    a.K = tapmajor_groups(d->Cg, d->K, TM);     // the kernel's step loop walks groups of CPN k-steps
+  }
 
   const TileCfg c = pick_tiles(TM, a.n_mt, d->Q, d->B, d->groups, d->stride, d->K, d->dil);
   if (c.MT == 0) return RTG_ERANGE;   // even the smallest block's patch exceeds RTG_PW_MAX
@@ -589,7 +642,8 @@ extern "C" int rtg_conv1d(const RtgConv1dDesc* d, const float* x1, const float* 
   const int gz = c.seg_len > 0 ? rtg_ceil_div(d->B, c.seg_nb) : d->B;
   if (gz > 65535) return RTG_ERANGE;
   dim3 grid(c.seg_len > 0 ? 1 : rtg_ceil_div(d->Q, BN), (unsigned)gy, gz);
-  const size_t lds_bytes = (size_t)2 * RTG_CK * a.ROW * sizeof(float);
+  a.tab_off = 2 * RTG_CK * a.ROW;
+  const size_t lds_bytes = (size_t)(2 * RTG_CK * a.ROW + (a.tapmajor ? a.K * RTG_CK : 0)) * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
 
 #define RTG_CASE(tm, mt, nt) \

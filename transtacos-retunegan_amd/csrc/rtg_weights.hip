@@ -39,11 +39,26 @@ __global__ __launch_bounds__(RTG_THREADS) void pack_kernel(const RtgPackJob* job
     const int m = (int)(t % TM); t /= TM;
     const int kk = (int)(t % KK); t /= KK;
     const int cp = (int)(t % CPN); t /= CPN;
-    const int tap = (int)(t % j.K); t /= j.K;
-    const int cc = (int)(t % n_cc); t /= n_cc;
-    const int mt = (int)(t % n_mt); t /= n_mt;
-    const int g = (int)t;
-    const int row = mt * TM + m, c = cc * RTG_CK + cp * KK + kk;
+    int tap, c, mt, g;
+    if (j.tap_major) {
+      // [g][mt][group][cp][kk][m]: k-step = group*CPN + cp = (channel, tap group); tap = tap group * KK + kk
+      const int TG = (j.K + KK - 1) / KK;
+      const int n_grp = (j.Cg * TG + CPN - 1) / CPN;
+      const int grp = (int)(t % n_grp); t /= n_grp;
+      mt = (int)(t % n_mt); t /= n_mt;
+      g = (int)t;
+      const int ks = grp * CPN + cp;
+      c = ks / TG;
+      tap = (ks - c * TG) * KK + kk;
+      if (tap >= j.K) c = j.Cg;            // padding taps: zero
+    } else {
+      tap = (int)(t % j.K); t /= j.K;
+      const int cc = (int)(t % n_cc); t /= n_cc;
+      mt = (int)(t % n_mt); t /= n_mt;
+      g = (int)t;
+      c = cc * RTG_CK + cp * KK + kk;
+    }
+    const int row = mt * TM + m;
     float val = 0.f;
     if (row < j.Mg && c < j.Cg) {
       long long srow = -1, sin = 0;

@@ -75,6 +75,10 @@ class ConvLayer:
             self.bwd_op = (L.PACK_FWD, 1, self.cin, self.cout, self.k, 1)
         self.fwd_tm = 32 if self.fwd_op[2] >= 32 else 16
         self.bwd_tm = 32 if self.bwd_op[2] >= 32 else 16
+        # tap-major K order where it needs fewer MFMAs (few input channels per group); 1-D operators only
+        one_d = self.kind != 'conv2d'
+        self.fwd_tap = int(one_d and lib.rtg_tapmajor_pays(self.fwd_op[3], self.fwd_op[4], self.fwd_tm) == 1)
+        self.bwd_tap = int(one_d and lib.rtg_tapmajor_pays(self.bwd_op[3], self.bwd_op[4], self.bwd_tm) == 1)
         # filled by the bank
         self.g_off = self.v_off = self.b_off = self.scale_off = 0
         self.fwd_off = self.bwd_off = 0
@@ -83,8 +87,10 @@ class ConvLayer:
         self.lid = -1
 
     def packed_sizes(self):
-        f = lib.rtg_packed_size(self.fwd_op[1], self.fwd_op[2], self.fwd_op[3], self.fwd_op[4], self.fwd_tm)
-        b = lib.rtg_packed_size(self.bwd_op[1], self.bwd_op[2], self.bwd_op[3], self.bwd_op[4], self.bwd_tm)
+        fs = lib.rtg_packed_size_tapmajor if self.fwd_tap else lib.rtg_packed_size
+        bs = lib.rtg_packed_size_tapmajor if self.bwd_tap else lib.rtg_packed_size
+        f = fs(self.fwd_op[1], self.fwd_op[2], self.fwd_op[3], self.fwd_op[4], self.fwd_tm)
+        b = bs(self.bwd_op[1], self.bwd_op[2], self.bwd_op[3], self.bwd_op[4], self.bwd_tm)
         return f, b
 
 
@@ -193,10 +199,11 @@ class WeightBank:
         self.max_pack = 0
         for ly in self.layers:
             norm.append(L.NormJob(ly.g_off, ly.v_off, ly.scale_off, ly.rows, ly.inner))
-            for (mode, g, mg, cg, k, s), off, size, tm in ((ly.fwd_op, ly.fwd_off, ly.fwd_size, ly.fwd_tm),
-                                                           (ly.bwd_op, ly.bwd_off, ly.bwd_size, ly.bwd_tm)):
+            for (mode, g, mg, cg, k, s), off, size, tm, tap in (
+                    (ly.fwd_op, ly.fwd_off, ly.fwd_size, ly.fwd_tm, ly.fwd_tap),
+                    (ly.bwd_op, ly.bwd_off, ly.bwd_size, ly.bwd_tm, ly.bwd_tap)):
                 pack.append(L.PackJob(ly.v_off, ly.scale_off, off, size, mode, g, mg, cg, k, ly.k, ly.inner_c, s, tm,
-                                      ly.kh))
+                                      ly.kh, tap))
                 self.max_pack = max(self.max_pack, size)
         self.norm_table = _table(norm, self.device)
         self.pack_table = _table(pack, self.device)

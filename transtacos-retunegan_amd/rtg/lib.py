@@ -15,7 +15,7 @@ class Conv1dDesc(C.Structure):
                                        'out_C', 'out_L', 'shuf_S', 'shuf_P', 'pre_mode')] + \
                [('pre_slope', C.c_float), ('mask_slope', C.c_float), ('out_scale', C.c_float), ('act', C.c_int),
                 ('act_slope', C.c_float), ('accumulate', C.c_int), ('tile_m', C.c_int), ('out_split', C.c_int)] + \
-               [(n, C.c_int) for n in ('h_in', 'h_k', 'h_stride', 'h_pad', 'h_n', 'h_mode')]
+               [(n, C.c_int) for n in ('h_in', 'h_k', 'h_stride', 'h_pad', 'h_n', 'h_mode', 'tap_major')]
 
 
 class WgradDesc(C.Structure):
@@ -34,7 +34,7 @@ class NormJob(C.Structure):
 class PackJob(C.Structure):
     _fields_ = [('v_off', C.c_longlong), ('scale_off', C.c_longlong), ('dst_off', C.c_longlong),
                 ('dst_size', C.c_longlong)] + \
-               [(n, C.c_int) for n in ('mode', 'groups', 'Mg', 'Cg', 'K', 'src_K', 'src_inner_c', 'S', 'tile_m', 'KH')]
+               [(n, C.c_int) for n in ('mode', 'groups', 'Mg', 'Cg', 'K', 'src_K', 'src_inner_c', 'S', 'tile_m', 'KH', 'tap_major')]
 
 
 class WnBwdJob(C.Structure):
@@ -67,6 +67,8 @@ PROTOTYPES = {
     'rtg_conv1d': (_I, [C.POINTER(Conv1dDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'rtg_conv1d_variant': (_I, [C.POINTER(Conv1dDesc)]),
     'rtg_packed_size': (_LL, [_I, _I, _I, _I, _I]),
+    'rtg_packed_size_tapmajor': (_LL, [_I, _I, _I, _I, _I]),
+    'rtg_tapmajor_pays': (_I, [_I, _I, _I]),
     'rtg_conv1d_wgrad': (_I, [C.POINTER(WgradDesc), _P, _P, _P, _P, _P, _P]),
     'rtg_wgrad_splits': (_I, [C.POINTER(WgradDesc)]),
     'rtg_weightnorm_scales': (_I, [_P, _I, _I, _P, _P, _P]),

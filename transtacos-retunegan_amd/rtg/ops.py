@@ -83,12 +83,12 @@ class ConvFn(torch.autograd.Function):
         if ly.kind == 'conv':
             d = _desc(B=B, C1=C1, C2=C2, L_in=L_in, groups=g, Cg=cg, Mg=mg, K=k, stride=ly.stride, dil=ly.dil,
                       pad=ly.pad, Q=L_out, out_C=ly.cout, out_L=L_out, pre_mode=pre_mode, pre_slope=pre_slope,
-                      out_scale=out_scale, act=act, act_slope=act_slope, tile_m=ly.fwd_tm)
+                      out_scale=out_scale, act=act, act_slope=act_slope, tile_m=ly.fwd_tm, tap_major=ly.fwd_tap)
         else:
             nq = (L_out - 1 + ly.pad) // ly.stride + 1
             d = _desc(B=B, C1=C1, C2=C2, L_in=L_in, groups=1, Cg=cg, Mg=mg, K=k, stride=1, dil=1, pad=k - 1, Q=nq,
                       out_C=ly.cout, out_L=L_out, shuf_S=ly.stride, shuf_P=ly.pad, pre_mode=pre_mode,
-                      pre_slope=pre_slope, out_scale=out_scale, act=act, act_slope=act_slope, tile_m=ly.fwd_tm)
+                      pre_slope=pre_slope, out_scale=out_scale, act=act, act_slope=act_slope, tile_m=ly.fwd_tm, tap_major=ly.fwd_tap)
         lc = L_out if ly.kind == 'conv' else L_in
         check(_timed('conv1d', lib.rtg_conv1d_variant(C.byref(d)) if PROFILE is not None else 0, _conv_flop(ly, B, lc),
                      lambda: lib.rtg_conv1d(C.byref(d), _p(x1), _p(x2), None, bank.fwd_ptr(ly), bank.bias_ptr(ly), None,
@@ -155,17 +155,18 @@ class ConvFn(torch.autograd.Function):
                 d = _desc(B=B, C1=ly.cout, L_in=L_out, groups=g, Cg=cg, Mg=mg, K=k, stride=1, dil=ly.dil,
                           pad=(ly.k - 1) * ly.dil - ly.pad, Q=L_in, out_C=ly.cin, out_L=L_in, pre_mode=gy_mode,
                           pre_slope=gy_slope, mask_slope=pre_slope, out_scale=out_scale, tile_m=ly.bwd_tm,
-                          out_split=split)
+                          out_split=split, tap_major=ly.bwd_tap)
             elif ly.kind == 'conv':
                 nq = (L_in - 1 + ly.pad) // ly.stride + 1
                 d = _desc(B=B, C1=ly.cout, L_in=L_out, groups=g, Cg=cg, Mg=mg, K=k, stride=1, dil=1, pad=k - 1, Q=nq,
                           out_C=ly.cin, out_L=L_in, shuf_S=ly.stride, shuf_P=ly.pad, pre_mode=gy_mode,
                           pre_slope=gy_slope, mask_slope=pre_slope, out_scale=out_scale, tile_m=ly.bwd_tm,
-                          out_split=split)
+                          out_split=split, tap_major=ly.bwd_tap)
             else:   # transposed conv: backward-data is the strided conv of dy
                 d = _desc(B=B, C1=ly.cout, L_in=L_out, groups=1, Cg=cg, Mg=mg, K=k, stride=ly.stride, dil=1,
                           pad=ly.pad, Q=L_in, out_C=ly.cin, out_L=L_in, pre_mode=gy_mode, pre_slope=gy_slope,
-                          mask_slope=pre_slope, out_scale=out_scale, tile_m=ly.bwd_tm, out_split=split)
+                          mask_slope=pre_slope, out_scale=out_scale, tile_m=ly.bwd_tm, out_split=split,
+                          tap_major=ly.bwd_tap)
             lc = L_out if ly.kind == 'conv' else L_in
             check(_timed('conv1d', lib.rtg_conv1d_variant(C.byref(d)) if PROFILE is not None else 0,
                          _conv_flop(ly, B, lc),
