@@ -32,3 +32,25 @@ tot = sum(a[1] for a in agg.values())
 print(f'total conv ms {tot:.2f}')
 for (label, variant), (n, ms, flop) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:70]:
     print(f'{ms:8.3f} ms  n={n:2d}  {flop / ms / 1e9:7.2f} TF/s  v{variant:<5d} {label}')
+
+# ---- totals by (pass, model part)
+import collections
+tot = collections.defaultdict(lambda: [0.0, 0.0, 0])
+for kernel, variant, flop, e0, e1, label in rec:
+    parts = label.split()
+    name = parts[1]
+    if name.startswith('discriminators'):
+        B = int(parts[2][1:])
+        model = 'MPD' if ('B192' in label or 'B320' in label or 'B448' in label or 'B704' in label or
+                          'B96 ' in label or 'B160' in label or 'B224' in label or 'B352' in label) else 'MSD'
+    else:
+        model = 'G'
+    k = (model, parts[0])
+    tot[k][0] += e0.elapsed_time(e1); tot[k][1] += flop; tot[k][2] += 1
+print('---- by model / pass')
+for k in sorted(tot):
+    ms, fl, n = tot[k]
+    print(f'{k[0]:4s} {k[1]:6s} n={n:4d} {ms:7.2f} ms  {fl / ms / 1e9:6.1f} TF/s')
+for m in ('G', 'MSD', 'MPD'):
+    ms = sum(v[0] for k, v in tot.items() if k[0] == m); fl = sum(v[1] for k, v in tot.items() if k[0] == m)
+    print(f'{m}: {ms:.2f} ms {fl / 1e9:.0f} GFLOP {fl / ms / 1e9:.1f} TF/s')

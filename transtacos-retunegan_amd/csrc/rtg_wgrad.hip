@@ -14,6 +14,8 @@
 // registers by bounds-checked buffer loads while the current tile is multiplied; LDS is single-buffered (two barriers
 // per tile) so that two workgroups fit a CU and cover each other's barrier phases.  Partials are stored per split
 // (fixed-order reduction in rtg_weightnorm_backward).
+#include <cstdlib>
+
 #include "rtg_common.h"
 
 namespace {
@@ -39,7 +41,9 @@ struct WgArgs {
   int splits;
   long long part_stride;
   int CKW, n_cchunk, m_blocks, n_ttiles, n_tiles_total, PW, ROW, ones_off, xbuf_sz;
-  int seg_len, seg_pitch, seg_nb, seg_pw;   // seg_len == 0: one clip per tile
+  int cont;                                 // 1: one virtual sequence over all clips, 0: tiles never cross clips
+  int seg_len, seg_pitch, seg_pw;           // virtual positions per clip, its pitch in the patch, its patch width
+  float inv_seg, inv_pitch;
   int two_d, h_in, h_k, h_stride, h_pad, h_n;   // second dimension, see RtgConv1dDesc
   int x_bytes, dy_bytes;
 };
@@ -90,7 +94,6 @@ __global__ __launch_bounds__(RTG_THREADS) void wgrad_kernel(const WgArgs a) {
   const int c0 = cchunk * a.CKW;
   const int cw = min(a.CKW, a.Cg - c0);
   const int m0 = mb * ROWS;                          // first row (within group) of this block
-  const bool packed = a.seg_len > 0;
 
   float* xb = lds;
   float* db = lds + a.xbuf_sz;
@@ -116,23 +119,16 @@ __global__ __launch_bounds__(RTG_THREADS) void wgrad_kernel(const WgArgs a) {
     b_base[j] = (cl < a.CKW) ? (cl * a.ROW + jj * a.dil + kk * a.stride) : (-(1 << 20) + kk * a.stride);
   }
 
-  // ---- static staging geometry
+  // n / d for 0 <= n < 2^24 through the float reciprocal, exact after one correction step either way
+  auto fdiv = [](int n, int d, float inv, int& rem) __attribute__((always_inline)) {
+    int q = (int)((float)n * inv);
+    int r = n - q * d;
+    if (r < 0) { --q; r += d; }
+    else if (r >= d) { ++q; r -= d; }
+    rem = r;
+    return q;
+  };
   int xseg[MAXIT], xw[MAXIT];
-#pragma unroll
-  for (int it = 0; it < MAXIT; ++it) {
-    const int o = lane + 64 * it;
-    if (packed) {
-      xseg[it] = o / a.seg_pitch;
-      xw[it] = o - xseg[it] * a.seg_pitch;
-      if (xseg[it] >= a.seg_nb || xw[it] >= a.seg_pw || o >= a.PW) xw[it] = -(1 << 28);   // never valid
-    } else {
-      xseg[it] = 0;
-      xw[it] = (o < a.PW) ? o : -(1 << 28);
-    }
-  }
-  const int dseg = packed ? lane / a.seg_len : 0;
-  const int dt = packed ? lane - dseg * a.seg_len : lane;
-  const bool dcol_ok = packed ? (dseg < a.seg_nb) : true;
 
   const rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.x1, 0, a.x_bytes, 0x00020000);
   const rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x2 ? a.x2 : a.x1), 0,
@@ -148,10 +144,32 @@ __global__ __launch_bounds__(RTG_THREADS) void wgrad_kernel(const WgArgs a) {
   float sx[XR][MAXIT], sd[DR], sa[DR];
 
   auto gload = [&](int tl) __attribute__((always_inline)) {
-    int b0, t0;
-    if (packed) { b0 = tl * a.seg_nb; t0 = 0; }
-    else        { b0 = tl / a.n_ttiles; t0 = (tl - b0 * a.n_ttiles) * TT; }
-    const int o_start = t0 * a.stride - a.pad;
+    // the reduction walks ONE virtual sequence: clip c owns positions [c*seg_len, c*seg_len + Q) (the rest of its
+    // seg_len slots is a gap with gy = 0, wide enough that the next clip's input patch does not overlap); tile tl
+    // covers virtual positions [tl*TT, tl*TT + TT) whatever clip boundaries fall inside it
+    // (long rows whose length fills whole tiles keep the cheaper per-clip tiling: tile = (clip, 64-step window))
+    int b0 = 0, o_start = -a.pad, t0 = 0, dseg = 0, dt = lane;
+    if (a.cont) {
+      const int v0 = tl * TT;
+#pragma unroll
+      for (int it = 0; it < MAXIT; ++it) {
+        const int o = lane + 64 * it;
+        int w;
+        xseg[it] = fdiv(v0 * a.stride + o, a.seg_pitch, a.inv_pitch, w);
+        xw[it] = (o < a.PW && w < a.seg_pw) ? w : -(1 << 28);             // never valid
+      }
+      dseg = fdiv(v0 + lane, a.seg_len, a.inv_seg, dt);
+    } else {
+      b0 = tl / a.n_ttiles;
+      t0 = (tl - b0 * a.n_ttiles) * TT;
+      o_start = t0 * a.stride - a.pad;
+#pragma unroll
+      for (int it = 0; it < MAXIT; ++it) {
+        xseg[it] = 0;
+        xw[it] = (lane + 64 * it < a.PW) ? lane + 64 * it : -(1 << 28);
+      }
+    }
+    const bool dcol_ok = true;
     if (a.two_d) {
       // channel (ci, kh) of clip (item, row r) reads input row r*h_stride - h_pad + kh of [items, C, h_in, L_in]
       const int cin = a.C1 / a.h_k;
@@ -312,7 +330,7 @@ constexpr int kNumShapes = sizeof(kShapes) / sizeof(Shape);
 
 struct WgGeom {
   int TM, shape, CKW, n_cchunk, m_blocks, n_ttiles, n_tiles_total, PW, ROW, maxit;
-  int seg_len, seg_nb, seg_pw;
+  int seg_len, seg_pw, cont;
 };
 
 int geometry(const RtgWgradDesc* d, WgGeom* o) {
@@ -344,20 +362,21 @@ int geometry(const RtgWgradDesc* d, WgGeom* o) {
     }
   }
   if (o->shape < 0) return RTG_ERANGE;
-  // segment packing for short rows
+  // one virtual sequence over all clips: seg_len slots per clip (its Q outputs + the gap that separates patches)
   const int extra = (d->K - 1) * d->dil + 1 - d->stride;
   const int Lseg = d->Q + (extra > 0 ? (extra + d->stride - 1) / d->stride : 0);
   o->seg_pw = (d->Q - 1) * d->stride + (d->K - 1) * d->dil + 1;
-  if (2 * Lseg <= TT && d->B >= 2) {
-    o->seg_len = Lseg;
-    o->seg_nb = TT / Lseg < d->B ? TT / Lseg : d->B;
+  o->seg_len = Lseg;
+  if ((long long)d->B * Lseg * d->stride + RTG_PW_MAX >= (1ll << 24)) return RTG_ERANGE;   // float-reciprocal division
+  const int per_clip = rtg_ceil_div(d->Q, TT);
+  o->cont = ((double)d->Q / Lseg > 1.08 * (double)d->Q / ((double)per_clip * TT) && d->B >= 2) ? 1 : 0;
+  if (const char* f = getenv("RTG_DEV_WGRAD_CONT")) o->cont = (f[0] == '1' && d->B >= 2) ? 1 : 0;   // tuning aid
+  if (o->cont) {
     o->n_ttiles = 1;
-    o->n_tiles_total = rtg_ceil_div(d->B, o->seg_nb);
+    o->n_tiles_total = rtg_ceil_div((long long)d->B * Lseg, TT);
   } else {
-    o->seg_len = 0;
-    o->seg_nb = 1;
-    o->n_ttiles = rtg_ceil_div(d->Q, TT);
-    o->n_tiles_total = d->B * o->n_ttiles;
+    o->n_ttiles = per_clip;
+    o->n_tiles_total = d->B * per_clip;
   }
   const int want = (d->K * d->dil) & 31;
   int row = o->PW;
@@ -456,8 +475,9 @@ extern "C" int rtg_conv1d_wgrad(const RtgWgradDesc* d, const float* x1, const fl
   a.splits = d->splits; a.part_stride = d->part_stride;
   a.CKW = g.CKW; a.n_cchunk = g.n_cchunk; a.m_blocks = g.m_blocks;
   a.n_ttiles = g.n_ttiles; a.n_tiles_total = g.n_tiles_total; a.PW = g.PW; a.ROW = g.ROW;
-  a.seg_len = g.seg_len; a.seg_nb = g.seg_nb; a.seg_pw = g.seg_pw;
-  a.seg_pitch = g.seg_len > 0 ? g.seg_len * d->stride : 1;
+  a.seg_len = g.seg_len; a.seg_pw = g.seg_pw; a.cont = g.cont;
+  a.seg_pitch = g.seg_len * d->stride;
+  a.inv_seg = 1.0f / (float)a.seg_len; a.inv_pitch = 1.0f / (float)a.seg_pitch;
   const bool two_d = d->h_k > 1 || d->h_n > 1;
   a.two_d = two_d ? 1 : 0;
   a.h_in = two_d ? d->h_in : 1; a.h_k = two_d ? d->h_k : 1; a.h_stride = two_d ? d->h_stride : 1;
