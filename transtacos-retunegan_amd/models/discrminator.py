@@ -16,7 +16,7 @@ import hparam as hp
 from utils import *  # noqa: F401,F403
 from utils import LRELU_SLOPE
 from rtg import ops
-from .layers import WNConv, BankedModel, conv
+from .layers import WNConv, BankedModel, conv, fork_join
 
 PI = 3.14159265358979
 
@@ -89,6 +89,27 @@ def _split(t, B):
     return r, g
 
 
+def _sub_runner(d, tok, inp, frozen):
+    """closure running one sub-discriminator on (real, fake): separately when D is frozen (real half without autograd),
+    as one 2B batch otherwise.  Returns (logit_r, logit_g, fmap_r, fmap_g)."""
+    def run():
+        if frozen:
+            with torch.no_grad():
+                lr, fr = d.run(tok, inp[0])
+            lg, fg = d.run(tok, inp[1])
+            return lr, lg, fr, fg
+        B = inp[0].shape[0] // 2
+        l2, f2 = d.run(tok, inp[0])
+        lr, lg = _split(l2, B)
+        fs = [_split(f, B) for f in f2]
+        return lr, lg, [a for a, _ in fs], [b for _, b in fs]
+    return run
+
+
+def _collect(outs):
+    return ([o[0] for o in outs], [o[1] for o in outs], [o[2] for o in outs], [o[3] for o in outs])
+
+
 class _MultiBase(BankedModel):
     pass
 
@@ -103,30 +124,20 @@ class MultiScaleDiscriminator(_MultiBase):
 
     def forward(self, y, y_hat):
         tok = self.token()
-        B = y.shape[0]
         frozen = _frozen(self) and not y.requires_grad
-        y_d_rs, y_d_gs, fmap_rs, fmap_gs = [], [], [], []
+        # inputs of the three scales: y, AvgPool(y), AvgPool(AvgPool(y)) (discrminator.py:126-127)
         xs = [y, y_hat] if frozen else [torch.cat([y, y_hat], dim=0)]
-        for i, d in enumerate(self.discriminators):
-            if frozen:
-                with torch.no_grad():
-                    lr, fr = d.run(tok, xs[0])
-                lg, fg = d.run(tok, xs[1])
-            else:
-                l2, f2 = d.run(tok, xs[0])
-                lr, lg = _split(l2, B)
-                fs = [_split(f, B) for f in f2]
-                fr, fg = [a for a, _ in fs], [b for _, b in fs]
-            y_d_rs.append(lr); fmap_rs.append(fr)
-            y_d_gs.append(lg); fmap_gs.append(fg)
+        inputs = []
+        for i in range(len(self.discriminators)):
+            inputs.append(list(xs))
             if i != len(self.discriminators) - 1:
                 if frozen:
                     with torch.no_grad():
-                        xs[0] = ops.AvgPoolFn.apply(xs[0])
-                    xs[1] = ops.AvgPoolFn.apply(xs[1])
+                        x0 = ops.AvgPoolFn.apply(xs[0])
+                    xs = [x0, ops.AvgPoolFn.apply(xs[1])]
                 else:
-                    xs[0] = ops.AvgPoolFn.apply(xs[0])
-        return y_d_rs, y_d_gs, fmap_rs, fmap_gs
+                    xs = [ops.AvgPoolFn.apply(xs[0])]
+        return _collect(fork_join([_sub_runner(d, tok, inp, frozen) for d, inp in zip(self.discriminators, inputs)]))
 
 
 class MultiPeriodDiscriminator(_MultiBase):
@@ -138,23 +149,9 @@ class MultiPeriodDiscriminator(_MultiBase):
 
     def forward(self, y, y_hat):
         tok = self.token()
-        B = y.shape[0]
         frozen = _frozen(self) and not y.requires_grad
-        y_d_rs, y_d_gs, fmap_rs, fmap_gs = [], [], [], []
-        x2 = None if frozen else torch.cat([y, y_hat], dim=0)
-        for d in self.discriminators:
-            if frozen:
-                with torch.no_grad():
-                    lr, fr = d.run(tok, y)
-                lg, fg = d.run(tok, y_hat)
-            else:
-                l2, f2 = d.run(tok, x2)
-                lr, lg = _split(l2, B)
-                fs = [_split(f, B) for f in f2]
-                fr, fg = [a for a, _ in fs], [b for _, b in fs]
-            y_d_rs.append(lr); fmap_rs.append(fr)
-            y_d_gs.append(lg); fmap_gs.append(fg)
-        return y_d_rs, y_d_gs, fmap_rs, fmap_gs
+        inp = [y, y_hat] if frozen else [torch.cat([y, y_hat], dim=0)]
+        return _collect(fork_join([_sub_runner(d, tok, inp, frozen) for d in self.discriminators]))
 
 
 class StftDiscriminator(nn.Module):
@@ -183,18 +180,6 @@ class MultiStftDiscriminator(_MultiBase):
 
     def forward(self, phs, ph_hats):
         tok = self.token()
-        ph_d_rs, ph_d_gs, fmap_rs, fmap_gs = [], [], [], []
-        for d, ph, ph_hat in zip(self.discriminators, phs, ph_hats):
-            B = ph.shape[0]
-            if _frozen(self) and not ph.requires_grad:
-                with torch.no_grad():
-                    lr, fr = d.run(tok, ph)
-                lg, fg = d.run(tok, ph_hat)
-            else:
-                l2, f2 = d.run(tok, torch.cat([ph, ph_hat], dim=0))
-                lr, lg = _split(l2, B)
-                fs = [_split(f, B) for f in f2]
-                fr, fg = [a for a, _ in fs], [b for _, b in fs]
-            ph_d_rs.append(lr); fmap_rs.append(fr)
-            ph_d_gs.append(lg); fmap_gs.append(fg)
-        return ph_d_rs, ph_d_gs, fmap_rs, fmap_gs
+        frozen = _frozen(self) and not phs[0].requires_grad
+        inputs = [[ph, ph_hat] if frozen else [torch.cat([ph, ph_hat], dim=0)] for ph, ph_hat in zip(phs, ph_hats)]
+        return _collect(fork_join([_sub_runner(d, tok, inp, frozen) for d, inp in zip(self.discriminators, inputs)]))

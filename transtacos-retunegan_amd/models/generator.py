@@ -10,7 +10,7 @@ import hparam as hp
 from utils import *  # noqa: F401,F403
 from utils import LRELU_SLOPE
 from rtg import ops
-from .layers import WNConv, BankedModel, conv, ACT_LRELU, ACT_TANH
+from .layers import WNConv, BankedModel, conv, fork_join, ACT_LRELU, ACT_TANH
 
 device = 'cuda' if torch.cuda.is_available() else 'cpu'
 
@@ -153,7 +153,8 @@ class Generator_RefineGAN_small(BankedModel):
             z = conv(tok, self.merge[i], z, o[self.n_layer - i - 1])               # cat([z, skip]) fused
             z = self.noise(z, nz(2 * i))
             nk = self.num_kernels
-            z = _Mean3.apply(*[self.resblocks[i * nk + j].run(tok, z) for j in range(nk)])
+            z = _Mean3.apply(*fork_join([(lambda blk=self.resblocks[i * nk + j], zz=z: blk.run(tok, zz))
+                                         for j in range(nk)]))
             z = self.noise(z, nz(2 * i + 1))
         return conv(tok, self.conv_post, z, pre_slope=LRELU_SLOPE, act=ACT_TANH)
 

@@ -90,5 +90,52 @@ class BankedModel(nn.Module):
             super().zero_grad(set_to_none=set_to_none)
 
 
+import os
+
+_FORK_STREAMS = {}
+_FORK_DEPTH = [0]
+if hasattr(torch.autograd.graph, 'set_warn_on_accumulate_grad_stream_mismatch'):
+    # leaves are accumulated on the stream of their first use while forked branches run elsewhere: intended
+    torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
+
+
+def _record(obj, stream):
+    if torch.is_tensor(obj):
+        obj.record_stream(stream)
+        base = getattr(obj, '_rtg_base', None)
+        if base is not None:
+            base.record_stream(stream)
+    elif isinstance(obj, (list, tuple)):
+        for o in obj:
+            _record(o, stream)
+
+
+def fork_join(fns):
+    """Run independent sub-networks (the 3 MSD scales, the 4 MPD periods, the 3 MTD resolutions, the 3 ResBlock3
+    branches) on separate HIP streams so that their kernels overlap: each of these launches only fills the chip for part
+    of its duration (ramp-up, last partial wave of workgroups), a second queue fills the idle CUs.  Autograd replays the
+    backward of every op on the stream of its forward, so the backward overlaps the same way.  RTG_STREAMS=0 disables."""
+    if len(fns) < 2 or os.environ.get('RTG_STREAMS', '1') == '0' or ops.PROFILE is not None:
+        return [f() for f in fns]
+    main = torch.cuda.current_stream()
+    depth = _FORK_DEPTH[0]
+    pool = _FORK_STREAMS.setdefault((main.device, depth), [])     # nested forks get their own streams
+    while len(pool) < len(fns):
+        pool.append(torch.cuda.Stream(device=main.device))
+    outs = []
+    _FORK_DEPTH[0] = depth + 1
+    try:
+        for f, s in zip(fns, pool):
+            s.wait_stream(main)
+            with torch.cuda.stream(s):
+                outs.append(f())
+    finally:
+        _FORK_DEPTH[0] = depth
+    for s in pool[:len(fns)]:
+        main.wait_stream(s)
+    _record(outs, main)          # produced on a side stream, consumed (and later freed) on the main one
+    return outs
+
+
 def conv(tok, m, x1, x2=None, res=None, pre_slope=1.0, act=ACT_NONE, act_slope=1.0, out_scale=1.0):
     return ops.conv(tok, m._layer, x1, x2, res, pre_slope, act, act_slope, out_scale)

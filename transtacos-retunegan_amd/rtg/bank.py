@@ -148,6 +148,8 @@ class WeightBank:
         self._wn_dirty = True
         self._keep = []          # tensors that must outlive the async kernels reading them within one flush
         self.on_flush = None     # optional callback(gflat) once a backward's weight gradients are complete (DP)
+        self._bwd_streams = set()    # streams that ran weight-gradient kernels since the last flush
+        self._flush_stream = None    # stream the last flush (writes into gflat) was queued on
 
     # ------------------------------------------------------------------ parameters as views of the flat buffers
     def _bind_params(self):
@@ -238,6 +240,9 @@ class WeightBank:
         return C.c_void_p(self.flat.data_ptr() + 4 * ly.b_off)
 
     # ------------------------------------------------------------------ backward-side: partial slots and the flush
+    def note_backward_stream(self):
+        self._bwd_streams.add(torch.cuda.current_stream())
+
     def partial_slot(self, ly, splits, tok_id):
         """Returns (tensor, stride, immediate): the split-partial buffer the wgrad of `ly` must write for this token.
         immediate=True means the slot was busy (layer used by another pending forward): the caller must reduce it
@@ -267,6 +272,12 @@ class WeightBank:
                                           _p(self.gflat), _stream()), 'weightnorm_backward')
 
     def _flush(self, tok_id):
+        cur = torch.cuda.current_stream()
+        self._flush_stream = cur
+        for s in self._bwd_streams:          # conv backward kernels of forked sub-networks ran on side streams and
+            if s != cur:                     # hand no tensor to this node: order them before the reduction by hand
+                cur.wait_stream(s)
+        self._bwd_streams.clear()
         owned = [ly for ly in self.layers if self._owner[ly.lid] == tok_id]
         if not owned:
             return
@@ -290,7 +301,14 @@ class WeightBank:
             self._keep = self._keep[-32:]
 
     # ------------------------------------------------------------------ optimizer-facing helpers
+    def sync_grads(self):
+        """Make the current stream wait for the last flush: it may have been queued on a forked stream, and autograd only
+        joins the streams of leaf accumulations at the end of backward()."""
+        if self._flush_stream is not None and self._flush_stream != torch.cuda.current_stream():
+            torch.cuda.current_stream().wait_stream(self._flush_stream)
+
     def zero_grad(self):
+        self.sync_grads()
         self.gflat.zero_()
         if self.grads_detached():
             self.rebind_grads()

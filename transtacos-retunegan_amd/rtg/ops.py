@@ -196,6 +196,7 @@ class ConvFn(torch.autograd.Function):
             if splits < 1:
                 raise L.RtgError(f'wgrad geometry refused for {ly.name}: {splits}')
             part, stride, immediate = bank.partial_slot(ly, splits, ctx.tok_id)
+            bank.note_backward_stream()
             wd.splits, wd.part_stride = splits, stride
             lc = L_out if ly.kind == 'conv' else L_in
             check(_timed('wgrad', 32 if wd.Mg >= 32 else 16, _conv_flop(ly, B, lc),
@@ -285,6 +286,7 @@ class Conv2dFn(torch.autograd.Function):
             if splits < 1:
                 raise L.RtgError(f'wgrad geometry refused for {ly.name}: {splits}')
             part, stride, immediate = bank.partial_slot(ly, splits, ctx.tok_id)
+            bank.note_backward_stream()
             wd.splits, wd.part_stride = splits, stride
             check(_timed('wgrad', 32 if wd.Mg >= 32 else 16, flop,
                          lambda: lib.rtg_conv1d_wgrad(C.byref(wd), _p(x), None, _p(dy), None, _p(part), st),

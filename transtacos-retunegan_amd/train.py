@@ -23,7 +23,7 @@ import hparam as h  # noqa: F401  (train.py:17 imports it under both names)
 from models import *  # noqa: F401,F403
 from models import (multi_stft_loss, dynamic_loss, discriminator_loss, generator_loss, feature_loss,
                     MultiScaleDiscriminator, MultiPeriodDiscriminator, MultiStftDiscriminator)
-from models.layers import BankedModel
+from models.layers import BankedModel, fork_join
 from models.loss import stft_cache
 from rtg.lib import lib, check, RtgError
 
@@ -88,6 +88,7 @@ class AdamW:
         for m in self.models:
             s = self._st(m)
             bank = s['bank']
+            bank.sync_grads()
             check(lib.rtg_adamw(_p(bank.flat), _p(bank.gflat), _p(s['exp_avg']), _p(s['exp_avg_sq']), bank.n_params,
                                 _p(s['step']), _p(loss_flag), lr, self.betas[0], self.betas[1], self.eps,
                                 self.weight_decay, self.grad_scale, _stream()), 'adamw')
@@ -240,20 +241,21 @@ class Trainer:
         if self.mtd is not None:
             S, S_g = multi_stft_loss(y, y_g_hat_detach, ret_specs=True)
         losses = {}
-        r, g, _, _ = self.msd(y, y_g_hat_detach)
-        losses['disc_s'] = discriminator_loss(r, g)
+        # the discriminator stacks are independent: run them on separate streams (models.layers.fork_join)
+        jobs = [('disc_s', lambda: self.msd(y, y_g_hat_detach))]
         if self.mpd is not None:
-            r, g, _, _ = self.mpd(y, y_g_hat_detach)
-            losses['disc_p'] = discriminator_loss(r, g)
+            jobs.append(('disc_p', lambda: self.mpd(y, y_g_hat_detach)))
         if self.mtd is not None:
-            r, g, _, _ = self.mtd(S, S_g)
-            losses['disc_t'] = discriminator_loss(r, g)
+            jobs.append(('disc_t', lambda: self.mtd(S, S_g)))
+        for (tag, _), (r, g, _, _) in zip(jobs, fork_join([j for _, j in jobs])):
+            losses[tag] = discriminator_loss(r, g)
         total = sum(losses.values())
         losses['disc_all'] = total
         total.backward()
         if self.dp.enabled:
             for d in self.discs:
                 if getattr(d.bank(), 'on_flush', None) is None:
+                    d.bank().sync_grads()
                     self.dp.reduce_async(d.bank().gflat)
             self.dp.wait()
         self.optim_d.step(self.dp.reduce_flag(total.detach().clone().reshape(1)))
@@ -275,13 +277,12 @@ class Trainer:
             total = total + losses['dyn'] * hp.w_loss_dyn
         self._freeze(True)       # the reference lets D weight gradients accumulate and discards them at the next
         try:                     # optim_d.zero_grad() (train.py:133): skipping them changes no result
-            for tag, d, a, b in (('s', self.msd, y, y_g_hat), ('p', self.mpd, y, y_g_hat),
-                                 ('t', self.mtd, None, None)):
-                if d is None:
-                    continue
-                if tag == 't':
-                    a, b = S, S_g_hat
-                r, g, fr, fg = d(a, b)
+            jobs = [('s', lambda: self.msd(y, y_g_hat))]
+            if self.mpd is not None:
+                jobs.append(('p', lambda: self.mpd(y, y_g_hat)))
+            if self.mtd is not None:
+                jobs.append(('t', lambda: self.mtd(S, S_g_hat)))
+            for (tag, _), (r, g, fr, fg) in zip(jobs, fork_join([j for _, j in jobs])):
                 losses['gen_' + tag] = generator_loss(g, r)
                 losses['fm_' + tag] = feature_loss(fr, fg)
                 total = total + losses['gen_' + tag] + losses['fm_' + tag] * hp.w_loss_fm
@@ -290,6 +291,7 @@ class Trainer:
         finally:
             self._freeze(False)
         if self.dp.enabled:
+            self.generator.bank().sync_grads()
             self.dp.reduce_async(self.generator.bank().gflat)
             self.dp.wait()
         self.optim_g.step(self.dp.reduce_flag(total.detach().clone().reshape(1)))
