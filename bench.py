@@ -69,7 +69,10 @@ def cpu_baseline(budget_s=12.0):
     g, msd = O.Generator(), O.MSD()
     og, od = O.make_optimizers(g, [msd])
     x, y_tmpl, y = O.synthetic_batch(2, 8192, 1)
-    cores = torch.get_num_threads()
+    # the batch-2 step does not scale past ~16 threads (measured on the 256-CPU host: 8/16 threads 0.25 s/step, 32 threads
+    # 0.62, 64 threads 2.0, all 128 default threads 7): use the best setting, not the default oversubscription
+    cores = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(cores)
     for _ in range(2):
         O.train_step(g, og, od, x, y_tmpl, y, msd, None, None, 1)
     n, t0 = 0, time.perf_counter()
@@ -81,7 +84,8 @@ def cpu_baseline(budget_s=12.0):
             break
     return {'value': round(2 * 8192 / SAMPLE_RATE / (el / n), 4), 'unit': 'audio-s/s', 'cores': cores, 'kind': 'port',
             'sample': f'{n} steps of configs[0] (UNet-G + MSD, batch 2 x 8192 samples, 1 D-step + 1 G-step) '
-                      f'in {el:.1f} s on {cores} torch CPU threads; oracle/rtg_oracle.py'}
+                      f'in {el:.1f} s on {cores} torch CPU threads (host has {os.cpu_count()} logical CPUs; more threads are slower '
+                      f'at batch 2); oracle/rtg_oracle.py'}
 
 
 def roofline(trainer, batch):
