@@ -81,6 +81,9 @@ typedef struct RtgConv1dDesc {
   int tap_major;               /* weights packed in the tap-major order (RtgPackJob.tap_major): for layers with few input
                                   channels per group (C_in = 1 first layers, grouped MSD convs) the MFMA K dimension
                                   walks (channel, 64/tile_m consecutive taps) instead of padding the channels to 16   */
+  int tile_cfg;                /* block shape: 0 = the library's heuristic, else MT*100 + NT*10 + WM as listed by
+                                  rtg_conv1d_tile_candidates (wave tile MT x NT MFMA tiles, WM x 4/WM waves).  Every
+                                  shape gives bit-identical results; callers time the candidates once per layer      */
 } RtgConv1dDesc;
 
 int rtg_conv1d(const RtgConv1dDesc* d, const float* x1, const float* x2, const float* aux, const float* wp,
@@ -89,6 +92,9 @@ int rtg_conv1d(const RtgConv1dDesc* d, const float* x1, const float* x2, const f
 /* which template instantiation rtg_conv1d would launch for this descriptor: tile_m*100 + MT*10 + NT (wave tile =
  * MT x NT MFMA tiles), or a negative RTG_E* code.  Used by bench.py to attribute time per kernel. */
 int rtg_conv1d_variant(const RtgConv1dDesc* d);
+/* the block shapes (RtgConv1dDesc.tile_cfg codes) valid for this descriptor, best-guess first; returns how many were
+ * written to cfgs[0..max) or a negative RTG_E* code */
+int rtg_conv1d_tile_candidates(const RtgConv1dDesc* d, int* cfgs, int max);
 
 /* number of floats of the packed weight buffer for a layer with the given logical shape */
 long long rtg_packed_size(int groups, int Mg, int Cg, int K, int tile_m);
@@ -122,12 +128,17 @@ typedef struct RtgWgradDesc {
   /* second dimension, as in RtgConv1dDesc (h_mode is always 0 here): x is [items, C1/h_k, h_in, L_in], dy is
    * [items, groups*Mg, h_n, dy_L], B = items * h_n clips */
   int h_in, h_k, h_stride, h_pad, h_n;
+  int shape_cfg;               /* block shape: 0 = the library's heuristic, else a code listed by
+                                  rtg_wgrad_shape_candidates.  The shape does not change the summation order (the
+                                  number of splits does)                                                             */
 } RtgWgradDesc;
 
 int rtg_conv1d_wgrad(const RtgWgradDesc* d, const float* x1, const float* x2, const float* dy, const float* gy_aux,
                      float* part, void* stream);
-/* suggested number of splits for a problem (>= 1) */
+/* suggested number of splits for a problem and its block shape (>= 1) */
 int rtg_wgrad_splits(const RtgWgradDesc* d);
+/* the block shapes (RtgWgradDesc.shape_cfg codes) valid for this problem, best-guess first; returns the count written */
+int rtg_wgrad_shape_candidates(const RtgWgradDesc* d, int* cfgs, int max);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Weight bank: old-style weight norm (torch.nn.utils.weight_norm, dim=0: every conv of the path, e.g.

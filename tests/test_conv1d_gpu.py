@@ -201,3 +201,28 @@ def test_bad_descriptor_is_refused():
     assert lib.rtg_conv1d(C.byref(d), _ptr(x), None, None, _ptr(x), None, None, None, _ptr(x), None, None) == -1
     d = Conv1dDesc(**base_desc(1, 8, 0, 16, 1, 8, 8, 3, 1, 1, 1, 16, 8, 16, 32))
     assert lib.rtg_conv1d(C.byref(d), None, None, None, _ptr(x), None, None, None, _ptr(x), None, None) == -3
+
+
+@pytest.mark.parametrize('case', [FWD_CASES[1], FWD_CASES[5], FWD_CASES[11], FWD_CASES[14], (40, 64, 96, 15, 5, 1, 1, 2, 1, 32)])
+def test_every_block_shape_gives_identical_bits(case):
+    """RtgConv1dDesc.tile_cfg: all candidates listed by rtg_conv1d_tile_candidates compute the same bits (the tuner in
+    rtg/tune.py relies on it), and an unlisted code is refused."""
+    from rtg.lib import lib, Conv1dDesc
+    B, Cin, Cout, L, K, s, d, p, g, TM = case
+    gen = torch.Generator().manual_seed(7)
+    x = torch.randn(B, Cin, L, generator=gen)
+    w = torch.randn(Cout, Cin // g, K, generator=gen) / np.sqrt(Cin // g * K)
+    bias = torch.randn(Cout, generator=gen)
+    L_out = (L + 2 * p - d * (K - 1) - 1) // s + 1
+    wp = packref.pack_logical(packref.logical_fwd(w.numpy(), g), TM)
+    desc = base_desc(B, Cin, 0, L, g, Cin // g, Cout // g, K, s, d, p, L_out, Cout, L_out, TM, pre_mode=1, pre_slope=0.15)
+    cands = (C.c_int * 16)()
+    n = lib.rtg_conv1d_tile_candidates(C.byref(Conv1dDesc(**desc)), cands, 16)
+    assert n >= 2
+    ref = run_conv(desc, x, wp, bias=bias, out_shape=(B, Cout, L_out))
+    assert torch.isfinite(ref).all()
+    for c in cands[:n]:
+        out = run_conv(dict(desc, tile_cfg=c), x, wp, bias=bias, out_shape=(B, Cout, L_out))
+        assert torch.equal(out, ref), f'tile_cfg {c} differs'
+    bad = Conv1dDesc(**dict(desc, tile_cfg=999))
+    assert lib.rtg_conv1d_variant(C.byref(bad)) < 0

@@ -77,3 +77,41 @@ def test_wgrad_and_weightnorm_backward(case):
                           ('bias', bias.grad, slice(rows + rows * inner, None))):
         err = (got[sl] - ref).abs().max().item()
         assert err <= 2e-4 * ref.abs().max().item() + 1e-5, (name, err, ref.abs().max().item())
+
+
+@pytest.mark.parametrize('case', [CASES[0], CASES[4], CASES[9], CASES[11]])
+def test_every_wgrad_block_shape_agrees(case):
+    """RtgWgradDesc.shape_cfg: every shape listed by rtg_wgrad_shape_candidates gives the same sum of partials as the
+    heuristic one (fp32 summation order differs only through the number of splits)."""
+    from rtg.lib import lib, WgradDesc, check
+    B, Cin, Cout, L, K, s, d, p, g = case
+    gen = torch.Generator().manual_seed(11)
+    Lo = (L + 2 * p - d * (K - 1) - 1) // s + 1
+    x, dy = torch.randn(B, Cin, L, generator=gen).cuda(), torch.randn(B, Cout, Lo, generator=gen).cuda()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    need = Cout * ((Cin // g) * K + 1)
+
+    def run(cfg):
+        wd = WgradDesc(B=B, C1=Cin, C2=0, L_in=L, groups=g, Cg=Cin // g, Mg=Cout // g, K=K, stride=s, dil=d, pad=p, Q=Lo,
+                       dy_L=Lo, pre_mode=1, pre_slope=0.15, gy_mode=0, gy_slope=1.0, gy_scale=1.0, splits=1,
+                       part_stride=0, shape_cfg=cfg)
+        splits = lib.rtg_wgrad_splits(C.byref(wd))
+        assert splits >= 1
+        part = torch.full((splits * need,), float('nan'), device='cuda')
+        wd.splits, wd.part_stride = splits, need
+        check(lib.rtg_conv1d_wgrad(C.byref(wd), _ptr(x), None, _ptr(dy), None, _ptr(part), st))
+        torch.cuda.synchronize()
+        return part.view(splits, need).double().sum(0).cpu()
+
+    cands = (C.c_int * 8)()
+    probe = WgradDesc(B=B, C1=Cin, C2=0, L_in=L, groups=g, Cg=Cin // g, Mg=Cout // g, K=K, stride=s, dil=d, pad=p, Q=Lo,
+                      dy_L=Lo, pre_mode=1, pre_slope=0.15, gy_mode=0, gy_slope=1.0, gy_scale=1.0, splits=1, part_stride=0)
+    n = lib.rtg_wgrad_shape_candidates(C.byref(probe), cands, 8)
+    assert n >= 2
+    ref = run(0)
+    assert torch.isfinite(ref).all()
+    for c in cands[:n]:
+        got = run(c)
+        assert (got - ref).abs().max().item() <= 1e-4 * ref.abs().max().item(), f'shape_cfg {c}'
+    probe.shape_cfg = 99
+    assert lib.rtg_wgrad_splits(C.byref(probe)) < 0

@@ -484,7 +484,15 @@ inline int segment_len(int Q, int stride, int K, int dil) {
   return Q + (extra > 0 ? (extra + stride - 1) / stride : 0);
 }
 
-TileCfg pick_tiles(int TM, int n_mt, int Q, int B, int groups, int stride, int K, int dil) {
+// Scores every block shape valid for the problem (score <= 0: not applicable); returns the number of shapes.
+constexpr int kMaxTileCfgs = 16;
+struct ScoredCfg {
+  TileCfg c;
+  double score;
+};
+inline int tile_code(const TileCfg& c) { return c.MT * 100 + c.NT * 10 + c.WM; }
+
+int score_tiles(int TM, int n_mt, int Q, int B, int groups, int stride, int K, int dil, ScoredCfg* out) {
   static const int c32[][4] = {{2, 2, 1, 4}, {2, 2, 2, 2}, {2, 2, 4, 1}, {1, 2, 1, 4}, {1, 2, 2, 2}, {1, 2, 4, 1},
                                {1, 4, 1, 4}, {1, 4, 2, 2}, {2, 1, 1, 4}, {2, 1, 2, 2}, {2, 1, 4, 1}, {1, 1, 1, 4},
                                {1, 1, 2, 2}, {1, 1, 4, 1}};
@@ -493,8 +501,7 @@ TileCfg pick_tiles(int TM, int n_mt, int Q, int B, int groups, int stride, int K
   const int(*cs)[4] = TM == 32 ? c32 : c16;
   const int n = TM == 32 ? (int)(sizeof(c32) / sizeof(c32[0])) : (int)(sizeof(c16) / sizeof(c16[0]));
   const int Lseg = segment_len(Q, stride, K, dil);
-  TileCfg best = {0, 0, 0, 0, 0, 0};
-  double best_score = -1.0;
+  int cnt = 0;
   for (int i = 0; i < n; ++i) {
     TileCfg c = {cs[i][0], cs[i][1], cs[i][2], cs[i][3], 0, 0};
     const int BN = c.WN * c.NT * TM;
@@ -518,14 +525,24 @@ TileCfg pick_tiles(int TM, int n_mt, int Q, int B, int groups, int stride, int K
     const double blocks = (double)m_blocks * n_blocks_q * groups;
     const double fill = blocks >= 512.0 ? 1.0 : blocks / 512.0;
     const double reuse = (double)(c.MT * c.NT) / (c.MT + c.NT);   // MFMAs per operand fragment fetched
-    double score = eff * fill * (0.6 + 0.4 * (reuse > 1.0 ? 1.0 : reuse));
-    if (const char* f = getenv("RTG_DEV_FORCE_TILE")) {      // tuning aid: "MT,NT,WM" pins the block shape
-      int fm = 0, fn = 0, fw = 0;
-      if (sscanf(f, "%d,%d,%d", &fm, &fn, &fw) == 3 && fm == c.MT && fn == c.NT && fw == c.WM) score += 100.0;
-    }
-    if (score > best_score) {
-      best_score = score;
-      best = c;
+    out[cnt].c = c;
+    out[cnt].score = eff * fill * (0.6 + 0.4 * (reuse > 1.0 ? 1.0 : reuse)) + 1e-9;
+    ++cnt;
+  }
+  return cnt;
+}
+
+// forced: a RtgConv1dDesc.tile_cfg code, or 0 for the best score.  MT == 0 in the result: nothing applicable.
+TileCfg pick_tiles(int TM, int n_mt, int Q, int B, int groups, int stride, int K, int dil, int forced) {
+  ScoredCfg sc[kMaxTileCfgs];
+  const int n = score_tiles(TM, n_mt, Q, B, groups, stride, K, dil, sc);
+  TileCfg best = {0, 0, 0, 0, 0, 0};
+  double best_score = -1.0;
+  for (int i = 0; i < n; ++i) {
+    if (forced ? tile_code(sc[i].c) == forced : sc[i].score > best_score) {
+      best = sc[i].c;
+      best_score = sc[i].score;
+      if (forced) break;
     }
   }
   return best;
@@ -538,9 +555,30 @@ extern "C" int rtg_conv1d_variant(const RtgConv1dDesc* d) {
   if ((d->tile_m != 32 && d->tile_m != 16) || d->Mg < 1 || d->Q < 1 || d->B < 1 || d->groups < 1 || d->stride < 1 ||
       d->K < 1 || d->dil < 1)
     return RTG_EINVAL;
-  const TileCfg c = pick_tiles(d->tile_m, rtg_ceil_div(d->Mg, d->tile_m), d->Q, d->B, d->groups, d->stride, d->K, d->dil);
-  if (c.MT == 0) return RTG_ERANGE;
+  const TileCfg c = pick_tiles(d->tile_m, rtg_ceil_div(d->Mg, d->tile_m), d->Q, d->B, d->groups, d->stride, d->K, d->dil,
+                               d->tile_cfg);
+  if (c.MT == 0) return d->tile_cfg ? RTG_EINVAL : RTG_ERANGE;
   return d->tile_m * 100 + c.MT * 10 + c.NT;
+}
+
+extern "C" int rtg_conv1d_tile_candidates(const RtgConv1dDesc* d, int* cfgs, int max) {
+  if (!d || !cfgs) return RTG_ENULL;
+  if ((d->tile_m != 32 && d->tile_m != 16) || d->Mg < 1 || d->Q < 1 || d->B < 1 || d->groups < 1 || d->stride < 1 ||
+      d->K < 1 || d->dil < 1 || max < 1)
+    return RTG_EINVAL;
+  ScoredCfg sc[kMaxTileCfgs];
+  const int n = score_tiles(d->tile_m, rtg_ceil_div(d->Mg, d->tile_m), d->Q, d->B, d->groups, d->stride, d->K, d->dil, sc);
+  // best-guess first (selection sort by score; n <= 14)
+  int cnt = 0;
+  for (int k = 0; k < n && cnt < max; ++k) {
+    int bi = -1;
+    for (int i = 0; i < n; ++i)
+      if (sc[i].score > 0.0 && (bi < 0 || sc[i].score > sc[bi].score)) bi = i;
+    if (bi < 0) break;
+    cfgs[cnt++] = tile_code(sc[bi].c);
+    sc[bi].score = -1.0;
+  }
+  return cnt;
 }
 
 extern "C" long long rtg_packed_size(int groups, int Mg, int Cg, int K, int tile_m) {
@@ -619,8 +657,8 @@ extern "C" int rtg_conv1d(const RtgConv1dDesc* d, const float* x1, const float* 
     a.K = tapmajor_groups(d->Cg, d->K, TM);     // the kernel's step loop walks groups of CPN k-steps
   }
 
-  const TileCfg c = pick_tiles(TM, a.n_mt, d->Q, d->B, d->groups, d->stride, d->K, d->dil);
-  if (c.MT == 0) return RTG_ERANGE;   // even the smallest block's patch exceeds RTG_PW_MAX
+  const TileCfg c = pick_tiles(TM, a.n_mt, d->Q, d->B, d->groups, d->stride, d->K, d->dil, d->tile_cfg);
+  if (c.MT == 0) return d->tile_cfg ? RTG_EINVAL : RTG_ERANGE;   // unknown shape / even the smallest patch exceeds RTG_PW_MAX
   a.WM = c.WM; a.WN = c.WN;
   const int BN = c.WN * c.NT * TM;
   a.PW = patch_width(BN, d->stride, d->K, d->dil);

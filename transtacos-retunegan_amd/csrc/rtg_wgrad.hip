@@ -51,6 +51,7 @@ int geometry(const RtgWgradDesc* d, WgGeom* o) {
   double best = -1.0;
   o->shape = -1;
   for (int s = 0; s < kNumShapes; ++s) {
+    if (d->shape_cfg && s != d->shape_cfg - 1) continue;        // caller-selected block shape
     const Shape sh = kShapes[s];
     const int bm = sh.WM * sh.MTW, bn = (4 / sh.WM) * sh.NTW;     // block tile in MFMA tiles
     int ckw = (bn * TM - 1) / d->K;
@@ -68,7 +69,7 @@ int geometry(const RtgWgradDesc* d, WgGeom* o) {
       o->shape = s; o->CKW = ckw; o->n_cchunk = n_cchunk; o->m_blocks = m_blocks;
     }
   }
-  if (o->shape < 0) return RTG_ERANGE;
+  if (o->shape < 0) return d->shape_cfg ? RTG_EINVAL : RTG_ERANGE;
   // one virtual sequence over all clips: seg_len slots per clip (its Q outputs + the gap that separates patches)
   const int extra = (d->K - 1) * d->dil + 1 - d->stride;
   const int Lseg = d->Q + (extra > 0 ? (extra + d->stride - 1) / d->stride : 0);
@@ -99,6 +100,7 @@ int validate(const RtgWgradDesc* d) {
   if (d->C1 + d->C2 != d->groups * d->Cg) return RTG_EINVAL;
   if (d->groups > 1 && d->C2 != 0) return RTG_EINVAL;
   if (d->stride > 8) return RTG_ERANGE;
+  if (d->shape_cfg < 0 || d->shape_cfg > kNumShapes) return RTG_EINVAL;
   const bool two_d = d->h_k > 1 || d->h_n > 1;
   if (two_d) {
     if (d->h_in < 1 || d->h_k < 1 || d->h_stride < 1 || d->h_pad < 0 || d->h_n < 1) return RTG_EINVAL;
@@ -147,6 +149,27 @@ extern "C" int rtg_wgrad_splits(const RtgWgradDesc* d) {
     if (t < best) { best = t; best_s = s; }
   }
   return (int)best_s;
+}
+
+extern "C" int rtg_wgrad_shape_candidates(const RtgWgradDesc* d, int* cfgs, int max) {
+  if (!d || !cfgs) return RTG_ENULL;
+  if (max < 1) return RTG_EINVAL;
+  int st = validate(d);
+  if (st) return st;
+  RtgWgradDesc t = *d;
+  WgGeom g;
+  t.shape_cfg = 0;
+  st = geometry(&t, &g);
+  if (st) return st;
+  int cnt = 0;
+  cfgs[cnt++] = g.shape + 1;                                    // the heuristic's choice first
+  for (int s = 0; s < kNumShapes && cnt < max; ++s) {
+    if (s == g.shape) continue;
+    t.shape_cfg = s + 1;
+    WgGeom gs;
+    if (geometry(&t, &gs) == RTG_OK) cfgs[cnt++] = s + 1;
+  }
+  return cnt;
 }
 
 extern "C" int rtg_conv1d_wgrad(const RtgWgradDesc* d, const float* x1, const float* x2, const float* dy,

@@ -7,7 +7,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from rtg import ops
+from rtg import ops, tune
 from rtg.bank import WeightBank
 from rtg.lib import ACT_NONE, ACT_LRELU, ACT_TANH, RtgError  # noqa: F401
 
@@ -115,7 +115,7 @@ def fork_join(fns):
     branches) on separate HIP streams so that their kernels overlap: each of these launches only fills the chip for part
     of its duration (ramp-up, last partial wave of workgroups), a second queue fills the idle CUs.  Autograd replays the
     backward of every op on the stream of its forward, so the backward overlaps the same way.  RTG_STREAMS=0 disables."""
-    if len(fns) < 2 or os.environ.get('RTG_STREAMS', '1') == '0' or ops.PROFILE is not None:
+    if len(fns) < 2 or os.environ.get('RTG_STREAMS', '1') == '0' or ops.PROFILE is not None or tune.ACTIVE:
         return [f() for f in fns]
     main = torch.cuda.current_stream()
     depth = _FORK_DEPTH[0]

@@ -15,7 +15,7 @@ class Conv1dDesc(C.Structure):
                                        'out_C', 'out_L', 'shuf_S', 'shuf_P', 'pre_mode')] + \
                [('pre_slope', C.c_float), ('mask_slope', C.c_float), ('out_scale', C.c_float), ('act', C.c_int),
                 ('act_slope', C.c_float), ('accumulate', C.c_int), ('tile_m', C.c_int), ('out_split', C.c_int)] + \
-               [(n, C.c_int) for n in ('h_in', 'h_k', 'h_stride', 'h_pad', 'h_n', 'h_mode', 'tap_major')]
+               [(n, C.c_int) for n in ('h_in', 'h_k', 'h_stride', 'h_pad', 'h_n', 'h_mode', 'tap_major', 'tile_cfg')]
 
 
 class WgradDesc(C.Structure):
@@ -23,7 +23,7 @@ class WgradDesc(C.Structure):
                                        'dy_L', 'pre_mode')] + \
                [('pre_slope', C.c_float), ('gy_mode', C.c_int), ('gy_slope', C.c_float), ('gy_scale', C.c_float),
                 ('splits', C.c_int),
-                ('part_stride', C.c_longlong)] + [(n, C.c_int) for n in ('h_in', 'h_k', 'h_stride', 'h_pad', 'h_n')]
+                ('part_stride', C.c_longlong)] + [(n, C.c_int) for n in ('h_in', 'h_k', 'h_stride', 'h_pad', 'h_n', 'shape_cfg')]
 
 
 class NormJob(C.Structure):
@@ -66,11 +66,13 @@ _I, _F, _LL, _ULL = C.c_int, C.c_float, C.c_longlong, C.c_ulonglong
 PROTOTYPES = {
     'rtg_conv1d': (_I, [C.POINTER(Conv1dDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'rtg_conv1d_variant': (_I, [C.POINTER(Conv1dDesc)]),
+    'rtg_conv1d_tile_candidates': (_I, [C.POINTER(Conv1dDesc), C.POINTER(C.c_int), _I]),
     'rtg_packed_size': (_LL, [_I, _I, _I, _I, _I]),
     'rtg_packed_size_tapmajor': (_LL, [_I, _I, _I, _I, _I]),
     'rtg_tapmajor_pays': (_I, [_I, _I, _I]),
     'rtg_conv1d_wgrad': (_I, [C.POINTER(WgradDesc), _P, _P, _P, _P, _P, _P]),
     'rtg_wgrad_splits': (_I, [C.POINTER(WgradDesc)]),
+    'rtg_wgrad_shape_candidates': (_I, [C.POINTER(WgradDesc), C.POINTER(C.c_int), _I]),
     'rtg_weightnorm_scales': (_I, [_P, _I, _I, _P, _P, _P]),
     'rtg_weights_pack': (_I, [_P, _I, _LL, _P, _P, _P, _P]),
     'rtg_weightnorm_backward': (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P]),

@@ -5,6 +5,7 @@ import ctypes as C
 import torch
 
 from . import lib as L
+from . import tune
 from .lib import lib, check
 
 
@@ -41,6 +42,27 @@ def _timed(kernel, variant, flop, launch, label=''):
     e1.record()
     PROFILE.append((kernel, variant, flop, e0, e1, label))
     return r
+
+
+def _run_conv(d, args, flop, label, what):
+    """rtg_conv1d with the tuned block shape (rtg/tune.py); args = everything after the descriptor"""
+    d.tile_cfg = tune.conv_cfg(d, lambda: lib.rtg_conv1d(C.byref(d), *args))
+    check(_timed('conv1d', lib.rtg_conv1d_variant(C.byref(d)) if PROFILE is not None else 0, flop,
+                 lambda: lib.rtg_conv1d(C.byref(d), *args), label), what)
+
+
+def _run_wgrad(wd, ptrs, st, bank, ly, tok_id, flop, label, what):
+    """rtg_conv1d_wgrad into the bank's partial slot with the tuned block shape; ptrs = (x1, x2, dy, gy_aux)"""
+    wd.shape_cfg = tune.wgrad_cfg(wd, lambda part: lib.rtg_conv1d_wgrad(C.byref(wd), *ptrs, _p(part), st))
+    splits = lib.rtg_wgrad_splits(C.byref(wd))
+    if splits < 1:
+        raise L.RtgError(f'wgrad geometry refused for {ly.name}: {splits}')
+    part, stride, immediate = bank.partial_slot(ly, splits, tok_id)
+    bank.note_backward_stream()
+    wd.splits, wd.part_stride = splits, stride
+    check(_timed('wgrad', 32 if wd.Mg >= 32 else 16, flop,
+                 lambda: lib.rtg_conv1d_wgrad(C.byref(wd), *ptrs, _p(part), st), f'{label} splits{splits}'), what)
+    return part, splits, immediate
 
 
 def _conv_flop(ly, B, L_conv_out):
@@ -90,9 +112,8 @@ class ConvFn(torch.autograd.Function):
                       out_C=ly.cout, out_L=L_out, shuf_S=ly.stride, shuf_P=ly.pad, pre_mode=pre_mode,
                       pre_slope=pre_slope, out_scale=out_scale, act=act, act_slope=act_slope, tile_m=ly.fwd_tm, tap_major=ly.fwd_tap)
         lc = L_out if ly.kind == 'conv' else L_in
-        check(_timed('conv1d', lib.rtg_conv1d_variant(C.byref(d)) if PROFILE is not None else 0, _conv_flop(ly, B, lc),
-                     lambda: lib.rtg_conv1d(C.byref(d), _p(x1), _p(x2), None, bank.fwd_ptr(ly), bank.bias_ptr(ly), None,
-                                            _p(res), _p(out), None, _stream()), f'fwd {ly.name} B{B} L{L_in}'), f'conv1d fwd {ly.name}')
+        _run_conv(d, (_p(x1), _p(x2), None, bank.fwd_ptr(ly), bank.bias_ptr(ly), None, _p(res), _p(out), None, _stream()),
+                  _conv_flop(ly, B, lc), f'fwd {ly.name} B{B} L{L_in}', f'conv1d fwd {ly.name}')
         ctx.ly, ctx.bank, ctx.tok_id = ly, bank, token._rtg_id
         ctx.cfg = (pre_slope, act, act_slope, out_scale, res_is_input, res is not None)
         ctx.save_for_backward(x1, x2, out if act != L.ACT_NONE else None)
@@ -168,10 +189,8 @@ class ConvFn(torch.autograd.Function):
                           mask_slope=pre_slope, out_scale=out_scale, tile_m=ly.bwd_tm, out_split=split,
                           tap_major=ly.bwd_tap)
             lc = L_out if ly.kind == 'conv' else L_in
-            check(_timed('conv1d', lib.rtg_conv1d_variant(C.byref(d)) if PROFILE is not None else 0,
-                         _conv_flop(ly, B, lc),
-                         lambda: lib.rtg_conv1d(C.byref(d), _p(dy), None, _p(out), bank.bwd_ptr(ly), None, _p(mask),
-                                                _p(resg), _p(dx1), _p(dx2), st), f'dgrad {ly.name} B{B} L{L_in}'), f'conv1d bwd-data {ly.name}')
+            _run_conv(d, (_p(dy), None, _p(out), bank.bwd_ptr(ly), None, _p(mask), _p(resg), _p(dx1), _p(dx2), st),
+                      _conv_flop(ly, B, lc), f'dgrad {ly.name} B{B} L{L_in}', f'conv1d bwd-data {ly.name}')
             if not need_x1:
                 dx1 = None
 
@@ -192,17 +211,10 @@ class ConvFn(torch.autograd.Function):
                                  pre_slope=1.0, gy_mode=pre_mode, gy_slope=pre_slope, gy_scale=out_scale, splits=1,
                                  part_stride=0)
                 a1, a2, gyt, aux = dy, None, x1, None
-            splits = lib.rtg_wgrad_splits(C.byref(wd))
-            if splits < 1:
-                raise L.RtgError(f'wgrad geometry refused for {ly.name}: {splits}')
-            part, stride, immediate = bank.partial_slot(ly, splits, ctx.tok_id)
-            bank.note_backward_stream()
-            wd.splits, wd.part_stride = splits, stride
             lc = L_out if ly.kind == 'conv' else L_in
-            check(_timed('wgrad', 32 if wd.Mg >= 32 else 16, _conv_flop(ly, B, lc),
-                         lambda: lib.rtg_conv1d_wgrad(C.byref(wd), _p(a1), _p(a2), _p(gyt), _p(aux), _p(part), st),
-                         f'wgrad {ly.name} B{B} L{L_in} splits{splits}'),
-                  f'conv1d wgrad {ly.name}')
+            part, splits, immediate = _run_wgrad(wd, (_p(a1), _p(a2), _p(gyt), _p(aux)), st, bank, ly, ctx.tok_id,
+                                                 _conv_flop(ly, B, lc), f'wgrad {ly.name} B{B} L{L_in}',
+                                                 f'conv1d wgrad {ly.name}')
             if ly.kind == 'convT':   # bias gradient of a transposed conv: plain channel sum of dy
                 check(lib.rtg_channel_sum(_p(dy), C.c_void_p(bank.gflat.data_ptr() + 4 * ly.b_off), B, ly.cout, L_out,
                                           st), 'channel_sum')
@@ -239,10 +251,8 @@ class Conv2dFn(torch.autograd.Function):
                   pad=ly.pad, Q=Wo, out_C=ly.cout, out_L=Wo, pre_mode=pre_mode, pre_slope=pre_slope, tile_m=ly.fwd_tm,
                   h_in=H, h_k=ly.kh, h_stride=ly.sh, h_pad=ly.ph, h_n=Ho, h_mode=0)
         flop = 2.0 * B * Ho * Wo * ly.cout * Cin * ly.kh * ly.k
-        check(_timed('conv1d', lib.rtg_conv1d_variant(C.byref(d)) if PROFILE is not None else 0, flop,
-                     lambda: lib.rtg_conv1d(C.byref(d), _p(x), None, None, bank.fwd_ptr(ly), bank.bias_ptr(ly), None,
-                                            None, _p(out), None, _stream()), f'fwd2d {ly.name} B{B} {H}x{W}'),
-              f'conv2d fwd {ly.name}')
+        _run_conv(d, (_p(x), None, None, bank.fwd_ptr(ly), bank.bias_ptr(ly), None, None, _p(out), None, _stream()),
+                  flop, f'fwd2d {ly.name} B{B} {H}x{W}', f'conv2d fwd {ly.name}')
         ctx.ly, ctx.bank, ctx.tok_id, ctx.pre_slope = ly, bank, token._rtg_id, pre_slope
         ctx.save_for_backward(x)
         ctx.set_materialize_grads(False)
@@ -272,25 +282,16 @@ class Conv2dFn(torch.autograd.Function):
             else:
                 d = _desc(stride=1, pad=k - 1, Q=(W - 1 + ly.pad) // ly.stride + 1, shuf_S=ly.stride, shuf_P=ly.pad,
                           **common)
-            check(_timed('conv1d', lib.rtg_conv1d_variant(C.byref(d)) if PROFILE is not None else 0, flop,
-                         lambda: lib.rtg_conv1d(C.byref(d), _p(dy), None, None, bank.bwd_ptr(ly), None, _p(mask), None,
-                                                _p(dx), None, st), f'dgrad2d {ly.name} B{B} {H}x{W}'),
-                  f'conv2d bwd-data {ly.name}')
+            _run_conv(d, (_p(dy), None, None, bank.bwd_ptr(ly), None, _p(mask), None, _p(dx), None, st),
+                      flop, f'dgrad2d {ly.name} B{B} {H}x{W}', f'conv2d bwd-data {ly.name}')
         if ctx.needs_input_grad[0]:
             pre_mode = L.PRE_LRELU if pre_slope != 1.0 else L.PRE_NONE
             wd = L.WgradDesc(B=B * Ho, C1=Cin * ly.kh, C2=0, L_in=W, groups=1, Cg=Cin * ly.kh, Mg=ly.cout, K=ly.k,
                              stride=ly.stride, dil=1, pad=ly.pad, Q=Wo, dy_L=Wo, pre_mode=pre_mode, pre_slope=pre_slope,
                              gy_mode=L.PRE_NONE, gy_slope=1.0, gy_scale=1.0, splits=1, part_stride=0, h_in=H,
                              h_k=ly.kh, h_stride=ly.sh, h_pad=ly.ph, h_n=Ho)
-            splits = lib.rtg_wgrad_splits(C.byref(wd))
-            if splits < 1:
-                raise L.RtgError(f'wgrad geometry refused for {ly.name}: {splits}')
-            part, stride, immediate = bank.partial_slot(ly, splits, ctx.tok_id)
-            bank.note_backward_stream()
-            wd.splits, wd.part_stride = splits, stride
-            check(_timed('wgrad', 32 if wd.Mg >= 32 else 16, flop,
-                         lambda: lib.rtg_conv1d_wgrad(C.byref(wd), _p(x), None, _p(dy), None, _p(part), st),
-                         f'wgrad2d {ly.name} B{B} {H}x{W} splits{splits}'), f'conv2d wgrad {ly.name}')
+            part, splits, immediate = _run_wgrad(wd, (_p(x), None, _p(dy), None), st, bank, ly, ctx.tok_id, flop,
+                                                 f'wgrad2d {ly.name} B{B} {H}x{W}', f'conv2d wgrad {ly.name}')
             if immediate:
                 bank.flush_one(ly, part, splits)
         return None, dx, None, None

@@ -1,0 +1,97 @@
+"""Per-problem choice of the MFMA kernels' block shape by timing.
+
+The conv / wgrad kernels come in several block shapes (wave tile x wave grid).  Which one is fastest for a layer depends
+on how its rows, clips and output channels quantise onto 256 CUs, and a static score misses by 10-20 % on the
+discriminator layers.  So the first train step times the candidates the library lists for each distinct descriptor
+(`rtg_conv1d_tile_candidates`, `rtg_wgrad_shape_candidates`) on the live tensors and keeps the fastest; later steps look
+the choice up.  The block shape never changes a result bit (the summation order of every output element is the same for
+all shapes), so tuning is invisible to the parity tests.  RTG_TUNE=0 keeps the library's heuristic everywhere.
+
+While `ACTIVE` is set the sub-networks run serially on one stream (models.layers.fork_join) so that the timings are not
+disturbed by neighbours; `train.Trainer` sets it for its first step and again after a step that met an untuned problem.
+"""
+import ctypes as C
+import os
+
+import torch
+
+from .lib import lib
+
+ENABLED = os.environ.get('RTG_TUNE', '1') != '0'
+ACTIVE = False
+MISSED = False
+REPS = 3
+_conv, _wgrad = {}, {}
+
+
+def _time(launch):
+    st = launch()                                   # warm-up: code object load, caches
+    if st:
+        return None
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(REPS):
+        launch()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1)
+
+
+def _miss():
+    global MISSED
+    MISSED = MISSED or ENABLED
+    return 0
+
+
+def conv_cfg(d, launch):
+    """tile_cfg for descriptor `d`; `launch()` runs rtg_conv1d with `d` as it stands and returns its status."""
+    d.tile_cfg = 0
+    key = bytes(d)
+    cfg = _conv.get(key)
+    if cfg is not None:
+        return cfg
+    if not (ENABLED and ACTIVE):
+        return _miss()
+    cands = (C.c_int * 16)()
+    n = lib.rtg_conv1d_tile_candidates(C.byref(d), cands, 16)
+    best, best_t = 0, None
+    for c in cands[:max(n, 0)]:
+        d.tile_cfg = c
+        t = _time(launch)
+        if t is not None and (best_t is None or t < best_t):
+            best, best_t = c, t
+    d.tile_cfg = 0
+    _conv[key] = best
+    return best
+
+
+def wgrad_cfg(wd, run):
+    """shape_cfg for wgrad descriptor `wd`; `run(part)` launches rtg_conv1d_wgrad with `wd` into the scratch `part`."""
+    wd.shape_cfg, wd.splits, wd.part_stride = 0, 1, 0
+    key = bytes(wd)
+    cfg = _wgrad.get(key)
+    if cfg is not None:
+        return cfg
+    if not (ENABLED and ACTIVE):
+        return _miss()
+    cands = (C.c_int * 8)()
+    n = lib.rtg_wgrad_shape_candidates(C.byref(wd), cands, 8)
+    need = wd.groups * wd.Mg * (wd.Cg * wd.K + 1)
+    best, best_t = 0, None
+    for c in cands[:max(n, 0)]:
+        wd.shape_cfg = c
+        splits = lib.rtg_wgrad_splits(C.byref(wd))
+        if splits < 1:
+            continue
+        part = torch.empty(splits * need, device='cuda')
+        wd.splits, wd.part_stride = splits, need
+        t = _time(lambda: run(part))
+        if t is not None and (best_t is None or t < best_t):
+            best, best_t = c, t
+    wd.shape_cfg, wd.splits, wd.part_stride = 0, 1, 0
+    _wgrad[key] = best
+    return best
+
+
+def stats():
+    return {'conv_problems': len(_conv), 'wgrad_problems': len(_wgrad)}

@@ -25,6 +25,7 @@ from models import (multi_stft_loss, dynamic_loss, discriminator_loss, generator
                     MultiScaleDiscriminator, MultiPeriodDiscriminator, MultiStftDiscriminator)
 from models.layers import BankedModel, fork_join
 from models.loss import stft_cache
+from rtg import tune
 from rtg.lib import lib, check, RtgError
 
 device = 'cuda' if torch.cuda.is_available() else 'cpu'
@@ -223,6 +224,7 @@ class Trainer:
         self.dp.broadcast_parameters()
         self.generator.noise.salt = None
         self.steps = 0
+        self._tuned = False
         for m in (self.generator, *self.discs):
             m.train()
         if self.dp.enabled:
@@ -300,14 +302,22 @@ class Trainer:
     def train_step(self, x, y_tmpl, y, noise_list=None):
         """One iteration of the batch loop (train.py:121-193).  x [B,80,T/256], y_tmpl / y [B,1,T] on the GPU.
         Returns (d_losses, g_losses) as device scalars — nothing here synchronises with the host."""
-        with stft_cache():
-            y_g_hat = self.generator(x, y_tmpl, noise_list) if noise_list is not None else self.generator(x, y_tmpl)
-            assert y.shape[-1] == y_g_hat.shape[-1]
-            y_det = y_g_hat.detach()
-            dl = {}
-            for _ in range(self.d_train_times):
-                dl = self.d_step(y, y_det)
-            gl = self.g_step(y, y_g_hat)
+        # the first step (and one after any step that met a new problem shape) also times the block shapes of every
+        # conv / wgrad launch and keeps the fastest (rtg/tune.py); it is an ordinary train step otherwise
+        tune.ACTIVE = tune.ENABLED and (not self._tuned or tune.MISSED)
+        tune.MISSED = False
+        try:
+            with stft_cache():
+                y_g_hat = self.generator(x, y_tmpl, noise_list) if noise_list is not None else self.generator(x, y_tmpl)
+                assert y.shape[-1] == y_g_hat.shape[-1]
+                y_det = y_g_hat.detach()
+                dl = {}
+                for _ in range(self.d_train_times):
+                    dl = self.d_step(y, y_det)
+                gl = self.g_step(y, y_g_hat)
+        finally:
+            self._tuned = self._tuned or tune.ACTIVE
+            tune.ACTIVE = False
         self.steps += 1
         return dl, gl
 
