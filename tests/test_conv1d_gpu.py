@@ -226,3 +226,25 @@ def test_every_block_shape_gives_identical_bits(case):
         assert torch.equal(out, ref), f'tile_cfg {c} differs'
     bad = Conv1dDesc(**dict(desc, tile_cfg=999))
     assert lib.rtg_conv1d_variant(C.byref(bad)) < 0
+
+
+@pytest.mark.parametrize('case', [FWD_CASES[7], FWD_CASES[8], FWD_CASES[9], FWD_CASES[15], (40, 1, 32, 911, 5, 3, 1, 2, 1, 32)])
+def test_thin_kernels_match_the_mfma_path(case):
+    """One-input-channel / one-output-channel shapes run on the bandwidth kernels of rtg_thin.hip (variant 1 / 2) and
+    agree with the MFMA kernel forced through tile_cfg, including mask and residual operands."""
+    from rtg.lib import lib, Conv1dDesc
+    B, Cin, Cout, L, K, s, d, p, g, TM = case
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(B, Cin, L, generator=gen)
+    w = torch.randn(Cout, Cin // g, K, generator=gen) / np.sqrt(Cin // g * K)
+    bias = torch.randn(Cout, generator=gen)
+    L_out = (L + 2 * p - d * (K - 1) - 1) // s + 1
+    mask, res = torch.randn(B, Cout, L_out, generator=gen), torch.randn(B, Cout, L_out, generator=gen)
+    wp = packref.pack_logical(packref.logical_fwd(w.numpy(), g), TM)
+    desc = base_desc(B, Cin, 0, L, g, Cin // g, Cout // g, K, s, d, p, L_out, Cout, L_out, TM, pre_mode=1, pre_slope=0.15,
+                     mask_slope=0.2, out_scale=0.7, act=1, act_slope=0.1)
+    assert lib.rtg_conv1d_variant(C.byref(Conv1dDesc(**desc))) in (1, 2)
+    thin = run_conv(desc, x, wp, bias=bias, mask=mask, res=res, out_shape=(B, Cout, L_out))
+    mfma = run_conv(dict(desc, tile_cfg=111), x, wp, bias=bias, mask=mask, res=res, out_shape=(B, Cout, L_out))
+    assert lib.rtg_conv1d_variant(C.byref(Conv1dDesc(**dict(desc, tile_cfg=111)))) >= 100
+    np.testing.assert_allclose(thin.numpy(), mfma.numpy(), rtol=2e-5, atol=2e-5)

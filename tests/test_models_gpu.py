@@ -111,8 +111,7 @@ def test_generator_backward_golden(nets, oracle, gold):
     close_stats(got, gold['ggrad_g_stats'], numels(g), rtol=2e-3, atol=1e-5, sum_rel=2e-3)   # see the flip note below
 
 
-def test_generator_grads_elementwise_vs_oracle(nets, onets, oracle):
-    g, og = nets[0], onets[0]
+def _g_grad_errors(g, og, oracle):
     x, y_tmpl, _ = oracle.golden_inputs(seed=3)
     gen = torch.Generator().manual_seed(5)
     dy = torch.randn(2, 1, 8192, generator=gen)
@@ -121,15 +120,40 @@ def test_generator_grads_elementwise_vs_oracle(nets, onets, oracle):
     og(x, y_tmpl).backward(dy)
     torch.cuda.synchronize()
     op = dict(og.named_parameters())
-    for n, p in g.named_parameters():
-        if n == 'noise.w':
-            continue
-        ref = op[n].grad
-        # leaky-relu's derivative jumps at 0: an activation that lands within fp32 rounding of 0 (|x| ~ 1e-7, seen on
-        # these inputs) takes a different branch on the GPU than on the CPU and perturbs every upstream gradient a
-        # little; the relative L2 error is robust to such isolated flips while any kernel bug is O(1)
-        err = (p.grad.cpu() - ref).norm().item() / (ref.norm().item() + 1e-20)
-        assert err <= 2e-3, (n, err)
+    return {n: (p.grad.cpu() - op[n].grad).norm().item() / (op[n].grad.norm().item() + 1e-20)
+            for n, p in g.named_parameters() if n != 'noise.w'}
+
+
+def test_generator_grads_elementwise_vs_oracle(nets, onets, oracle):
+    """Every parameter gradient of G against the CPU oracle: relative L2 error per tensor.
+
+    What limits the agreement is not the kernels but the kink of the leaky-relu: its derivative jumps at 0, and an
+    activation that lands within fp32 rounding of 0 (|x| ~ 1e-7 of ~2e7 activations: zero to a few per pass) takes the
+    other branch on the GPU than on the CPU.  One flip moves the gradients upstream of it by up to ~1/sqrt(positions)
+    (measured 2e-4 .. 2e-3); without a flip the HIP path agrees with a float64 run of the oracle to 2e-6.  So: every
+    run must stay below 5e-3 (a kernel bug is O(1) in its own layer), and over three initialisations (the
+    reference's default init under three seeds, noise switched off because the device RNG differs by construction)
+    the median of the worst-tensor error must show the flip-free accuracy."""
+    from models import Generator_RefineGAN_small
+    worst = []
+    for seed in (114514, 11, 7):
+        torch.manual_seed(seed)
+        g = Generator_RefineGAN_small().to(DEV).train()
+        og = oracle.Generator().train()
+        og.load_state_dict({k: v.cpu() for k, v in g.state_dict().items()})
+        with torch.no_grad():
+            g.noise.w.zero_(); og.noise.w.zero_()
+        err = _g_grad_errors(g, og, oracle)
+        n_bad = max(err, key=err.get)
+        assert err[n_bad] <= 5e-3, (seed, n_bad, err[n_bad])
+        worst.append(err[n_bad])
+    assert sorted(worst)[1] <= 1e-4, worst
+    # det_fill weights (the golden fixtures' parameter set): unscaled +-1 weights put more activations next to 0, and in
+    # the ResidualStacks that run on 2 x 32 .. 2 x 2048 positions one flip is worth up to 1/sqrt(positions)
+    err = _g_grad_errors(nets[0], onets[0], oracle)
+    n_bad = max(err, key=err.get)
+    assert err[n_bad] <= 2e-2, (n_bad, err[n_bad])
+    assert sorted(err.values())[len(err) // 2] <= 2e-4, sorted(err.values())[len(err) // 2]
 
 
 @pytest.mark.parametrize('which', ['msd', 'mpd'])

@@ -550,11 +550,17 @@ TileCfg pick_tiles(int TM, int n_mt, int Q, int B, int groups, int stride, int K
 
 }  // namespace
 
+// rtg_thin.hip: bandwidth kernels for the one-input-channel / one-output-channel shapes
+int rtg_thin_kind(const RtgConv1dDesc* d);
+int rtg_thin_launch(int kind, const RtgConv1dDesc* d, const float* x, const float* aux, const float* wp,
+                    const float* bias, const float* mask, const float* res, float* out, hipStream_t s);
+
 extern "C" int rtg_conv1d_variant(const RtgConv1dDesc* d) {
   if (!d) return RTG_ENULL;
   if ((d->tile_m != 32 && d->tile_m != 16) || d->Mg < 1 || d->Q < 1 || d->B < 1 || d->groups < 1 || d->stride < 1 ||
       d->K < 1 || d->dil < 1)
     return RTG_EINVAL;
+  if (d->tile_cfg == 0 && rtg_thin_kind(d)) return rtg_thin_kind(d);
   const TileCfg c = pick_tiles(d->tile_m, rtg_ceil_div(d->Mg, d->tile_m), d->Q, d->B, d->groups, d->stride, d->K, d->dil,
                                d->tile_cfg);
   if (c.MT == 0) return d->tile_cfg ? RTG_EINVAL : RTG_ERANGE;
@@ -566,6 +572,10 @@ extern "C" int rtg_conv1d_tile_candidates(const RtgConv1dDesc* d, int* cfgs, int
   if ((d->tile_m != 32 && d->tile_m != 16) || d->Mg < 1 || d->Q < 1 || d->B < 1 || d->groups < 1 || d->stride < 1 ||
       d->K < 1 || d->dil < 1 || max < 1)
     return RTG_EINVAL;
+  if (rtg_thin_kind(d)) {       // served by a bandwidth kernel: nothing to choose (0 = the library's default)
+    cfgs[0] = 0;
+    return 1;
+  }
   ScoredCfg sc[kMaxTileCfgs];
   const int n = score_tiles(d->tile_m, rtg_ceil_div(d->Mg, d->tile_m), d->Q, d->B, d->groups, d->stride, d->K, d->dil, sc);
   // best-guess first (selection sort by score; n <= 14)
@@ -633,6 +643,11 @@ extern "C" int rtg_conv1d(const RtgConv1dDesc* d, const float* x1, const float* 
                                   : (long long)d->B * d->C1 * d->L_in * 4;
   if (x_bytes >= (1ll << 31) || (long long)d->B * d->C2 * d->L_in * 4 >= (1ll << 31)) return RTG_ERANGE;   // 32-bit offsets
   if ((long long)(two_d ? d->B / d->h_n : d->B) * d->out_C * (two_d ? d->h_n : 1) * d->out_L * 4 >= (1ll << 31)) return RTG_ERANGE;
+
+  if (d->tile_cfg == 0) {
+    const int thin = rtg_thin_kind(d);
+    if (thin) return rtg_thin_launch(thin, d, x1, aux, wp, bias, mask, res, out, (hipStream_t)stream);
+  }
 
   ConvArgs a;
   a.x1 = x1; a.x2 = x2; a.aux = (d->pre_mode >= RTG_PRE_MUL_DLRELU) ? aux : nullptr; a.wp = wp; a.bias = bias;
