@@ -1,0 +1,491 @@
+// rtg_conv1d_kernel.h — the implicit-GEMM Conv1d MFMA kernel (see rtg_conv1d.hip for the operator and the mapping).
+// Included by one translation unit per (TM, MT, NT) block shape (rtg_conv1d_t*.hip) so that the instances compile in
+// parallel; rtg_conv1d.hip holds the host side.
+#pragma once
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+
+#include "rtg_common.h"
+
+namespace rtg_cv {
+
+#ifdef RTG_STAMPS
+#define RTG_STAMP(i) do { if (a.dbg) a.dbg[((size_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define RTG_STAMP2(i) do { if (a.dbg && blockIdx.x < 512 && (i) < 128) a.dbg[(4u << 20) + ((size_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * 128 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define RTG_STAMP(i) do {} while (0)
+#define RTG_STAMP2(i) do {} while (0)
+#endif
+
+struct ConvArgs {
+  const float *x1, *x2, *aux, *wp, *bias, *mask, *res;
+  float *out, *out2;
+  int out_split;
+  int B, C1, C2, L_in, groups, Cg, Mg, K, stride, dil, pad, Q, out_C, out_L, shuf_S, shuf_P;
+  int pre_mode;
+  float pre_slope, mask_slope, out_scale;
+  int act;
+  float act_slope;
+  int accumulate;
+  int n_cc, n_mt, WM, WN, PW, PH, ROW, m_blocks;
+  int seg_len, seg_pitch, seg_nb, seg_pw;   // segment packing (seg_len == 0: one clip per block column)
+  // 2-D mode (h_k > 1 or h_n > 1): a "clip" is one (batch item, output row) pair and a "channel" one (channel, kernel
+  // row) pair; the kernel row picks which input row of the [items, C, h_in, L_in] tensor the patch row comes from
+  int two_d, h_in, h_k, h_stride, h_pad, h_n, h_mode;
+  int x_bytes, aux_bytes;
+  // tap-major K order (few input channels per group): the k-steps walk (channel, group of KK taps) instead of
+  // (tap, group of KK channels); `K` then counts groups of CPN k-steps, K_real the taps, tab_off the LDS offset table
+  int tapmajor, K_real, TG, tab_off;
+  // block -> work mapping (XCD-aware, see the kernel): q tiles, total work items, work items per XCD
+  int gx, total, per_xcd;
+#ifdef RTG_STAMPS
+  unsigned long long* dbg;   // diagnostic builds only (tools/dev_build.sh): per-block s_memtime stamps
+#endif
+};
+
+template <int TM>
+struct Mfma;
+template <>
+struct Mfma<32> {
+  using acc_t = f32x16;
+  static constexpr int NREG = 16;
+  static __device__ __forceinline__ acc_t run(float a, float b, acc_t c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ int row(int lane, int r) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+};
+template <>
+struct Mfma<16> {
+  using acc_t = f32x4;
+  static constexpr int NREG = 4;
+  static __device__ __forceinline__ acc_t run(float a, float b, acc_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ int row(int lane, int r) { return (lane >> 4) * 4 + r; }
+};
+
+// Global -> register staging of RPW patch rows of channel chunk `cc` through buffer loads: out-of-range elements
+// (zero padding, channels past Cg, other clips' rows) get an offset beyond num_records, for which the hardware returns
+// 0 without touching memory — no branches, no clamping, all loads of a chunk issue back to back.
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+#define RTG_OOB 0x80000000u
+
+__device__ __forceinline__ float buf_load(rsrc_t r, unsigned off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+}
+
+template <bool AUX, int RPW, int MAXIT>
+__device__ __forceinline__ void stage_rows(const ConvArgs& a, rsrc_t r1, rsrc_t r2, rsrc_t raux,
+                                           float (&st)[RPW][MAXIT], const unsigned (&eb)[MAXIT],
+                                           const unsigned (&epos)[MAXIT], const int (&ehq)[MAXIT],
+                                           const int (&ehr)[MAXIT], int cc, int wave, int g, float slope,
+                                           bool aux_tanh) {
+  if (a.two_d) {
+    // 2-D: virtual channel c = (ci, kh); the patch row of clip (item, row) comes from input row hq +- kh/stride
+    const int cin = a.C1 / a.h_k;
+    const unsigned item_bytes = (unsigned)cin * (unsigned)a.h_in * (unsigned)a.L_in * 4u;
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      const int c = cc * RTG_CK + wave * RPW + i;
+      const int ci = c / a.h_k, kh = c - ci * a.h_k;
+      int khq, khr, sgn;
+      if (a.h_mode == 0) { khq = kh; khr = 0; sgn = 1; }                       // forward: row = ho*s - p + kh
+      else { khq = kh / a.h_stride; khr = kh - khq * a.h_stride; sgn = -1; }   // backward-data: (h + p - kh) / s
+      const unsigned rowoob = (c < a.Cg) ? 0u : RTG_OOB;
+#pragma unroll
+      for (int it = 0; it < MAXIT; ++it) {
+        const int hrow = ehq[it] + sgn * khq;
+        const bool hok = ehr[it] == khr && hrow >= 0 && hrow < a.h_in;
+        const unsigned offs = hok ? (eb[it] * item_bytes + (unsigned)(ci * a.h_in + hrow) * (unsigned)a.L_in * 4u +
+                                     (epos[it] & ~RTG_OOB)) | (epos[it] & RTG_OOB) | rowoob
+                                  : RTG_OOB;
+        float v = buf_load(r1, offs);
+        if (AUX) {
+          const float av = buf_load(raux, offs);
+          v *= aux_tanh ? (1.f - av * av) : (av > 0.f ? 1.f : slope);
+        }
+        st[i][it] = v;
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < RPW; ++i) {
+    const int c = cc * RTG_CK + wave * RPW + i;
+    const int gc = g * a.Cg + c;
+    const bool in1 = gc < a.C1;
+    const rsrc_t r = in1 ? r1 : r2;
+    const unsigned cstride = (unsigned)(in1 ? a.C1 : a.C2) * (unsigned)a.L_in * 4u;   // bytes per clip
+    const unsigned rowoff = (unsigned)(in1 ? gc : gc - a.C1) * (unsigned)a.L_in * 4u;
+    const unsigned rowoob = (c < a.Cg) ? 0u : RTG_OOB;
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+      // valid byte offsets stay below 2^31 (host-checked); the OOB bit is OR-ed in, never added
+      const unsigned offs = (eb[it] * cstride + rowoff + (epos[it] & ~RTG_OOB)) | (epos[it] & RTG_OOB) | rowoob;
+      float v = buf_load(r, offs);
+      if (AUX) {
+        const float av = buf_load(raux, offs);
+        v *= aux_tanh ? (1.f - av * av) : (av > 0.f ? 1.f : slope);
+      }
+      st[i][it] = v;       // the leaky-relu of the plain path is applied when the tile is written to LDS, so that
+                           // nothing here waits for the loads: they stay in flight under the MFMA loop
+    }
+  }
+}
+
+template <int TM, int MT, int NT, int MAXIT>   // MAXIT: 64-float pieces of a patch row each lane stages (>= PW / 64)
+__global__ __launch_bounds__(RTG_THREADS) void conv1d_mfma_kernel(const ConvArgs a) {
+  using M = Mfma<TM>;
+  using acc_t = typename M::acc_t;
+  constexpr int KK = 64 / TM;           // K-values consumed per MFMA
+  constexpr int CPN = RTG_CK / KK;      // MFMA k-steps per (chunk, tap)
+  constexpr int RPW = RTG_CK / 4;       // patch rows staged per wave
+
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  RTG_STAMP(0);
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / a.WN, wn = wave - wm * a.WN;
+  // Work item of this block.  Workgroups are dealt round-robin over the 8 XCDs (block b and b+8 share an XCD and its
+  // L2), so block b takes item (b % 8) * per_xcd + b / 8: each XCD walks a CONTIGUOUS range of items, and the items are
+  // ordered with the row blocks of one input patch next to each other (m block fastest, then group, q tile, clip) —
+  // the m blocks that re-read the same patch run on the same XCD at about the same time and hit its L2 instead of
+  // fetching the patch once per row block from HBM.  (Speed only: any placement computes the same result.)
+  const int item = (int)(blockIdx.x & 7u) * a.per_xcd + (int)(blockIdx.x >> 3);
+  if (item >= a.total) return;
+  int wrk = item;
+  const int mb = wrk % a.m_blocks;
+  wrk /= a.m_blocks;
+  const int g = wrk % a.groups;
+  wrk /= a.groups;
+  const int bx = wrk % a.gx, bz = wrk / a.gx;
+  const int mt0 = (mb * a.WM + wm) * MT;
+  const int BN = a.WN * NT * TM;
+  const bool packed = a.seg_len > 0;
+  const int b0 = packed ? bz * a.seg_nb : bz;   // first clip of this block
+  const int q_blk = packed ? 0 : bx * BN;
+  const int o_start = q_blk * a.stride - a.pad;
+  const int bufsz = RTG_CK * a.ROW;
+
+  // ---- staging geometry (per thread, independent of the channel chunk): LDS offset, clip index and byte position
+  // within the row (with the out-of-bounds bit set for zero padding / other clips)
+  int loff[MAXIT], ehq[MAXIT], ehr[MAXIT];
+  unsigned epos[MAXIT], eb[MAXIT];
+#pragma unroll
+  for (int it = 0; it < MAXIT; ++it) {
+    const int o = lane + 64 * it;
+    loff[it] = o;
+    if (a.stride != 1) loff[it] = (o % a.stride) * a.PH + o / a.stride;   // uniform branch: no division for stride 1
+    int pos, bb;
+    bool ok = o < a.PW;
+    if (packed) {
+      const int seg = o / a.seg_pitch, w = o - seg * a.seg_pitch;
+      bb = b0 + seg;
+      pos = w - a.pad;
+      ok = ok && seg < a.seg_nb && bb < a.B && w < a.seg_pw;
+    } else {
+      bb = b0;
+      pos = o_start + o;
+    }
+    ok = ok && pos >= 0 && pos < a.L_in;
+    epos[it] = ok ? (unsigned)pos * 4u : RTG_OOB;
+    eb[it] = ok ? (unsigned)bb : 0u;
+    ehq[it] = 0;
+    ehr[it] = 0;
+    if (a.two_d) {                       // clip -> (batch item, row); see stage_rows
+      const int item = (int)eb[it] / a.h_n, hh = (int)eb[it] - item * a.h_n;
+      eb[it] = (unsigned)item;
+      if (a.h_mode == 0) {
+        ehq[it] = hh * a.h_stride - a.h_pad;
+      } else {
+        ehq[it] = (hh + a.h_pad) / a.h_stride;
+        ehr[it] = (hh + a.h_pad) - ehq[it] * a.h_stride;
+      }
+    }
+  }
+  float st[RPW][MAXIT];
+  const bool aux_tanh = a.pre_mode == RTG_PRE_MUL_DTANH;
+  const float slope = (a.pre_mode == RTG_PRE_NONE) ? 1.f : a.pre_slope;
+  const float wslope = (a.pre_mode == RTG_PRE_LRELU) ? a.pre_slope : 1.f;   // applied at the LDS write
+  const rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.x1, 0, a.x_bytes, 0x00020000);
+  const rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x2 ? a.x2 : a.x1), 0,
+                                                      a.x2 ? a.B * a.C2 * a.L_in * 4 : 0, 0x00020000);
+  const rsrc_t raux = __builtin_amdgcn_make_buffer_rsrc((void*)(a.aux ? a.aux : a.x1), 0, a.aux_bytes, 0x00020000);
+
+  auto stage = [&](int cc) __attribute__((always_inline)) {
+    if (a.aux) stage_rows<true, RPW, MAXIT>(a, r1, r2, raux, st, eb, epos, ehq, ehr, cc, wave, g, slope, aux_tanh);
+    else stage_rows<false, RPW, MAXIT>(a, r1, r2, raux, st, eb, epos, ehq, ehr, cc, wave, g, slope, aux_tanh);
+  };
+  auto swrite = [&](float* buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      float* rowp = buf + (wave * RPW + i) * a.ROW;
+#pragma unroll
+      for (int it = 0; it < MAXIT; ++it)
+        if (lane + 64 * it < a.PW) {
+          float v = st[i][it];
+          // keep the consumption of the prefetched values BELOW the MFMA loop: without this the compiler hoists the
+          // activation (and with it the s_waitcnt for the loads) above the loop and the prefetch hides nothing
+          asm volatile("" : "+v"(v) : : "memory");
+          rowp[loff[it]] = v > 0.f ? v : v * wslope;
+        }
+    }
+  };
+
+  // ---- accumulators
+  acc_t acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < M::NREG; ++r) acc[i][j][r] = 0.f;
+
+  // ---- operand addressing
+  const int n_lane = lane & (TM - 1), kk = lane / TM;
+  const int bbase = kk * a.ROW + wn * NT * TM + n_lane;
+  const float* wptr[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    int mt = mt0 + i;
+    if (mt > a.n_mt - 1) mt = a.n_mt - 1;   // clamped duplicate tile, discarded in the epilogue
+    wptr[i] = a.wp + ((size_t)(g * a.n_mt + mt) * a.n_cc) * a.K * (RTG_CK * TM) + lane;
+  }
+  const int n_steps = a.n_cc * a.K;
+  // two named A-fragment register sets used alternately (no loop-carried copy: with a copy at the end of the tap the
+  // compiler waits for the JUST-issued prefetch in the middle of the MFMA phase, one exposed L2 latency per tap)
+  float a0[MT][CPN], a1[MT][CPN];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int cp = 0; cp < CPN; ++cp) a0[i][cp] = wptr[i][cp * 64];
+
+  int* tab = reinterpret_cast<int*>(lds + a.tab_off);
+  if (a.tapmajor) {
+    // LDS offset of every (k-step, kk): channel row + (phase-de-interleaved) tap offset; padding entries point at 0
+    for (int e = tid; e < a.K * CPN * KK; e += RTG_THREADS) {
+      const int ks = e / KK, k2 = e - ks * KK;
+      const int c = ks / a.TG, j = (ks - c * a.TG) * KK + k2;
+      int off = 0;
+      if (c < a.Cg && j < a.K_real) {
+        const int td = j * a.dil;
+        off = c * a.ROW + ((a.stride == 1) ? td : (td % a.stride) * a.PH + td / a.stride);
+      }
+      tab[e] = off;
+    }
+  }
+  stage(0);
+  RTG_STAMP(1);
+  swrite(lds);
+  __syncthreads();
+  RTG_STAMP(2);
+
+  int cc = 0, tap = 0;
+  // one (chunk, tap) step: prefetch the next step's A fragments into `nxt`, multiply with `cur`
+  auto do_step = [&](int step, float (&cur)[MT][CPN], float (&nxt)[MT][CPN]) __attribute__((always_inline)) {
+    const float* buf = lds + (cc & 1) * bufsz;
+    if (step + 1 < n_steps) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int cp = 0; cp < CPN; ++cp) nxt[i][cp] = wptr[i][(size_t)(step + 1) * (RTG_CK * TM) + cp * 64];
+    }
+    // the next chunk's patch is requested AFTER the weight prefetch, on the chunk's first tap: vmcnt retires in order,
+    // so the wait for `nxt` one tap later does not include these loads, the wait two taps later finds them landed
+    if (tap == 0 && cc + 1 < a.n_cc) stage(cc + 1);
+    const int td = tap * a.dil;
+    const int tapoff = (a.stride == 1) ? td : (td % a.stride) * a.PH + td / a.stride;
+    const float* bp = buf + bbase + tapoff;
+    // read phase: all B fragments of this (chunk, tap) into distinct registers, THEN the MFMA phase — the compiler
+    // otherwise recycles one register pair and serialises ds_read -> wait -> 2 MFMAs per k-step; with two waves
+    // per SIMD one wave's read phase overlaps the other's MFMA phase
+    float bf[CPN][NT];
+    if (a.tapmajor) {
+      int boff[CPN];
+#pragma unroll
+      for (int cp = 0; cp < CPN; ++cp) boff[cp] = tab[(tap * CPN + cp) * KK + kk];
+      const float* b0p = buf + wn * NT * TM + n_lane;
+#pragma unroll
+      for (int cp = 0; cp < CPN; ++cp)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bf[cp][j] = b0p[boff[cp] + j * TM];
+    } else {
+#pragma unroll
+      for (int cp = 0; cp < CPN; ++cp)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bf[cp][j] = bp[cp * KK * a.ROW + j * TM];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int cp = 0; cp < CPN; ++cp)
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = M::run(cur[i][cp], bf[cp][j], acc[i][j]);
+    __builtin_amdgcn_sched_barrier(0);
+    if (++tap == a.K) {
+      tap = 0;
+      if (cc + 1 < a.n_cc) swrite(lds + ((cc + 1) & 1) * bufsz);
+      __syncthreads();
+      ++cc;
+    }
+  };
+  int step = 0;
+  for (; step + 1 < n_steps; step += 2) {
+    do_step(step, a0, a1);
+    do_step(step + 1, a1, a0);
+  }
+  if (step < n_steps) do_step(step, a0, a1);
+  RTG_STAMP(3);
+
+  // ---- epilogue, fast path (plain store): 32-bit element offsets, every optional operand (bias, mask, residual,
+  // accumulate) read through a buffer descriptor that has ZERO records when the operand is absent (the load then
+  // returns 0 without touching memory), invalid rows / columns stored to an out-of-range offset (dropped by the
+  // hardware): no per-element branches, all loads of a tile in flight together, stores issue back to back
+  if (a.shuf_S == 1 && a.out_split == 0 && !a.two_d) {
+    const int out_bytes = a.B * a.out_C * a.out_L * 4;
+    const rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, out_bytes, 0x00020000);
+    const rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(a.bias ? a.bias : a.out), 0, a.bias ? a.out_C * 4 : 0,
+                                                        0x00020000);
+    const rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc((void*)(a.mask ? a.mask : a.out), 0, a.mask ? out_bytes : 0,
+                                                        0x00020000);
+    const rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)(a.res ? a.res : a.out), 0, a.res ? out_bytes : 0,
+                                                        0x00020000);
+    const rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, a.accumulate ? out_bytes : 0, 0x00020000);
+    const float mslope = a.mask ? a.mask_slope : 1.f;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      if (mt0 + i >= a.n_mt) continue;
+      const int mbase = (mt0 + i) * TM;
+      float bv[M::NREG];
+#pragma unroll
+      for (int r = 0; r < M::NREG; ++r) {
+        const int m = mbase + M::row(lane, r);
+        bv[r] = buf_load(rb, m < a.Mg ? (unsigned)(g * a.Mg + m) * 4u : RTG_OOB);
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        int q = q_blk + (wn * NT + j) * TM + n_lane;
+        int b = b0;
+        bool ok = true;
+        if (packed) {
+          const int seg = q / a.seg_len;
+          q -= seg * a.seg_len;
+          b = b0 + seg;
+          ok = seg < a.seg_nb && b < a.B;
+        }
+        ok = ok && q < a.Q;
+        const unsigned col = ok ? ((unsigned)(b * a.out_C + g * a.Mg + mbase) * (unsigned)a.out_L + (unsigned)q) * 4u
+                                : RTG_OOB;
+        unsigned off[M::NREG];
+        float mv[M::NREG], rv[M::NREG], av[M::NREG];
+#pragma unroll
+        for (int r = 0; r < M::NREG; ++r) {
+          const int row = M::row(lane, r);
+          off[r] = (mbase + row < a.Mg) ? (col + (unsigned)row * (unsigned)a.out_L * 4u) | (col & RTG_OOB) : RTG_OOB;
+          mv[r] = buf_load(rm, off[r]);
+          rv[r] = buf_load(rr, off[r]);
+          av[r] = buf_load(ra, off[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < M::NREG; ++r) {
+          float v = acc[i][j][r] + bv[r];
+          v *= (mv[r] > 0.f ? 1.f : mslope);
+          v = (v + rv[r]) * a.out_scale;
+          if (a.act == RTG_ACT_LRELU) v = rtg_lrelu(v, a.act_slope);
+          else if (a.act == RTG_ACT_TANH) v = tanhf(v);
+          v += av[r];
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ro, off[r], 0, 0);
+        }
+      }
+    }
+    RTG_STAMP(4);
+    return;
+  }
+
+  // ---- epilogue, general path (polyphase shuffle store, concat-split store, 2-D outputs)
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    if (mt0 + i >= a.n_mt) continue;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      int q = q_blk + (wn * NT + j) * TM + n_lane;
+      int b = b0;
+      if (packed) {
+        const int seg = q / a.seg_len;
+        q -= seg * a.seg_len;
+        b = b0 + seg;
+        if (seg >= a.seg_nb || b >= a.B) continue;
+      }
+      if (q >= a.Q) continue;
+      int hh = 0;
+      if (a.two_d) {                     // clip -> (batch item, output row)
+        const int item = b / a.h_n;
+        hh = b - item * a.h_n;
+        b = item;
+      }
+#pragma unroll
+      for (int r = 0; r < M::NREG; ++r) {
+        const int m = (mt0 + i) * TM + M::row(lane, r);
+        if (m >= a.Mg) continue;
+        const int mrow = g * a.Mg + m;
+        int ch = mrow, u = q;
+        if (a.shuf_S > 1) {
+          ch = mrow / a.shuf_S;
+          u = q * a.shuf_S + (mrow - ch * a.shuf_S) - a.shuf_P;
+          if (u < 0 || u >= a.out_L) continue;
+        }
+        float* dst = a.out;
+        size_t idx;
+        if (a.out_split > 0) {
+          if (ch >= a.out_split) {
+            dst = a.out2;
+            idx = ((size_t)b * (a.out_C - a.out_split) + (ch - a.out_split)) * a.out_L + u;
+          } else {
+            idx = ((size_t)b * a.out_split + ch) * a.out_L + u;
+          }
+          if (!dst) continue;
+        } else {
+          idx = (((size_t)b * a.out_C + ch) * a.h_n + hh) * a.out_L + u;   // h_n == 1, hh == 0 in 1-D
+        }
+        float v = acc[i][j][r];
+        if (a.bias) v += a.bias[ch];
+        if (a.mask) v *= (a.mask[idx] > 0.f ? 1.f : a.mask_slope);
+        if (a.res) v += a.res[idx];
+        v *= a.out_scale;
+        if (a.act == RTG_ACT_LRELU) v = rtg_lrelu(v, a.act_slope);
+        else if (a.act == RTG_ACT_TANH) v = tanhf(v);
+        if (a.accumulate) v += dst[idx];
+        dst[idx] = v;
+      }
+    }
+  }
+  RTG_STAMP(4);
+}
+
+template <int TM, int MT, int NT, int MAXIT>
+int launch_it(const ConvArgs& a, dim3 grid, size_t lds_bytes, hipStream_t s) {
+  auto k = conv1d_mfma_kernel<TM, MT, NT, MAXIT>;
+  if (lds_bytes > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return -(1000 + (int)e);
+  }
+  hipLaunchKernelGGL(k, grid, dim3(RTG_THREADS), lds_bytes, s, a);
+  return rtg_launch_status();
+}
+
+template <int TM, int MT, int NT>
+int launch(const ConvArgs& a, dim3 grid, size_t lds_bytes, hipStream_t s) {
+  if (a.PW <= 3 * 64) return launch_it<TM, MT, NT, 3>(a, grid, lds_bytes, s);
+  if (a.PW <= 5 * 64) return launch_it<TM, MT, NT, 5>(a, grid, lds_bytes, s);
+  return launch_it<TM, MT, NT, RTG_PW_MAX / 64>(a, grid, lds_bytes, s);
+}
+
+}  // namespace rtg_cv
+
+#define RTG_CONV_DEFINE(tm, mt, nt)                                                                         \
+  int rtg_conv1d_launch_##tm##_##mt##_##nt(const rtg_cv::ConvArgs& a, dim3 grid, size_t lds_bytes, hipStream_t s) { \
+    return rtg_cv::launch<tm, mt, nt>(a, grid, lds_bytes, s);                                                \
+  }

@@ -1,0 +1,4 @@
+// rtg_conv1d_t3214.hip — conv1d_mfma_kernel instances of block shape TM=32, MT=1, NT=4
+#include "rtg_conv1d_kernel.h"
+
+RTG_CONV_DEFINE(32, 1, 4)

@@ -1,0 +1,4 @@
+// rtg_conv1d_t3222.hip — conv1d_mfma_kernel instances of block shape TM=32, MT=2, NT=2
+#include "rtg_conv1d_kernel.h"
+
+RTG_CONV_DEFINE(32, 2, 2)
