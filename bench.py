@@ -88,6 +88,25 @@ def cpu_baseline(budget_s=12.0):
                       f'at batch 2); oracle/rtg_oracle.py'}
 
 
+def _pmc_for(prefix):
+    """launch-weighted HBM bytes and matrix-pipe busy fraction of the kernels whose name starts with `prefix`, from the
+    newest profiles/*_pmc.json"""
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, 'profiles', '*_pmc.json')))
+    if not files:
+        return None
+    ks = json.load(open(files[-1]))['kernels']
+    n = b = m = 0.0
+    for name, e in ks.items():
+        if name.startswith(prefix):
+            n += e['launches']
+            b += e['launches'] * (e['hbm_read_MB_per_launch'] + e['hbm_write_MB_per_launch']) * 1e6
+            m += e['launches'] * e.get('mfma_busy_frac', 0.0)
+    if n == 0:
+        return None
+    return {'traffic': round(b / n), 'mfma_busy': round(m / n, 3), 'source': 'profiles/' + os.path.basename(files[-1])}
+
+
 def roofline(trainer, batch):
     """Live per-kernel timing of ONE extra step: every conv launch bracketed by HIP events on its launch stream."""
     from rtg import ops
@@ -114,6 +133,21 @@ def roofline(trainer, batch):
            'frac': round(achieved / PEAK_FP32_MATRIX_TFLOPS, 4), 'traffic': None, 'kernel': name,
            'launches_per_step': n, 'avg_launch_us': round(secs / n * 1e6, 2),
            'algorithmic_gflop_per_launch': round(flop / n / 1e9, 4)}
+    # HBM traffic and matrix-pipe occupancy of that kernel from the committed PMC passes (rocprofv3 --pmc cannot run inside
+    # this process): profiles/*_pmc.json, written by tools/pmc_pass.sh + tools/pmc_summary.py from this same command
+    pmc = _pmc_for(f'conv1d_mfma_kernel<{variant // 100}, {variant // 10 % 10}, {variant % 10},' if kernel == 'conv1d'
+                   else f'wgrad_kernel<{variant},')
+    if pmc:
+        out['traffic'] = pmc['traffic']
+        out['traffic_unit'] = 'bytes/launch (HBM read + write, PMC FETCH_SIZE x2 + WRITE_SIZE)'
+        out['mfma_busy_frac_pmc'] = pmc['mfma_busy']
+        out['pmc_source'] = pmc['source']
+    # the UNet-G conv stack alone (north-star target: >= 30 % of the fp32 matrix peak)
+    g_flop = sum(f for k_, v_, f, e0, e1, lb in rec if not lb.split()[1].startswith('discriminators'))
+    g_s = sum(e0.elapsed_time(e1) * 1e-3 for k_, v_, f, e0, e1, lb in rec if not lb.split()[1].startswith('discriminators'))
+    if g_s > 0:
+        out['unet_g_conv_stack'] = {'tflops': round(g_flop / g_s / 1e12, 3), 'frac': round(g_flop / g_s / 1e12 / PEAK_FP32_MATRIX_TFLOPS, 4),
+                                    'ms_per_step': round(g_s * 1e3, 3), 'gflop_per_step': round(g_flop / 1e9, 2)}
     total_flop = sum(a[2] for a in agg.values())
     total_s = sum(a[1] for a in agg.values())
     out['all_conv_kernels'] = {'tflops': round(total_flop / total_s / 1e12, 3), 'ms_per_step': round(total_s * 1e3, 3),
