@@ -241,10 +241,12 @@ int rtg_period_fold_bwd(const float* dout, float* dy, int B, int T, int p, int H
  *   RTG_LOSS_L1         |a - b|                         F.l1_loss                    (loss.py:154)
  *   RTG_LOSS_L1_L1LOG   |a - b| + |log a - log b|       mel + log-mel L1             (loss.py:51-52)
  *   RTG_LOSS_MSE_TARGET (target - a)^2                  LSGAN terms, equal-length rows (loss.py:121-122,142)
+ *   RTG_LOSS_MSE_REL    (target - (a - b))^2            relative LSGAN terms, b detached: no gradient to b
+ *                                                        (loss.py:116,136: hparam.relative_gan_loss)
  * Partials are summed in fixed order (ws needs 64 * n_jobs floats).  The backward writes (not accumulates)
  * d loss / d a into da and / or d loss / d b into db, scaled by w_j / n_j and by the device scalar *gscale (NULL = 1). */
 #define RTG_MAX_LOSS_JOBS 48
-enum { RTG_LOSS_L1 = 0, RTG_LOSS_L1_L1LOG = 1, RTG_LOSS_MSE_TARGET = 2 };
+enum { RTG_LOSS_L1 = 0, RTG_LOSS_L1_L1LOG = 1, RTG_LOSS_MSE_TARGET = 2, RTG_LOSS_MSE_REL = 3 };
 typedef struct RtgLossJob {
   const float* a; const float* b; float* da; float* db;
   long long n; float w; float target;
@@ -257,6 +259,19 @@ int rtg_dyn_loss_fwd(const float* y, const float* g, int rows, int L, int k, flo
                      void* stream);
 int rtg_dyn_loss_bwd(const float* y, const float* g, int rows, int L, int k, float w, const float* gscale, float* dg,
                      void* stream);
+/* envelope_loss (loss.py:66-72): mean |max_k(y) - max_k(g)| + mean |max_k(-y) - max_k(-g)|, same windows and tie rule as
+ * rtg_dyn_loss_*.  ws: 256 floats.  Backward w.r.t. g. */
+int rtg_env_loss_fwd(const float* y, const float* g, int rows, int L, int k, float w, float* ws, float* loss_out,
+                     void* stream);
+int rtg_env_loss_bwd(const float* y, const float* g, int rows, int L, int k, float w, const float* gscale, float* dg,
+                     void* stream);
+/* strip_mirror_loss (loss.py:86-98) of y [rows, L] (an odd L drops the last sample): with u_i = y[2i] - y[2i+1] and
+ * d_i = u_i - mean(u) (= the difference of the separately de-meaned even and odd strips, means taken over ALL rows),
+ * loss = w * mean_i( -log(min(|d_i| + 1e-9, 1)) ).  stats: 4 device floats kept for the backward (sum u, sum f'(d), ...);
+ * ws: 256 floats.  Backward w.r.t. y (writes every element of dy, the dropped tail sample gets 0). */
+int rtg_strip_mirror_fwd(const float* y, int rows, int L, float w, float* ws, float* stats, float* loss_out, void* stream);
+int rtg_strip_mirror_bwd(const float* y, int rows, int L, float w, const float* stats, const float* gscale, float* dy,
+                         void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * rtg_adamw — torch.optim.AdamW step (train.py:80-81,160,193) over a flat fp32 parameter buffer:

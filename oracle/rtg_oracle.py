@@ -4,6 +4,7 @@ A from-scratch restatement, in stock PyTorch fp32 CPU ops, of what the reference
 (all citations are relative to /root/reference):
 
   * UNet-G  `Generator_RefineGAN_small`      retunegan/models/generator.py:670-796
+  * `Generator_RefineGAN` / `ResBlock`       retunegan/models/generator.py:560-667, 109-131
   * `ResidualStack` / `ResBlock3` / noise    retunegan/models/generator.py:33-77, 133-155, 19-30
   * MSD / MPD / MTD                          retunegan/models/discrminator.py:17-129, 132-244, 247-330
   * `get_stft_torch`                         retunegan/audio.py:150-170
@@ -157,6 +158,58 @@ class Generator(nn.Module):
             y = self.resblock[i](self.downs[i](y))
         y = F.leaky_relu(y, LRELU_SLOPE)
         z = self.conv_fuse(torch.cat([x, y], dim=1))
+        for i in range(3):
+            z = self.ups[i](F.leaky_relu(z, LRELU_SLOPE))
+            z = self.merge[i](torch.cat([z, skips[2 - i]], dim=1))
+            z = self.noise(z, None if noise_list is None else noise_list[2 * i])
+            z = sum(self.resblocks[3 * i + j](z) for j in range(3)) / 3
+            z = self.noise(z, None if noise_list is None else noise_list[2 * i + 1])
+        return torch.tanh(self.conv_post(F.leaky_relu(z, LRELU_SLOPE)))
+
+
+class ResBlock(nn.Module):
+    """generator.py:109-131: x = conv_d(lrelu(x)) + x for the two dilations."""
+
+    def __init__(self, ch, k, dils=(1, 3)):
+        super().__init__()
+        self.convs = nn.ModuleList([WNConv('conv1d', ch, ch, k, padding=(k * d - d) // 2, dilation=d) for d in dils])
+        for c in self.convs:
+            c.burn_init_rng()                                      # generator.py:119
+
+    def forward(self, x):
+        for c in self.convs:
+            x = c(F.leaky_relu(x, LRELU_SLOPE)) + x
+        return x
+
+
+class GeneratorFull(nn.Module):
+    """generator.py:560-667 (`Generator_RefineGAN`, the full-size model)."""
+
+    def __init__(self):
+        super().__init__()
+        rates, ks = [8, 8, 4], [15, 15, 7]                         # hparam.py:61-62
+        rk, rd = [3, 5, 7], [[1, 2], [2, 6], [3, 12]]              # hparam.py:64-65
+        self.conv_pre_y = WNConv('conv1d', 1, 32, 7, padding=3)
+        self.downs = nn.ModuleList([WNConv('conv1d', 32 * 2 ** i, 64 * 2 ** i, k, u, padding=k // 2)
+                                    for i, (u, k) in enumerate(zip(rates[::-1], ks[::-1]))])
+        self.resblock = nn.ModuleList([ResBlock(64 * 2 ** i, 5, (1, 3)) for i in range(3)])
+        self.conv_pre = WNConv('conv1d', N_MEL, 256, 7, padding=3)
+        self.ups = nn.ModuleList([WNConv('convT1d', 512 // 2 ** i, 256 // 2 ** i, k, u, padding=k // 2,
+                                         output_padding=u - 1) for i, (u, k) in enumerate(zip(rates, ks))])
+        self.resblocks = nn.ModuleList([ResBlock(256 // 2 ** i, k, d) for i in range(3) for k, d in zip(rk, rd)])
+        self.merge = nn.ModuleList([WNConv('conv1d', 384, 256, 7, padding=3), WNConv('conv1d', 192, 128, 7, padding=3),
+                                    WNConv('conv1d', 96, 64, 7, padding=3)])
+        self.conv_post = WNConv('conv1d', 64, 1, 7, padding=3)
+        self.noise = _Noise()
+
+    def forward(self, x, y, noise_list=None):
+        skips = []
+        y = self.conv_pre_y(y)
+        for i in range(3):
+            y = F.leaky_relu(y, LRELU_SLOPE)
+            skips.append(y)
+            y = self.resblock[i](self.downs[i](y))
+        z = torch.cat([self.conv_pre(x), y], dim=1)
         for i in range(3):
             z = self.ups[i](F.leaky_relu(z, LRELU_SLOPE))
             z = self.merge[i](torch.cat([z, skips[2 - i]], dim=1))
@@ -383,12 +436,17 @@ def strip_mirror_loss(y):           # loss.py:86-98
     return torch.mean(-torch.log(torch.clamp_max(torch.abs(even - odd) + 1e-9, max=1.0)))
 
 
-def discriminator_loss(disc_r, disc_g):   # loss.py:102-125, non-relative branch
+def discriminator_loss(disc_r, disc_g, relative=False):   # loss.py:102-125 (relative: hparam.relative_gan_loss, :116)
+    if relative:
+        return sum(torch.mean(torch.mean((1 - (dr - dg.detach())) ** 2, dim=-1)) + torch.mean(torch.mean(dg ** 2, dim=-1))
+                   for dr, dg in zip(disc_r, disc_g))
     return sum(torch.mean(torch.mean((1 - dr) ** 2, dim=-1)) + torch.mean(torch.mean(dg ** 2, dim=-1))
                for dr, dg in zip(disc_r, disc_g))
 
 
-def generator_loss(disc_g, disc_r=None):  # loss.py:129-145, non-relative branch
+def generator_loss(disc_g, disc_r=None, relative=False):  # loss.py:129-145 (relative branch :136)
+    if relative:
+        return sum(torch.mean(torch.mean((dg - dr.detach()) ** 2, dim=-1)) for dg, dr in zip(disc_g, disc_r))
     return sum(torch.mean(torch.mean((1 - dg) ** 2, dim=-1)) for dg in disc_g)
 
 

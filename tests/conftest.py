@@ -21,6 +21,12 @@ def gold():
 
 
 @pytest.fixture(scope='session')
+def gold4():
+    """fixtures of the SURVEY.md 8 f3/f4 rows (oracle/gen_golden_f4.py)"""
+    return dict(np.load(os.path.join(REPO, 'tests', 'golden', 'retunegan_f4_b2_t8192.npz'), allow_pickle=False))
+
+
+@pytest.fixture(scope='session')
 def oracle():
     """The CPU oracle (test infrastructure; see oracle/rtg_oracle.py header)."""
     import importlib.util

@@ -340,10 +340,9 @@ __global__ __launch_bounds__(RTG_THREADS) void conv1d_mfma_kernel(const ConvArgs
   if (step < n_steps) do_step(step, a0, a1);
   RTG_STAMP(3);
 
-  // ---- epilogue, fast path (plain store): 32-bit element offsets, every optional operand (bias, mask, residual,
-  // accumulate) read through a buffer descriptor that has ZERO records when the operand is absent (the load then
-  // returns 0 without touching memory), invalid rows / columns stored to an out-of-range offset (dropped by the
-  // hardware): no per-element branches, all loads of a tile in flight together, stores issue back to back
+  // ---- epilogue, fast path (plain store): 32-bit element offsets through buffer descriptors, invalid rows / columns
+  // loaded from / stored to an out-of-range offset (returned as 0 / dropped by the hardware): no per-element branches,
+  // all loads of a tile in flight together, stores issue back to back
   if (a.shuf_S == 1 && a.out_split == 0 && !a.two_d) {
     const int out_bytes = a.B * a.out_C * a.out_L * 4;
     const rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, out_bytes, 0x00020000);
@@ -385,9 +384,29 @@ __global__ __launch_bounds__(RTG_THREADS) void conv1d_mfma_kernel(const ConvArgs
         for (int r = 0; r < M::NREG; ++r) {
           const int row = M::row(lane, r);
           off[r] = (mbase + row < a.Mg) ? (col + (unsigned)row * (unsigned)a.out_L * 4u) | (col & RTG_OOB) : RTG_OOB;
-          mv[r] = buf_load(rm, off[r]);
-          rv[r] = buf_load(rr, off[r]);
-          av[r] = buf_load(ra, off[r]);
+        }
+        // optional operands: uniform branches per tile (an absent operand costs no load instructions at all; a load
+        // through a zero-record descriptor would still occupy the address unit for a full wave)
+        if (a.mask) {
+#pragma unroll
+          for (int r = 0; r < M::NREG; ++r) mv[r] = buf_load(rm, off[r]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < M::NREG; ++r) mv[r] = 1.f;
+        }
+        if (a.res) {
+#pragma unroll
+          for (int r = 0; r < M::NREG; ++r) rv[r] = buf_load(rr, off[r]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < M::NREG; ++r) rv[r] = 0.f;
+        }
+        if (a.accumulate) {
+#pragma unroll
+          for (int r = 0; r < M::NREG; ++r) av[r] = buf_load(ra, off[r]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < M::NREG; ++r) av[r] = 0.f;
         }
 #pragma unroll
         for (int r = 0; r < M::NREG; ++r) {

@@ -161,7 +161,7 @@ constexpr int LOSS_GX = 64;      // partial sums per job
 __device__ __forceinline__ float loss_term(int kind, float a, float b, float target) {
   if (kind == RTG_LOSS_L1) return fabsf(a - b);
   if (kind == RTG_LOSS_L1_L1LOG) return fabsf(a - b) + fabsf(logf(a) - logf(b));
-  const float e = target - a;      // RTG_LOSS_MSE_TARGET
+  const float e = target - (kind == RTG_LOSS_MSE_REL ? a - b : a);      // RTG_LOSS_MSE_TARGET / _REL
   return e * e;
 }
 
@@ -198,6 +198,8 @@ __global__ __launch_bounds__(RTG_THREADS) void loss_bwd_kernel(int kind, const L
       const float la = logf(a), lb = logf(b);
       const float sl = (la > lb) ? 1.f : ((la < lb) ? -1.f : 0.f);
       ga = s + sl / a; gb = -s - sl / b;
+    } else if (kind == RTG_LOSS_MSE_REL) {
+      ga = -2.f * (j.target - (a - b)); gb = 0.f;      // b is detached in the reference (loss.py:116,136)
     } else {
       ga = -2.f * (j.target - a); gb = 0.f;
     }
@@ -216,7 +218,7 @@ __device__ __forceinline__ void wave_argmax(float& v, int& idx) {
   }
 }
 
-template <bool BWD>
+template <bool BWD, bool ENV>      // ENV: envelope_loss (two separate |max - max| terms) instead of dynamic_loss
 __global__ __launch_bounds__(RTG_THREADS) void dyn_kernel(const float* __restrict__ y, const float* __restrict__ g,
                                                           int rows, int L, int k, float scale,
                                                           const float* __restrict__ gscale, float* __restrict__ ws,
@@ -242,6 +244,24 @@ __global__ __launch_bounds__(RTG_THREADS) void dyn_kernel(const float* __restric
     wave_argmax(ymn, d1);
     wave_argmax(gmx, gimx);
     wave_argmax(gmn, gimn);
+    if (ENV) {
+      if (!BWD) {
+        if (lane == 0) total += fabsf(ymx - gmx) + fabsf(ymn - gmn);
+      } else {
+        // d/dg |ymx - max(g)| = -sign(ymx - gmx) at argmax(g);  d/dg |ymn - max(-g)| = +sign(ymn - gmn) at argmax(-g)
+        const float k0 = scale * (gscale ? *gscale : 1.f);
+        const float c1 = -((ymx > gmx) ? 1.f : ((ymx < gmx) ? -1.f : 0.f)) * k0;
+        const float c2 = ((ymn > gmn) ? 1.f : ((ymn < gmn) ? -1.f : 0.f)) * k0;
+        float* dr = dg + (size_t)r * L + w0;
+        for (int i = lane; i < k; i += 64) {
+          float v = 0.f;
+          if (i == gimx) v += c1;
+          if (i == gimn) v += c2;
+          dr[i] = v;
+        }
+      }
+      continue;
+    }
     const float dy_ = fabsf(ymx + ymn), sg = gmx + gmn, dgv = fabsf(sg);
     if (!BWD) {
       if (lane == 0) total += fabsf(dy_ - dgv);
@@ -370,7 +390,8 @@ extern "C" int rtg_period_fold_bwd(const float* dout, float* dy, int B, int T, i
 static int fill_jobs(LossJobs* lj, int kind, const RtgLossJob* jobs, int n_jobs, bool bwd) {
   if (!jobs) return RTG_ENULL;
   if (n_jobs < 1 || n_jobs > RTG_MAX_LOSS_JOBS) return RTG_EINVAL;
-  if (kind != RTG_LOSS_L1 && kind != RTG_LOSS_L1_L1LOG && kind != RTG_LOSS_MSE_TARGET) return RTG_EINVAL;
+  if (kind != RTG_LOSS_L1 && kind != RTG_LOSS_L1_L1LOG && kind != RTG_LOSS_MSE_TARGET && kind != RTG_LOSS_MSE_REL)
+    return RTG_EINVAL;
   lj->n_jobs = n_jobs;
   for (int i = 0; i < n_jobs; ++i) {
     if (!jobs[i].a || jobs[i].n < 1) return RTG_EINVAL;
@@ -403,29 +424,140 @@ extern "C" int rtg_loss_bwd(int kind, const RtgLossJob* jobs, int n_jobs, const 
   RTG_LAUNCH(loss_bwd_kernel, dim3(gx, n_jobs), RTG_THREADS, 0, stream, kind, lj, gscale);
 }
 
-extern "C" int rtg_dyn_loss_fwd(const float* y, const float* g, int rows, int L, int k, float w, float* ws,
-                                float* loss_out, void* stream) {
+template <bool ENV>
+static int dyn_fwd_impl(const float* y, const float* g, int rows, int L, int k, float w, float* ws, float* loss_out,
+                        void* stream) {
   RTG_REQ(y && g && ws && loss_out);
   if (rows < 1 || k < 1 || L < k) return RTG_EINVAL;
   const int nwin = rows * (L / k);
   int gx = (nwin + 3) / 4;
   if (gx > 256) gx = 256;
-  hipLaunchKernelGGL(dyn_kernel<false>, dim3(gx), dim3(RTG_THREADS), 0, (hipStream_t)stream, y, g, rows, L, k,
+  hipLaunchKernelGGL((dyn_kernel<false, ENV>), dim3(gx), dim3(RTG_THREADS), 0, (hipStream_t)stream, y, g, rows, L, k,
                      w / (float)nwin, (const float*)nullptr, ws, (float*)nullptr);
   int st = rtg_launch_status();
   if (st) return st;
   RTG_LAUNCH(loss_finish_kernel, 1, 64, 0, stream, gx, ws, loss_out);
 }
 
-extern "C" int rtg_dyn_loss_bwd(const float* y, const float* g, int rows, int L, int k, float w, const float* gscale,
-                                float* dg, void* stream) {
+template <bool ENV>
+static int dyn_bwd_impl(const float* y, const float* g, int rows, int L, int k, float w, const float* gscale, float* dg,
+                        void* stream) {
   RTG_REQ(y && g && dg);
   if (rows < 1 || k < 1 || L < k) return RTG_EINVAL;
   const int nwin = rows * (L / k);
   int gx = (nwin + 3) / 4;
   if (gx > 256) gx = 256;
-  RTG_LAUNCH(dyn_kernel<true>, gx, RTG_THREADS, 0, stream, y, g, rows, L, k, w / (float)nwin, gscale, (float*)nullptr,
-             dg);
+  RTG_LAUNCH((dyn_kernel<true, ENV>), gx, RTG_THREADS, 0, stream, y, g, rows, L, k, w / (float)nwin, gscale,
+             (float*)nullptr, dg);
+}
+
+extern "C" int rtg_dyn_loss_fwd(const float* y, const float* g, int rows, int L, int k, float w, float* ws,
+                                float* loss_out, void* stream) {
+  return dyn_fwd_impl<false>(y, g, rows, L, k, w, ws, loss_out, stream);
+}
+extern "C" int rtg_dyn_loss_bwd(const float* y, const float* g, int rows, int L, int k, float w, const float* gscale,
+                                float* dg, void* stream) {
+  return dyn_bwd_impl<false>(y, g, rows, L, k, w, gscale, dg, stream);
+}
+extern "C" int rtg_env_loss_fwd(const float* y, const float* g, int rows, int L, int k, float w, float* ws,
+                                float* loss_out, void* stream) {
+  return dyn_fwd_impl<true>(y, g, rows, L, k, w, ws, loss_out, stream);
+}
+extern "C" int rtg_env_loss_bwd(const float* y, const float* g, int rows, int L, int k, float w, const float* gscale,
+                                float* dg, void* stream) {
+  return dyn_bwd_impl<true>(y, g, rows, L, k, w, gscale, dg, stream);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// strip_mirror_loss (loss.py:86-98): u_i = y[2i] - y[2i+1], d_i = u_i - mean(u), f(d) = -log(min(|d| + 1e-9, 1))
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int SM_GX = 128;
+__device__ __forceinline__ float sm_u(const float* __restrict__ y, int L, int half, long long i) {
+  const long long r = i / half, c = i - r * half;
+  const float* p = y + r * L + 2 * c;
+  return p[0] - p[1];
+}
+// PASS 0: partial sums of u.  PASS 1: partial sums of f(d) and f'(d), with mean(u) = stats[0] / n
+template <int PASS>
+__global__ __launch_bounds__(RTG_THREADS) void sm_reduce_kernel(const float* __restrict__ y, int L, int half,
+                                                                long long n, const float* __restrict__ stats,
+                                                                float* __restrict__ ws) {
+  __shared__ float red[4];
+  const float mu = PASS ? stats[0] / (float)n : 0.f;
+  float s0 = 0.f, s1 = 0.f;
+  for (long long i = (long long)blockIdx.x * RTG_THREADS + threadIdx.x; i < n; i += (long long)SM_GX * RTG_THREADS) {
+    const float u = sm_u(y, L, half, i);
+    if (PASS == 0) {
+      s0 += u;
+    } else {
+      const float d = u - mu, m = fabsf(d) + 1e-9f;
+      if (m <= 1.f) {                       // clamp_max passes the gradient up to and including the bound
+        s0 += -logf(m);
+        s1 += -((d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f)) / m;
+      }
+    }
+  }
+  s0 = rtg_block_sum(s0, red);
+  s1 = rtg_block_sum(s1, red);
+  if (threadIdx.x == 0) {
+    ws[blockIdx.x] = s0;
+    ws[SM_GX + blockIdx.x] = s1;
+  }
+}
+// sums the partials in fixed order: PASS 0 -> stats[0] = sum u; PASS 1 -> stats[1] = sum f', *loss_out += w * sum f / n
+__global__ __launch_bounds__(64) void sm_finish_kernel(int pass, const float* __restrict__ ws, float* __restrict__ stats,
+                                                       float* __restrict__ loss_out, float w_over_n) {
+  float a = 0.f, b = 0.f;
+  for (int i = threadIdx.x; i < SM_GX; i += 64) { a += ws[i]; b += ws[SM_GX + i]; }
+  a = rtg_wave_sum(a);
+  b = rtg_wave_sum(b);
+  if (threadIdx.x == 0) {
+    if (pass == 0) {
+      stats[0] = a;
+    } else {
+      stats[1] = b;
+      *loss_out += a * w_over_n;
+    }
+  }
+}
+__global__ __launch_bounds__(RTG_THREADS) void sm_bwd_kernel(const float* __restrict__ y, int rows, int L, int half,
+                                                             long long n, const float* __restrict__ stats, float k,
+                                                             const float* __restrict__ gscale, float* __restrict__ dy) {
+  const float mu = stats[0] / (float)n, mfp = stats[1] / (float)n, kk = k * (gscale ? *gscale : 1.f);
+  for (long long i = (long long)blockIdx.x * RTG_THREADS + threadIdx.x; i < n; i += (long long)gridDim.x * RTG_THREADS) {
+    const long long r = i / half, c = i - r * half;
+    const float* p = y + r * L + 2 * c;
+    const float d = (p[0] - p[1]) - mu, m = fabsf(d) + 1e-9f;
+    const float fp = (m <= 1.f) ? -((d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f)) / m : 0.f;
+    const float gu = kk * (fp - mfp);       // d loss / d u_i: the mean(u) term couples every element
+    float* q = dy + r * L + 2 * c;
+    q[0] = gu;
+    q[1] = -gu;
+  }
+  if ((L & 1) && blockIdx.x == 0)
+    for (int r = threadIdx.x; r < rows; r += RTG_THREADS) dy[(size_t)r * L + L - 1] = 0.f;
+}
+
+extern "C" int rtg_strip_mirror_fwd(const float* y, int rows, int L, float w, float* ws, float* stats, float* loss_out,
+                                    void* stream) {
+  RTG_REQ(y && ws && stats && loss_out);
+  if (rows < 1 || L < 2) return RTG_EINVAL;
+  const int half = L / 2;
+  const long long n = (long long)rows * half;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(sm_reduce_kernel<0>, dim3(SM_GX), dim3(RTG_THREADS), 0, s, y, L, half, n, (const float*)stats, ws);
+  hipLaunchKernelGGL(sm_finish_kernel, dim3(1), dim3(64), 0, s, 0, (const float*)ws, stats, loss_out, 0.f);
+  hipLaunchKernelGGL(sm_reduce_kernel<1>, dim3(SM_GX), dim3(RTG_THREADS), 0, s, y, L, half, n, (const float*)stats, ws);
+  RTG_LAUNCH(sm_finish_kernel, 1, 64, 0, stream, 1, (const float*)ws, stats, loss_out, w / (float)n);
+}
+
+extern "C" int rtg_strip_mirror_bwd(const float* y, int rows, int L, float w, const float* stats, const float* gscale,
+                                    float* dy, void* stream) {
+  RTG_REQ(y && stats && dy);
+  if (rows < 1 || L < 2) return RTG_EINVAL;
+  const int half = L / 2;
+  const long long n = (long long)rows * half;
+  RTG_LAUNCH(sm_bwd_kernel, grid_for(n), RTG_THREADS, 0, stream, y, rows, L, half, n, stats, w / (float)n, gscale, dy);
 }
 
 extern "C" int rtg_adamw(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n,

@@ -78,6 +78,26 @@ class ResBlock3(nn.Module):
         return x
 
 
+class ResBlock(nn.Module):
+    """generator.py:109-131 (HiFiGAN block of the full-size RefineGAN): twice x <- conv_d(lrelu_.15(x)) + x."""
+
+    def __init__(self, channels, kernel_size=3, dilation=(1, 3)):
+        super().__init__()
+        self.convs = nn.ModuleList([WNConv('conv', channels, channels, kernel_size, dil=d,
+                                           pad=get_padding(kernel_size, d)) for d in dilation])
+        for c in self.convs:
+            c.burn_init_rng()       # self.convs.apply(init_weights), generator.py:119
+
+    def run(self, tok, x, final_act_slope=None):
+        n = len(self.convs)
+        for i, c in enumerate(self.convs):
+            if i == n - 1 and final_act_slope is not None:
+                x = conv(tok, c, x, res=x, pre_slope=LRELU_SLOPE, act=ACT_LRELU, act_slope=final_act_slope)
+            else:
+                x = conv(tok, c, x, res=x, pre_slope=LRELU_SLOPE)
+        return x
+
+
 class _Mean3(torch.autograd.Function):
     """(a + b + c) / 3 — the average of the three ResBlock3 branches (generator.py:776-778)."""
 
@@ -161,4 +181,64 @@ class Generator_RefineGAN_small(BankedModel):
     def remove_weight_norm(self):
         """generator.py:790-796 (inference, retunegan/server.py:81).  The kernels always consume g*v/||v||, so the
         result of the forward is unchanged; kept for API compatibility."""
+        self._wn_removed = True
+
+
+class Generator_RefineGAN(BankedModel):
+    """The full-size RefineGAN (retunegan/models/generator.py:560-667; `hparam.generator_ver = 'RefineGAN'`): same UNet
+    at twice the channels with 2-conv ResBlocks, the mel entering through its own conv_pre and the encoder output
+    concatenated to it before the first upsampling.  Same constructor / forward signature and state-dict keys."""
+
+    def __init__(self):
+        super().__init__()
+        self.num_kernels = len(hp.resblock_kernel_sizes)
+        self.num_upsamples = len(hp.upsample_rates)
+        self.n_layer = self.num_upsamples
+        ch = 32
+        uic = hp.upsample_initial_channel
+        self.conv_pre_y = WNConv('conv', 1, ch, 7, pad=3)
+        self.downs = nn.ModuleList([
+            WNConv('conv', ch * 2 ** i, ch * 2 ** (i + 1), k, stride=u, pad=k // 2)
+            for i, (u, k) in enumerate(zip(hp.upsample_rates[::-1], hp.upsample_kernel_sizes[::-1]))])
+        self.resblock = nn.ModuleList([ResBlock(ch * 2 ** (i + 1), 5, [1, 3]) for i in range(len(self.downs))])
+        self.conv_pre = WNConv('conv', hp.n_mel, uic, 7, pad=3)
+        self.ups = nn.ModuleList([
+            WNConv('convT', uic // (2 ** i) * 2, uic // (2 ** (i + 1)) * 2, k, stride=u, pad=k // 2, out_pad=u - 1)
+            for i, (u, k) in enumerate(zip(hp.upsample_rates, hp.upsample_kernel_sizes))])
+        self.resblocks = nn.ModuleList([ResBlock(uic // (2 ** i), k, d) for i in range(len(self.ups))
+                                        for k, d in zip(hp.resblock_kernel_sizes, hp.resblock_dilation_sizes)])
+        self.merge = nn.ModuleList([WNConv('conv', 256 + 128, 256, 7, pad=3), WNConv('conv', 128 + 64, 128, 7, pad=3),
+                                    WNConv('conv', 64 + 32, 64, 7, pad=3)])
+        self.conv_post = WNConv('conv', ch * 2, 1, 7, pad=3)
+        self.noise = GaussianNoise()
+        self._wn_removed = False
+
+    def _extra_bank_params(self):
+        return [('noise.w', self.noise.w)]
+
+    def forward(self, x, y, noise_list=None):
+        tok = self.token()
+        nz = (lambda i: None) if noise_list is None else (lambda i: noise_list[i])
+        o = []
+        # every skip is lrelu(.) of the previous stage: fused as that stage's output activation (generator.py:619-626)
+        y = conv(tok, self.conv_pre_y, y, act=ACT_LRELU, act_slope=LRELU_SLOPE)
+        for i in range(self.n_layer):
+            o.append(y)
+            y = conv(tok, self.downs[i], y)
+            # the last encoder output meets the mel before the decoder's first lrelu (generator.py:633-638)
+            y = self.resblock[i].run(tok, y, final_act_slope=LRELU_SLOPE)
+        x = conv(tok, self.conv_pre, x, act=ACT_LRELU, act_slope=LRELU_SLOPE)
+        z = torch.cat([x, y], dim=1)                   # lrelu(cat) == cat(lrelu, lrelu)
+        for i in range(self.n_layer):
+            z = conv(tok, self.ups[i], z, pre_slope=LRELU_SLOPE if i > 0 else 1.0)
+            z = conv(tok, self.merge[i], z, o[self.n_layer - i - 1])
+            z = self.noise(z, nz(2 * i))
+            nk = self.num_kernels
+            z = _Mean3.apply(*fork_join([(lambda blk=self.resblocks[i * nk + j], zz=z: blk.run(tok, zz))
+                                         for j in range(nk)]))
+            z = self.noise(z, nz(2 * i + 1))
+        return conv(tok, self.conv_post, z, pre_slope=LRELU_SLOPE, act=ACT_TANH)
+
+    def remove_weight_norm(self):
+        """generator.py:661-667; see Generator_RefineGAN_small.remove_weight_norm."""
         self._wn_removed = True

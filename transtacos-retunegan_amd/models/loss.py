@@ -10,7 +10,7 @@ import hparam as hp
 from audio import get_stft_torch, stft_mel_spec  # noqa: F401
 from utils import PI  # noqa: F401
 from rtg import ops
-from rtg.lib import LOSS_L1, LOSS_L1_L1LOG, LOSS_MSE_TARGET, RtgError
+from rtg.lib import LOSS_L1, LOSS_L1_L1LOG, LOSS_MSE_TARGET, LOSS_MSE_REL, RtgError  # noqa: F401
 
 _real_cache = {}
 
@@ -72,8 +72,8 @@ def multi_stft_loss(y, y_g, ret_loss=False, ret_specs=False):
 
 
 def envelope_loss(y, y_g):
-    """loss.py:66-72 — switched off by hparam.py:88; not on the default hot path."""
-    raise RtgError('envelope_loss is disabled in hparam.py:88 and has no kernel yet (SURVEY.md §8 f4)')
+    """loss.py:66-72: mean |max160(y) - max160(y_g)| + mean |max160(-y) - max160(-y_g)| (off by default, hparam.py:88)."""
+    return ops.DynLossFn.apply(y, y_g, hp.envelope_pool_k, True)
 
 
 def dynamic_loss(y, y_g):
@@ -82,8 +82,8 @@ def dynamic_loss(y, y_g):
 
 
 def strip_mirror_loss(y):
-    """loss.py:86-98 — switched off by hparam.py:87; not on the default hot path."""
-    raise RtgError('strip_mirror_loss is disabled in hparam.py:87 and has no kernel yet (SURVEY.md §8 f4)')
+    """loss.py:86-98 (off by default, hparam.py:87)."""
+    return ops.StripMirrorFn.apply(y)
 
 
 def _base(t):
@@ -91,18 +91,23 @@ def _base(t):
 
 
 def discriminator_loss(disc_r, disc_g):
-    """loss.py:102-125 (non-relative branch): sum_k mean((1 - dr_k)^2) + mean(dg_k^2)."""
+    """loss.py:102-125: sum_k mean((1 - dr_k)^2) + mean(dg_k^2); with hparam.relative_gan_loss the real term is
+    mean((1 - (dr_k - dg_k.detach()))^2) (loss.py:116)."""
+    rs, gs = [_base(d) for d in disc_r], [_base(d) for d in disc_g]
     if hp.relative_gan_loss:
-        raise RtgError('relative_gan_loss (hparam.py:86) is off on the path and has no kernel yet')
-    return (ops.multi_loss(LOSS_MSE_TARGET, [_base(d) for d in disc_r], target=1.0) +
-            ops.multi_loss(LOSS_MSE_TARGET, [_base(d) for d in disc_g], target=0.0))
+        real = ops.multi_loss(LOSS_MSE_REL, rs, [g.detach() for g in gs], target=1.0)
+    else:
+        real = ops.multi_loss(LOSS_MSE_TARGET, rs, target=1.0)
+    return real + ops.multi_loss(LOSS_MSE_TARGET, gs, target=0.0)
 
 
 def generator_loss(disc_g, disc_r):
-    """loss.py:129-145 (non-relative branch): sum_k mean((1 - dg_k)^2)."""
+    """loss.py:129-145: sum_k mean((1 - dg_k)^2); with hparam.relative_gan_loss mean((dg_k - dr_k.detach())^2)
+    (loss.py:136)."""
+    gs = [_base(d) for d in disc_g]
     if hp.relative_gan_loss:
-        raise RtgError('relative_gan_loss (hparam.py:86) is off on the path and has no kernel yet')
-    return ops.multi_loss(LOSS_MSE_TARGET, [_base(d) for d in disc_g], target=1.0)
+        return ops.multi_loss(LOSS_MSE_REL, gs, [_base(d).detach() for d in disc_r], target=0.0)
+    return ops.multi_loss(LOSS_MSE_TARGET, gs, target=1.0)
 
 
 def feature_loss(fmap_r, fmap_g):

@@ -56,7 +56,7 @@ PRE_NONE, PRE_LRELU, PRE_MUL_DLRELU, PRE_MUL_DTANH = 0, 1, 2, 3
 ACT_NONE, ACT_LRELU, ACT_TANH = 0, 1, 2
 PACK_FWD, PACK_DGRAD_S1, PACK_DGRAD_POLY, PACK_CONVT_POLY, PACK_DGRAD_2D = 0, 1, 2, 3, 4
 CK = 16
-LOSS_L1, LOSS_L1_L1LOG, LOSS_MSE_TARGET = 0, 1, 2
+LOSS_L1, LOSS_L1_L1LOG, LOSS_MSE_TARGET, LOSS_MSE_REL = 0, 1, 2, 3
 MAX_LOSS_JOBS = 48
 
 _P = C.c_void_p
@@ -91,6 +91,10 @@ PROTOTYPES = {
     'rtg_loss_bwd': (_I, [_I, _P, _I, _P, _P]),
     'rtg_dyn_loss_fwd': (_I, [_P, _P, _I, _I, _I, _F, _P, _P, _P]),
     'rtg_dyn_loss_bwd': (_I, [_P, _P, _I, _I, _I, _F, _P, _P, _P]),
+    'rtg_env_loss_fwd': (_I, [_P, _P, _I, _I, _I, _F, _P, _P, _P]),
+    'rtg_env_loss_bwd': (_I, [_P, _P, _I, _I, _I, _F, _P, _P, _P]),
+    'rtg_strip_mirror_fwd': (_I, [_P, _I, _I, _F, _P, _P, _P, _P]),
+    'rtg_strip_mirror_bwd': (_I, [_P, _I, _I, _F, _P, _P, _P, _P]),
     'rtg_adamw': (_I, [_P, _P, _P, _P, _LL, _P, _P, _F, _F, _F, _F, _F, _F, _P]),
     'rtg_abi_version': (_I, []),
     'rtg_build_info': (C.c_char_p, []),

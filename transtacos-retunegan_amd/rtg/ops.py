@@ -440,28 +440,56 @@ def multi_loss(kind, a_list, b_list=None, weights=None, target=0.0):
 
 
 class DynLossFn(torch.autograd.Function):
-    """dynamic_loss (retunegan/models/loss.py:76-82); gradient w.r.t. the generated wave only."""
+    """dynamic_loss (retunegan/models/loss.py:76-82) or, with env=True, envelope_loss (loss.py:66-72); gradient w.r.t.
+    the generated wave only."""
 
     @staticmethod
-    def forward(ctx, y, g, k):
+    def forward(ctx, y, g, k, env=False):
         _need_cuda(y, g)
         y, g = _c(y), _c(g)
         rows, Lx = y.numel() // y.shape[-1], y.shape[-1]
         loss = torch.zeros(1, device=y.device)
         ws = torch.empty(256, device=y.device)
-        check(lib.rtg_dyn_loss_fwd(_p(y), _p(g), rows, Lx, k, 1.0, _p(ws), _p(loss), _stream()), 'dyn fwd')
+        fwd = lib.rtg_env_loss_fwd if env else lib.rtg_dyn_loss_fwd
+        check(fwd(_p(y), _p(g), rows, Lx, k, 1.0, _p(ws), _p(loss), _stream()), 'dyn/env fwd')
         ctx.save_for_backward(y, g)
-        ctx.cfg = (rows, Lx, k)
+        ctx.cfg = (rows, Lx, k, env)
         return loss.reshape(())
 
     @staticmethod
     def backward(ctx, gout):
         y, g = ctx.saved_tensors
-        rows, Lx, k = ctx.cfg
+        rows, Lx, k, env = ctx.cfg
         dg = torch.empty_like(g)
-        check(lib.rtg_dyn_loss_bwd(_p(y), _p(g), rows, Lx, k, 1.0, _p(_c(gout).reshape(1)), _p(dg), _stream()),
-              'dyn bwd')
-        return None, dg, None
+        bwd = lib.rtg_env_loss_bwd if env else lib.rtg_dyn_loss_bwd
+        check(bwd(_p(y), _p(g), rows, Lx, k, 1.0, _p(_c(gout).reshape(1)), _p(dg), _stream()), 'dyn/env bwd')
+        return None, dg, None, None
+
+
+class StripMirrorFn(torch.autograd.Function):
+    """strip_mirror_loss (retunegan/models/loss.py:86-98) of a wave [B, 1, T]."""
+
+    @staticmethod
+    def forward(ctx, y):
+        _need_cuda(y)
+        y = _c(y)
+        rows, Lx = y.numel() // y.shape[-1], y.shape[-1]
+        loss = torch.zeros(1, device=y.device)
+        ws = torch.empty(256, device=y.device)
+        stats = torch.zeros(4, device=y.device)
+        check(lib.rtg_strip_mirror_fwd(_p(y), rows, Lx, 1.0, _p(ws), _p(stats), _p(loss), _stream()), 'strip-mirror fwd')
+        ctx.save_for_backward(y, stats)
+        ctx.cfg = (rows, Lx)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        y, stats = ctx.saved_tensors
+        rows, Lx = ctx.cfg
+        dy = torch.empty_like(y)
+        check(lib.rtg_strip_mirror_bwd(_p(y), rows, Lx, 1.0, _p(stats), _p(_c(gout).reshape(1)), _p(dy), _stream()),
+              'strip-mirror bwd')
+        return dy
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -271,12 +271,13 @@ class Trainer:
             losses['mstft'], (S, S_g_hat) = multi_stft_loss(y, y_g_hat, ret_loss=True, ret_specs=True)
         else:
             losses['mstft'] = multi_stft_loss(y, y_g_hat, ret_loss=True)
-        if hp.envelope_loss or hp.strip_mirror_loss:
-            raise RtgError('envelope / strip-mirror losses are off in hparam.py:87-88 and not on the hot path')
+        losses['env'] = envelope_loss(y, y_g_hat) if hp.envelope_loss else None          # train.py:166-168
         losses['dyn'] = dynamic_loss(y, y_g_hat) if hp.dynamic_loss else None
+        losses['sm'] = strip_mirror_loss(y_g_hat) if hp.strip_mirror_loss else None
         total = losses['mstft'] * hp.w_loss_mstft
-        if losses['dyn'] is not None:
-            total = total + losses['dyn'] * hp.w_loss_dyn
+        for key, w in (('env', hp.w_loss_env), ('dyn', hp.w_loss_dyn), ('sm', hp.w_loss_sm)):
+            if losses[key] is not None:
+                total = total + losses[key] * w
         self._freeze(True)       # the reference lets D weight gradients accumulate and discards them at the next
         try:                     # optim_d.zero_grad() (train.py:133): skipping them changes no result
             jobs = [('s', lambda: self.msd(y, y_g_hat))]
