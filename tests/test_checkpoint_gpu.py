@@ -1,0 +1,55 @@
+"""a checkpoint pair in the reference's layout (train.py:263-273: `g_<steps>` = {'generator': state_dict},
+`do_<steps>` = {'msd', 'mpd', 'optim_g', 'optim_d', 'steps', 'epoch'} with torch.optim.AdamW state dicts), written by stock
+torch modules / optimizers with the reference's key set, resumes on the HIP path and continues like the CPU oracle; and
+the HIP path's own checkpoint loads back into stock torch modules.  GPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_resume_from_reference_layout_and_continue(oracle, tmp_path):
+    from train import Trainer
+    og, omsd, ompd = oracle.Generator(), oracle.MSD(), oracle.MPD()
+    for m in (og, omsd, ompd):
+        oracle.det_fill(m)
+    oog, ood = oracle.make_optimizers(og, [omsd, ompd])
+    x, y_tmpl, y = oracle.golden_inputs(batch=1)
+    oracle.train_step(og, oog, ood, x, y_tmpl, y, omsd, ompd, None, 1)           # populates the AdamW moments
+    torch.save({'generator': og.state_dict()}, os.path.join(tmp_path, 'g_00000001'))
+    torch.save({'msd': omsd.state_dict(), 'mpd': ompd.state_dict(), 'optim_g': oog.state_dict(),
+                'optim_d': ood.state_dict(), 'steps': 1, 'epoch': 0}, os.path.join(tmp_path, 'do_00000001'))
+
+    tr = Trainer(use_mpd=True, use_mtd=False, d_train_times=1, dev='cuda:0')
+    assert tr.resume(str(tmp_path)) == 0 and tr.steps == 1
+    with torch.no_grad():
+        tr.generator.noise.w.zero_(); og.noise.w.zero_()                          # device RNG differs by construction
+    dl, gl = tr.train_step(x.cuda(), y_tmpl.cuda(), y.cuda())
+    odl, ogl = oracle.train_step(og, oog, ood, x, y_tmpl, y, omsd, ompd, None, 1)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(dl['disc_all'].item(), sum(odl.values()).item(), rtol=1e-3)
+    np.testing.assert_allclose(gl['gen_all'].item(), ogl['total'].item(), rtol=1e-3)
+    # second-step parameters: the moments of step 1 came from the checkpoint (an AdamW step from zero moments would move
+    # every weight by exactly lr; with carried moments the move is smaller: compare against the oracle's)
+    op = dict(og.named_parameters())
+    for n, p in tr.generator.named_parameters():
+        if n == 'noise.w':
+            continue
+        d = (p.detach().cpu() - op[n].detach()).abs().mean().item()
+        assert d < 0.25 * 1.8e-4, (n, d)
+
+    # and back: the HIP path's checkpoint loads into stock torch modules / optimizers
+    tr.save(str(tmp_path), epoch=0)
+    g2 = oracle.Generator()
+    g2.load_state_dict(torch.load(os.path.join(tmp_path, f'g_{tr.steps:08d}'), map_location='cpu')['generator'])
+    do = torch.load(os.path.join(tmp_path, f'do_{tr.steps:08d}'), map_location='cpu')
+    m2, p2 = oracle.MSD(), oracle.MPD()
+    m2.load_state_dict(do['msd']); p2.load_state_dict(do['mpd'])
+    og2, od2 = oracle.make_optimizers(g2, [m2, p2])
+    og2.load_state_dict(do['optim_g']); od2.load_state_dict(do['optim_d'])
+    assert do['steps'] == tr.steps and do['epoch'] == 0
+    for n, p in tr.generator.named_parameters():
+        np.testing.assert_array_equal(p.detach().cpu().numpy(), dict(g2.named_parameters())[n].detach().numpy())
