@@ -30,7 +30,7 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--workload', default='config2', choices=['config1', 'config2', 'config4'])
+    ap.add_argument('--workload', default='config2', choices=['config1', 'config2', 'config4', 'config5'])
     ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (default: the workload\'s)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
@@ -42,7 +42,44 @@ WORKLOADS = {
     'config1': ('UNet-G + MSD, 1 D-step (BASELINE configs[0] shape on the GPU)', False, False, 1, 2, 8192),
     'config2': ('UNet-G + MSD/MPD, multi-STFT loss, d_train_times=2 (BASELINE configs[1])', True, False, 2, 32, 8192),
     'config4': ('UNet-G + MSD/MPD/MTD full stack (BASELINE configs[3])', True, True, 2, 32, 8192),
+    # BASELINE configs[4]: "1 s" clips = 86 frames = 22016 samples (22050 is not a multiple of the hop)
+    'config5': ('finetune-shaped feed (BASELINE configs[4]): full stack, linear-spec -> mel + host Griffin-Lim reference '
+                'wave per utterance (cached like data.py:33-40), per-step crop, pinned double-buffered async H2D',
+                True, True, 2, 16, 22016),
 }
+
+
+def finetune_feeder(batch, T, seed, device, pool=48):
+    """Host side of BASELINE configs[4]: a pool of synthetic utterances (normalised linear spectrograms of ~2 s of noise
+    -> natural scale -> mel and Griffin-Lim reference wave, data.py:61-77), then per step a random `T`-sample crop of
+    `batch` of them, copied through pinned buffers on a side stream (data.PinnedFeeder)."""
+    import numpy as np
+    import hparam as hp
+    import audio as A
+    import data as D
+    rng = np.random.RandomState(seed)
+    frames = T // hp.hop_length
+    utts = []
+    for _ in range(pool):
+        n = (frames + 40 + rng.randint(0, 40)) * hp.hop_length
+        wav = (rng.rand(n).astype(np.float32) * 2 - 1) * 0.5
+        S = np.abs(A.stft_np(wav[:-1]))
+        db = 20 * np.log10(np.maximum(1e-5, S)) - hp.ref_level_db
+        mag_n = np.clip(2 * hp.max_abs_value * ((db - hp.min_level_db) / -hp.min_level_db) - hp.max_abs_value,
+                        -hp.max_abs_value, hp.max_abs_value).astype(np.float32)
+        utts.extend(D.finetune_batch_from_mags([mag_n], [wav]))
+
+    def make_batch(step):
+        items = []
+        for _ in range(batch):
+            mel, tmpl, wav = utts[rng.randint(0, pool)]
+            cp = rng.randint(0, mel.shape[1] - frames)
+            items.append((mel[:, cp:cp + frames], tmpl[cp * hp.hop_length:(cp + frames) * hp.hop_length],
+                          wav[cp * hp.hop_length:(cp + frames) * hp.hop_length]))
+        return D.collate(items)
+
+    return D.PinnedFeeder(make_batch, device)
+
 
 
 def synthetic_batch(batch, T, seed, device):
@@ -179,17 +216,23 @@ def main():
         batch = a.batch
     torch.manual_seed(hp.randseed)          # identical initial weights on every rank (and broadcast from rank 0)
     tr = Trainer(use_mpd=use_mpd, use_mtd=use_mtd, d_train_times=d_times, dev=device)
-    data = synthetic_batch(batch, T, hp.randseed + rank, device)
+    feeder = None
+    if a.workload == 'config5':
+        feeder = finetune_feeder(batch, T, hp.randseed + rank, device)
+        next_batch = feeder.next
+    else:
+        data = synthetic_batch(batch, T, hp.randseed + rank, device)
+        next_batch = lambda: data  # noqa: E731
 
     for _ in range(a.warmup):
-        tr.train_step(*data)
+        tr.train_step(*next_batch())
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        dl, gl = tr.train_step(*data)
+        dl, gl = tr.train_step(*next_batch())
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -203,6 +246,9 @@ def main():
     loss_d = dl['disc_all'].item()
 
     roof = None
+    data = next_batch()
+    if feeder is not None:
+        feeder.close()
     if not a.no_roofline and rank == 0:
         roof = roofline(tr, data)
     if world > 1:
@@ -217,7 +263,7 @@ def main():
         out = {
             'metric': 'G+D train-step audio-seconds/sec', 'value': round(value, 2), 'unit': 'audio-s/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(ms, 3),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic' if feeder is None else 'synthetic, fed from pinned host memory every step',
             'config': {'workload': f'{a.workload}: {desc}', 'per_gpu_batch': batch, 'clip_samples': T,
                        'global_batch': world * batch, 'd_train_times': d_times,
                        'parallelism': f'dp{world}' if world > 1 else 'single'},

@@ -103,3 +103,121 @@ def get_stft_torch(y, n_fft, win_length, hop_length):
     the train step consumes `stft_mel_spec` directly (log-magnitude / phase-over-PI straight from the kernel)."""
     mel, spec = stft_mel_spec(y, n_fft, win_length, hop_length, want_spec=True)
     return torch.exp(spec[:, 0]), mel, spec[:, 1] * PI
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Host-side DSP of the finetune data path (SURVEY.md 8 f1): numpy only.  librosa==0.8.1 (requirements.txt:1) is a
+# third-party dependency absent from /root/reference and from this image, so its published algorithms are restated
+# here; no reference test or fixture pins them: PARITY UNPINNED for this block (tests check the defining properties).
+# ---------------------------------------------------------------------------------------------------------------
+def align_wav(wav, r=hp.hop_length):
+    """audio.py:37-41: zero-pad to a multiple of the hop."""
+    d = len(wav) % r
+    return np.pad(wav, (0, r - d)) if d else wav
+
+
+def _padded_window(win_length, n_fft):
+    """scipy/librosa 'hann' with fftbins=True (periodic), zero-padded to n_fft, centred (librosa.util.pad_center)"""
+    w = 0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(win_length) / win_length)
+    lp = (n_fft - win_length) // 2
+    return np.pad(w, (lp, n_fft - win_length - lp))
+
+
+def stft_np(y, n_fft=hp.n_fft, hop_length=hp.hop_length, win_length=hp.win_length):
+    """librosa.stft(center=True, pad_mode='reflect'): [1 + n_fft/2, 1 + len(y) // hop] complex64."""
+    w = _padded_window(win_length, n_fft)
+    yp = np.pad(np.asarray(y, dtype=np.float32), n_fft // 2, mode='reflect')
+    n_frames = 1 + (len(yp) - n_fft) // hop_length
+    idx = np.arange(n_fft)[:, None] + hop_length * np.arange(n_frames)[None, :]
+    return np.fft.rfft(w[:, None] * yp[idx], axis=0).astype(np.complex64)
+
+
+def istft_np(D, hop_length=hp.hop_length, win_length=hp.win_length, length=None):
+    """librosa.istft(center=True): windowed overlap-add divided by the window's squared-sum envelope, n_fft/2 trimmed
+    from both ends, cut / zero-padded to `length`."""
+    n_fft = 2 * (D.shape[0] - 1)
+    n_frames = D.shape[1]
+    w = _padded_window(win_length, n_fft)
+    frames = np.fft.irfft(D, n=n_fft, axis=0) * w[:, None]
+    n = n_fft + hop_length * (n_frames - 1)
+    y = np.zeros(n, dtype=np.float64)
+    env = np.zeros(n, dtype=np.float64)
+    w2 = w * w
+    for t in range(n_frames):
+        s = t * hop_length
+        y[s:s + n_fft] += frames[:, t]
+        env[s:s + n_fft] += w2
+    ok = env > np.finfo(np.float32).tiny
+    y[ok] /= env[ok]
+    y = y[n_fft // 2:]
+    if length is None:
+        y = y[:len(y) - n_fft // 2]
+    else:
+        y = y[:length] if len(y) >= length else np.pad(y, (0, length - len(y)))
+    return y.astype(np.float32)
+
+
+def get_mag(y, clamp_low=True):
+    """audio.py:115-119: log magnitude spectrogram [F, T] (natural log, floor eps)."""
+    S = np.abs(stft_np(y))
+    return np.log(S.clip(min=eps) if clamp_low else S).astype(np.float32)
+
+
+def _griffinlim(S, wavlen=None):
+    """audio.py:131-136 -> librosa.griffinlim(S ** gl_power, n_iter=gl_iters, momentum=gl_momentum, init='random',
+    random_state=randseed, length=wavlen): the fast Griffin-Lim of Perraudin et al. as librosa 0.8.1 states it."""
+    if hp.gl_power:
+        S = S ** hp.gl_power
+    S = np.asarray(S, dtype=np.float32)
+    rng = np.random.RandomState(seed=hp.randseed)
+    angles = np.exp(2j * np.pi * rng.rand(*S.shape)).astype(np.complex64)
+    rebuilt = 0.0
+    n_fft = 2 * (S.shape[0] - 1)
+    for _ in range(hp.gl_iters):
+        tprev = rebuilt
+        inverse = istft_np(S * angles, hp.hop_length, hp.win_length, length=wavlen)
+        rebuilt = stft_np(inverse, n_fft, hp.hop_length, hp.win_length)
+        angles = rebuilt - (hp.gl_momentum / (1 + hp.gl_momentum)) * tprev
+        angles = (angles / (np.abs(angles) + 1e-16)).astype(np.complex64)
+    return istft_np(S * angles, hp.hop_length, hp.win_length, length=wavlen).astype(np.float32)
+
+
+def inv_mag(mag, wavlen=None):
+    """audio.py:139-147: exp() of a log-magnitude [F or F-1, T] (a 1024-bin input gets a zero DC row) -> Griffin-Lim wave.
+    NOTE (kept from the reference): the finetune path calls this with an already LINEAR magnitude (data.py:65,76), so
+    exp() is applied to it again."""
+    S = np.exp(mag)
+    F, T = mag.shape
+    if F == hp.n_freq - 1:
+        S = np.concatenate([np.zeros([1, T]), S], axis=0)
+    y = _griffinlim(S, wavlen)
+    if wavlen:
+        assert len(y) == wavlen
+    return y
+
+
+def _denormalize(S):
+    """transtacos/audio.py:195-196: [-max_abs, max_abs] -> [min_level_db, 0]"""
+    return ((S + hp.max_abs_value) * -hp.min_level_db) / (2 * hp.max_abs_value) + hp.min_level_db
+
+
+def spec_to_natural_scale(spec):
+    """transtacos/audio.py:80-82: normalised dB spectrogram -> linear magnitude, 10 ** ((denorm + ref_level_db) / 20)."""
+    return np.power(10.0, (_denormalize(spec) + hp.ref_level_db) * 0.05)
+
+
+def augment_spec(S, time_mask=True, freq_mask=True, prob=0.2, rounds=3, freq_width=9, time_width=3, rng=None):
+    """audio.py:72-99: random frequency / time band masks then a 3x3 mean blur (zero padded, count includes padding)."""
+    R = rng or np.random
+    F, T = S.shape
+    S = np.array(S, dtype=np.float32, copy=True)
+    for _ in range(rounds):
+        if freq_mask and R.random() < prob:
+            s, r = R.randint(0, F - freq_width), R.randint(1, freq_width)
+            S[s:s + r, :] = R.uniform(low=S.min(), high=S.mean())
+        if time_mask and R.random() < prob:
+            s, r = R.randint(0, T - time_width), R.randint(1, time_width)
+            S[:, s:s + r] = R.uniform(low=S.min(), high=S.mean())
+    P = np.pad(S, 1)
+    out = sum(P[i:i + F, j:j + T] for i in range(3) for j in range(3)) / 9.0
+    return out.astype(np.float32)
