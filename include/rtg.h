@@ -162,7 +162,7 @@ typedef struct RtgPackJob {      /* one per packed layout of a layer            
   int S;                         /* stride of the source conv (polyphase modes)                                */
   int tile_m;
   int KH;                        /* RTG_PACK_DGRAD_2D: kernel rows of the source [C_out][C_in][KH][src_K] weight;
-                                    packed rows = (ci, phase), packed channels = (co, kh)                      */
+                                    packed rows = (ci, phase), packed channels = (kh, co): kernel-row major                    */
   int tap_major;                 /* 1: [g][m-tile][k-step group][k-step][kk][m] with k-step = (channel, tap group)  */
 } RtgPackJob;
 

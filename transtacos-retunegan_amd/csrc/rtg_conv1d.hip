@@ -269,7 +269,18 @@ extern "C" int rtg_conv1d(const RtgConv1dDesc* d, const float* x1, const float* 
   }
   a.ROW = ((row + 15) / 32) * 32 + 16;          // == 16 (mod 32), >= row
   a.m_blocks = rtg_ceil_div(a.n_mt, c.WM * c.MT);
-  const int gz = c.seg_len > 0 ? rtg_ceil_div(d->B, c.seg_nb) : d->B;
+  int gz = c.seg_len > 0 ? rtg_ceil_div(d->B, c.seg_nb) : d->B;
+  if (two_d && d->h_mode == 1 && d->h_stride > 1 && c.seg_len > 0) {
+    // class-pure blocks of packed rows (rtg_conv1d_kernel.h, RowClass): per batch item, per residue class of the rows,
+    // ceil(rows of the class / seg_nb) blocks
+    int per_item = 0;
+    for (int r = 0; r < d->h_stride; ++r) {
+      int f = (r - d->h_pad) % d->h_stride;
+      if (f < 0) f += d->h_stride;
+      per_item += f < d->h_n ? rtg_ceil_div(rtg_ceil_div(d->h_n - f, d->h_stride), c.seg_nb) : 0;
+    }
+    gz = (d->B / d->h_n) * per_item;
+  }
   a.gx = c.seg_len > 0 ? 1 : rtg_ceil_div(d->Q, BN);
   const long long total = (long long)d->groups * a.m_blocks * a.gx * gz;
   if (total > (1ll << 30)) return RTG_ERANGE;

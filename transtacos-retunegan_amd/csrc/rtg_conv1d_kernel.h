@@ -44,6 +44,41 @@ struct ConvArgs {
 #endif
 };
 
+// 2-D backward-data over a row-strided convolution (h_mode == 1, h_stride > 1): input row h of dx only receives kernel
+// rows kh == (h + h_pad) (mod h_stride).  Blocks are therefore made class-pure: the z index of a block of packed clips
+// enumerates (batch item, residue class r, group of seg_nb rows of that class), so that the block walks only the
+// (kernel row, channel) chunks of its class instead of multiplying the other chunks with zeros.
+struct RowClass {
+  int item, cls, first, j0, cnt;     // rows of the block: first + (j0 + seg) * h_stride for seg < cnt
+};
+__device__ __forceinline__ int rtg_class_first(int r, int s, int pad) {
+  int f = (r - pad) % s;
+  return f < 0 ? f + s : f;
+}
+__device__ __forceinline__ RowClass rtg_block_rows(int bz, int H, int s, int pad, int seg_nb) {
+  int per_item = 0;
+  for (int r = 0; r < s; ++r) {
+    const int f = rtg_class_first(r, s, pad);
+    per_item += f < H ? ((H - f + s - 1) / s + seg_nb - 1) / seg_nb : 0;
+  }
+  RowClass rc;
+  rc.item = bz / per_item;
+  int rem = bz - rc.item * per_item;
+  rc.cls = 0; rc.first = 0; rc.j0 = 0; rc.cnt = 0;
+  for (int r = 0; r < s; ++r) {
+    const int f = rtg_class_first(r, s, pad);
+    const int n = f < H ? (H - f + s - 1) / s : 0;
+    const int nb = (n + seg_nb - 1) / seg_nb;
+    if (rem < nb) {
+      rc.cls = r; rc.first = f; rc.j0 = rem * seg_nb;
+      rc.cnt = n - rc.j0 < seg_nb ? n - rc.j0 : seg_nb;
+      break;
+    }
+    rem -= nb;
+  }
+  return rc;
+}
+
 template <int TM>
 struct Mfma;
 template <>
@@ -88,7 +123,9 @@ __device__ __forceinline__ void stage_rows(const ConvArgs& a, rsrc_t r1, rsrc_t 
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
       const int c = cc * RTG_CK + wave * RPW + i;
-      const int ci = c / a.h_k, kh = c - ci * a.h_k;
+      int ci, kh;
+      if (a.h_mode == 0) { ci = c / a.h_k; kh = c - ci * a.h_k; }     // forward: virtual channel = (channel, kernel row)
+      else { kh = c / cin; ci = c - kh * cin; }                       // backward-data: (kernel row, channel)
       int khq, khr, sgn;
       if (a.h_mode == 0) { khq = kh; khr = 0; sgn = 1; }                       // forward: row = ho*s - p + kh
       else { khq = kh / a.h_stride; khr = kh - khq * a.h_stride; sgn = -1; }   // backward-data: (h + p - kh) / s
@@ -165,6 +202,18 @@ __global__ __launch_bounds__(RTG_THREADS) void conv1d_mfma_kernel(const ConvArgs
   const int BN = a.WN * NT * TM;
   const bool packed = a.seg_len > 0;
   const int b0 = packed ? bz * a.seg_nb : bz;   // first clip of this block
+  const bool cls_mode = a.two_d && a.h_mode == 1 && a.h_stride > 1;
+  RowClass rc = {0, 0, 0, 0, 0};
+  if (cls_mode) {
+    if (packed) {
+      rc = rtg_block_rows(bz, a.h_n, a.h_stride, a.h_pad, a.seg_nb);
+    } else {                                     // one clip (row) per block
+      rc.item = b0 / a.h_n;
+      rc.first = b0 - rc.item * a.h_n;
+      rc.cls = (rc.first + a.h_pad) % a.h_stride;
+      rc.cnt = 1;
+    }
+  }
   const int q_blk = packed ? 0 : bx * BN;
   const int o_start = q_blk * a.stride - a.pad;
   const int bufsz = RTG_CK * a.ROW;
@@ -180,11 +229,13 @@ __global__ __launch_bounds__(RTG_THREADS) void conv1d_mfma_kernel(const ConvArgs
     if (a.stride != 1) loff[it] = (o % a.stride) * a.PH + o / a.stride;   // uniform branch: no division for stride 1
     int pos, bb;
     bool ok = o < a.PW;
+    int seg = 0;
     if (packed) {
-      const int seg = o / a.seg_pitch, w = o - seg * a.seg_pitch;
+      seg = o / a.seg_pitch;
+      const int w = o - seg * a.seg_pitch;
       bb = b0 + seg;
       pos = w - a.pad;
-      ok = ok && seg < a.seg_nb && bb < a.B && w < a.seg_pw;
+      ok = ok && seg < a.seg_nb && w < a.seg_pw && (cls_mode ? seg < rc.cnt : bb < a.B);
     } else {
       bb = b0;
       pos = o_start + o;
@@ -195,7 +246,12 @@ __global__ __launch_bounds__(RTG_THREADS) void conv1d_mfma_kernel(const ConvArgs
     ehq[it] = 0;
     ehr[it] = 0;
     if (a.two_d) {                       // clip -> (batch item, row); see stage_rows
-      const int item = (int)eb[it] / a.h_n, hh = (int)eb[it] - item * a.h_n;
+      int item = (int)eb[it] / a.h_n;
+      int hh = (int)eb[it] - item * a.h_n;
+      if (cls_mode) {
+        item = ok ? rc.item : 0;
+        hh = rc.first + (rc.j0 + seg) * a.h_stride;
+      }
       eb[it] = (unsigned)item;
       if (a.h_mode == 0) {
         ehq[it] = hh * a.h_stride - a.h_pad;
@@ -253,14 +309,27 @@ __global__ __launch_bounds__(RTG_THREADS) void conv1d_mfma_kernel(const ConvArgs
     if (mt > a.n_mt - 1) mt = a.n_mt - 1;   // clamped duplicate tile, discarded in the epilogue
     wptr[i] = a.wp + ((size_t)(g * a.n_mt + mt) * a.n_cc) * a.K * (RTG_CK * TM) + lane;
   }
-  const int n_steps = a.n_cc * a.K;
+  // chunks this block walks: all of them, or (strided 2-D backward-data, rows of one residue class, see RowClass)
+  // only the kernel rows of that class — virtual chunk v -> real chunk real_cc(v)
+  int n_cc = a.n_cc, sub_cpk = 0, sub_kh0 = 0;
+  if (cls_mode && ((a.C1 / a.h_k) % RTG_CK) == 0) {
+    sub_cpk = (a.C1 / a.h_k) / RTG_CK;
+    sub_kh0 = rc.cls;
+    const int nkh = rc.cls < a.h_k ? (a.h_k - rc.cls + a.h_stride - 1) / a.h_stride : 0;
+    n_cc = nkh * sub_cpk;
+  }
+  auto real_cc = [&](int v) __attribute__((always_inline)) {
+    return sub_cpk ? (sub_kh0 + (v / sub_cpk) * a.h_stride) * sub_cpk + v % sub_cpk : v;
+  };
+  const int n_steps = n_cc * a.K;
+  const size_t wstep = (size_t)RTG_CK * TM;      // floats per (chunk, tap) step of one m tile
   // two named A-fragment register sets used alternately (no loop-carried copy: with a copy at the end of the tap the
   // compiler waits for the JUST-issued prefetch in the middle of the MFMA phase, one exposed L2 latency per tap)
   float a0[MT][CPN], a1[MT][CPN];
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
-    for (int cp = 0; cp < CPN; ++cp) a0[i][cp] = wptr[i][cp * 64];
+    for (int cp = 0; cp < CPN; ++cp) a0[i][cp] = wptr[i][(size_t)real_cc(0) * a.K * wstep + cp * 64];
 
   int* tab = reinterpret_cast<int*>(lds + a.tab_off);
   if (a.tapmajor) {
@@ -276,7 +345,7 @@ __global__ __launch_bounds__(RTG_THREADS) void conv1d_mfma_kernel(const ConvArgs
       tab[e] = off;
     }
   }
-  stage(0);
+  stage(real_cc(0));
   RTG_STAMP(1);
   swrite(lds);
   __syncthreads();
@@ -287,14 +356,16 @@ __global__ __launch_bounds__(RTG_THREADS) void conv1d_mfma_kernel(const ConvArgs
   auto do_step = [&](int step, float (&cur)[MT][CPN], float (&nxt)[MT][CPN]) __attribute__((always_inline)) {
     const float* buf = lds + (cc & 1) * bufsz;
     if (step + 1 < n_steps) {
+      const bool wrap = tap + 1 == a.K;
+      const size_t nofs = ((size_t)real_cc(wrap ? cc + 1 : cc) * a.K + (wrap ? 0 : tap + 1)) * wstep;
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int cp = 0; cp < CPN; ++cp) nxt[i][cp] = wptr[i][(size_t)(step + 1) * (RTG_CK * TM) + cp * 64];
+        for (int cp = 0; cp < CPN; ++cp) nxt[i][cp] = wptr[i][nofs + cp * 64];
     }
     // the next chunk's patch is requested AFTER the weight prefetch, on the chunk's first tap: vmcnt retires in order,
     // so the wait for `nxt` one tap later does not include these loads, the wait two taps later finds them landed
-    if (tap == 0 && cc + 1 < a.n_cc) stage(cc + 1);
+    if (tap == 0 && cc + 1 < n_cc) stage(real_cc(cc + 1));
     const int td = tap * a.dil;
     const int tapoff = (a.stride == 1) ? td : (td % a.stride) * a.PH + td / a.stride;
     const float* bp = buf + bbase + tapoff;
@@ -327,7 +398,7 @@ __global__ __launch_bounds__(RTG_THREADS) void conv1d_mfma_kernel(const ConvArgs
     __builtin_amdgcn_sched_barrier(0);
     if (++tap == a.K) {
       tap = 0;
-      if (cc + 1 < a.n_cc) swrite(lds + ((cc + 1) & 1) * bufsz);
+      if (cc + 1 < n_cc) swrite(lds + ((cc + 1) & 1) * bufsz);
       __syncthreads();
       ++cc;
     }
@@ -432,17 +503,22 @@ __global__ __launch_bounds__(RTG_THREADS) void conv1d_mfma_kernel(const ConvArgs
     for (int j = 0; j < NT; ++j) {
       int q = q_blk + (wn * NT + j) * TM + n_lane;
       int b = b0;
+      int seg = 0;
       if (packed) {
-        const int seg = q / a.seg_len;
+        seg = q / a.seg_len;
         q -= seg * a.seg_len;
         b = b0 + seg;
-        if (seg >= a.seg_nb || b >= a.B) continue;
+        if (seg >= a.seg_nb || (cls_mode ? seg >= rc.cnt : b >= a.B)) continue;
       }
       if (q >= a.Q) continue;
       int hh = 0;
       if (a.two_d) {                     // clip -> (batch item, output row)
-        const int item = b / a.h_n;
+        int item = b / a.h_n;
         hh = b - item * a.h_n;
+        if (cls_mode) {
+          item = rc.item;
+          hh = rc.first + (rc.j0 + seg) * a.h_stride;
+        }
         b = item;
       }
 #pragma unroll

@@ -69,9 +69,11 @@ __global__ __launch_bounds__(RTG_THREADS) void pack_kernel(const RtgPackJob* job
         srow = (long long)g * j.Cg + c;
         sin = (long long)row * j.src_K + (j.src_K - 1 - tap);
       } else if (j.mode == RTG_PACK_DGRAD_2D) {
-        // source [C_out][C_in][KH][src_K]; packed rows (ci, phase r), packed channels (co, kh), taps along W
+        // source [C_out][C_in][KH][src_K]; packed rows (ci, phase r), packed channels (kh, co) — kernel row major, so
+        // that a block of one row residue class walks whole chunk ranges (rtg_conv1d_kernel.h) —, taps along W
         const int ch = row / j.S, r = row - ch * j.S;
-        const int co = c / j.KH, kh = c - co * j.KH;
+        const int n_co = j.Cg / j.KH;
+        const int kh = c / n_co, co = c - kh * n_co;
         const int jj = r + (j.K - 1 - tap) * j.S;
         if (jj < j.src_K) {
           srow = co;
