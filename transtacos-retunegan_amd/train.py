@@ -52,8 +52,11 @@ class AdamW:
         if params and isinstance(params[0], BankedModel):
             models = params
         else:
-            ids = {id(p) for p in params}
-            models = [m for m in BankedModel._registry if any(id(p) in ids for p in m.parameters())]
+            pos = {id(p): i for i, p in enumerate(params)}
+            models = [m for m in BankedModel._registry if any(id(p) in pos for p in m.parameters())]
+            # in the order the caller listed the parameters (the registry is an unordered weak set): the per-parameter
+            # indices of state_dict() / load_state_dict() must follow torch.optim's numbering
+            models.sort(key=lambda m: min(pos.get(id(p), len(pos)) for p in m.parameters()))
             covered = sum(sum(1 for _ in m.parameters()) for m in models)
             if covered != len(params):
                 raise RtgError('AdamW: parameters must cover whole RetuneGAN models (generator / msd / mpd / mtd)')
