@@ -53,3 +53,31 @@ def test_resume_from_reference_layout_and_continue(oracle, tmp_path):
     assert do['steps'] == tr.steps and do['epoch'] == 0
     for n, p in tr.generator.named_parameters():
         np.testing.assert_array_equal(p.detach().cpu().numpy(), dict(g2.named_parameters())[n].detach().numpy())
+
+
+def test_graphed_step_matches_eager(oracle):
+    """Trainer.train_step_graphed (the step replayed from HIP graphs) against the eager step: same weights, same
+    inputs, noise off (its seeds are launch arguments) -> same losses and the same updated parameters."""
+    from train import Trainer
+
+    def make():
+        torch.manual_seed(5)
+        tr = Trainer(use_mpd=True, use_mtd=False, d_train_times=2, dev='cuda:0')
+        with torch.no_grad():
+            tr.generator.noise.w.zero_()
+        return tr
+    x, y_tmpl, y = [t.cuda() for t in oracle.synthetic_batch(4, 8192, 3)]
+    a, b = make(), make()
+    for _ in range(2):                       # eager warm-up (block-shape tuning) on both
+        a.train_step(x, y_tmpl, y); b.train_step(x, y_tmpl, y)
+    for _ in range(3):
+        dla, gla = a.train_step(x, y_tmpl, y)
+        dlb, glb = b.train_step_graphed(x, y_tmpl, y)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(gla['gen_all'].item(), glb['gen_all'].item(), rtol=1e-5)
+    np.testing.assert_allclose(dla['disc_all'].item(), dlb['disc_all'].item(), rtol=1e-5)
+    # the two trainers tune their block shapes independently (different split-K orders of the weight gradients: rounding
+    # noise), and AdamW turns a sign flip of a ~0 gradient into a +-lr move: compare against a fraction of lr
+    for (n, p), (_, q) in zip(a.generator.named_parameters(), b.generator.named_parameters()):
+        d = (p.detach() - q.detach()).abs()
+        assert d.mean().item() < 0.1 * 1.8e-4 and d.max().item() < 5 * 1.8e-4, (n, d.mean().item(), d.max().item())

@@ -111,7 +111,24 @@ def _collect(outs):
 
 
 class _MultiBase(BankedModel):
-    pass
+    """`branches(a, b)` refreshes the packed weights and returns one closure per sub-discriminator; `forward` runs them
+    on forked streams.  `run_stacks` forks the sub-discriminators of SEVERAL stacks in one flat fork (what the trainer
+    uses: 7 - 10 independent streams off the current one instead of a fork inside a fork)."""
+
+    def forward(self, a, b):
+        return _collect(fork_join(self.branches(a, b)))
+
+
+def run_stacks(calls):
+    """calls: [(stack, a, b)] -> [(logits_r, logits_g, fmaps_r, fmaps_g)] per stack, all sub-discriminators of all
+    stacks forked side by side."""
+    brs, spans = [], []
+    for stack, a, b in calls:
+        bs = stack.branches(a, b)
+        spans.append((len(brs), len(brs) + len(bs)))
+        brs += bs
+    outs = fork_join(brs)
+    return [_collect(outs[lo:hi]) for lo, hi in spans]
 
 
 class MultiScaleDiscriminator(_MultiBase):
@@ -122,7 +139,7 @@ class MultiScaleDiscriminator(_MultiBase):
         self.discriminators = nn.ModuleList([DiscriminatorS(use_sn=i == 0) for i in range(hp.msd_layers)])
         assert hp.downsample_pool_k == 4, 'rtg_avgpool4s2 implements AvgPool1d(4, 2, 1) (hparam.py:91)'
 
-    def forward(self, y, y_hat):
+    def branches(self, y, y_hat):
         tok = self.token()
         frozen = _frozen(self) and not y.requires_grad
         # inputs of the three scales: y, AvgPool(y), AvgPool(AvgPool(y)) (discrminator.py:126-127)
@@ -137,7 +154,7 @@ class MultiScaleDiscriminator(_MultiBase):
                     xs = [x0, ops.AvgPoolFn.apply(xs[1])]
                 else:
                     xs = [ops.AvgPoolFn.apply(xs[0])]
-        return _collect(fork_join([_sub_runner(d, tok, inp, frozen) for d, inp in zip(self.discriminators, inputs)]))
+        return [_sub_runner(d, tok, inp, frozen) for d, inp in zip(self.discriminators, inputs)]
 
 
 class MultiPeriodDiscriminator(_MultiBase):
@@ -147,11 +164,11 @@ class MultiPeriodDiscriminator(_MultiBase):
         super().__init__()
         self.discriminators = nn.ModuleList([DiscriminatorP(p) for p in hp.mpd_periods])
 
-    def forward(self, y, y_hat):
+    def branches(self, y, y_hat):
         tok = self.token()
         frozen = _frozen(self) and not y.requires_grad
         inp = [y, y_hat] if frozen else [torch.cat([y, y_hat], dim=0)]
-        return _collect(fork_join([_sub_runner(d, tok, inp, frozen) for d in self.discriminators]))
+        return [_sub_runner(d, tok, inp, frozen) for d in self.discriminators]
 
 
 class StftDiscriminator(nn.Module):
@@ -178,8 +195,8 @@ class MultiStftDiscriminator(_MultiBase):
         super().__init__()
         self.discriminators = nn.ModuleList([StftDiscriminator(i) for i in range(len(hp.multi_stft_params))])
 
-    def forward(self, phs, ph_hats):
+    def branches(self, phs, ph_hats):
         tok = self.token()
         frozen = _frozen(self) and not phs[0].requires_grad
         inputs = [[ph, ph_hat] if frozen else [torch.cat([ph, ph_hat], dim=0)] for ph, ph_hat in zip(phs, ph_hats)]
-        return _collect(fork_join([_sub_runner(d, tok, inp, frozen) for d, inp in zip(self.discriminators, inputs)]))
+        return [_sub_runner(d, tok, inp, frozen) for d, inp in zip(self.discriminators, inputs)]

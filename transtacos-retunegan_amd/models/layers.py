@@ -93,7 +93,7 @@ class BankedModel(nn.Module):
 import os
 
 _FORK_STREAMS = {}
-_FORK_DEPTH = [0]
+_FORK_PATH = [()]
 if hasattr(torch.autograd.graph, 'set_warn_on_accumulate_grad_stream_mismatch'):
     # leaves are accumulated on the stream of their first use while forked branches run elsewhere: intended
     torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
@@ -114,23 +114,26 @@ def fork_join(fns):
     """Run independent sub-networks (the 3 MSD scales, the 4 MPD periods, the 3 MTD resolutions, the 3 ResBlock3
     branches) on separate HIP streams so that their kernels overlap: each of these launches only fills the chip for part
     of its duration (ramp-up, last partial wave of workgroups), a second queue fills the idle CUs.  Autograd replays the
-    backward of every op on the stream of its forward, so the backward overlaps the same way.  RTG_STREAMS=0 disables."""
+    backward of every op on the stream of its forward, so the backward overlaps the same way.  Nested forks (the
+    discriminator stacks forked by the trainer, their sub-discriminators forked inside) get streams of their own per
+    branch: a stream never carries work of two different parents, which keeps the fork tree a tree (no false ordering
+    between e.g. MSD scale 0 and MPD period 0, and a shape HIP graph capture accepts).  RTG_STREAMS=0 disables."""
     if len(fns) < 2 or os.environ.get('RTG_STREAMS', '1') == '0' or ops.PROFILE is not None or tune.ACTIVE:
         return [f() for f in fns]
     main = torch.cuda.current_stream()
-    depth = _FORK_DEPTH[0]
-    pool = _FORK_STREAMS.setdefault((main.device, depth), [])     # nested forks get their own streams
+    path = _FORK_PATH[0]
+    pool = _FORK_STREAMS.setdefault((main.device, path), [])
     while len(pool) < len(fns):
         pool.append(torch.cuda.Stream(device=main.device))
     outs = []
-    _FORK_DEPTH[0] = depth + 1
     try:
-        for f, s in zip(fns, pool):
+        for i, (f, s) in enumerate(zip(fns, pool)):
             s.wait_stream(main)
+            _FORK_PATH[0] = path + (i,)
             with torch.cuda.stream(s):
                 outs.append(f())
     finally:
-        _FORK_DEPTH[0] = depth
+        _FORK_PATH[0] = path
     for s in pool[:len(fns)]:
         main.wait_stream(s)
     _record(outs, main)          # produced on a side stream, consumed (and later freed) on the main one

@@ -304,8 +304,11 @@ class WeightBank:
     def sync_grads(self):
         """Make the current stream wait for the last flush: it may have been queued on a forked stream, and autograd only
         joins the streams of leaf accumulations at the end of backward()."""
-        if self._flush_stream is not None and self._flush_stream != torch.cuda.current_stream():
-            torch.cuda.current_stream().wait_stream(self._flush_stream)
+        cur = torch.cuda.current_stream()
+        if self._flush_stream is not None and self._flush_stream != cur:
+            cur.wait_stream(self._flush_stream)
+            self._flush_stream = cur         # ordered behind it from here on: later syncs need not (and, between two
+                                             # HIP graph captures, must not) wait on the side stream again
 
     def zero_grad(self):
         self.sync_grads()

@@ -23,7 +23,8 @@ import hparam as h  # noqa: F401  (train.py:17 imports it under both names)
 from models import *  # noqa: F401,F403
 from models import (multi_stft_loss, dynamic_loss, discriminator_loss, generator_loss, feature_loss,
                     MultiScaleDiscriminator, MultiPeriodDiscriminator, MultiStftDiscriminator)
-from models.layers import BankedModel, fork_join
+from models.layers import BankedModel, fork_join  # noqa: F401
+from models.discrminator import run_stacks
 from models.loss import stft_cache
 from rtg import tune
 from rtg.lib import lib, check, RtgError
@@ -204,6 +205,10 @@ class DataParallel:
 # ---------------------------------------------------------------------------------------------------------------
 # the step
 # ---------------------------------------------------------------------------------------------------------------
+def _detached(losses):
+    return {k: (v.detach() if torch.is_tensor(v) else v) for k, v in losses.items()}
+
+
 class Trainer:
     """Owns the models and optimizers exactly as train.py:47-88 builds them and runs train.py:121-193 per batch."""
 
@@ -228,6 +233,8 @@ class Trainer:
         self.generator.noise.salt = None
         self.steps = 0
         self._tuned = False
+        self._graphs = None
+        self._static_in = self._static_out = None
         for m in (self.generator, *self.discs):
             m.train()
         if self.dp.enabled:
@@ -239,34 +246,42 @@ class Trainer:
             for p in d.parameters():
                 p.requires_grad_(not flag)
 
-    def d_step(self, y, y_g_hat_detach):
-        """train.py:133-160."""
+    def d_step(self, y, y_g_hat_detach, apply=True):
+        """train.py:133-160.  apply=False stops after the backward (graph segments: reduce + update come later)."""
         self.optim_d.zero_grad()
         S = S_g = None
         if self.mtd is not None:
             S, S_g = multi_stft_loss(y, y_g_hat_detach, ret_specs=True)
         losses = {}
         # the discriminator stacks are independent: run them on separate streams (models.layers.fork_join)
-        jobs = [('disc_s', lambda: self.msd(y, y_g_hat_detach))]
+        jobs = [('disc_s', (self.msd, y, y_g_hat_detach))]
         if self.mpd is not None:
-            jobs.append(('disc_p', lambda: self.mpd(y, y_g_hat_detach)))
+            jobs.append(('disc_p', (self.mpd, y, y_g_hat_detach)))
         if self.mtd is not None:
-            jobs.append(('disc_t', lambda: self.mtd(S, S_g)))
-        for (tag, _), (r, g, _, _) in zip(jobs, fork_join([j for _, j in jobs])):
+            jobs.append(('disc_t', (self.mtd, S, S_g)))
+        for (tag, _), (r, g, _, _) in zip(jobs, run_stacks([j for _, j in jobs])):
             losses[tag] = discriminator_loss(r, g)
         total = sum(losses.values())
         losses['disc_all'] = total
         total.backward()
+        losses = _detached(losses)           # nobody differentiates them again: let the autograd graph go now
+        if not apply:
+            for d in self.discs:             # join the streams the gradient flushes ran on (a graph segment ends here)
+                d.bank().sync_grads()
+            return losses
+        self._d_reduce()
+        self.optim_d.step(self.dp.reduce_flag(total.detach().clone().reshape(1)))
+        return losses
+
+    def _d_reduce(self):
         if self.dp.enabled:
             for d in self.discs:
                 if getattr(d.bank(), 'on_flush', None) is None:
                     d.bank().sync_grads()
                     self.dp.reduce_async(d.bank().gflat)
             self.dp.wait()
-        self.optim_d.step(self.dp.reduce_flag(total.detach().clone().reshape(1)))
-        return losses
 
-    def g_step(self, y, y_g_hat):
+    def g_step(self, y, y_g_hat, apply=True):
         """train.py:163-193."""
         self.optim_g.zero_grad()
         losses = {}
@@ -283,12 +298,12 @@ class Trainer:
                 total = total + losses[key] * w
         self._freeze(True)       # the reference lets D weight gradients accumulate and discards them at the next
         try:                     # optim_d.zero_grad() (train.py:133): skipping them changes no result
-            jobs = [('s', lambda: self.msd(y, y_g_hat))]
+            jobs = [('s', (self.msd, y, y_g_hat))]
             if self.mpd is not None:
-                jobs.append(('p', lambda: self.mpd(y, y_g_hat)))
+                jobs.append(('p', (self.mpd, y, y_g_hat)))
             if self.mtd is not None:
-                jobs.append(('t', lambda: self.mtd(S, S_g_hat)))
-            for (tag, _), (r, g, fr, fg) in zip(jobs, fork_join([j for _, j in jobs])):
+                jobs.append(('t', (self.mtd, S, S_g_hat)))
+            for (tag, _), (r, g, fr, fg) in zip(jobs, run_stacks([j for _, j in jobs])):
                 losses['gen_' + tag] = generator_loss(g, r)
                 losses['fm_' + tag] = feature_loss(fr, fg)
                 total = total + losses['gen_' + tag] + losses['fm_' + tag] * hp.w_loss_fm
@@ -296,12 +311,19 @@ class Trainer:
             total.backward()
         finally:
             self._freeze(False)
+        losses = _detached(losses)
+        if not apply:
+            self.generator.bank().sync_grads()
+            return losses
+        self._g_reduce()
+        self.optim_g.step(self.dp.reduce_flag(total.detach().clone().reshape(1)))
+        return losses
+
+    def _g_reduce(self):
         if self.dp.enabled:
             self.generator.bank().sync_grads()
             self.dp.reduce_async(self.generator.bank().gflat)
             self.dp.wait()
-        self.optim_g.step(self.dp.reduce_flag(total.detach().clone().reshape(1)))
-        return losses
 
     def train_step(self, x, y_tmpl, y, noise_list=None):
         """One iteration of the batch loop (train.py:121-193).  x [B,80,T/256], y_tmpl / y [B,1,T] on the GPU.
@@ -325,9 +347,109 @@ class Trainer:
         self.steps += 1
         return dl, gl
 
+    # -- the same step replayed from HIP graphs
+    def train_step_graphed(self, x, y_tmpl, y):
+        """train_step() captured once into HIP graphs and replayed: the ~900 kernel launches of a step (and the forks /
+        joins of the sub-network streams) are issued by the graph executor instead of the Python autograd machinery.
+        Measured on MI355X at batch 32 it is NOT faster than the eager step (41.6 vs 41.7 ms: the step is bound by the
+        GPU-side cost of its many short kernels, not by the host), so bench.py and the default trainer stay eager; the
+        path is kept for hosts with slow cores.  ROCm 7.2 notes: a fork inside a forked stream crashes
+        hipStreamEndCapture (hence the flat fork of run_stacks), and a capturing stream must not wait on a stream of
+        an earlier capture (WeightBank.sync_grads re-homes the flush stream).  The step is cut where data parallelism exchanges
+        gradients — [G forward, D backward] | [D update, D backward] ... | [D update, G backward] | [G update] — and the
+        all-reduces run eagerly between the segments, so one code path serves 1 and N GPUs.  Inputs are copied into
+        static buffers; the returned loss dicts hold static device scalars overwritten by every replay.  The learning
+        rate is a launch argument: end_epoch() drops the graphs and the next step captures them again."""
+        if self._graphs is None:
+            if not self._tuned or tune.MISSED:                  # block shapes are timed eagerly, never under capture
+                for _ in range(2):
+                    self.train_step(x, y_tmpl, y)
+            self._capture(x, y_tmpl, y)
+        sx, sy_tmpl, sy = self._static_in
+        for dst, src in ((sx, x), (sy_tmpl, y_tmpl), (sy, y)):
+            if dst.data_ptr() != src.data_ptr():
+                dst.copy_(src, non_blocking=True)
+        for graph, after in self._graphs:
+            graph.replay()
+            if after is not None:
+                after()
+        self.steps += 1
+        return self._static_out
+
+    def _capture(self, x, y_tmpl, y):
+        assert x.is_cuda and not tune.ACTIVE
+        self._static_in = (x.clone(), y_tmpl.clone(), y.clone())
+        sx, sy_tmpl, sy = self._static_in
+        if self.generator.noise.salt is None:   # the noise seeds are launch arguments: mix in a device
+            self.generator.noise.salt = self.optim_g.step_tensor(self.generator)   # word that changes every step
+        hooks = [(d, d.bank().on_flush) for d in self.discs]
+        for d, _ in hooks:
+            d.bank().on_flush = None                            # collectives stay outside the graphs
+        pool = torch.cuda.graph_pool_handle()
+        cap = torch.cuda.Stream()
+        cap.wait_stream(torch.cuda.current_stream())
+        state = {}
+        n_d = self.d_train_times
+
+        def seg_first():
+            state['cache'] = stft_cache()
+            state['cache'].__enter__()
+            state['y_hat'] = self.generator(sx, sy_tmpl)
+            state['dl'] = self.d_step(sy, state['y_hat'].detach(), apply=False)
+
+        def seg_d(i):
+            def run():
+                self.optim_d.step(state['flag'])
+                if i < n_d:
+                    state['dl'] = self.d_step(sy, state['y_hat'].detach(), apply=False)
+                else:
+                    state['gl'] = self.g_step(sy, state['y_hat'], apply=False)
+                    state['cache'].__exit__(None, None, None)
+            return run
+
+        def seg_last():
+            self.optim_g.step(state['flag'])
+
+        def flag_of(key):
+            def run():
+                state['flag'] = state[key]['disc_all' if key == 'dl' else 'gen_all'].detach().clone().reshape(1)
+            return run
+
+        def after_d():
+            self._d_reduce()
+            self.dp.reduce_flag(state['flag'])
+
+        def after_g():
+            self._g_reduce()
+            self.dp.reduce_flag(state['flag'])
+
+        segs = [(lambda: (seg_first(), flag_of('dl')()), after_d)]
+        for i in range(1, n_d + 1):
+            last_d = i == n_d
+            segs.append((lambda i=i, last_d=last_d: (seg_d(i)(), flag_of('gl' if last_d else 'dl')()),
+                         after_g if last_d else after_d))
+        segs.append((seg_last, None))
+        graphs = []
+        try:
+            with torch.cuda.stream(cap):
+                for body, after in segs:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, pool=pool, stream=cap):
+                        body()
+                    graphs.append((g, after if self.dp.enabled else None))
+                    if os.environ.get('RTG_GRAPH_DEBUG'):
+                        print(f'captured graph segment {len(graphs)} of {len(segs)}', flush=True)
+        finally:
+            for d, h in hooks:
+                d.bank().on_flush = h
+        torch.cuda.current_stream().wait_stream(cap)
+        self._graphs = graphs
+        self._static_out = (state['dl'], state['gl'])
+
     def end_epoch(self):
         self.scheduler_g.step()
         self.scheduler_d.step()
+        self._graphs = None            # the learning rate is baked into the captured AdamW launches
 
     # -- checkpoints in the reference's layout (train.py:263-273)
     def checkpoint_dicts(self, epoch):
