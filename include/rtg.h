@@ -89,6 +89,18 @@ typedef struct RtgConv1dDesc {
 int rtg_conv1d(const RtgConv1dDesc* d, const float* x1, const float* x2, const float* aux, const float* wp,
                const float* bias, const float* mask, const float* res, float* out, float* out2, void* stream);
 
+/* Up to RTG_MAX_GROUP (4) independent convolutions in ONE launch: the sub-discriminators of a stack (3 MSD scales, 4 MPD
+ * periods, 3 MTD resolutions; discrminator.py:104-129,225-244,311-330) run the same layer on different clips with
+ * different weights; each alone often gives a CU less than one workgroup, side by side they fill the chip.  Every
+ * descriptor must carry the same non-zero tile_cfg and the same tile_m (one kernel instance serves the group); results
+ * are bit-identical to n separate rtg_conv1d calls. */
+#define RTG_MAX_GROUP 4
+typedef struct RtgConvPtrs {
+  const float *x1, *x2, *aux, *wp, *bias, *mask, *res;
+  float *out, *out2;
+} RtgConvPtrs;
+int rtg_conv1d_group(int n, const RtgConv1dDesc* descs, const RtgConvPtrs* ptrs, void* stream);
+
 /* which template instantiation rtg_conv1d would launch for this descriptor: tile_m*100 + MT*10 + NT (wave tile =
  * MT x NT MFMA tiles), or a negative RTG_E* code.  Used by bench.py to attribute time per kernel. */
 int rtg_conv1d_variant(const RtgConv1dDesc* d);

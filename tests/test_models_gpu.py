@@ -253,3 +253,30 @@ def test_cpu_input_is_refused(nets):
     from rtg.lib import RtgError
     with pytest.raises(RtgError):
         nets[0](torch.zeros(1, 80, 32), torch.zeros(1, 1, 8192))
+
+
+def test_grouped_launch_path_matches_forked_streams(nets, oracle, gold):
+    """RTG_GROUP=1 (sibling sub-discriminators layer by layer through rtg_conv1d_group) gives the same logits, feature
+    maps and parameter gradients as the default forked-stream execution: the grouped launch is bit-identical per
+    member, the weight-gradient split-K order is the tuner's choice in both (rounding-level differences only)."""
+    import models.discrminator as D
+    from models import discriminator_loss
+    _, _, y = oracle.golden_inputs()
+    yd = torch.from_numpy(gold['y_hat'])
+    for d in (nets[1], nets[2]):
+        res = []
+        for grouped in (False, True):
+            D.GROUPED = grouped
+            try:
+                d.zero_grad()
+                lr, lg, fr, fg = D.run_stacks([(d, y.to(DEV), yd.to(DEV))])[0]
+                discriminator_loss(lr, lg).backward()
+                torch.cuda.synchronize()
+                res.append(([t.detach().clone() for t in lr + lg], [getattr(f, '_rtg_base', f).detach().clone() for fl in fr for f in fl],
+                            d.bank().gflat.clone()))
+            finally:
+                D.GROUPED = False
+        for a, b in zip(res[0][0] + res[0][1], res[1][0] + res[1][1]):
+            assert torch.equal(a, b)
+        ga, gb = res[0][2], res[1][2]
+        assert ((ga - gb).norm() / ga.norm()).item() < 1e-5

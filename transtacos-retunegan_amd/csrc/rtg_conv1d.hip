@@ -31,6 +31,15 @@ int rtg_conv1d_launch_16_1_1(const rtg_cv::ConvArgs&, dim3, size_t, hipStream_t)
 int rtg_conv1d_launch_16_1_2(const rtg_cv::ConvArgs&, dim3, size_t, hipStream_t);
 int rtg_conv1d_launch_16_1_4(const rtg_cv::ConvArgs&, dim3, size_t, hipStream_t);
 
+int rtg_conv1d_launch_group_32_1_1(const rtg_cv::GroupArgs&, size_t, hipStream_t);
+int rtg_conv1d_launch_group_32_1_2(const rtg_cv::GroupArgs&, size_t, hipStream_t);
+int rtg_conv1d_launch_group_32_1_4(const rtg_cv::GroupArgs&, size_t, hipStream_t);
+int rtg_conv1d_launch_group_32_2_1(const rtg_cv::GroupArgs&, size_t, hipStream_t);
+int rtg_conv1d_launch_group_32_2_2(const rtg_cv::GroupArgs&, size_t, hipStream_t);
+int rtg_conv1d_launch_group_16_1_1(const rtg_cv::GroupArgs&, size_t, hipStream_t);
+int rtg_conv1d_launch_group_16_1_2(const rtg_cv::GroupArgs&, size_t, hipStream_t);
+int rtg_conv1d_launch_group_16_1_4(const rtg_cv::GroupArgs&, size_t, hipStream_t);
+
 using rtg_cv::ConvArgs;
 
 #ifdef RTG_STAMPS
@@ -194,9 +203,17 @@ extern "C" long long rtg_packed_size_tapmajor(int groups, int Mg, int Cg, int K,
   return (long long)groups * n_mt * tapmajor_groups(Cg, K, tile_m) * RTG_CK * tile_m;
 }
 
-extern "C" int rtg_conv1d(const RtgConv1dDesc* d, const float* x1, const float* x2, const float* aux, const float* wp,
-                          const float* bias, const float* mask, const float* res, float* out, float* out2,
-                          void* stream) {
+// One problem's kernel arguments, grid and LDS size from its descriptor (shared by the single and the grouped launch).
+// thin_ok: may be served by a bandwidth kernel (rtg_thin.hip) -> returns 1 with *thin set.
+struct ConvPlan {
+  ConvArgs a;
+  unsigned blocks;
+  size_t lds_bytes;
+  int TM, MT, NT;
+};
+
+static int conv_plan(const RtgConv1dDesc* d, const float* x1, const float* x2, const float* aux, const float* wp,
+                     const float* bias, const float* mask, const float* res, float* out, float* out2, ConvPlan* pl) {
   if (!d || !x1 || !wp) return RTG_ENULL;
   if (d->out_split == 0 ? !out : (!out && !out2)) return RTG_ENULL;
   if (d->out_split < 0 || d->out_split >= d->out_C) return RTG_EINVAL;
@@ -223,12 +240,7 @@ extern "C" int rtg_conv1d(const RtgConv1dDesc* d, const float* x1, const float* 
   if (x_bytes >= (1ll << 31) || (long long)d->B * d->C2 * d->L_in * 4 >= (1ll << 31)) return RTG_ERANGE;   // 32-bit offsets
   if ((long long)(two_d ? d->B / d->h_n : d->B) * d->out_C * (two_d ? d->h_n : 1) * d->out_L * 4 >= (1ll << 31)) return RTG_ERANGE;
 
-  if (d->tile_cfg == 0) {
-    const int thin = rtg_thin_kind(d);
-    if (thin) return rtg_thin_launch(thin, d, x1, aux, wp, bias, mask, res, out, (hipStream_t)stream);
-  }
-
-  ConvArgs a;
+  ConvArgs& a = pl->a;
   a.x1 = x1; a.x2 = x2; a.aux = (d->pre_mode >= RTG_PRE_MUL_DLRELU) ? aux : nullptr; a.wp = wp; a.bias = bias;
   a.mask = mask; a.res = res; a.out = out; a.out2 = out2; a.out_split = d->out_split;
   a.B = d->B; a.C1 = d->C1; a.C2 = d->C2; a.L_in = d->L_in; a.groups = d->groups; a.Cg = d->Cg; a.Mg = d->Mg;
@@ -286,22 +298,73 @@ extern "C" int rtg_conv1d(const RtgConv1dDesc* d, const float* x1, const float* 
   if (total > (1ll << 30)) return RTG_ERANGE;
   a.total = (int)total;
   a.per_xcd = rtg_ceil_div(total, 8);
-  dim3 grid((unsigned)(8 * a.per_xcd));
+  pl->blocks = (unsigned)(8 * a.per_xcd);
 #ifdef RTG_STAMPS
   a.dbg = rtg_dev_stamps();
 #endif
   a.tab_off = 2 * RTG_CK * a.ROW;
   size_t lds_bytes = (size_t)(2 * RTG_CK * a.ROW + (a.tapmajor ? a.K * RTG_CK : 0)) * sizeof(float);
-  hipStream_t s = (hipStream_t)stream;
 #ifdef RTG_STAMPS
   if (const char* e = getenv("RTG_DEV_OCC")) {            // diagnostic builds: cap the resident blocks per CU through LDS
     const int cap = atoi(e);
     if (cap > 0 && lds_bytes < (size_t)(160 * 1024 / cap - 1024)) lds_bytes = 160 * 1024 / cap - 1024;
   }
 #endif
+  pl->lds_bytes = lds_bytes;
+  pl->TM = TM; pl->MT = c.MT; pl->NT = c.NT;
+  return RTG_OK;
+}
 
+extern "C" int rtg_conv1d(const RtgConv1dDesc* d, const float* x1, const float* x2, const float* aux, const float* wp,
+                          const float* bias, const float* mask, const float* res, float* out, float* out2,
+                          void* stream) {
+  if (!d) return RTG_ENULL;
+  if (d->tile_cfg == 0 && x1 && wp) {
+    const int thin = rtg_thin_kind(d);
+    if (thin > 0) {
+      return rtg_thin_launch(thin, d, x1, aux, wp, bias, mask, res, out, (hipStream_t)stream);
+    }
+  }
+  ConvPlan pl;
+  const int st = conv_plan(d, x1, x2, aux, wp, bias, mask, res, out, out2, &pl);
+  if (st != RTG_OK) return st;
+  hipStream_t s = (hipStream_t)stream;
+  const ConvArgs& a = pl.a;
+  const dim3 grid(pl.blocks);
+  const size_t lds_bytes = pl.lds_bytes;
 #define RTG_CASE(tm, mt, nt) \
-  if (TM == tm && c.MT == mt && c.NT == nt) return rtg_conv1d_launch_##tm##_##mt##_##nt(a, grid, lds_bytes, s);
+  if (pl.TM == tm && pl.MT == mt && pl.NT == nt) return rtg_conv1d_launch_##tm##_##mt##_##nt(a, grid, lds_bytes, s);
+  RTG_CASE(32, 1, 1) RTG_CASE(32, 1, 2) RTG_CASE(32, 1, 4) RTG_CASE(32, 2, 1) RTG_CASE(32, 2, 2)
+  RTG_CASE(16, 1, 1) RTG_CASE(16, 1, 2) RTG_CASE(16, 1, 4)
+#undef RTG_CASE
+  return RTG_ERANGE;
+}
+
+extern "C" int rtg_conv1d_group(int n, const RtgConv1dDesc* descs, const RtgConvPtrs* ptrs, void* stream) {
+  if (!descs || !ptrs) return RTG_ENULL;
+  if (n < 1 || n > RTG_MAX_GROUP) return RTG_EINVAL;
+  rtg_cv::GroupArgs ga;
+  ga.n = n;
+  size_t lds_bytes = 0;
+  unsigned end = 0;
+  int TM = 0, MT = 0, NT = 0;
+  for (int i = 0; i < n; ++i) {
+    if (descs[i].tile_cfg == 0) return RTG_EINVAL;          // the caller fixes ONE block shape for the whole group
+    ConvPlan pl;
+    const RtgConvPtrs& q = ptrs[i];
+    const int st = conv_plan(&descs[i], q.x1, q.x2, q.aux, q.wp, q.bias, q.mask, q.res, q.out, q.out2, &pl);
+    if (st != RTG_OK) return st;
+    if (i == 0) { TM = pl.TM; MT = pl.MT; NT = pl.NT; }
+    else if (pl.TM != TM || pl.MT != MT || pl.NT != NT) return RTG_EINVAL;
+    ga.p[i] = pl.a;
+    end += pl.blocks;
+    ga.blk_end[i] = end;
+    lds_bytes = pl.lds_bytes > lds_bytes ? pl.lds_bytes : lds_bytes;
+  }
+  for (int i = n; i < RTG_MAX_GROUP; ++i) ga.blk_end[i] = end;
+  hipStream_t s = (hipStream_t)stream;
+#define RTG_CASE(tm, mt, nt) \
+  if (TM == tm && MT == mt && NT == nt) return rtg_conv1d_launch_group_##tm##_##mt##_##nt(ga, lds_bytes, s);
   RTG_CASE(32, 1, 1) RTG_CASE(32, 1, 2) RTG_CASE(32, 1, 4) RTG_CASE(32, 2, 1) RTG_CASE(32, 2, 2)
   RTG_CASE(16, 1, 1) RTG_CASE(16, 1, 2) RTG_CASE(16, 1, 4)
 #undef RTG_CASE

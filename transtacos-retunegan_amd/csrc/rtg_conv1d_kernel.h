@@ -171,8 +171,17 @@ __device__ __forceinline__ void stage_rows(const ConvArgs& a, rsrc_t r1, rsrc_t 
   }
 }
 
+// Up to RTG_MAX_GROUP independent convolutions in ONE launch (rtg_conv1d_group): the sub-discriminators of a stack run
+// the same layer shape family on different clips with different weights, and each alone often gives a CU less than one
+// block; side by side they fill the chip and share one launch.  blk_end[i] = first block after problem i.
+struct GroupArgs {
+  int n;
+  unsigned blk_end[RTG_MAX_GROUP];
+  ConvArgs p[RTG_MAX_GROUP];
+};
+
 template <int TM, int MT, int NT, int MAXIT>   // MAXIT: 64-float pieces of a patch row each lane stages (>= PW / 64)
-__global__ __launch_bounds__(RTG_THREADS) void conv1d_mfma_kernel(const ConvArgs a) {
+__device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a, const unsigned bid) {
   using M = Mfma<TM>;
   using acc_t = typename M::acc_t;
   constexpr int KK = 64 / TM;           // K-values consumed per MFMA
@@ -190,7 +199,7 @@ __global__ __launch_bounds__(RTG_THREADS) void conv1d_mfma_kernel(const ConvArgs
   // ordered with the row blocks of one input patch next to each other (m block fastest, then group, q tile, clip) —
   // the m blocks that re-read the same patch run on the same XCD at about the same time and hit its L2 instead of
   // fetching the patch once per row block from HBM.  (Speed only: any placement computes the same result.)
-  const int item = (int)(blockIdx.x & 7u) * a.per_xcd + (int)(blockIdx.x >> 3);
+  const int item = (int)(bid & 7u) * a.per_xcd + (int)(bid >> 3);
   if (item >= a.total) return;
   int wrk = item;
   const int mb = wrk % a.m_blocks;
@@ -561,6 +570,43 @@ __global__ __launch_bounds__(RTG_THREADS) void conv1d_mfma_kernel(const ConvArgs
 }
 
 template <int TM, int MT, int NT, int MAXIT>
+__global__ __launch_bounds__(RTG_THREADS) void conv1d_mfma_kernel(const ConvArgs a) {
+  conv1d_mfma_body<TM, MT, NT, MAXIT>(a, blockIdx.x);
+}
+
+template <int TM, int MT, int NT, int MAXIT>
+__global__ __launch_bounds__(RTG_THREADS) void conv1d_mfma_group_kernel(const GroupArgs ga) {
+  int pid = 0;
+  unsigned start = 0;
+  for (int i = 0; i + 1 < ga.n; ++i)
+    if (blockIdx.x >= ga.blk_end[i]) {
+      pid = i + 1;
+      start = ga.blk_end[i];
+    }
+  conv1d_mfma_body<TM, MT, NT, MAXIT>(ga.p[pid], blockIdx.x - start);     // every grid is a multiple of 8 blocks
+}
+
+template <int TM, int MT, int NT, int MAXIT>
+int launch_group_it(const GroupArgs& ga, size_t lds_bytes, hipStream_t s) {
+  auto k = conv1d_mfma_group_kernel<TM, MT, NT, MAXIT>;
+  if (lds_bytes > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return -(1000 + (int)e);
+  }
+  hipLaunchKernelGGL(k, dim3(ga.blk_end[ga.n - 1]), dim3(RTG_THREADS), lds_bytes, s, ga);
+  return rtg_launch_status();
+}
+
+template <int TM, int MT, int NT>
+int launch_group(const GroupArgs& ga, size_t lds_bytes, hipStream_t s) {
+  int pw = 0;
+  for (int i = 0; i < ga.n; ++i) pw = ga.p[i].PW > pw ? ga.p[i].PW : pw;
+  if (pw <= 3 * 64) return launch_group_it<TM, MT, NT, 3>(ga, lds_bytes, s);
+  if (pw <= 5 * 64) return launch_group_it<TM, MT, NT, 5>(ga, lds_bytes, s);
+  return launch_group_it<TM, MT, NT, RTG_PW_MAX / 64>(ga, lds_bytes, s);
+}
+
+template <int TM, int MT, int NT, int MAXIT>
 int launch_it(const ConvArgs& a, dim3 grid, size_t lds_bytes, hipStream_t s) {
   auto k = conv1d_mfma_kernel<TM, MT, NT, MAXIT>;
   if (lds_bytes > 64 * 1024) {
@@ -583,4 +629,7 @@ int launch(const ConvArgs& a, dim3 grid, size_t lds_bytes, hipStream_t s) {
 #define RTG_CONV_DEFINE(tm, mt, nt)                                                                         \
   int rtg_conv1d_launch_##tm##_##mt##_##nt(const rtg_cv::ConvArgs& a, dim3 grid, size_t lds_bytes, hipStream_t s) { \
     return rtg_cv::launch<tm, mt, nt>(a, grid, lds_bytes, s);                                                \
+  }                                                                                                         \
+  int rtg_conv1d_launch_group_##tm##_##mt##_##nt(const rtg_cv::GroupArgs& ga, size_t lds_bytes, hipStream_t s) { \
+    return rtg_cv::launch_group<tm, mt, nt>(ga, lds_bytes, s);                                             \
   }

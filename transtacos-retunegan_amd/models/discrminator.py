@@ -8,6 +8,8 @@ Differences in execution, not in results:
   * DiscriminatorP's [B,1,T/p,p] view + (k,1) Conv2d is executed as Conv1d over T/p with the period folded into the
     batch ([B*p, C, T/p]); feature maps are handed back as [B,C,T/p,p] views, logits in the reference's order.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F  # noqa: F401
@@ -36,6 +38,37 @@ def _run_stack(tok, convs, conv_post, x):
     return conv(tok, conv_post, h, pre_slope=LRELU_SLOPE), fmap
 
 
+# RTG_GROUP=1: sibling sub-discriminators run layer by layer in grouped launches (rtg_conv1d_group) instead of on forked
+# streams.  Measured on MI355X (config 2, batch 32): a grouped launch beats its members run back to back by 11-34 %, but
+# the forked streams already overlap them as well — 42.7 ms/step grouped vs 42.3 forked — so forking stays the default.
+GROUPED = os.environ.get('RTG_GROUP', '0') == '1'
+
+
+def _groupable(c):
+    ly = c._layer
+    return ly is not None and ly.kind == 'conv' and ly.cin // ly.groups > 1 and ly.cout // ly.groups > 1
+
+
+def _run_stacks_lockstep(tok, subs, xs):
+    """The sibling sub-discriminators `subs` (same architecture, own weights) on their inputs `xs`, layer by layer: every
+    layer position is ONE grouped launch (rtg_conv1d_group) forward and ONE backward-data instead of len(subs) small
+    ones; the 1-channel first / last layers run on the bandwidth kernels as before.  Returns [(logit, fmap)] per sub."""
+    n = len(subs)
+    hs = list(xs)
+    fmaps = [[] for _ in range(n)]
+    for li in range(len(subs[0].convs)):
+        cs = [d.convs[li] for d in subs]
+        slope = LRELU_SLOPE if li > 0 else 1.0
+        if all(_groupable(c) for c in cs):
+            hs = ops.group_conv(tok, [c._layer for c in cs], hs, pre_slope=slope)
+        else:
+            hs = [conv(tok, c, h, pre_slope=slope) for c, h in zip(cs, hs)]
+        for f, h in zip(fmaps, hs):
+            f.append(h)
+    logits = [conv(tok, d.conv_post, h, pre_slope=LRELU_SLOPE) for d, h in zip(subs, hs)]
+    return list(zip(logits, fmaps))
+
+
 class DiscriminatorS(nn.Module):
     """discrminator.py:17-101, active branch 'MelGAN_small' (:36-45).  `use_sn` is ignored by the reference too."""
 
@@ -45,6 +78,12 @@ class DiscriminatorS(nn.Module):
                 (512, 512, 41, 4, 20, 64), (512, 512, 5, 1, 2, 1)]
         self.convs = nn.ModuleList([WNConv('conv', ci, co, k, stride=s, pad=p, groups=g) for ci, co, k, s, p, g in spec])
         self.conv_post = WNConv('conv', 512, 1, 3, pad=1)
+
+    def pre(self, x):
+        return x
+
+    def post(self, logit, fmap, B):
+        return torch.flatten(logit, 1, -1), fmap
 
     def run(self, tok, x):
         logit, fmap = _run_stack(tok, self.convs, self.conv_post, x)
@@ -65,10 +104,14 @@ class DiscriminatorP(nn.Module):
     def run(self, tok, x):
         """x [B,1,T] -> (logits [B, H'*p], feature maps as [B,C,H,p] views whose `_rtg_base` is the contiguous
         [B*p,C,H] tensor the kernels produced)."""
+        logit, fmap = _run_stack(tok, self.convs, self.conv_post, self.pre(x))
+        return self.post(logit, fmap, x.shape[0])
+
+    def pre(self, x):
+        return ops.PeriodFoldFn.apply(x, self.period)
+
+    def post(self, logit, fmap, B):
         p = self.period
-        B = x.shape[0]
-        xf = ops.PeriodFoldFn.apply(x, p)
-        logit, fmap = _run_stack(tok, self.convs, self.conv_post, xf)
         views = []
         for f in fmap:
             v = f.view(B, p, f.shape[1], f.shape[2]).permute(0, 2, 3, 1)
@@ -118,17 +161,51 @@ class _MultiBase(BankedModel):
     def forward(self, a, b):
         return _collect(fork_join(self.branches(a, b)))
 
+    def sub_inputs(self, a, b, frozen):
+        """per sub-discriminator: [real, fake] (frozen) or [cat(real, fake)]"""
+        raise NotImplementedError
+
+    def run_grouped(self, a, b):
+        """the whole stack layer by layer in grouped launches; same return value as forward()"""
+        tok = self.token()
+        frozen = _frozen(self) and not (a[0] if isinstance(a, (list, tuple)) else a).requires_grad
+        subs = list(self.discriminators)
+        inputs = self.sub_inputs(a, b, frozen)
+
+        def lockstep(xs, batch):
+            res = _run_stacks_lockstep(tok, subs, [d.pre(x) for d, x in zip(subs, xs)])
+            return [d.post(lg, fm, batch) for d, (lg, fm) in zip(subs, res)]
+        if frozen:
+            B = inputs[0][0].shape[0]
+            with torch.no_grad():
+                real = lockstep([inp[0] for inp in inputs], B)
+            fake = lockstep([inp[1] for inp in inputs], B)
+            return ([r[0] for r in real], [f[0] for f in fake], [r[1] for r in real], [f[1] for f in fake])
+        B2 = inputs[0][0].shape[0]
+        both = lockstep([inp[0] for inp in inputs], B2)
+        outs = []
+        for l2, f2 in both:
+            lr, lg = _split(l2, B2 // 2)
+            fs = [_split(f, B2 // 2) for f in f2]
+            outs.append((lr, lg, [x for x, _ in fs], [y for _, y in fs]))
+        return _collect(outs)
+
 
 def run_stacks(calls):
-    """calls: [(stack, a, b)] -> [(logits_r, logits_g, fmaps_r, fmaps_g)] per stack, all sub-discriminators of all
-    stacks forked side by side."""
+    """calls: [(stack, a, b)] -> [(logits_r, logits_g, fmaps_r, fmaps_g)] per stack.  A stack whose sub-discriminators
+    share an architecture of 1-D convs (MSD, MPD) runs layer by layer in grouped launches (one branch of the fork); the
+    sub-discriminators of the others (MTD) are forked side by side — one flat fork in all."""
     brs, spans = [], []
     for stack, a, b in calls:
-        bs = stack.branches(a, b)
-        spans.append((len(brs), len(brs) + len(bs)))
+        if GROUPED and getattr(stack, 'groupable', False):
+            bs = [(lambda st=stack, a=a, b=b: st.run_grouped(a, b))]
+            spans.append((len(brs), None))
+        else:
+            bs = stack.branches(a, b)
+            spans.append((len(brs), len(brs) + len(bs)))
         brs += bs
     outs = fork_join(brs)
-    return [_collect(outs[lo:hi]) for lo, hi in spans]
+    return [outs[lo] if hi is None else _collect(outs[lo:hi]) for lo, hi in spans]
 
 
 class MultiScaleDiscriminator(_MultiBase):
@@ -139,9 +216,15 @@ class MultiScaleDiscriminator(_MultiBase):
         self.discriminators = nn.ModuleList([DiscriminatorS(use_sn=i == 0) for i in range(hp.msd_layers)])
         assert hp.downsample_pool_k == 4, 'rtg_avgpool4s2 implements AvgPool1d(4, 2, 1) (hparam.py:91)'
 
+    groupable = True
+
     def branches(self, y, y_hat):
         tok = self.token()
         frozen = _frozen(self) and not y.requires_grad
+        inputs = self.sub_inputs(y, y_hat, frozen)
+        return [_sub_runner(d, tok, inp, frozen) for d, inp in zip(self.discriminators, inputs)]
+
+    def sub_inputs(self, y, y_hat, frozen):
         # inputs of the three scales: y, AvgPool(y), AvgPool(AvgPool(y)) (discrminator.py:126-127)
         xs = [y, y_hat] if frozen else [torch.cat([y, y_hat], dim=0)]
         inputs = []
@@ -154,7 +237,7 @@ class MultiScaleDiscriminator(_MultiBase):
                     xs = [x0, ops.AvgPoolFn.apply(xs[1])]
                 else:
                     xs = [ops.AvgPoolFn.apply(xs[0])]
-        return [_sub_runner(d, tok, inp, frozen) for d, inp in zip(self.discriminators, inputs)]
+        return inputs
 
 
 class MultiPeriodDiscriminator(_MultiBase):
@@ -164,11 +247,16 @@ class MultiPeriodDiscriminator(_MultiBase):
         super().__init__()
         self.discriminators = nn.ModuleList([DiscriminatorP(p) for p in hp.mpd_periods])
 
+    groupable = True
+
+    def sub_inputs(self, y, y_hat, frozen):
+        inp = [y, y_hat] if frozen else [torch.cat([y, y_hat], dim=0)]
+        return [inp for _ in self.discriminators]
+
     def branches(self, y, y_hat):
         tok = self.token()
         frozen = _frozen(self) and not y.requires_grad
-        inp = [y, y_hat] if frozen else [torch.cat([y, y_hat], dim=0)]
-        return [_sub_runner(d, tok, inp, frozen) for d in self.discriminators]
+        return [_sub_runner(d, tok, inp, frozen) for d, inp in zip(self.discriminators, self.sub_inputs(y, y_hat, frozen))]
 
 
 class StftDiscriminator(nn.Module):
@@ -194,6 +282,8 @@ class MultiStftDiscriminator(_MultiBase):
     def __init__(self):
         super().__init__()
         self.discriminators = nn.ModuleList([StftDiscriminator(i) for i in range(len(hp.multi_stft_params))])
+
+    groupable = False      # 2-D convs: not served by the grouped launch yet
 
     def branches(self, phs, ph_hats):
         tok = self.token()

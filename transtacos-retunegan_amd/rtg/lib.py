@@ -18,6 +18,13 @@ class Conv1dDesc(C.Structure):
                [(n, C.c_int) for n in ('h_in', 'h_k', 'h_stride', 'h_pad', 'h_n', 'h_mode', 'tap_major', 'tile_cfg')]
 
 
+class ConvPtrs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ('x1', 'x2', 'aux', 'wp', 'bias', 'mask', 'res', 'out', 'out2')]
+
+
+MAX_GROUP = 4
+
+
 class WgradDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in ('B', 'C1', 'C2', 'L_in', 'groups', 'Cg', 'Mg', 'K', 'stride', 'dil', 'pad', 'Q',
                                        'dy_L', 'pre_mode')] + \
@@ -65,6 +72,7 @@ _I, _F, _LL, _ULL = C.c_int, C.c_float, C.c_longlong, C.c_ulonglong
 # name -> (restype, argtypes); must list every symbol include/rtg.h declares (checked by tests/test_abi.py)
 PROTOTYPES = {
     'rtg_conv1d': (_I, [C.POINTER(Conv1dDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'rtg_conv1d_group': (_I, [_I, C.POINTER(Conv1dDesc), C.POINTER(ConvPtrs), _P]),
     'rtg_conv1d_variant': (_I, [C.POINTER(Conv1dDesc)]),
     'rtg_conv1d_tile_candidates': (_I, [C.POINTER(Conv1dDesc), C.POINTER(C.c_int), _I]),
     'rtg_packed_size': (_LL, [_I, _I, _I, _I, _I]),

@@ -298,6 +298,118 @@ class Conv2dFn(torch.autograd.Function):
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# grouped convolution: the same layer of up to MAX_GROUP sub-discriminators in one launch (rtg_conv1d_group)
+# ---------------------------------------------------------------------------------------------------------------
+def _fwd_desc(ly, B, C1, L_in, pre_slope):
+    """descriptor of a plain Conv1d forward (no concat, residual or output activation: what the D stacks use)"""
+    L_out = _conv_out_len(ly, L_in)
+    mode, g, mg, cg, k, s = ly.fwd_op
+    pre_mode = L.PRE_LRELU if pre_slope != 1.0 else L.PRE_NONE
+    return _desc(B=B, C1=C1, C2=0, L_in=L_in, groups=g, Cg=cg, Mg=mg, K=k, stride=ly.stride, dil=ly.dil, pad=ly.pad,
+                 Q=L_out, out_C=ly.cout, out_L=L_out, pre_mode=pre_mode, pre_slope=pre_slope, tile_m=ly.fwd_tm,
+                 tap_major=ly.fwd_tap), L_out
+
+
+def _dgrad_desc(ly, B, L_in, L_out, pre_slope):
+    """backward-data of the same (mask = leaky-relu derivative of the layer's input when it was pre-activated)"""
+    mode, g, mg, cg, k, s = ly.bwd_op
+    if ly.stride == 1:
+        return _desc(B=B, C1=ly.cout, L_in=L_out, groups=g, Cg=cg, Mg=mg, K=k, stride=1, dil=ly.dil,
+                     pad=(ly.k - 1) * ly.dil - ly.pad, Q=L_in, out_C=ly.cin, out_L=L_in, mask_slope=pre_slope,
+                     tile_m=ly.bwd_tm, tap_major=ly.bwd_tap)
+    nq = (L_in - 1 + ly.pad) // ly.stride + 1
+    return _desc(B=B, C1=ly.cout, L_in=L_out, groups=g, Cg=cg, Mg=mg, K=k, stride=1, dil=1, pad=k - 1, Q=nq,
+                 out_C=ly.cin, out_L=L_in, shuf_S=ly.stride, shuf_P=ly.pad, mask_slope=pre_slope, tile_m=ly.bwd_tm,
+                 tap_major=ly.bwd_tap)
+
+
+def _launch_group(descs, ptr_rows, flops, label, what):
+    n = len(descs)
+    darr = (L.Conv1dDesc * n)(*descs)
+    parr = (L.ConvPtrs * n)(*[L.ConvPtrs(*[(t.data_ptr() if torch.is_tensor(t) else t) for t in row]) for row in ptr_rows])
+    st = _stream()
+    cfg = tune.group_cfg(darr, n, lambda: lib.rtg_conv1d_group(n, darr, parr, st))
+    if cfg == 0:
+        return False
+    for i in range(n):
+        darr[i].tile_cfg = cfg
+    check(_timed('conv1d', lib.rtg_conv1d_variant(C.byref(darr[0])) if PROFILE is not None else 0, sum(flops),
+                 lambda: lib.rtg_conv1d_group(n, darr, parr, st), label), what)
+    return True
+
+
+class GroupConvFn(torch.autograd.Function):
+    """outs[i] = conv_i(leaky_relu(xs[i], pre_slope)) + bias_i for the same layer position of n sub-discriminators (same
+    bank): forward and backward-data are ONE launch each for the whole group, the weight gradients go through the
+    per-layer wgrad kernels into the bank as usual."""
+
+    @staticmethod
+    def forward(ctx, token, lys, pre_slope, *xs):
+        _need_cuda(*xs)
+        bank = token._rtg_bank
+        xs = [_c(x) for x in xs]
+        descs, rows, outs, flops = [], [], [], []
+        for ly, x in zip(lys, xs):
+            B, C1, L_in = x.shape
+            assert C1 == ly.cin and ly.kind == 'conv'
+            d, L_out = _fwd_desc(ly, B, C1, L_in, pre_slope)
+            out = torch.empty(B, ly.cout, L_out, device=x.device, dtype=torch.float32)
+            descs.append(d); outs.append(out); flops.append(_conv_flop(ly, B, L_out))
+            rows.append((x, None, None, bank.fwd_ptr(ly).value, bank.bias_ptr(ly).value, None, None, out, None))
+        if not _launch_group(descs, rows, flops, f'fwd group {lys[0].name} x{len(lys)}', f'conv1d group fwd {lys[0].name}'):
+            raise L.RtgError(f'no common block shape for the group of {lys[0].name}')
+        ctx.lys, ctx.bank, ctx.tok_id, ctx.pre_slope = lys, bank, token._rtg_id, pre_slope
+        ctx.save_for_backward(*xs)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        lys, bank, pre_slope = ctx.lys, ctx.bank, ctx.pre_slope
+        xs = ctx.saved_tensors
+        dys = [_c(dy) for dy in dys]
+        st = _stream()
+        need_x = any(ctx.needs_input_grad[3:])
+        dxs = [None] * len(xs)
+        if need_x:
+            descs, rows, flops = [], [], []
+            for i, (ly, x, dy) in enumerate(zip(lys, xs, dys)):
+                B, C1, L_in = x.shape
+                L_out = dy.shape[-1]
+                dxs[i] = torch.empty_like(x)
+                descs.append(_dgrad_desc(ly, B, L_in, L_out, pre_slope))
+                flops.append(_conv_flop(ly, B, L_out))
+                rows.append((dy, None, None, bank.bwd_ptr(ly).value, None, x if pre_slope != 1.0 else None, None, dxs[i], None))
+            if not _launch_group(descs, rows, flops, f'dgrad group {lys[0].name} x{len(lys)}',
+                                 f'conv1d group bwd-data {lys[0].name}'):
+                raise L.RtgError(f'no common block shape for the dgrad group of {lys[0].name}')
+        if ctx.needs_input_grad[0]:
+            pre_mode = L.PRE_LRELU if pre_slope != 1.0 else L.PRE_NONE
+
+            def wgrad_of(ly, x, dy):
+                def run():
+                    B, C1, L_in = x.shape
+                    L_out = dy.shape[-1]
+                    wd = L.WgradDesc(B=B, C1=C1, C2=0, L_in=L_in, groups=ly.groups, Cg=ly.cin // ly.groups,
+                                     Mg=ly.cout // ly.groups, K=ly.k, stride=ly.stride, dil=ly.dil, pad=ly.pad, Q=L_out,
+                                     dy_L=L_out, pre_mode=pre_mode, pre_slope=pre_slope, gy_mode=L.PRE_NONE, gy_slope=1.0,
+                                     gy_scale=1.0, splits=1, part_stride=0)
+                    part, splits, immediate = _run_wgrad(wd, (_p(x), None, _p(dy), None), _stream(), bank, ly, ctx.tok_id,
+                                                         _conv_flop(ly, B, L_out), f'wgrad {ly.name} B{B} L{L_in}',
+                                                         f'conv1d wgrad {ly.name}')
+                    if immediate:
+                        bank.flush_one(ly, part, splits)
+                return run
+            for ly, x, dy in zip(lys, xs, dys):      # (forking these over streams measured slower: 43.9 vs 42.7 ms/step)
+                wgrad_of(ly, x, dy)()
+        return (None, None, None, *dxs)
+
+
+def group_conv(token, lys, xs, pre_slope=1.0):
+    """lys: rtg.bank.ConvLayer of each group member (same position in sibling sub-discriminators); xs: their inputs"""
+    return list(GroupConvFn.apply(token, tuple(lys), float(pre_slope), *xs))
+
+
+# ---------------------------------------------------------------------------------------------------------------
 # GaussianNoise
 # ---------------------------------------------------------------------------------------------------------------
 class NoiseFn(torch.autograd.Function):

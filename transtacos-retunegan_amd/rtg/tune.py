@@ -21,7 +21,7 @@ ENABLED = os.environ.get('RTG_TUNE', '1') != '0'
 ACTIVE = False
 MISSED = False
 REPS = 3
-_conv, _wgrad = {}, {}
+_conv, _wgrad, _group = {}, {}, {}
 
 
 def _time(launch):
@@ -93,5 +93,39 @@ def wgrad_cfg(wd, run):
     return best
 
 
+def group_cfg(darr, n, launch):
+    """common tile_cfg for the n descriptors of a grouped launch (ctypes array `darr`); `launch()` runs rtg_conv1d_group
+    on it as it stands.  0: the members have no block shape in common."""
+    for i in range(n):
+        darr[i].tile_cfg = 0
+    key = b''.join(bytes(darr[i]) for i in range(n))
+    cfg = _group.get(key)
+    if cfg is not None:
+        return cfg
+    lists = []
+    for i in range(n):
+        cands = (C.c_int * 16)()
+        k = lib.rtg_conv1d_tile_candidates(C.byref(darr[i]), cands, 16)
+        lists.append([c for c in cands[:max(k, 0)] if c != 0])
+    common = [c for c in lists[0] if all(c in l for l in lists[1:])]
+    if not common:
+        _group[key] = 0
+        return 0
+    if not (ENABLED and ACTIVE):
+        _miss()
+        return common[0]
+    best, best_t = common[0], None
+    for c in common:
+        for i in range(n):
+            darr[i].tile_cfg = c
+        t = _time(launch)
+        if t is not None and (best_t is None or t < best_t):
+            best, best_t = c, t
+    for i in range(n):
+        darr[i].tile_cfg = 0
+    _group[key] = best
+    return best
+
+
 def stats():
-    return {'conv_problems': len(_conv), 'wgrad_problems': len(_wgrad)}
+    return {'conv_problems': len(_conv), 'wgrad_problems': len(_wgrad), 'group_problems': len(_group)}
