@@ -280,3 +280,36 @@ def test_grouped_launch_path_matches_forked_streams(nets, oracle, gold):
             assert torch.equal(a, b)
         ga, gb = res[0][2], res[1][2]
         assert ((ga - gb).norm() / ga.norm()).item() < 1e-5
+
+
+@pytest.mark.parametrize('B,T', [(1, 256 * 3), (3, 256 * 9), (2, 256 * 86)])
+def test_generator_other_lengths_and_batches(nets, onets, oracle, B, T):
+    """ragged / minimum / finetune-sized inputs: any frame count and batch size the reference accepts (T = 256 x frames;
+    86 frames = the "1 s" clips of BASELINE configs[4])"""
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    x = torch.randn(B, 80, T // 256, generator=g).abs()
+    y_tmpl = torch.rand(B, 1, T, generator=g) * 2 - 1
+    with torch.no_grad():
+        got = nets[0](x.to(DEV), y_tmpl.to(DEV)).cpu()
+        ref = onets[0](x, y_tmpl)
+    assert got.shape == (B, 1, T)
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), atol=1e-4, rtol=0)
+
+
+@pytest.mark.parametrize('which,T', [('msd', 8000), ('mpd', 8000), ('msd', 700), ('mpd', 700), ('mpd', 22016)])
+def test_discriminators_on_lengths_that_are_not_multiples_of_anything(nets, onets, oracle, which, T):
+    """clip lengths that are no multiple of the hop, of the periods or of the pooling stride (reflect padding of the
+    period fold, odd AvgPool lengths), batch 1"""
+    d, od = (nets[1], onets[1]) if which == 'msd' else (nets[2], onets[2])
+    g = torch.Generator().manual_seed(T)
+    y = torch.rand(1, 1, T, generator=g) * 2 - 1
+    yh = torch.rand(1, 1, T, generator=g) * 2 - 1
+    with torch.no_grad():
+        lr, lg, fr, fg = d(y.to(DEV), yh.to(DEV))
+        olr, olg, ofr, ofg = od(y, yh)
+    for a, b in zip(lr + lg, olr + olg):
+        assert a.shape == b.shape
+        np.testing.assert_allclose(a.cpu().numpy(), b.numpy(), rtol=1e-3, atol=2e-4)
+    for a, b in zip([f for fl in fr + fg for f in fl], [f for fl in ofr + ofg for f in fl]):
+        assert a.shape == b.shape
+        np.testing.assert_allclose(a.cpu().numpy(), b.numpy(), rtol=1e-3, atol=5e-4)
