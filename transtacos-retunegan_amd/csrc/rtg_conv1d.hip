@@ -22,14 +22,6 @@
 // The kernel lives in rtg_conv1d_kernel.h; its block-shape instances are compiled in rtg_conv1d_t*.hip.
 #include "rtg_conv1d_kernel.h"
 
-int rtg_conv1d_launch_32_1_1(const rtg_cv::ConvArgs&, dim3, size_t, hipStream_t);
-int rtg_conv1d_launch_32_1_2(const rtg_cv::ConvArgs&, dim3, size_t, hipStream_t);
-int rtg_conv1d_launch_32_1_4(const rtg_cv::ConvArgs&, dim3, size_t, hipStream_t);
-int rtg_conv1d_launch_32_2_1(const rtg_cv::ConvArgs&, dim3, size_t, hipStream_t);
-int rtg_conv1d_launch_32_2_2(const rtg_cv::ConvArgs&, dim3, size_t, hipStream_t);
-int rtg_conv1d_launch_16_1_1(const rtg_cv::ConvArgs&, dim3, size_t, hipStream_t);
-int rtg_conv1d_launch_16_1_2(const rtg_cv::ConvArgs&, dim3, size_t, hipStream_t);
-int rtg_conv1d_launch_16_1_4(const rtg_cv::ConvArgs&, dim3, size_t, hipStream_t);
 
 int rtg_conv1d_launch_group_32_1_1(const rtg_cv::GroupArgs&, size_t, hipStream_t);
 int rtg_conv1d_launch_group_32_1_2(const rtg_cv::GroupArgs&, size_t, hipStream_t);
@@ -329,11 +321,15 @@ extern "C" int rtg_conv1d(const RtgConv1dDesc* d, const float* x1, const float* 
   const int st = conv_plan(d, x1, x2, aux, wp, bias, mask, res, out, out2, &pl);
   if (st != RTG_OK) return st;
   hipStream_t s = (hipStream_t)stream;
-  const ConvArgs& a = pl.a;
-  const dim3 grid(pl.blocks);
+  // a single problem is a group of one: the grouped kernel reads its arguments from the kernarg segment on demand
+  // (0 SGPR spills) where a by-value ConvArgs is preloaded into SGPRs and spills 60-100 of them to VGPR lanes
+  rtg_cv::GroupArgs ga;
+  ga.n = 1;
+  ga.p[0] = pl.a;
+  for (int i = 0; i < RTG_MAX_GROUP; ++i) ga.blk_end[i] = pl.blocks;
   const size_t lds_bytes = pl.lds_bytes;
 #define RTG_CASE(tm, mt, nt) \
-  if (pl.TM == tm && pl.MT == mt && pl.NT == nt) return rtg_conv1d_launch_##tm##_##mt##_##nt(a, grid, lds_bytes, s);
+  if (pl.TM == tm && pl.MT == mt && pl.NT == nt) return rtg_conv1d_launch_group_##tm##_##mt##_##nt(ga, lds_bytes, s);
   RTG_CASE(32, 1, 1) RTG_CASE(32, 1, 2) RTG_CASE(32, 1, 4) RTG_CASE(32, 2, 1) RTG_CASE(32, 2, 2)
   RTG_CASE(16, 1, 1) RTG_CASE(16, 1, 2) RTG_CASE(16, 1, 4)
 #undef RTG_CASE

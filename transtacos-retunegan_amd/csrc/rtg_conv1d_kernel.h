@@ -180,7 +180,9 @@ struct GroupArgs {
   ConvArgs p[RTG_MAX_GROUP];
 };
 
-template <int TM, int MT, int NT, int MAXIT>   // MAXIT: 64-float pieces of a patch row each lane stages (>= PW / 64)
+// MAXIT: 64-float pieces of a patch row each lane stages (>= PW / 64).  CLS: strided 2-D backward-data with class-pure
+// blocks (RowClass) — a compile-time flag so that every other launch carries none of that bookkeeping.
+template <int TM, int MT, int NT, int MAXIT, bool CLS>
 __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a, const unsigned bid) {
   using M = Mfma<TM>;
   using acc_t = typename M::acc_t;
@@ -211,7 +213,7 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a, const unsign
   const int BN = a.WN * NT * TM;
   const bool packed = a.seg_len > 0;
   const int b0 = packed ? bz * a.seg_nb : bz;   // first clip of this block
-  const bool cls_mode = a.two_d && a.h_mode == 1 && a.h_stride > 1;
+  constexpr bool cls_mode = CLS;        // host: two_d && h_mode == 1 && h_stride > 1
   RowClass rc = {0, 0, 0, 0, 0};
   if (cls_mode) {
     if (packed) {
@@ -321,24 +323,26 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a, const unsign
   // chunks this block walks: all of them, or (strided 2-D backward-data, rows of one residue class, see RowClass)
   // only the kernel rows of that class — virtual chunk v -> real chunk real_cc(v)
   int n_cc = a.n_cc, sub_cpk = 0, sub_kh0 = 0;
-  if (cls_mode && ((a.C1 / a.h_k) % RTG_CK) == 0) {
+  if constexpr (cls_mode) if (((a.C1 / a.h_k) % RTG_CK) == 0) {
     sub_cpk = (a.C1 / a.h_k) / RTG_CK;
     sub_kh0 = rc.cls;
     const int nkh = rc.cls < a.h_k ? (a.h_k - rc.cls + a.h_stride - 1) / a.h_stride : 0;
     n_cc = nkh * sub_cpk;
   }
   auto real_cc = [&](int v) __attribute__((always_inline)) {
-    return sub_cpk ? (sub_kh0 + (v / sub_cpk) * a.h_stride) * sub_cpk + v % sub_cpk : v;
+    if constexpr (!cls_mode) return v;
+    else return sub_cpk ? (sub_kh0 + (v / sub_cpk) * a.h_stride) * sub_cpk + v % sub_cpk : v;
   };
   const int n_steps = n_cc * a.K;
   const size_t wstep = (size_t)RTG_CK * TM;      // floats per (chunk, tap) step of one m tile
+  size_t wofs = (size_t)real_cc(0) * a.K * wstep;   // offset of the step whose A fragments were requested last
   // two named A-fragment register sets used alternately (no loop-carried copy: with a copy at the end of the tap the
   // compiler waits for the JUST-issued prefetch in the middle of the MFMA phase, one exposed L2 latency per tap)
   float a0[MT][CPN], a1[MT][CPN];
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
-    for (int cp = 0; cp < CPN; ++cp) a0[i][cp] = wptr[i][(size_t)real_cc(0) * a.K * wstep + cp * 64];
+    for (int cp = 0; cp < CPN; ++cp) a0[i][cp] = wptr[i][wofs + cp * 64];
 
   int* tab = reinterpret_cast<int*>(lds + a.tab_off);
   if (a.tapmajor) {
@@ -365,8 +369,15 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a, const unsign
   auto do_step = [&](int step, float (&cur)[MT][CPN], float (&nxt)[MT][CPN]) __attribute__((always_inline)) {
     const float* buf = lds + (cc & 1) * bufsz;
     if (step + 1 < n_steps) {
-      const bool wrap = tap + 1 == a.K;
-      const size_t nofs = ((size_t)real_cc(wrap ? cc + 1 : cc) * a.K + (wrap ? 0 : tap + 1)) * wstep;
+      // weight offset of the next step: the next tap of this chunk, or (once per chunk) tap 0 of the next walked chunk
+      size_t nofs;
+      if constexpr (cls_mode) {
+        if (tap + 1 == a.K) wofs = (size_t)real_cc(cc + 1) * a.K * wstep;
+        else wofs += wstep;
+        nofs = wofs;
+      } else {
+        nofs = (size_t)(step + 1) * wstep;       // all chunks walked in order: a plain running offset
+      }
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -569,12 +580,7 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a, const unsign
   RTG_STAMP(4);
 }
 
-template <int TM, int MT, int NT, int MAXIT>
-__global__ __launch_bounds__(RTG_THREADS) void conv1d_mfma_kernel(const ConvArgs a) {
-  conv1d_mfma_body<TM, MT, NT, MAXIT>(a, blockIdx.x);
-}
-
-template <int TM, int MT, int NT, int MAXIT>
+template <int TM, int MT, int NT, int MAXIT, bool CLS>
 __global__ __launch_bounds__(RTG_THREADS) void conv1d_mfma_group_kernel(const GroupArgs ga) {
   int pid = 0;
   unsigned start = 0;
@@ -583,18 +589,30 @@ __global__ __launch_bounds__(RTG_THREADS) void conv1d_mfma_group_kernel(const Gr
       pid = i + 1;
       start = ga.blk_end[i];
     }
-  conv1d_mfma_body<TM, MT, NT, MAXIT>(ga.p[pid], blockIdx.x - start);     // every grid is a multiple of 8 blocks
+  conv1d_mfma_body<TM, MT, NT, MAXIT, CLS>(ga.p[pid], blockIdx.x - start);     // every grid is a multiple of 8 blocks
 }
 
-template <int TM, int MT, int NT, int MAXIT>
-int launch_group_it(const GroupArgs& ga, size_t lds_bytes, hipStream_t s) {
-  auto k = conv1d_mfma_group_kernel<TM, MT, NT, MAXIT>;
+template <int TM, int MT, int NT, int MAXIT, bool CLS>
+int launch_group_cls(const GroupArgs& ga, size_t lds_bytes, hipStream_t s) {
+  auto k = conv1d_mfma_group_kernel<TM, MT, NT, MAXIT, CLS>;
   if (lds_bytes > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return -(1000 + (int)e);
   }
   hipLaunchKernelGGL(k, dim3(ga.blk_end[ga.n - 1]), dim3(RTG_THREADS), lds_bytes, s, ga);
   return rtg_launch_status();
+}
+
+template <int TM, int MT, int NT, int MAXIT>
+int launch_group_it(const GroupArgs& ga, size_t lds_bytes, hipStream_t s) {
+  bool cls = false;
+  for (int i = 0; i < ga.n; ++i) {
+    const bool c = ga.p[i].two_d && ga.p[i].h_mode == 1 && ga.p[i].h_stride > 1;
+    if (i > 0 && c != cls) return RTG_EINVAL;      // one kernel instance per launch
+    cls = c;
+  }
+  return cls ? launch_group_cls<TM, MT, NT, MAXIT, true>(ga, lds_bytes, s)
+             : launch_group_cls<TM, MT, NT, MAXIT, false>(ga, lds_bytes, s);
 }
 
 template <int TM, int MT, int NT>
@@ -606,30 +624,9 @@ int launch_group(const GroupArgs& ga, size_t lds_bytes, hipStream_t s) {
   return launch_group_it<TM, MT, NT, RTG_PW_MAX / 64>(ga, lds_bytes, s);
 }
 
-template <int TM, int MT, int NT, int MAXIT>
-int launch_it(const ConvArgs& a, dim3 grid, size_t lds_bytes, hipStream_t s) {
-  auto k = conv1d_mfma_kernel<TM, MT, NT, MAXIT>;
-  if (lds_bytes > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e != hipSuccess) return -(1000 + (int)e);
-  }
-  hipLaunchKernelGGL(k, grid, dim3(RTG_THREADS), lds_bytes, s, a);
-  return rtg_launch_status();
-}
-
-template <int TM, int MT, int NT>
-int launch(const ConvArgs& a, dim3 grid, size_t lds_bytes, hipStream_t s) {
-  if (a.PW <= 3 * 64) return launch_it<TM, MT, NT, 3>(a, grid, lds_bytes, s);
-  if (a.PW <= 5 * 64) return launch_it<TM, MT, NT, 5>(a, grid, lds_bytes, s);
-  return launch_it<TM, MT, NT, RTG_PW_MAX / 64>(a, grid, lds_bytes, s);
-}
-
 }  // namespace rtg_cv
 
 #define RTG_CONV_DEFINE(tm, mt, nt)                                                                         \
-  int rtg_conv1d_launch_##tm##_##mt##_##nt(const rtg_cv::ConvArgs& a, dim3 grid, size_t lds_bytes, hipStream_t s) { \
-    return rtg_cv::launch<tm, mt, nt>(a, grid, lds_bytes, s);                                                \
-  }                                                                                                         \
   int rtg_conv1d_launch_group_##tm##_##mt##_##nt(const rtg_cv::GroupArgs& ga, size_t lds_bytes, hipStream_t s) { \
     return rtg_cv::launch_group<tm, mt, nt>(ga, lds_bytes, s);                                             \
   }

@@ -195,6 +195,8 @@ def run_stacks(calls):
     """calls: [(stack, a, b)] -> [(logits_r, logits_g, fmaps_r, fmaps_g)] per stack.  A stack whose sub-discriminators
     share an architecture of 1-D convs (MSD, MPD) runs layer by layer in grouped launches (one branch of the fork); the
     sub-discriminators of the others (MTD) are forked side by side — one flat fork in all."""
+    if os.environ.get('RTG_FLAT_FORK', '1') == '0':          # A/B knob: a fork per stack around the stacks' own forks
+        return fork_join([(lambda st=stack, a=a, b=b: st(a, b)) for stack, a, b in calls])
     brs, spans = [], []
     for stack, a, b in calls:
         if GROUPED and getattr(stack, 'groupable', False):
