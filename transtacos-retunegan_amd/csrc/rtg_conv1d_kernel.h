@@ -365,14 +365,24 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a, const unsign
   RTG_STAMP(2);
 
   int cc = 0, tap = 0;
+  // Loop-invariant scalars pinned in SGPRs (the empty asm keeps the compiler from re-loading them from the kernarg
+  // segment inside the loop: an s_load + s_waitcnt lgkmcnt(0) per step also drains the LDS reads in flight), the LDS
+  // word offset of every k-step row per lane, and the tap offset of strided layers tracked incrementally
+  // (tap * dil = q * stride + ph) instead of divided out every step.
+  int sK = a.K, sDil = a.dil, sStride = a.stride, sPH = a.PH, sBuf = bufsz, sTapm = a.tapmajor;
+  asm volatile("" : "+s"(sK), "+s"(sDil), "+s"(sStride), "+s"(sPH), "+s"(sBuf), "+s"(sTapm));
+  int brow[CPN];
+#pragma unroll
+  for (int cp = 0; cp < CPN; ++cp) brow[cp] = bbase + cp * KK * a.ROW;
+  int tq = 0, tph = 0;                          // tap * dil = tq * stride + tph
   // one (chunk, tap) step: prefetch the next step's A fragments into `nxt`, multiply with `cur`
   auto do_step = [&](int step, float (&cur)[MT][CPN], float (&nxt)[MT][CPN]) __attribute__((always_inline)) {
-    const float* buf = lds + (cc & 1) * bufsz;
+    const float* buf = lds + (cc & 1) * sBuf;
     if (step + 1 < n_steps) {
       // weight offset of the next step: the next tap of this chunk, or (once per chunk) tap 0 of the next walked chunk
       size_t nofs;
       if constexpr (cls_mode) {
-        if (tap + 1 == a.K) wofs = (size_t)real_cc(cc + 1) * a.K * wstep;
+        if (tap + 1 == sK) wofs = (size_t)real_cc(cc + 1) * a.K * wstep;
         else wofs += wstep;
         nofs = wofs;
       } else {
@@ -386,14 +396,13 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a, const unsign
     // the next chunk's patch is requested AFTER the weight prefetch, on the chunk's first tap: vmcnt retires in order,
     // so the wait for `nxt` one tap later does not include these loads, the wait two taps later finds them landed
     if (tap == 0 && cc + 1 < n_cc) stage(real_cc(cc + 1));
-    const int td = tap * a.dil;
-    const int tapoff = (a.stride == 1) ? td : (td % a.stride) * a.PH + td / a.stride;
-    const float* bp = buf + bbase + tapoff;
+    const int tapoff = tph * sPH + tq;           // stride 1: tph == 0, PH unused
+    const float* bp = buf + tapoff;
     // read phase: all B fragments of this (chunk, tap) into distinct registers, THEN the MFMA phase — the compiler
     // otherwise recycles one register pair and serialises ds_read -> wait -> 2 MFMAs per k-step; with two waves
     // per SIMD one wave's read phase overlaps the other's MFMA phase
     float bf[CPN][NT];
-    if (a.tapmajor) {
+    if (sTapm) {
       int boff[CPN];
 #pragma unroll
       for (int cp = 0; cp < CPN; ++cp) boff[cp] = tab[(tap * CPN + cp) * KK + kk];
@@ -406,7 +415,7 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a, const unsign
 #pragma unroll
       for (int cp = 0; cp < CPN; ++cp)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) bf[cp][j] = bp[cp * KK * a.ROW + j * TM];
+        for (int j = 0; j < NT; ++j) bf[cp][j] = bp[brow[cp] + j * TM];
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -416,8 +425,19 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a, const unsign
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = M::run(cur[i][cp], bf[cp][j], acc[i][j]);
     __builtin_amdgcn_sched_barrier(0);
-    if (++tap == a.K) {
+    tq += sDil;                                  // next tap (strided layers have dil == 1: at most one carry)
+    if (sStride != 1) {
+      tq -= sDil;
+      tph += sDil;
+      if (tph >= sStride) {
+        tph -= sStride;
+        ++tq;
+      }
+    }
+    if (++tap == sK) {
       tap = 0;
+      tq = 0;
+      tph = 0;
       if (cc + 1 < n_cc) swrite(lds + ((cc + 1) & 1) * bufsz);
       __syncthreads();
       ++cc;
