@@ -162,7 +162,7 @@ def roofline(trainer, batch):
     (kernel, variant), (n, secs, flop) = max(((k, v) for k, v in agg.items() if not (k[0] == 'conv1d' and k[1] < 100)),
                                              key=lambda kv: kv[1][1])
     if kernel == 'conv1d':
-        name = f'conv1d_mfma_kernel<{variant // 100},{variant // 10 % 10},{variant % 10}>'
+        name = f'conv1d_mfma_group_kernel<{variant // 100},{variant // 10 % 10},{variant % 10}>'
     else:
         name = f'wgrad_kernel<{variant}>'
     achieved = flop / secs / 1e12
@@ -172,7 +172,7 @@ def roofline(trainer, batch):
            'algorithmic_gflop_per_launch': round(flop / n / 1e9, 4)}
     # HBM traffic and matrix-pipe occupancy of that kernel from the committed PMC passes (rocprofv3 --pmc cannot run inside
     # this process): profiles/*_pmc.json, written by tools/pmc_pass.sh + tools/pmc_summary.py from this same command
-    pmc = _pmc_for(f'conv1d_mfma_kernel<{variant // 100}, {variant // 10 % 10}, {variant % 10},' if kernel == 'conv1d'
+    pmc = _pmc_for(f'conv1d_mfma_group_kernel<{variant // 100}, {variant // 10 % 10}, {variant % 10},' if kernel == 'conv1d'
                    else f'wgrad_kernel<{variant},')
     if pmc:
         out['traffic'] = pmc['traffic']
