@@ -11,6 +11,15 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Every kernel launch of the library: hipGetLastError() is per host thread and sticky, so an error left behind by an
+// unrelated earlier runtime call (e.g. a device query made before the context existed) would be reported as the
+// status of our launch.  Clear it first; what rtg_launch_status() sees afterwards belongs to this launch.
+#define RTG_KLAUNCH(...)              \
+  do {                                \
+    (void)hipGetLastError();          \
+    hipLaunchKernelGGL(__VA_ARGS__);  \
+  } while (0)
+
 static inline int rtg_launch_status() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? RTG_OK : -(1000 + (int)e);

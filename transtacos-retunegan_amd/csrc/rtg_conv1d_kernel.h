@@ -619,7 +619,7 @@ int launch_group_cls(const GroupArgs& ga, size_t lds_bytes, hipStream_t s) {
     hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return -(1000 + (int)e);
   }
-  hipLaunchKernelGGL(k, dim3(ga.blk_end[ga.n - 1]), dim3(RTG_THREADS), lds_bytes, s, ga);
+  RTG_KLAUNCH(k, dim3(ga.blk_end[ga.n - 1]), dim3(RTG_THREADS), lds_bytes, s, ga);
   return rtg_launch_status();
 }
 

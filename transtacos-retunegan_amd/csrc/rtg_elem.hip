@@ -326,7 +326,7 @@ __global__ void adamw_bump_kernel(float* step_state, const float* loss_flag) {
 #define RTG_REQ(c) \
   if (!(c)) return RTG_ENULL
 #define RTG_LAUNCH(k, g, b, sh, st, ...)                        \
-  hipLaunchKernelGGL(k, dim3(g), dim3(b), sh, (hipStream_t)st, __VA_ARGS__); \
+  RTG_KLAUNCH(k, dim3(g), dim3(b), sh, (hipStream_t)st, __VA_ARGS__); \
   return rtg_launch_status()
 
 extern "C" int rtg_noise_lrelu_fwd(const float* x, const float* w, const float* u_in, float* out, long long n,
@@ -407,7 +407,7 @@ extern "C" int rtg_loss_fwd(int kind, const RtgLossJob* jobs, int n_jobs, float*
   LossJobs lj;
   int st = fill_jobs(&lj, kind, jobs, n_jobs, false);
   if (st) return st;
-  hipLaunchKernelGGL(loss_fwd_kernel, dim3(LOSS_GX, n_jobs), dim3(RTG_THREADS), 0, (hipStream_t)stream, kind, lj, ws);
+  RTG_KLAUNCH(loss_fwd_kernel, dim3(LOSS_GX, n_jobs), dim3(RTG_THREADS), 0, (hipStream_t)stream, kind, lj, ws);
   st = rtg_launch_status();
   if (st) return st;
   RTG_LAUNCH(loss_finish_kernel, 1, 64, 0, stream, n_jobs * LOSS_GX, ws, loss_out);
@@ -432,7 +432,7 @@ static int dyn_fwd_impl(const float* y, const float* g, int rows, int L, int k, 
   const int nwin = rows * (L / k);
   int gx = (nwin + 3) / 4;
   if (gx > 256) gx = 256;
-  hipLaunchKernelGGL((dyn_kernel<false, ENV>), dim3(gx), dim3(RTG_THREADS), 0, (hipStream_t)stream, y, g, rows, L, k,
+  RTG_KLAUNCH((dyn_kernel<false, ENV>), dim3(gx), dim3(RTG_THREADS), 0, (hipStream_t)stream, y, g, rows, L, k,
                      w / (float)nwin, (const float*)nullptr, ws, (float*)nullptr);
   int st = rtg_launch_status();
   if (st) return st;
@@ -545,9 +545,9 @@ extern "C" int rtg_strip_mirror_fwd(const float* y, int rows, int L, float w, fl
   const int half = L / 2;
   const long long n = (long long)rows * half;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(sm_reduce_kernel<0>, dim3(SM_GX), dim3(RTG_THREADS), 0, s, y, L, half, n, (const float*)stats, ws);
-  hipLaunchKernelGGL(sm_finish_kernel, dim3(1), dim3(64), 0, s, 0, (const float*)ws, stats, loss_out, 0.f);
-  hipLaunchKernelGGL(sm_reduce_kernel<1>, dim3(SM_GX), dim3(RTG_THREADS), 0, s, y, L, half, n, (const float*)stats, ws);
+  RTG_KLAUNCH(sm_reduce_kernel<0>, dim3(SM_GX), dim3(RTG_THREADS), 0, s, y, L, half, n, (const float*)stats, ws);
+  RTG_KLAUNCH(sm_finish_kernel, dim3(1), dim3(64), 0, s, 0, (const float*)ws, stats, loss_out, 0.f);
+  RTG_KLAUNCH(sm_reduce_kernel<1>, dim3(SM_GX), dim3(RTG_THREADS), 0, s, y, L, half, n, (const float*)stats, ws);
   RTG_LAUNCH(sm_finish_kernel, 1, 64, 0, stream, 1, (const float*)ws, stats, loss_out, w / (float)n);
 }
 
@@ -565,7 +565,7 @@ extern "C" int rtg_adamw(float* params, const float* grads, float* exp_avg, floa
                          float weight_decay, float grad_scale, void* stream) {
   RTG_REQ(params && grads && exp_avg && exp_avg_sq && step_state);
   if (n < 1) return RTG_EINVAL;
-  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(RTG_THREADS), 0, (hipStream_t)stream, params, grads, exp_avg,
+  RTG_KLAUNCH(adamw_kernel, dim3(grid_for(n)), dim3(RTG_THREADS), 0, (hipStream_t)stream, params, grads, exp_avg,
                      exp_avg_sq, n, step_state, loss_flag, lr, beta1, beta2, eps, weight_decay, grad_scale);
   int st = rtg_launch_status();
   if (st) return st;

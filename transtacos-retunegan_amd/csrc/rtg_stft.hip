@@ -217,7 +217,7 @@ extern "C" int rtg_stft_forward(const RtgStftDesc* d, const float* y, const floa
   const size_t lds = (size_t)d->n_fft * 2 * sizeof(cpx) + (size_t)(d->n_fft / 2 + 1) * sizeof(float);
   if (lds > 64 * 1024)
     hipFuncSetAttribute((const void*)stft_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(stft_fwd_kernel, dim3(d->frames, d->B), dim3(RTG_THREADS), lds, (hipStream_t)stream, *d, y, window,
+  RTG_KLAUNCH(stft_fwd_kernel, dim3(d->frames, d->B), dim3(RTG_THREADS), lds, (hipStream_t)stream, *d, y, window,
                      twiddle, mel_lo, mel_len, mel_woff, mel_w, mel, spec, re, im);
   return rtg_launch_status();
 }
@@ -232,11 +232,11 @@ extern "C" int rtg_stft_backward(const RtgStftDesc* d, const float* re, const fl
   const size_t lds = (size_t)d->n_fft * 2 * sizeof(cpx) + 256 * sizeof(float);
   if (lds > 64 * 1024)
     hipFuncSetAttribute((const void*)stft_bwd_frame_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(stft_bwd_frame_kernel, dim3(d->frames, d->B), dim3(RTG_THREADS), lds, (hipStream_t)stream, *d, re,
+  RTG_KLAUNCH(stft_bwd_frame_kernel, dim3(d->frames, d->B), dim3(RTG_THREADS), lds, (hipStream_t)stream, *d, re,
                      im, dmel, dspec, window, twiddle, binmel_idx, binmel_w, frame_ws);
   int e = rtg_launch_status();
   if (e) return e;
-  hipLaunchKernelGGL(stft_ola_kernel, dim3(rtg_ceil_div(d->T, RTG_THREADS), d->B), dim3(RTG_THREADS), 0,
+  RTG_KLAUNCH(stft_ola_kernel, dim3(rtg_ceil_div(d->T, RTG_THREADS), d->B), dim3(RTG_THREADS), 0,
                      (hipStream_t)stream, *d, frame_ws, dy);
   return rtg_launch_status();
 }

@@ -185,12 +185,12 @@ int rtg_thin_launch(int kind, const RtgConv1dDesc* d, const float* x, const floa
     const long long gx = (a.n_pos + RTG_THREADS - 1) / RTG_THREADS;
     const int gy = rtg_ceil_div(d->Mg, kRowsPerBlock);
     if (gx > 0x7fffffffLL || gy > 65535) return RTG_ERANGE;
-    hipLaunchKernelGGL(thin_cin1_kernel, dim3((unsigned)gx, gy), dim3(RTG_THREADS), 0, s, a);
+    RTG_KLAUNCH(thin_cin1_kernel, dim3((unsigned)gx, gy), dim3(RTG_THREADS), 0, s, a);
   } else {
     const long long gx = (a.n_pos + 63) / 64;
     if (gx > 0x7fffffffLL) return RTG_ERANGE;
     const size_t lds = ((size_t)d->Cg * d->K + 64 * kCoutWaves) * sizeof(float);
-    hipLaunchKernelGGL(thin_cout1_kernel, dim3((unsigned)gx), dim3(64 * kCoutWaves), lds, s, a);
+    RTG_KLAUNCH(thin_cout1_kernel, dim3((unsigned)gx), dim3(64 * kCoutWaves), lds, s, a);
   }
   return rtg_launch_status();
 }

@@ -159,7 +159,7 @@ extern "C" int rtg_weightnorm_scales(const RtgNormJob* jobs_dev, int n_jobs, int
   if (!jobs_dev || !params || !scales) return RTG_ENULL;
   if (n_jobs < 1 || n_jobs > 65535 || max_rows < 1) return RTG_EINVAL;
   dim3 grid(max_rows > 1024 ? 1024 : max_rows, n_jobs);
-  hipLaunchKernelGGL(wn_scales_kernel, grid, dim3(RTG_THREADS), 0, (hipStream_t)stream, jobs_dev, params, scales);
+  RTG_KLAUNCH(wn_scales_kernel, grid, dim3(RTG_THREADS), 0, (hipStream_t)stream, jobs_dev, params, scales);
   return rtg_launch_status();
 }
 
@@ -170,7 +170,7 @@ extern "C" int rtg_weights_pack(const RtgPackJob* jobs_dev, int n_jobs, long lon
   long long gx = (max_dst_size + RTG_THREADS * 4 - 1) / (RTG_THREADS * 4);
   if (gx > 4096) gx = 4096;
   dim3 grid((unsigned)gx, n_jobs);
-  hipLaunchKernelGGL(pack_kernel, grid, dim3(RTG_THREADS), 0, (hipStream_t)stream, jobs_dev, params, scales, packed);
+  RTG_KLAUNCH(pack_kernel, grid, dim3(RTG_THREADS), 0, (hipStream_t)stream, jobs_dev, params, scales, packed);
   return rtg_launch_status();
 }
 
@@ -180,7 +180,7 @@ extern "C" int rtg_weightnorm_backward(const RtgWnBwdJob* jobs_dev, int n_jobs, 
   if (!jobs_dev || !params || !scales || !partials || !grads) return RTG_ENULL;
   if (n_jobs < 1 || n_jobs > 65535 || max_rows < 1 || max_inner < 1 || max_inner > 8192) return RTG_EINVAL;
   dim3 grid(max_rows > 1024 ? 1024 : max_rows, n_jobs);
-  hipLaunchKernelGGL(wn_bwd_kernel, grid, dim3(RTG_THREADS), (size_t)4 * ((max_inner + 63) & ~63) * sizeof(float),
+  RTG_KLAUNCH(wn_bwd_kernel, grid, dim3(RTG_THREADS), (size_t)4 * ((max_inner + 63) & ~63) * sizeof(float),
                      (hipStream_t)stream,
                      jobs_dev, params, scales, partials, grads);
   return rtg_launch_status();

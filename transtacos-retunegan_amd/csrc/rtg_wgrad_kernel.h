@@ -399,7 +399,7 @@ template <int TM, int MTW, int NTW, int WM, int MAXIT, int MODE>
 int launch(const WgArgs& a, dim3 grid, size_t lds_bytes, hipStream_t s) {
   auto k = wgrad_kernel<TM, MTW, NTW, WM, MAXIT, MODE>;
   if (lds_bytes > 64 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-  hipLaunchKernelGGL(k, grid, dim3(RTG_THREADS), lds_bytes, s, a);
+  RTG_KLAUNCH(k, grid, dim3(RTG_THREADS), lds_bytes, s, a);
   return rtg_launch_status();
 }
 

@@ -2,6 +2,10 @@
 import ctypes as C
 import os
 
+import torch  # noqa: F401  FIRST: librtg.so must bind to the HIP runtime PyTorch ships and initialises (loading the
+#                     library before torch pulls in /opt/rocm's libamdhip64 instead, and every launch then fails with
+#                     hipErrorNoDevice once torch has set the device up through its own copy)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('RTG_DEV_LIB') or os.path.join(os.path.dirname(_HERE), 'librtg.so')   # RTG_DEV_LIB: tuning builds
 
