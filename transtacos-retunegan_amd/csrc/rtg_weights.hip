@@ -98,47 +98,41 @@ __global__ __launch_bounds__(RTG_THREADS) void pack_kernel(const RtgPackJob* job
   }
 }
 
-// One block per (layer, row).  The split partials of the row are summed by the four waves in parallel (wave w takes
-// splits w, w+4, ...; 64 lanes = 64 consecutive elements, 4 independent loads in flight per lane) and combined through
-// LDS in fixed order, so the result is bitwise reproducible.
+// One block per (layer, row).  Every thread owns the elements tid, tid + 256, ... of the row and sums their split
+// partials itself, splits in ascending order (bitwise reproducible, no cross-wave combine), eight independent loads in
+// flight per element group: the kernel is a pure stream over the partial buffers (0.3 GB per model and pass) and lives on
+// memory-level parallelism.  The row sum is parked in LDS for the second pass (the weight-norm chain rule needs
+// <dW_row, v_row> before any element of dv can be written).
 __global__ __launch_bounds__(RTG_THREADS) void wn_bwd_kernel(const RtgWnBwdJob* jobs, const float* params,
                                                               const float* scales, const float* partials,
                                                               float* grads) {
-  extern __shared__ float dw[];            // [4][inner_pad] per-wave sums, then the row in dw[0..inner)
+  extern __shared__ float dw[];            // [inner] the reduced row
   __shared__ float red[4];
   const RtgWnBwdJob j = jobs[blockIdx.y];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int ipad = (j.inner + 63) & ~63;
   for (int r = blockIdx.x; r < j.rows; r += gridDim.x) {
     const float* v = params + j.v_off + (size_t)r * j.inner;
     const float* p0 = partials + j.part_off + (size_t)r * j.inner;
-    for (int i0 = 0; i0 < j.inner; i0 += 64) {
-      const int i = i0 + lane;
-      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-      if (i < j.inner) {
-        int sp = wave;
-        for (; sp + 12 < j.splits; sp += 16) {
-          s0 += p0[(size_t)sp * j.part_stride + i];
-          s1 += p0[(size_t)(sp + 4) * j.part_stride + i];
-          s2 += p0[(size_t)(sp + 8) * j.part_stride + i];
-          s3 += p0[(size_t)(sp + 12) * j.part_stride + i];
-        }
-        for (; sp < j.splits; sp += 4) s0 += p0[(size_t)sp * j.part_stride + i];
-      }
-      dw[wave * ipad + i] = (s0 + s1) + (s2 + s3);
-    }
-    __syncthreads();
     float dot = 0.f;
     for (int i = threadIdx.x; i < j.inner; i += RTG_THREADS) {
-      const float s = (dw[i] + dw[ipad + i]) + (dw[2 * ipad + i] + dw[3 * ipad + i]);
+      const float* p = p0 + i;
+      float s = 0.f;
+      int sp = 0;
+      for (; sp + 8 <= j.splits; sp += 8) {
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = p[(size_t)(sp + u) * j.part_stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += t[u];
+      }
+      for (; sp < j.splits; ++sp) s += p[(size_t)sp * j.part_stride];
+      dw[i] = s;
       dot += s * v[i];
-      dw[i] = s;                             // each element is read and rewritten by the same thread only
     }
     dot = rtg_block_sum(dot, red);
     const float scale = scales[j.scale_off + r], inv_n = scales[j.scale_off + j.rows + r];
     const float k2 = scale * dot * inv_n * inv_n;
     float* dv = grads + j.v_off + (size_t)r * j.inner;
-    for (int i = threadIdx.x; i < j.inner; i += RTG_THREADS) dv[i] += scale * dw[i] - k2 * v[i];
+    for (int i = threadIdx.x; i < j.inner; i += RTG_THREADS) dv[i] += scale * dw[i] - k2 * v[i];   // own elements only
     if (threadIdx.x == 0) {
       grads[j.g_off + r] += dot * inv_n;
       if (j.b_off >= 0) {
@@ -180,7 +174,7 @@ extern "C" int rtg_weightnorm_backward(const RtgWnBwdJob* jobs_dev, int n_jobs, 
   if (!jobs_dev || !params || !scales || !partials || !grads) return RTG_ENULL;
   if (n_jobs < 1 || n_jobs > 65535 || max_rows < 1 || max_inner < 1 || max_inner > 8192) return RTG_EINVAL;
   dim3 grid(max_rows > 1024 ? 1024 : max_rows, n_jobs);
-  RTG_KLAUNCH(wn_bwd_kernel, grid, dim3(RTG_THREADS), (size_t)4 * ((max_inner + 63) & ~63) * sizeof(float),
+  RTG_KLAUNCH(wn_bwd_kernel, grid, dim3(RTG_THREADS), (size_t)max_inner * sizeof(float),
                      (hipStream_t)stream,
                      jobs_dev, params, scales, partials, grads);
   return rtg_launch_status();
