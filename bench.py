@@ -30,7 +30,8 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--workload', default='config2', choices=['config1', 'config2', 'config4', 'config5'])
+    ap.add_argument('--workload', default='config2', choices=['config1', 'config2', 'config3', 'config4', 'config5'])
+    ap.add_argument('--dtype', default=None, choices=['fp32', 'bf16'], help='conv arithmetic (default: the workload\'s)')
     ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (default: the workload\'s)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
@@ -41,6 +42,9 @@ WORKLOADS = {
     # name: (description, use_mpd, use_mtd, d_train_times, per-GPU batch, T)
     'config1': ('UNet-G + MSD, 1 D-step (BASELINE configs[0] shape on the GPU)', False, False, 1, 2, 8192),
     'config2': ('UNet-G + MSD/MPD, multi-STFT loss, d_train_times=2 (BASELINE configs[1])', True, False, 2, 32, 8192),
+    'config3': ('full stack at 16384-sample clips, bf16 operands on the bf16 matrix cores, fp32 accumulation / losses / '
+                'optimizer (BASELINE configs[2]); weight gradients and the tap-major / 1-channel layers stay fp32',
+                True, True, 2, 32, 16384),
     'config4': ('UNet-G + MSD/MPD/MTD full stack (BASELINE configs[3])', True, True, 2, 32, 8192),
     # BASELINE configs[4]: "1 s" clips = 86 frames = 22016 samples (22050 is not a multiple of the hop)
     'config5': ('finetune-shaped feed (BASELINE configs[4]): full stack, linear-spec -> mel + host Griffin-Lim reference '
@@ -214,6 +218,8 @@ def main():
     desc, use_mpd, use_mtd, d_times, batch, T = WORKLOADS[a.workload]
     if a.batch:
         batch = a.batch
+    dtype = a.dtype or ('bf16' if a.workload == 'config3' else 'fp32')
+    hp.compute_dtype = dtype                # read when the weight banks are built
     torch.manual_seed(hp.randseed)          # identical initial weights on every rank (and broadcast from rank 0)
     tr = Trainer(use_mpd=use_mpd, use_mtd=use_mtd, d_train_times=d_times, dev=device)
     feeder = None
@@ -263,7 +269,8 @@ def main():
         out = {
             'metric': 'G+D train-step audio-seconds/sec', 'value': round(value, 2), 'unit': 'audio-s/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(ms, 3),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic' if feeder is None else 'synthetic, fed from pinned host memory every step',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32' if dtype == 'fp32' else 'bf16 operands, f32 accumulate (weight gradients f32)', 'data': 'synthetic' if feeder is None else 'synthetic, fed from pinned host memory every step',
             'config': {'workload': f'{a.workload}: {desc}', 'per_gpu_batch': batch, 'clip_samples': T,
                        'global_batch': world * batch, 'd_train_times': d_times,
                        'parallelism': f'dp{world}' if world > 1 else 'single'},

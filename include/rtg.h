@@ -84,6 +84,10 @@ typedef struct RtgConv1dDesc {
   int tile_cfg;                /* block shape: 0 = the library's heuristic, else MT*100 + NT*10 + WM as listed by
                                   rtg_conv1d_tile_candidates (wave tile MT x NT MFMA tiles, WM x 4/WM waves).  Every
                                   shape gives bit-identical results; callers time the candidates once per layer      */
+  int bf16;                    /* 1: operands rounded to bf16 (activations when they are staged, weights packed by
+                                  rtg_weights_pack with RtgPackJob.bf16) and multiplied on the bf16 matrix cores
+                                  (v_mfma_f32_32x32x8_bf16_1k / 16x16x16), fp32 accumulate, fp32 tensors in HBM
+                                  (BASELINE configs[2]).  Not with tap_major.                                  */
 } RtgConv1dDesc;
 
 int rtg_conv1d(const RtgConv1dDesc* d, const float* x1, const float* x2, const float* aux, const float* wp,
@@ -111,6 +115,7 @@ int rtg_conv1d_tile_candidates(const RtgConv1dDesc* d, int* cfgs, int max);
 /* number of floats of the packed weight buffer for a layer with the given logical shape */
 long long rtg_packed_size(int groups, int Mg, int Cg, int K, int tile_m);
 /* the same for the tap-major order, and whether that order needs fewer MFMAs than the channel-major one (1 / 0) */
+long long rtg_packed_size_bf16(int groups, int Mg, int Cg, int K, int tile_m);   /* floats (2 bf16 each) */
 long long rtg_packed_size_tapmajor(int groups, int Mg, int Cg, int K, int tile_m);
 int rtg_tapmajor_pays(int Cg, int K, int tile_m);
 
@@ -176,6 +181,9 @@ typedef struct RtgPackJob {      /* one per packed layout of a layer            
   int KH;                        /* RTG_PACK_DGRAD_2D: kernel rows of the source [C_out][C_in][KH][src_K] weight;
                                     packed rows = (ci, phase), packed channels = (kh, co): kernel-row major                    */
   int tap_major;                 /* 1: [g][m-tile][k-step group][k-step][kk][m] with k-step = (channel, tap group)  */
+  int bf16;                      /* 1: bf16 fragments [g][m-tile][chunk][tap][mfma][lane][4] (dst_size in floats =
+                                    rtg_packed_size_bf16); lane (kk, m) holds channels 8*mfma + 4*kk .. +3 of the chunk
+                                    (tile_m 32, two MFMAs per chunk) or 4*kk .. +3 (tile_m 16, one MFMA)             */
 } RtgPackJob;
 
 typedef struct RtgWnBwdJob {     /* one per weight-normed tensor                                               */

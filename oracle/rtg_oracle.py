@@ -74,8 +74,13 @@ class WNConv(nn.Module):
         n = v.flatten(1).norm(dim=1).reshape(self.weight_g.shape)
         return v * (self.weight_g / n)
 
+    bf16 = False        # set per instance by the bf16 tests: operands rounded to bf16, products and sums in fp32
+                        # (what the bf16 matrix cores compute; BASELINE configs[2])
+
     def forward(self, x):
         w = self.weight()
+        if self.bf16:
+            x, w = x.bfloat16().float(), w.bfloat16().float()
         if self.kind == 'conv1d':
             return F.conv1d(x, w, self.bias, self.stride, self.padding, self.dilation, self.groups)
         if self.kind == 'convT1d':

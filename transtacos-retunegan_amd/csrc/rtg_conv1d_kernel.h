@@ -182,7 +182,28 @@ struct GroupArgs {
 
 // MAXIT: 64-float pieces of a patch row each lane stages (>= PW / 64).  CLS: strided 2-D backward-data with class-pure
 // blocks (RowClass) — a compile-time flag so that every other launch carries none of that bookkeeping.
-template <int TM, int MT, int NT, int MAXIT, bool CLS>
+// BF: bf16 operands (activations rounded when they are written to LDS, weights packed as bf16 fragments), multiplied on
+// the bf16 matrix cores with fp32 accumulation — everything around the operands (geometry, staging loads, epilogue) is
+// shared with the fp32 path.
+typedef short bf4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+template <int TM>
+struct MfmaBf;
+template <>
+struct MfmaBf<32> {
+  static __device__ __forceinline__ f32x16 run(bf4 a, bf4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a, b, c, 0, 0, 0);
+  }
+};
+template <>
+struct MfmaBf<16> {
+  static __device__ __forceinline__ f32x4 run(bf4 a, bf4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+  }
+};
+
+template <int TM, int MT, int NT, int MAXIT, bool CLS, bool BF>
 __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a, const unsigned bid) {
   using M = Mfma<TM>;
   using acc_t = typename M::acc_t;
@@ -301,6 +322,29 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a, const unsign
     }
   };
 
+  // bf16: the wave's four channel rows of one position become ONE 8-byte LDS element [channel group = wave][position]
+  // (the 4 consecutive K values a lane of the bf16 MFMA holds), written with a single ds_write_b64
+  auto swrite_bf = [&](float* buf) __attribute__((always_inline)) {
+    static_assert(RPW == 4, "one 4-channel group per wave");
+    u32x2* rowp = reinterpret_cast<u32x2*>(buf) + wave * a.ROW;
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it)
+      if (lane + 64 * it < a.PW) {
+        unsigned short hb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float v = st[i][it];
+          asm volatile("" : "+v"(v) : : "memory");
+          v = v > 0.f ? v : v * wslope;
+          hb[i] = __builtin_bit_cast(unsigned short, (__bf16)v);
+        }
+        u32x2 pk;
+        pk.x = (unsigned)hb[0] | ((unsigned)hb[1] << 16);
+        pk.y = (unsigned)hb[2] | ((unsigned)hb[3] << 16);
+        rowp[loff[it]] = pk;
+      }
+  };
+
   // ---- accumulators
   acc_t acc[MT][NT];
 #pragma unroll
@@ -336,6 +380,80 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a, const unsign
   const int n_steps = n_cc * a.K;
   const size_t wstep = (size_t)RTG_CK * TM;      // floats per (chunk, tap) step of one m tile
   size_t wofs = (size_t)real_cc(0) * a.K * wstep;   // offset of the step whose A fragments were requested last
+  if constexpr (BF) {
+    // ---------------- bf16 main loop: NMF MFMAs per (chunk, tap) step (8 or 16 channels each), same pipeline as below
+    constexpr int NMF = TM == 32 ? 2 : 1;
+    const u32x2* wpb[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      int mt = mt0 + i;
+      if (mt > a.n_mt - 1) mt = a.n_mt - 1;
+      wpb[i] = reinterpret_cast<const u32x2*>(a.wp) + ((size_t)(g * a.n_mt + mt) * a.n_cc) * a.K * (NMF * 64) + lane;
+    }
+    bf4 A0[MT][NMF], A1[MT][NMF];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int mf = 0; mf < NMF; ++mf) A0[i][mf] = __builtin_bit_cast(bf4, wpb[i][mf * 64]);
+    stage(0);
+    swrite_bf(lds);
+    __syncthreads();
+    int sK = a.K, sDil = a.dil, sStride = a.stride, sPH = a.PH, sBuf = bufsz, sROW = a.ROW;
+    asm volatile("" : "+s"(sK), "+s"(sDil), "+s"(sStride), "+s"(sPH), "+s"(sBuf), "+s"(sROW));
+    const int colbase = wn * NT * TM + n_lane;
+    int cc = 0, tap = 0, tq = 0, tph = 0;
+    auto step_bf = [&](int step, bf4 (&cur)[MT][NMF], bf4 (&nxt)[MT][NMF]) __attribute__((always_inline)) {
+      const u32x2* buf = reinterpret_cast<const u32x2*>(lds + (cc & 1) * sBuf);
+      if (step + 1 < n_steps) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int mf = 0; mf < NMF; ++mf)
+            nxt[i][mf] = __builtin_bit_cast(bf4, wpb[i][(size_t)(step + 1) * (NMF * 64) + mf * 64]);
+      }
+      if (tap == 0 && cc + 1 < n_cc) stage(cc + 1);
+      const int tapoff = tph * sPH + tq;
+      bf4 bfr[NMF][NT];
+#pragma unroll
+      for (int mf = 0; mf < NMF; ++mf)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int c4 = TM == 32 ? 2 * mf + kk : kk;
+          bfr[mf][j] = __builtin_bit_cast(bf4, buf[c4 * sROW + colbase + j * TM + tapoff]);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int mf = 0; mf < NMF; ++mf)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = MfmaBf<TM>::run(cur[i][mf], bfr[mf][j], acc[i][j]);
+      __builtin_amdgcn_sched_barrier(0);
+      tq += sDil;
+      if (sStride != 1) {
+        tq -= sDil;
+        tph += sDil;
+        if (tph >= sStride) {
+          tph -= sStride;
+          ++tq;
+        }
+      }
+      if (++tap == sK) {
+        tap = 0;
+        tq = 0;
+        tph = 0;
+        if (cc + 1 < n_cc) swrite_bf(lds + ((cc + 1) & 1) * sBuf);
+        __syncthreads();
+        ++cc;
+      }
+    };
+    int step = 0;
+    for (; step + 1 < n_steps; step += 2) {
+      step_bf(step, A0, A1);
+      step_bf(step + 1, A1, A0);
+    }
+    if (step < n_steps) step_bf(step, A0, A1);
+  } else {
   // two named A-fragment register sets used alternately (no loop-carried copy: with a copy at the end of the tap the
   // compiler waits for the JUST-issued prefetch in the middle of the MFMA phase, one exposed L2 latency per tap)
   float a0[MT][CPN], a1[MT][CPN];
@@ -449,6 +567,7 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a, const unsign
     do_step(step + 1, a1, a0);
   }
   if (step < n_steps) do_step(step, a0, a1);
+  }
   RTG_STAMP(3);
 
   // ---- epilogue, fast path (plain store): 32-bit element offsets through buffer descriptors, invalid rows / columns
@@ -600,7 +719,7 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a, const unsign
   RTG_STAMP(4);
 }
 
-template <int TM, int MT, int NT, int MAXIT, bool CLS>
+template <int TM, int MT, int NT, int MAXIT, bool CLS, bool BF>
 __global__ __launch_bounds__(RTG_THREADS) void conv1d_mfma_group_kernel(const GroupArgs ga) {
   int pid = 0;
   unsigned start = 0;
@@ -609,12 +728,12 @@ __global__ __launch_bounds__(RTG_THREADS) void conv1d_mfma_group_kernel(const Gr
       pid = i + 1;
       start = ga.blk_end[i];
     }
-  conv1d_mfma_body<TM, MT, NT, MAXIT, CLS>(ga.p[pid], blockIdx.x - start);     // every grid is a multiple of 8 blocks
+  conv1d_mfma_body<TM, MT, NT, MAXIT, CLS, BF>(ga.p[pid], blockIdx.x - start);     // every grid is a multiple of 8 blocks
 }
 
-template <int TM, int MT, int NT, int MAXIT, bool CLS>
+template <int TM, int MT, int NT, int MAXIT, bool CLS, bool BF>
 int launch_group_cls(const GroupArgs& ga, size_t lds_bytes, hipStream_t s) {
-  auto k = conv1d_mfma_group_kernel<TM, MT, NT, MAXIT, CLS>;
+  auto k = conv1d_mfma_group_kernel<TM, MT, NT, MAXIT, CLS, BF>;
   if (lds_bytes > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return -(1000 + (int)e);
@@ -624,29 +743,35 @@ int launch_group_cls(const GroupArgs& ga, size_t lds_bytes, hipStream_t s) {
 }
 
 template <int TM, int MT, int NT, int MAXIT>
-int launch_group_it(const GroupArgs& ga, size_t lds_bytes, hipStream_t s) {
+int launch_group_it(const GroupArgs& ga, size_t lds_bytes, int bf, hipStream_t s) {
   bool cls = false;
   for (int i = 0; i < ga.n; ++i) {
     const bool c = ga.p[i].two_d && ga.p[i].h_mode == 1 && ga.p[i].h_stride > 1;
     if (i > 0 && c != cls) return RTG_EINVAL;      // one kernel instance per launch
     cls = c;
   }
-  return cls ? launch_group_cls<TM, MT, NT, MAXIT, true>(ga, lds_bytes, s)
-             : launch_group_cls<TM, MT, NT, MAXIT, false>(ga, lds_bytes, s);
+  if (bf) {
+    for (int i = 0; i < ga.n; ++i)
+      if (ga.p[i].tapmajor) return RTG_EINVAL;
+    return cls ? RTG_EINVAL : launch_group_cls<TM, MT, NT, MAXIT, false, true>(ga, lds_bytes, s);
+  }
+  return cls ? launch_group_cls<TM, MT, NT, MAXIT, true, false>(ga, lds_bytes, s)
+             : launch_group_cls<TM, MT, NT, MAXIT, false, false>(ga, lds_bytes, s);
 }
 
 template <int TM, int MT, int NT>
-int launch_group(const GroupArgs& ga, size_t lds_bytes, hipStream_t s) {
+int launch_group(const GroupArgs& ga, size_t lds_bytes, int bf, hipStream_t s) {
   int pw = 0;
   for (int i = 0; i < ga.n; ++i) pw = ga.p[i].PW > pw ? ga.p[i].PW : pw;
-  if (pw <= 3 * 64) return launch_group_it<TM, MT, NT, 3>(ga, lds_bytes, s);
-  if (pw <= 5 * 64) return launch_group_it<TM, MT, NT, 5>(ga, lds_bytes, s);
-  return launch_group_it<TM, MT, NT, RTG_PW_MAX / 64>(ga, lds_bytes, s);
+  if (pw <= 3 * 64) return launch_group_it<TM, MT, NT, 3>(ga, lds_bytes, bf, s);
+  if (pw <= 5 * 64) return launch_group_it<TM, MT, NT, 5>(ga, lds_bytes, bf, s);
+  return launch_group_it<TM, MT, NT, RTG_PW_MAX / 64>(ga, lds_bytes, bf, s);
 }
 
 }  // namespace rtg_cv
 
 #define RTG_CONV_DEFINE(tm, mt, nt)                                                                         \
-  int rtg_conv1d_launch_group_##tm##_##mt##_##nt(const rtg_cv::GroupArgs& ga, size_t lds_bytes, hipStream_t s) { \
-    return rtg_cv::launch_group<tm, mt, nt>(ga, lds_bytes, s);                                             \
+  int rtg_conv1d_launch_group_##tm##_##mt##_##nt(const rtg_cv::GroupArgs& ga, size_t lds_bytes, int bf,        \
+                                                 hipStream_t s) {                                              \
+    return rtg_cv::launch_group<tm, mt, nt>(ga, lds_bytes, bf, s);                                           \
   }

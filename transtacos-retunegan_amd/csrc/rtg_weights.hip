@@ -27,14 +27,77 @@ __global__ __launch_bounds__(RTG_THREADS) void wn_scales_kernel(const RtgNormJob
   }
 }
 
+// the effective weight g*v/||v|| that packed row `row` (of group g) applies to packed channel c at packed tap `tap`
+__device__ __forceinline__ float pack_logical(const RtgPackJob& j, const float* params, const float* scales, int g,
+                                            int row, int c, int tap) {
+  const int inner = j.src_inner_c * j.src_K;
+  float val = 0.f;
+  if (row < j.Mg && c < j.Cg) {
+    long long srow = -1, sin = 0;
+    if (j.mode == RTG_PACK_FWD) {
+      srow = (long long)g * j.Mg + row;
+      sin = (long long)c * j.src_K + tap;
+    } else if (j.mode == RTG_PACK_DGRAD_S1) {
+      srow = (long long)g * j.Cg + c;
+      sin = (long long)row * j.src_K + (j.src_K - 1 - tap);
+    } else if (j.mode == RTG_PACK_DGRAD_2D) {
+      // source [C_out][C_in][KH][src_K]; packed rows (ci, phase r), packed channels (kh, co) — kernel row major, so
+      // that a block of one row residue class walks whole chunk ranges (rtg_conv1d_kernel.h) —, taps along W
+      const int ch = row / j.S, r = row - ch * j.S;
+      const int n_co = j.Cg / j.KH;
+      const int kh = c / n_co, co = c - kh * n_co;
+      const int jj = r + (j.K - 1 - tap) * j.S;
+      if (jj < j.src_K) {
+        srow = co;
+        sin = ((long long)ch * j.KH + kh) * j.src_K + jj;
+      }
+    } else {
+      const int ch = row / j.S, r = row - ch * j.S;
+      const int jj = r + (j.K - 1 - tap) * j.S;
+      if (jj < j.src_K) {
+        if (j.mode == RTG_PACK_DGRAD_POLY) {
+          srow = (long long)g * j.Cg + c;
+          sin = (long long)ch * j.src_K + jj;
+        } else {   // RTG_PACK_CONVT_POLY (groups == 1): source [C_in][C_out][K]
+          srow = c;
+          sin = (long long)ch * j.src_K + jj;
+        }
+      }
+    }
+    if (srow >= 0) val = params[j.v_off + srow * inner + sin] * scales[j.scale_off + srow];
+  }
+  return val;
+}
+
 __global__ __launch_bounds__(RTG_THREADS) void pack_kernel(const RtgPackJob* jobs, const float* params,
                                                            const float* scales, float* packed) {
   const RtgPackJob j = jobs[blockIdx.y];
   const int TM = j.tile_m, KK = 64 / TM, CPN = RTG_CK / KK;
   const int n_mt = (j.Mg + TM - 1) / TM, n_cc = (j.Cg + RTG_CK - 1) / RTG_CK;
-  const int inner = j.src_inner_c * j.src_K;
   for (long long e = (long long)blockIdx.x * RTG_THREADS + threadIdx.x; e < j.dst_size;
        e += (long long)gridDim.x * RTG_THREADS) {
+    if (j.bf16) {
+      // two bf16 per 32-bit slot: elements (2e, 2e+1) of [g][mt][cc][tap][mfma][lane][4]
+      const int NMF = TM == 32 ? 2 : 1;
+      unsigned bits = 0;
+      for (int h = 0; h < 2; ++h) {
+        long long t2 = 2 * e + h;
+        const int el = (int)(t2 % 4); t2 /= 4;
+        const int ln = (int)(t2 % 64); t2 /= 64;
+        const int mf = (int)(t2 % NMF); t2 /= NMF;
+        const int tap2 = (int)(t2 % j.K); t2 /= j.K;
+        const int cc2 = (int)(t2 % n_cc); t2 /= n_cc;
+        const int mt2 = (int)(t2 % n_mt); t2 /= n_mt;
+        const int g2 = (int)t2;
+        const int kk2 = ln / TM, m2 = ln - kk2 * TM;
+        const int c2 = cc2 * RTG_CK + (TM == 32 ? 8 * mf + 4 * kk2 : 4 * kk2) + el;
+        const float v = pack_logical(j, params, scales, g2, mt2 * TM + m2, c2, tap2);
+        const unsigned short b = __builtin_bit_cast(unsigned short, (__bf16)v);
+        bits |= (unsigned)b << (16 * h);
+      }
+      packed[j.dst_off + e] = __builtin_bit_cast(float, bits);
+      continue;
+    }
     long long t = e;
     const int m = (int)(t % TM); t /= TM;
     const int kk = (int)(t % KK); t /= KK;
@@ -58,42 +121,7 @@ __global__ __launch_bounds__(RTG_THREADS) void pack_kernel(const RtgPackJob* job
       g = (int)t;
       c = cc * RTG_CK + cp * KK + kk;
     }
-    const int row = mt * TM + m;
-    float val = 0.f;
-    if (row < j.Mg && c < j.Cg) {
-      long long srow = -1, sin = 0;
-      if (j.mode == RTG_PACK_FWD) {
-        srow = (long long)g * j.Mg + row;
-        sin = (long long)c * j.src_K + tap;
-      } else if (j.mode == RTG_PACK_DGRAD_S1) {
-        srow = (long long)g * j.Cg + c;
-        sin = (long long)row * j.src_K + (j.src_K - 1 - tap);
-      } else if (j.mode == RTG_PACK_DGRAD_2D) {
-        // source [C_out][C_in][KH][src_K]; packed rows (ci, phase r), packed channels (kh, co) — kernel row major, so
-        // that a block of one row residue class walks whole chunk ranges (rtg_conv1d_kernel.h) —, taps along W
-        const int ch = row / j.S, r = row - ch * j.S;
-        const int n_co = j.Cg / j.KH;
-        const int kh = c / n_co, co = c - kh * n_co;
-        const int jj = r + (j.K - 1 - tap) * j.S;
-        if (jj < j.src_K) {
-          srow = co;
-          sin = ((long long)ch * j.KH + kh) * j.src_K + jj;
-        }
-      } else {
-        const int ch = row / j.S, r = row - ch * j.S;
-        const int jj = r + (j.K - 1 - tap) * j.S;
-        if (jj < j.src_K) {
-          if (j.mode == RTG_PACK_DGRAD_POLY) {
-            srow = (long long)g * j.Cg + c;
-            sin = (long long)ch * j.src_K + jj;
-          } else {   // RTG_PACK_CONVT_POLY (groups == 1): source [C_in][C_out][K]
-            srow = c;
-            sin = (long long)ch * j.src_K + jj;
-          }
-        }
-      }
-      if (srow >= 0) val = params[j.v_off + srow * inner + sin] * scales[j.scale_off + srow];
-    }
+    const float val = pack_logical(j, params, scales, g, mt * TM + m, c, tap);
     packed[j.dst_off + e] = val;
   }
 }

@@ -89,3 +89,8 @@ w_loss_sm = 0.01
 
 # --- eval (hparam.py:118)
 valid_limit = batch_size * 4
+
+# --- extension (not in the reference): arithmetic of the convolutions on the MI355X path.  'fp32' = exact fp32 matrix
+# cores (BASELINE configs[1]); 'bf16' = operands rounded to bf16 on the bf16 matrix cores, fp32 accumulation, fp32 tensors,
+# fp32 losses and optimizer (BASELINE configs[2]); read when a model's weight bank is built.
+compute_dtype = 'fp32'

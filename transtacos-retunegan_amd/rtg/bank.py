@@ -79,6 +79,15 @@ class ConvLayer:
         one_d = self.kind != 'conv2d'
         self.fwd_tap = int(one_d and lib.rtg_tapmajor_pays(self.fwd_op[3], self.fwd_op[4], self.fwd_tm) == 1)
         self.bwd_tap = int(one_d and lib.rtg_tapmajor_pays(self.bwd_op[3], self.bwd_op[4], self.bwd_tm) == 1)
+        # bf16 operands (hparam.compute_dtype): per operator, where the bf16 kernel variant applies — not the tap-major K
+        # order, not the 1-channel shapes of the bandwidth kernels, not the class-pure strided 2-D backward-data
+        import hparam as hp
+        want_bf = getattr(hp, 'compute_dtype', 'fp32') == 'bf16'
+
+        def ok(op, tap):
+            return bool(want_bf and not tap and op[2] > 1 and op[3] > 1)
+        self.fwd_bf = int(ok(self.fwd_op, self.fwd_tap))
+        self.bwd_bf = int(ok(self.bwd_op, self.bwd_tap) and not (self.kind == 'conv2d' and getattr(self, 'sh', 1) > 1))
         # filled by the bank
         self.g_off = self.v_off = self.b_off = self.scale_off = 0
         self.fwd_off = self.bwd_off = 0
@@ -87,8 +96,8 @@ class ConvLayer:
         self.lid = -1
 
     def packed_sizes(self):
-        fs = lib.rtg_packed_size_tapmajor if self.fwd_tap else lib.rtg_packed_size
-        bs = lib.rtg_packed_size_tapmajor if self.bwd_tap else lib.rtg_packed_size
+        fs = lib.rtg_packed_size_bf16 if self.fwd_bf else (lib.rtg_packed_size_tapmajor if self.fwd_tap else lib.rtg_packed_size)
+        bs = lib.rtg_packed_size_bf16 if self.bwd_bf else (lib.rtg_packed_size_tapmajor if self.bwd_tap else lib.rtg_packed_size)
         f = fs(self.fwd_op[1], self.fwd_op[2], self.fwd_op[3], self.fwd_op[4], self.fwd_tm)
         b = bs(self.bwd_op[1], self.bwd_op[2], self.bwd_op[3], self.bwd_op[4], self.bwd_tm)
         return f, b
@@ -201,11 +210,11 @@ class WeightBank:
         self.max_pack = 0
         for ly in self.layers:
             norm.append(L.NormJob(ly.g_off, ly.v_off, ly.scale_off, ly.rows, ly.inner))
-            for (mode, g, mg, cg, k, s), off, size, tm, tap in (
-                    (ly.fwd_op, ly.fwd_off, ly.fwd_size, ly.fwd_tm, ly.fwd_tap),
-                    (ly.bwd_op, ly.bwd_off, ly.bwd_size, ly.bwd_tm, ly.bwd_tap)):
+            for (mode, g, mg, cg, k, s), off, size, tm, tap, bf in (
+                    (ly.fwd_op, ly.fwd_off, ly.fwd_size, ly.fwd_tm, ly.fwd_tap, ly.fwd_bf),
+                    (ly.bwd_op, ly.bwd_off, ly.bwd_size, ly.bwd_tm, ly.bwd_tap, ly.bwd_bf)):
                 pack.append(L.PackJob(ly.v_off, ly.scale_off, off, size, mode, g, mg, cg, k, ly.k, ly.inner_c, s, tm,
-                                      ly.kh, tap))
+                                      ly.kh, tap, bf))
                 self.max_pack = max(self.max_pack, size)
         self.norm_table = _table(norm, self.device)
         self.pack_table = _table(pack, self.device)

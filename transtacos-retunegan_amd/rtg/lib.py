@@ -19,7 +19,7 @@ class Conv1dDesc(C.Structure):
                                        'out_C', 'out_L', 'shuf_S', 'shuf_P', 'pre_mode')] + \
                [('pre_slope', C.c_float), ('mask_slope', C.c_float), ('out_scale', C.c_float), ('act', C.c_int),
                 ('act_slope', C.c_float), ('accumulate', C.c_int), ('tile_m', C.c_int), ('out_split', C.c_int)] + \
-               [(n, C.c_int) for n in ('h_in', 'h_k', 'h_stride', 'h_pad', 'h_n', 'h_mode', 'tap_major', 'tile_cfg')]
+               [(n, C.c_int) for n in ('h_in', 'h_k', 'h_stride', 'h_pad', 'h_n', 'h_mode', 'tap_major', 'tile_cfg', 'bf16')]
 
 
 class ConvPtrs(C.Structure):
@@ -45,7 +45,7 @@ class NormJob(C.Structure):
 class PackJob(C.Structure):
     _fields_ = [('v_off', C.c_longlong), ('scale_off', C.c_longlong), ('dst_off', C.c_longlong),
                 ('dst_size', C.c_longlong)] + \
-               [(n, C.c_int) for n in ('mode', 'groups', 'Mg', 'Cg', 'K', 'src_K', 'src_inner_c', 'S', 'tile_m', 'KH', 'tap_major')]
+               [(n, C.c_int) for n in ('mode', 'groups', 'Mg', 'Cg', 'K', 'src_K', 'src_inner_c', 'S', 'tile_m', 'KH', 'tap_major', 'bf16')]
 
 
 class WnBwdJob(C.Structure):
@@ -81,6 +81,7 @@ PROTOTYPES = {
     'rtg_conv1d_tile_candidates': (_I, [C.POINTER(Conv1dDesc), C.POINTER(C.c_int), _I]),
     'rtg_packed_size': (_LL, [_I, _I, _I, _I, _I]),
     'rtg_packed_size_tapmajor': (_LL, [_I, _I, _I, _I, _I]),
+    'rtg_packed_size_bf16': (_LL, [_I, _I, _I, _I, _I]),
     'rtg_tapmajor_pays': (_I, [_I, _I, _I]),
     'rtg_conv1d_wgrad': (_I, [C.POINTER(WgradDesc), _P, _P, _P, _P, _P, _P]),
     'rtg_wgrad_splits': (_I, [C.POINTER(WgradDesc)]),

@@ -105,12 +105,14 @@ class ConvFn(torch.autograd.Function):
         if ly.kind == 'conv':
             d = _desc(B=B, C1=C1, C2=C2, L_in=L_in, groups=g, Cg=cg, Mg=mg, K=k, stride=ly.stride, dil=ly.dil,
                       pad=ly.pad, Q=L_out, out_C=ly.cout, out_L=L_out, pre_mode=pre_mode, pre_slope=pre_slope,
-                      out_scale=out_scale, act=act, act_slope=act_slope, tile_m=ly.fwd_tm, tap_major=ly.fwd_tap)
+                      out_scale=out_scale, act=act, act_slope=act_slope, tile_m=ly.fwd_tm, tap_major=ly.fwd_tap,
+                      bf16=ly.fwd_bf)
         else:
             nq = (L_out - 1 + ly.pad) // ly.stride + 1
             d = _desc(B=B, C1=C1, C2=C2, L_in=L_in, groups=1, Cg=cg, Mg=mg, K=k, stride=1, dil=1, pad=k - 1, Q=nq,
                       out_C=ly.cout, out_L=L_out, shuf_S=ly.stride, shuf_P=ly.pad, pre_mode=pre_mode,
-                      pre_slope=pre_slope, out_scale=out_scale, act=act, act_slope=act_slope, tile_m=ly.fwd_tm, tap_major=ly.fwd_tap)
+                      pre_slope=pre_slope, out_scale=out_scale, act=act, act_slope=act_slope, tile_m=ly.fwd_tm, tap_major=ly.fwd_tap,
+                      bf16=ly.fwd_bf)
         lc = L_out if ly.kind == 'conv' else L_in
         _run_conv(d, (_p(x1), _p(x2), None, bank.fwd_ptr(ly), bank.bias_ptr(ly), None, _p(res), _p(out), None, _stream()),
                   _conv_flop(ly, B, lc), f'fwd {ly.name} B{B} L{L_in}', f'conv1d fwd {ly.name}')
@@ -176,18 +178,18 @@ class ConvFn(torch.autograd.Function):
                 d = _desc(B=B, C1=ly.cout, L_in=L_out, groups=g, Cg=cg, Mg=mg, K=k, stride=1, dil=ly.dil,
                           pad=(ly.k - 1) * ly.dil - ly.pad, Q=L_in, out_C=ly.cin, out_L=L_in, pre_mode=gy_mode,
                           pre_slope=gy_slope, mask_slope=pre_slope, out_scale=out_scale, tile_m=ly.bwd_tm,
-                          out_split=split, tap_major=ly.bwd_tap)
+                          out_split=split, tap_major=ly.bwd_tap, bf16=ly.bwd_bf)
             elif ly.kind == 'conv':
                 nq = (L_in - 1 + ly.pad) // ly.stride + 1
                 d = _desc(B=B, C1=ly.cout, L_in=L_out, groups=g, Cg=cg, Mg=mg, K=k, stride=1, dil=1, pad=k - 1, Q=nq,
                           out_C=ly.cin, out_L=L_in, shuf_S=ly.stride, shuf_P=ly.pad, pre_mode=gy_mode,
                           pre_slope=gy_slope, mask_slope=pre_slope, out_scale=out_scale, tile_m=ly.bwd_tm,
-                          out_split=split, tap_major=ly.bwd_tap)
+                          out_split=split, tap_major=ly.bwd_tap, bf16=ly.bwd_bf)
             else:   # transposed conv: backward-data is the strided conv of dy
                 d = _desc(B=B, C1=ly.cout, L_in=L_out, groups=1, Cg=cg, Mg=mg, K=k, stride=ly.stride, dil=1,
                           pad=ly.pad, Q=L_in, out_C=ly.cin, out_L=L_in, pre_mode=gy_mode, pre_slope=gy_slope,
                           mask_slope=pre_slope, out_scale=out_scale, tile_m=ly.bwd_tm, out_split=split,
-                          tap_major=ly.bwd_tap)
+                          tap_major=ly.bwd_tap, bf16=ly.bwd_bf)
             lc = L_out if ly.kind == 'conv' else L_in
             _run_conv(d, (_p(dy), None, _p(out), bank.bwd_ptr(ly), None, _p(mask), _p(resg), _p(dx1), _p(dx2), st),
                       _conv_flop(ly, B, lc), f'dgrad {ly.name} B{B} L{L_in}', f'conv1d bwd-data {ly.name}')
@@ -249,7 +251,7 @@ class Conv2dFn(torch.autograd.Function):
         pre_mode = L.PRE_LRELU if pre_slope != 1.0 else L.PRE_NONE
         d = _desc(B=B * Ho, C1=Cin * ly.kh, L_in=W, groups=1, Cg=Cin * ly.kh, Mg=ly.cout, K=ly.k, stride=ly.stride,
                   pad=ly.pad, Q=Wo, out_C=ly.cout, out_L=Wo, pre_mode=pre_mode, pre_slope=pre_slope, tile_m=ly.fwd_tm,
-                  h_in=H, h_k=ly.kh, h_stride=ly.sh, h_pad=ly.ph, h_n=Ho, h_mode=0)
+                  h_in=H, h_k=ly.kh, h_stride=ly.sh, h_pad=ly.ph, h_n=Ho, h_mode=0, bf16=ly.fwd_bf)
         flop = 2.0 * B * Ho * Wo * ly.cout * Cin * ly.kh * ly.k
         _run_conv(d, (_p(x), None, None, bank.fwd_ptr(ly), bank.bias_ptr(ly), None, None, _p(out), None, _stream()),
                   flop, f'fwd2d {ly.name} B{B} {H}x{W}', f'conv2d fwd {ly.name}')
@@ -276,7 +278,7 @@ class Conv2dFn(torch.autograd.Function):
             mask = x if pre_slope != 1.0 else None
             common = dict(B=B * H, C1=ly.cout * ly.kh, L_in=Wo, groups=1, Cg=cg, Mg=mg, K=k, out_C=Cin, out_L=W,
                           mask_slope=pre_slope, tile_m=ly.bwd_tm, h_in=Ho, h_k=ly.kh, h_stride=ly.sh, h_pad=ly.ph,
-                          h_n=H, h_mode=1)
+                          h_n=H, h_mode=1, bf16=ly.bwd_bf)
             if ly.stride == 1:
                 d = _desc(stride=1, pad=(ly.k - 1) - ly.pad, Q=W, **common)
             else:
@@ -307,7 +309,7 @@ def _fwd_desc(ly, B, C1, L_in, pre_slope):
     pre_mode = L.PRE_LRELU if pre_slope != 1.0 else L.PRE_NONE
     return _desc(B=B, C1=C1, C2=0, L_in=L_in, groups=g, Cg=cg, Mg=mg, K=k, stride=ly.stride, dil=ly.dil, pad=ly.pad,
                  Q=L_out, out_C=ly.cout, out_L=L_out, pre_mode=pre_mode, pre_slope=pre_slope, tile_m=ly.fwd_tm,
-                 tap_major=ly.fwd_tap), L_out
+                 tap_major=ly.fwd_tap, bf16=ly.fwd_bf), L_out
 
 
 def _dgrad_desc(ly, B, L_in, L_out, pre_slope):
@@ -316,11 +318,11 @@ def _dgrad_desc(ly, B, L_in, L_out, pre_slope):
     if ly.stride == 1:
         return _desc(B=B, C1=ly.cout, L_in=L_out, groups=g, Cg=cg, Mg=mg, K=k, stride=1, dil=ly.dil,
                      pad=(ly.k - 1) * ly.dil - ly.pad, Q=L_in, out_C=ly.cin, out_L=L_in, mask_slope=pre_slope,
-                     tile_m=ly.bwd_tm, tap_major=ly.bwd_tap)
+                     tile_m=ly.bwd_tm, tap_major=ly.bwd_tap, bf16=ly.bwd_bf)
     nq = (L_in - 1 + ly.pad) // ly.stride + 1
     return _desc(B=B, C1=ly.cout, L_in=L_out, groups=g, Cg=cg, Mg=mg, K=k, stride=1, dil=1, pad=k - 1, Q=nq,
                  out_C=ly.cin, out_L=L_in, shuf_S=ly.stride, shuf_P=ly.pad, mask_slope=pre_slope, tile_m=ly.bwd_tm,
-                 tap_major=ly.bwd_tap)
+                 tap_major=ly.bwd_tap, bf16=ly.bwd_bf)
 
 
 def _launch_group(descs, ptr_rows, flops, label, what):
