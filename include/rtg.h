@@ -148,6 +148,8 @@ typedef struct RtgWgradDesc {
   int shape_cfg;               /* block shape: 0 = the library's heuristic, else a code listed by
                                   rtg_wgrad_shape_candidates.  The shape does not change the summation order (the
                                   number of splits does)                                                             */
+  int bf16;                    /* 1: both operands rounded to bf16 as they are read from LDS, bf16 matrix cores, fp32
+                                  accumulation and fp32 split partials (BASELINE configs[2])                         */
 } RtgWgradDesc;
 
 int rtg_conv1d_wgrad(const RtgWgradDesc* d, const float* x1, const float* x2, const float* dy, const float* gy_aux,

@@ -128,3 +128,14 @@ def test_single_layer_bf16_is_exact_on_rounded_operands(bf16_mode, cin, cout, k,
     gin = torch.nn.grad.conv1d_input(xa.shape, w, rb(dy), stride, (k * dil - dil) // 2, dil)
     dref = gin * torch.where(x.detach() > 0, 1.0, 0.15)
     np.testing.assert_allclose(x.grad.cpu().numpy(), dref.cpu().numpy(), rtol=1e-5, atol=3e-4 * dref.abs().max().item())
+    # weight gradients: wgrad(rb(lrelu x), rb(dy)) in fp32, then the weight-norm chain rule in fp32 (straight-through
+    # rounding on a stock torch graph with the same parameters)
+    st = lambda t: t + (rb(t) - t).detach()
+    v = m.c.weight_v.detach().clone().requires_grad_(True)
+    gg = m.c.weight_g.detach().clone().requires_grad_(True)
+    b = m.c.bias.detach().clone().requires_grad_(True)
+    wfull = v * (gg / v.flatten(1).norm(dim=1).reshape(gg.shape))
+    F.conv1d(st(xa), st(wfull), b, stride, (k * dil - dil) // 2, dil).backward(rb(dy))
+    for name, ours, ref_ in (('v', m.c.weight_v.grad, v.grad), ('g', m.c.weight_g.grad, gg.grad), ('bias', m.c.bias.grad, b.grad)):
+        err = ((ours - ref_).norm() / ref_.norm()).item()
+        assert err < 2e-4, (name, err)

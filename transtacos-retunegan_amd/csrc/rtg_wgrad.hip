@@ -24,6 +24,10 @@ int rtg_wgrad_launch_m0(int, int, int, const rtg_wg::WgArgs&, dim3, size_t, hipS
 int rtg_wgrad_launch_m1(int, int, int, const rtg_wg::WgArgs&, dim3, size_t, hipStream_t);
 int rtg_wgrad_launch_m2(int, int, int, const rtg_wg::WgArgs&, dim3, size_t, hipStream_t);
 int rtg_wgrad_launch_m3(int, int, int, const rtg_wg::WgArgs&, dim3, size_t, hipStream_t);
+int rtg_wgrad_launch_m4(int, int, int, const rtg_wg::WgArgs&, dim3, size_t, hipStream_t);
+int rtg_wgrad_launch_m5(int, int, int, const rtg_wg::WgArgs&, dim3, size_t, hipStream_t);
+int rtg_wgrad_launch_m6(int, int, int, const rtg_wg::WgArgs&, dim3, size_t, hipStream_t);
+int rtg_wgrad_launch_m7(int, int, int, const rtg_wg::WgArgs&, dim3, size_t, hipStream_t);
 
 namespace {
 using namespace rtg_wg;
@@ -216,10 +220,14 @@ extern "C" int rtg_conv1d_wgrad(const RtgWgradDesc* d, const float* x1, const fl
   if (gy > 65535) return RTG_ERANGE;
   dim3 grid(d->splits, (unsigned)gy, 1);
   hipStream_t s = (hipStream_t)stream;
-  switch ((g.cont ? 1 : 0) | (two_d ? 2 : 0)) {
+  switch ((g.cont ? 1 : 0) | (two_d ? 2 : 0) | (d->bf16 ? 4 : 0)) {
     case 0: return rtg_wgrad_launch_m0(g.TM, g.shape, g.maxit, a, grid, lds_bytes, s);
     case 1: return rtg_wgrad_launch_m1(g.TM, g.shape, g.maxit, a, grid, lds_bytes, s);
     case 2: return rtg_wgrad_launch_m2(g.TM, g.shape, g.maxit, a, grid, lds_bytes, s);
-    default: return rtg_wgrad_launch_m3(g.TM, g.shape, g.maxit, a, grid, lds_bytes, s);
+    case 3: return rtg_wgrad_launch_m3(g.TM, g.shape, g.maxit, a, grid, lds_bytes, s);
+    case 4: return rtg_wgrad_launch_m4(g.TM, g.shape, g.maxit, a, grid, lds_bytes, s);
+    case 5: return rtg_wgrad_launch_m5(g.TM, g.shape, g.maxit, a, grid, lds_bytes, s);
+    case 6: return rtg_wgrad_launch_m6(g.TM, g.shape, g.maxit, a, grid, lds_bytes, s);
+    default: return rtg_wgrad_launch_m7(g.TM, g.shape, g.maxit, a, grid, lds_bytes, s);
   }
 }

@@ -35,6 +35,17 @@ struct WgArgs {
   int x_bytes, dy_bytes;
 };
 
+typedef short bf4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ bf4 to_bf4(float v0, float v1, float v2, float v3) {
+  bf4 r;
+  r.x = __builtin_bit_cast(short, (__bf16)v0);
+  r.y = __builtin_bit_cast(short, (__bf16)v1);
+  r.z = __builtin_bit_cast(short, (__bf16)v2);
+  r.w = __builtin_bit_cast(short, (__bf16)v3);
+  return r;
+}
+
 template <int TM>
 struct MfmaW;
 template <>
@@ -43,6 +54,9 @@ struct MfmaW<32> {
   static constexpr int NREG = 16;
   static __device__ __forceinline__ acc_t run(float a, float b, acc_t c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ acc_t runbf(bf4 a, bf4 b, acc_t c) {
+    return __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a, b, c, 0, 0, 0);
   }
   static __device__ __forceinline__ int row(int lane, int r) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 };
@@ -53,6 +67,9 @@ struct MfmaW<16> {
   static __device__ __forceinline__ acc_t run(float a, float b, acc_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
   }
+  static __device__ __forceinline__ acc_t runbf(bf4 a, bf4 b, acc_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+  }
   static __device__ __forceinline__ int row(int lane, int r) { return (lane >> 4) * 4 + r; }
 };
 
@@ -61,6 +78,10 @@ template <int TM, int MTW, int NTW, int WM, int MAXIT, int MODE>
 __global__ __launch_bounds__(RTG_THREADS) void wgrad_kernel(const WgArgs a) {
   using M = MfmaW<TM>;
   constexpr bool CONT = (MODE & 1) != 0, TWO_D = (MODE & 2) != 0;   // compile-time addressing mode
+  // bit 2: bf16 operands — the fp32 tiles in LDS are rounded to bf16 as they are read into fragments (a lane holds 4
+  // consecutive reduction positions), multiplied on the bf16 matrix cores, accumulated in fp32
+  constexpr bool BF = (MODE & 4) != 0;
+  constexpr int KL = BF ? 4 : 1;                // consecutive reduction positions per lane and MFMA
   using acc_t = typename M::acc_t;
   constexpr int WN = 4 / WM;
   constexpr int KK = 64 / TM;
@@ -98,13 +119,13 @@ __global__ __launch_bounds__(RTG_THREADS) void wgrad_kernel(const WgArgs a) {
     for (int j = 0; j < NTW; ++j)
 #pragma unroll
       for (int r = 0; r < M::NREG; ++r) acc[i][j][r] = 0.f;
-    a_base[i] = ((wm * MTW + i) * TM + n_lane) * ROWD + kk;
+    a_base[i] = ((wm * MTW + i) * TM + n_lane) * ROWD + kk * KL;
   }
 #pragma unroll
   for (int j = 0; j < NTW; ++j) {
     const int n = (wn * NTW + j) * TM + n_lane;      // column within the chunk
     const int cl = n / a.K, jj = n - cl * a.K;
-    b_base[j] = (cl < a.CKW) ? (cl * a.ROW + jj * a.dil + kk * a.stride) : (-(1 << 20) + kk * a.stride);
+    b_base[j] = (cl < a.CKW) ? (cl * a.ROW + jj * a.dil + kk * KL * a.stride) : (-(1 << 20) + kk * KL * a.stride);
   }
 
   // n / d for 0 <= n < 2^24 through the float reciprocal, exact after one correction step either way
@@ -351,6 +372,32 @@ __global__ __launch_bounds__(RTG_THREADS) void wgrad_kernel(const WgArgs a) {
     for (int i = 0; i < MTW; ++i) ap[i] = db + a_base[i];
 #pragma unroll
     for (int j = 0; j < NTW; ++j) bp[j] = (b_base[j] >= 0) ? xb + b_base[j] : ones + (b_base[j] + (1 << 20));
+    if constexpr (BF) {
+      constexpr int KS = KK * 4;                 // reduction positions per bf16 MFMA: 8 (32x32x8) or 16 (16x16x16)
+      constexpr int GB = 4;                      // MFMA k-steps per read phase
+#pragma unroll
+      for (int t0 = 0; t0 < TT; t0 += GB * KS) {
+        bf4 af[MTW][GB], bfv[NTW][GB];
+#pragma unroll
+        for (int u = 0; u < GB; ++u) {
+          const int t = t0 + u * KS;
+#pragma unroll
+          for (int i = 0; i < MTW; ++i) af[i][u] = to_bf4(ap[i][t], ap[i][t + 1], ap[i][t + 2], ap[i][t + 3]);
+#pragma unroll
+          for (int j = 0; j < NTW; ++j)
+            bfv[j][u] = to_bf4(bp[j][t * a.stride], bp[j][(t + 1) * a.stride], bp[j][(t + 2) * a.stride],
+                               bp[j][(t + 3) * a.stride]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < GB; ++u)
+#pragma unroll
+          for (int i = 0; i < MTW; ++i)
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) acc[i][j] = M::runbf(af[i][u], bfv[j][u], acc[i][j]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else
 #pragma unroll
     for (int t0 = 0; t0 < TT; t0 += GRP * KK) {
       float af[MTW][GRP], bf[NTW][GRP];

@@ -1,0 +1,4 @@
+// rtg_wgrad_m4.hip — wgrad kernel instances of addressing mode 0 (per-clip tiling, 1-D rows) with bf16 operands (mode bit 2)
+#include "rtg_wgrad_kernel.h"
+
+RTG_WGRAD_DEFINE_MODE(4)

@@ -34,7 +34,7 @@ class WgradDesc(C.Structure):
                                        'dy_L', 'pre_mode')] + \
                [('pre_slope', C.c_float), ('gy_mode', C.c_int), ('gy_slope', C.c_float), ('gy_scale', C.c_float),
                 ('splits', C.c_int),
-                ('part_stride', C.c_longlong)] + [(n, C.c_int) for n in ('h_in', 'h_k', 'h_stride', 'h_pad', 'h_n', 'shape_cfg')]
+                ('part_stride', C.c_longlong)] + [(n, C.c_int) for n in ('h_in', 'h_k', 'h_stride', 'h_pad', 'h_n', 'shape_cfg', 'bf16')]
 
 
 class NormJob(C.Structure):

@@ -53,6 +53,7 @@ def _run_conv(d, args, flop, label, what):
 
 def _run_wgrad(wd, ptrs, st, bank, ly, tok_id, flop, label, what):
     """rtg_conv1d_wgrad into the bank's partial slot with the tuned block shape; ptrs = (x1, x2, dy, gy_aux)"""
+    wd.bf16 = int(getattr(ly, 'wgrad_bf', 0))
     wd.shape_cfg = tune.wgrad_cfg(wd, lambda part: lib.rtg_conv1d_wgrad(C.byref(wd), *ptrs, _p(part), st))
     splits = lib.rtg_wgrad_splits(C.byref(wd))
     if splits < 1:
