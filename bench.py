@@ -22,6 +22,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_FP32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32, dense
+PEAK_HBM_GBS = 8000.0                # MI355X_MICROARCH.md: HBM3E spec (6.3 TB/s measured achievable)
 SAMPLE_RATE = 22050
 
 
@@ -148,7 +149,7 @@ def _pmc_for(prefix):
     return {'traffic': round(b / n), 'mfma_busy': round(m / n, 3), 'source': 'profiles/' + os.path.basename(files[-1])}
 
 
-def roofline(trainer, batch):
+def roofline(trainer, batch, bf16=False):
     """Live per-kernel timing of ONE extra step: every conv launch bracketed by HIP events on its launch stream."""
     from rtg import ops
     ops.PROFILE = []
@@ -156,14 +157,15 @@ def roofline(trainer, batch):
     torch.cuda.synchronize()
     rec, ops.PROFILE = ops.PROFILE, None
     agg = {}
-    for kernel, variant, flop, e0, e1, _label in rec:
+    for kernel, variant, flop, e0, e1, _label, nbytes in rec:
         k = (kernel, variant)
-        a = agg.setdefault(k, [0, 0.0, 0.0])
+        a = agg.setdefault(k, [0, 0.0, 0.0, 0.0])
         a[0] += 1
         a[1] += e0.elapsed_time(e1) * 1e-3
         a[2] += flop
+        a[3] += nbytes
     # the dominant MATRIX kernel (the bandwidth kernels of the 1-channel layers, variants < 100, are reported in by_kernel)
-    (kernel, variant), (n, secs, flop) = max(((k, v) for k, v in agg.items() if not (k[0] == 'conv1d' and k[1] < 100)),
+    (kernel, variant), (n, secs, flop, nbytes) = max(((k, v) for k, v in agg.items() if not (k[0] == 'conv1d' and k[1] < 100)),
                                              key=lambda kv: kv[1][1])
     if kernel == 'conv1d':
         name = f'conv1d_mfma_group_kernel<{variant // 100},{variant // 10 % 10},{variant % 10}>'
@@ -178,17 +180,25 @@ def roofline(trainer, batch):
     # this process): profiles/*_pmc.json, written by tools/pmc_pass.sh + tools/pmc_summary.py from this same command
     pmc = _pmc_for(f'conv1d_mfma_group_kernel<{variant // 100}, {variant // 10 % 10}, {variant % 10},' if kernel == 'conv1d'
                    else f'wgrad_kernel<{variant},')
-    if pmc:
+    if pmc and not bf16:                     # the committed PMC passes are of the fp32 instances
         out['traffic'] = pmc['traffic']
         out['traffic_unit'] = 'bytes/launch (HBM read + write, PMC FETCH_SIZE x2 + WRITE_SIZE)'
         out['mfma_busy_frac_pmc'] = pmc['mfma_busy']
         out['pmc_source'] = pmc['source']
     # the UNet-G conv stack alone (north-star target: >= 30 % of the fp32 matrix peak)
-    g_flop = sum(f for k_, v_, f, e0, e1, lb in rec if not lb.split()[1].startswith('discriminators'))
-    g_s = sum(e0.elapsed_time(e1) * 1e-3 for k_, v_, f, e0, e1, lb in rec if not lb.split()[1].startswith('discriminators'))
+    g_flop = sum(f for k_, v_, f, e0, e1, lb, _nb in rec if not lb.split()[1].startswith('discriminators'))
+    g_s = sum(e0.elapsed_time(e1) * 1e-3 for k_, v_, f, e0, e1, lb, _nb in rec if not lb.split()[1].startswith('discriminators'))
     if g_s > 0:
-        out['unet_g_conv_stack'] = {'tflops': round(g_flop / g_s / 1e12, 3), 'frac': round(g_flop / g_s / 1e12 / PEAK_FP32_MATRIX_TFLOPS, 4),
+        out['unet_g_conv_stack'] = {'tflops': round(g_flop / g_s / 1e12, 3),
+                                    'frac': None if bf16 else round(g_flop / g_s / 1e12 / PEAK_FP32_MATRIX_TFLOPS, 4),
                                     'ms_per_step': round(g_s * 1e3, 3), 'gflop_per_step': round(g_flop / 1e9, 2)}
+    if bf16 and kernel == 'conv1d' and nbytes > 0:
+        # at bf16 matrix rates (2.5 PFLOP/s dense: ridge ~312 flop/B) the conv layers (60-180 flop/B, fp32 tensors) are
+        # bound by HBM: price the launches by their algorithmic bytes (every operand tensor once) against 8 TB/s
+        gbs = nbytes / secs / 1e9
+        out.update({'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                    'frac': round(gbs / PEAK_HBM_GBS, 4), 'algorithmic_MB_per_launch': round(nbytes / n / 1e6, 2),
+                    'matrix_tflops': round(achieved, 2), 'matrix_peak_bf16_tflops': 2500.0})
     total_flop = sum(a[2] for a in agg.values())
     total_s = sum(a[1] for a in agg.values())
     out['all_conv_kernels'] = {'tflops': round(total_flop / total_s / 1e12, 3), 'ms_per_step': round(total_s * 1e3, 3),
@@ -256,7 +266,7 @@ def main():
     if feeder is not None:
         feeder.close()
     if not a.no_roofline and rank == 0:
-        roof = roofline(tr, data)
+        roof = roofline(tr, data, bf16=dtype == 'bf16')
     if world > 1:
         dist.barrier()
     cpu = None

@@ -25,7 +25,7 @@ tr.train_step(*data)
 torch.cuda.synchronize()
 rec, ops.PROFILE = ops.PROFILE, None
 agg = {}
-for kernel, variant, flop, e0, e1, label in rec:
+for kernel, variant, flop, e0, e1, label, _nb in rec:
     a = agg.setdefault((label, variant), [0, 0.0, 0.0])
     a[0] += 1; a[1] += e0.elapsed_time(e1); a[2] += flop
 tot = sum(a[1] for a in agg.values())
@@ -36,7 +36,7 @@ for (label, variant), (n, ms, flop) in sorted(agg.items(), key=lambda kv: -kv[1]
 # ---- totals by (pass, model part)
 import collections
 tot = collections.defaultdict(lambda: [0.0, 0.0, 0])
-for kernel, variant, flop, e0, e1, label in rec:
+for kernel, variant, flop, e0, e1, label, _nb in rec:
     parts = label.split()
     name = parts[1]
     if name.startswith('discriminators'):

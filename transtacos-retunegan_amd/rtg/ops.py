@@ -33,22 +33,34 @@ def _c(t):
 PROFILE = None
 
 
-def _timed(kernel, variant, flop, launch, label=''):
+def _timed(kernel, variant, flop, launch, label='', nbytes=0):
     if PROFILE is None:
         return launch()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     r = launch()
     e1.record()
-    PROFILE.append((kernel, variant, flop, e0, e1, label))
+    PROFILE.append((kernel, variant, flop, e0, e1, label, nbytes))
     return r
+
+
+def _conv_bytes(d, args):
+    """algorithmic HBM bytes of one rtg_conv1d launch: every operand tensor once (fp32), weights once"""
+    two_d = d.h_k > 1 or d.h_n > 1
+    x = (d.B // max(d.h_n, 1)) * (d.C1 // max(d.h_k, 1)) * d.h_in * d.L_in if two_d else d.B * (d.C1 + d.C2) * d.L_in
+    out = d.B * d.out_C * d.out_L
+    n = x + out + d.groups * d.Mg * d.Cg * d.K // (2 if d.bf16 else 1)
+    aux, mask, res = args[2], args[5], args[6]
+    n += x if aux else 0
+    n += out * ((1 if mask else 0) + (1 if res else 0))
+    return 4 * n
 
 
 def _run_conv(d, args, flop, label, what):
     """rtg_conv1d with the tuned block shape (rtg/tune.py); args = everything after the descriptor"""
     d.tile_cfg = tune.conv_cfg(d, lambda: lib.rtg_conv1d(C.byref(d), *args))
     check(_timed('conv1d', lib.rtg_conv1d_variant(C.byref(d)) if PROFILE is not None else 0, flop,
-                 lambda: lib.rtg_conv1d(C.byref(d), *args), label), what)
+                 lambda: lib.rtg_conv1d(C.byref(d), *args), label, _conv_bytes(d, args) if PROFILE is not None else 0), what)
 
 
 def _run_wgrad(wd, ptrs, st, bank, ly, tok_id, flop, label, what):
