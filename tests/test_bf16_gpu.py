@@ -139,3 +139,30 @@ def test_single_layer_bf16_is_exact_on_rounded_operands(bf16_mode, cin, cout, k,
     for name, ours, ref_ in (('v', m.c.weight_v.grad, v.grad), ('g', m.c.weight_g.grad, gg.grad), ('bias', m.c.bias.grad, b.grad)):
         err = ((ours - ref_).norm() / ref_.norm()).item()
         assert err < 2e-4, (name, err)
+
+
+def test_mtd_forward_backward_bf16(oracle, gold, bf16_mode):
+    """the 2-D stack (MTD) in bf16: forward against the bf16-rounding oracle on the same spectra; gradients against the
+    fp32 oracle gradients at bf16 noise level (strided 2-D backward-data stays fp32, the rest is bf16)"""
+    from models import MultiStftDiscriminator, multi_stft_loss, discriminator_loss
+    mtd, omtd = MultiStftDiscriminator(), oracle.MTD()
+    oracle.det_fill(mtd); oracle.det_fill(omtd)
+    mtd.to(DEV).train()
+    n, tot = _mirror_flags(mtd, omtd)
+    assert n >= tot - 3                                   # all but the three 1-output-channel conv_post layers
+    assert any(ly.bwd_bf for ly in mtd.bank().layers) and not all(ly.bwd_bf for ly in mtd.bank().layers)
+    _, _, y = oracle.golden_inputs()
+    yd = torch.from_numpy(gold['y_hat'])
+    S, Sg = multi_stft_loss(y.to(DEV), yd.to(DEV), ret_specs=True)
+    lr, lg, fr, fg = mtd(S, [s.detach() for s in Sg])
+    olr, olg, _, _ = omtd([s.cpu() for s in S], [s.detach().cpu() for s in Sg])
+    for a, b in zip(lr + lg, olr + olg):
+        assert ((a.detach().cpu() - b.detach()).norm() / b.detach().norm()).item() < 5e-3
+    loss, oloss = discriminator_loss(lr, lg), oracle.discriminator_loss(olr, olg)
+    np.testing.assert_allclose(loss.item(), oloss.item(), rtol=5e-3)
+    mtd.zero_grad(); omtd.zero_grad()
+    loss.backward(); oloss.backward()
+    torch.cuda.synchronize()
+    op = dict(omtd.named_parameters())
+    errs = {nm: ((p.grad.cpu() - op[nm].grad).norm() / (op[nm].grad.norm() + 1e-20)).item() for nm, p in mtd.named_parameters()}
+    assert sorted(errs.values())[len(errs) // 2] < 2e-2 and max(errs.values()) < 1e-1, max(errs.items(), key=lambda kv: kv[1])
