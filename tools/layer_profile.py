@@ -14,6 +14,7 @@ import hparam as hp  # noqa: E402
 
 wl = sys.argv[1] if len(sys.argv) > 1 else 'config2'
 desc, use_mpd, use_mtd, d_times, batch, T = bench.WORKLOADS[wl]
+hp.compute_dtype = os.environ.get('RTG_DTYPE', 'fp32')
 torch.manual_seed(hp.randseed)
 tr = Trainer(use_mpd=use_mpd, use_mtd=use_mtd, d_train_times=d_times, dev='cuda')
 data = bench.synthetic_batch(batch, T, 1, 'cuda')

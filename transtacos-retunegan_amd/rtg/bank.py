@@ -14,6 +14,7 @@ Autograd coupling: `prepare()` returns a token produced by a custom Function; ev
 token's backward runs after the last conv backward of that forward pass and flushes the partials.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -83,6 +84,13 @@ class ConvLayer:
         # order, not the 1-channel shapes of the bandwidth kernels, not the class-pure strided 2-D backward-data
         import hparam as hp
         want_bf = getattr(hp, 'compute_dtype', 'fp32') == 'bf16'
+        if want_bf and os.environ.get('RTG_BF16_NOTAP', '1') == '1':
+            # at bf16 matrix rates padding 8 channels per group to a 16-channel chunk costs less than staying on the
+            # fp32 tap-major path: the grouped MSD layers run channel-major in bf16
+            if self.fwd_tap and self.fwd_op[3] >= 8:
+                self.fwd_tap = 0
+            if self.bwd_tap and self.bwd_op[3] >= 8:
+                self.bwd_tap = 0
 
         def ok(op, tap):
             return bool(want_bf and not tap and op[2] > 1 and op[3] > 1)
