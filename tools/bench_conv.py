@@ -23,12 +23,13 @@ def run(kind, B, Cin, Cout, L, K, s, d, p, g, iters=20):
     flop = 2.0 * B * Lo * Cout * (Cin // g) * K
     if kind == 'fwd':
         tm = 32 if Cout // g >= 32 else 16
-        n = lib.rtg_packed_size(g, Cout // g, Cin // g, K, tm)
-        wp = torch.randn(n, device=dev) * 0.05
+        bf = int(os.environ.get('BENCH_BF16', '0'))
+        n = (lib.rtg_packed_size_bf16 if bf else lib.rtg_packed_size)(g, Cout // g, Cin // g, K, tm)
+        wp = (torch.randn(2 * n, device=dev) * 0.05).bfloat16().view(torch.float32) if bf else torch.randn(n, device=dev) * 0.05
         out = torch.empty(B, Cout, Lo, device=dev)
         desc = Conv1dDesc(B=B, C1=Cin, C2=0, L_in=L, groups=g, Cg=Cin // g, Mg=Cout // g, K=K, stride=s, dil=d, pad=p,
                           Q=Lo, out_C=Cout, out_L=Lo, shuf_S=1, shuf_P=0, pre_mode=1, pre_slope=0.15, mask_slope=1.0,
-                          out_scale=1.0, act=0, act_slope=1.0, accumulate=0, tile_m=tm, out_split=0)
+                          out_scale=1.0, act=0, act_slope=1.0, accumulate=0, tile_m=tm, out_split=0, bf16=bf)
         var = lib.rtg_conv1d_variant(C.byref(desc))
 
         def call():
