@@ -180,7 +180,9 @@ class DataParallel:
             return
         if flat_grad.is_cuda:
             if self.comm_stream is None:
-                self.comm_stream = torch.cuda.Stream()
+                # high priority: its own hardware queue, so that the RCCL kernels neither wait behind nor hold up the
+                # compute kernels of a forked stream that would otherwise share a queue with it (4 queues per process)
+                self.comm_stream = torch.cuda.Stream(priority=-1)
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
                 w = dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
