@@ -222,6 +222,9 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a, const unsign
   // ordered with the row blocks of one input patch next to each other (m block fastest, then group, q tile, clip) —
   // the m blocks that re-read the same patch run on the same XCD at about the same time and hit its L2 instead of
   // fetching the patch once per row block from HBM.  (Speed only: any placement computes the same result.)
+#ifdef RTG_EXP_EMPTY
+  return;
+#endif
   const int item = (int)(bid & 7u) * a.per_xcd + (int)(bid >> 3);
   if (item >= a.total) return;
   int wrk = item;
@@ -377,7 +380,11 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a, const unsign
     if constexpr (!cls_mode) return v;
     else return sub_cpk ? (sub_kh0 + (v / sub_cpk) * a.h_stride) * sub_cpk + v % sub_cpk : v;
   };
+#ifdef RTG_EXP_SKIPLOOP
+  const int n_steps = 0;
+#else
   const int n_steps = n_cc * a.K;
+#endif
   const size_t wstep = (size_t)RTG_CK * TM;      // floats per (chunk, tap) step of one m tile
   size_t wofs = (size_t)real_cc(0) * a.K * wstep;   // offset of the step whose A fragments were requested last
   if constexpr (BF) {

@@ -90,6 +90,9 @@ __global__ __launch_bounds__(RTG_THREADS) void wgrad_kernel(const WgArgs a) {
   constexpr int XR = (MAXIT <= 4) ? 8 : 4;     // patch rows staged per wave (CKW <= 4*XR)
   constexpr int GRP = 8;                       // k-steps per read phase
 
+#ifdef RTG_EXP_EMPTY
+  return;
+#endif
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
