@@ -104,9 +104,9 @@ class _Mean3(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b, c):
         import ctypes as C
-        from rtg.lib import lib, check
+        from rtg.lib import lib, check, current_stream_ptr as _sp
         out = torch.empty_like(a)
-        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        st = _sp()
         third = 1.0 / 3
         check(lib.rtg_axpby(C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(out.data_ptr()), a.numel(),
                             third, third, 0, st), 'mean3')
@@ -117,11 +117,11 @@ class _Mean3(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         import ctypes as C
-        from rtg.lib import lib, check
+        from rtg.lib import lib, check, current_stream_ptr as _sp
         dy = dy.contiguous()
         g = torch.empty_like(dy)
         check(lib.rtg_axpby(C.c_void_p(dy.data_ptr()), None, C.c_void_p(g.data_ptr()), dy.numel(), 1.0 / 3, 0.0, 0,
-                            C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'mean3 bwd')
+                            _sp()), 'mean3 bwd')
         return g, g, g
 
 

@@ -20,10 +20,11 @@ import torch
 
 from . import lib as L
 from .lib import lib, check
+from .lib import current_stream_ptr as _lib_stream_ptr
 
 
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return _lib_stream_ptr()
 
 
 def _p(t):

@@ -138,8 +138,11 @@ class _Lib:
             self._dll = dll
         return self._dll
 
-    def __getattr__(self, name):
-        return getattr(self.load(), name)
+    def __getattr__(self, name):                 # first use of a symbol only: the function is cached on the instance
+        fn = getattr(self.load(), name)
+        if not name.startswith('_'):
+            self.__dict__[name] = fn
+        return fn
 
 
 lib = _Lib()
@@ -148,3 +151,14 @@ lib = _Lib()
 def check(status, what=''):
     if status != 0:
         raise RtgError(f'librtg call {what} failed with status {status}')
+
+
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
+def current_stream_ptr():
+    """raw handle of torch's current HIP stream on the current device as a ctypes pointer (torch.cuda.current_stream()
+    builds a Stream object per call: ~5 us, 900 times per train step)"""
+    if _raw_stream is not None:
+        return C.c_void_p(_raw_stream(torch.cuda.current_device()))
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -27,7 +27,7 @@ from models.layers import BankedModel, fork_join  # noqa: F401
 from models.discrminator import run_stacks
 from models.loss import stft_cache
 from rtg import tune
-from rtg.lib import lib, check, RtgError
+from rtg.lib import lib, check, RtgError, current_stream_ptr as _lib_stream_ptr
 
 device = 'cuda' if torch.cuda.is_available() else 'cpu'
 
@@ -37,7 +37,7 @@ def _p(t):
 
 
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return _lib_stream_ptr()
 
 
 # ---------------------------------------------------------------------------------------------------------------
