@@ -29,7 +29,8 @@ def run(kind, B, Cin, Cout, L, K, s, d, p, g, iters=20):
         out = torch.empty(B, Cout, Lo, device=dev)
         desc = Conv1dDesc(B=B, C1=Cin, C2=0, L_in=L, groups=g, Cg=Cin // g, Mg=Cout // g, K=K, stride=s, dil=d, pad=p,
                           Q=Lo, out_C=Cout, out_L=Lo, shuf_S=1, shuf_P=0, pre_mode=1, pre_slope=0.15, mask_slope=1.0,
-                          out_scale=1.0, act=0, act_slope=1.0, accumulate=0, tile_m=tm, out_split=0, bf16=bf)
+                          out_scale=1.0, act=0, act_slope=1.0, accumulate=0, tile_m=tm, out_split=0, bf16=bf,
+                          tile_cfg=int(os.environ.get('BENCH_TILE', '0')))
         var = lib.rtg_conv1d_variant(C.byref(desc))
 
         def call():

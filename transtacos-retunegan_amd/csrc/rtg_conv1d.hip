@@ -13,8 +13,9 @@
 //               buffered across channel chunks; every tap / every output row re-reads it from LDS with ds_read_b32 at
 //               lane-consecutive addresses (strided convs de-interleave the patch by phase: bank-conflict free).
 //   short rows  when a clip's output row is much shorter than the block tile (MPD / MSD tails: 10..128 positions)
-//               several clips are packed side by side into one tile ("segments" of seg_len virtual positions), so the
-//               MFMA columns are not spent on padding.
+//               several clips are packed into one tile: the columns enumerate (clip, q) densely, the staged patch
+//               gives every clip a "segment" of seg_len virtual positions (outputs + halo gap), so the MFMA columns
+//               are spent neither on padding nor on the halo.
 //   A operand   weights are pre-packed (rtg_weights_pack) so that one MFMA fragment is 64 consecutive floats:
 //               each wave loads its fragments straight from L2 with one coalesced 256-B load, prefetched one
 //               (chunk, tap) step ahead — no LDS traffic and no barrier for weights.
@@ -85,12 +86,15 @@ int score_tiles(int TM, int n_mt, int Q, int B, int groups, int stride, int K, i
   for (int i = 0; i < n; ++i) {
     TileCfg c = {cs[i][0], cs[i][1], cs[i][2], cs[i][3], 0, 0};
     const int BN = c.WN * c.NT * TM;
-    if (patch_width(BN, stride, K, dil) > RTG_PW_MAX) continue;
     const int mrows = c.WM * c.MT;
     const int m_blocks = rtg_ceil_div(n_mt, mrows);
     double eff_q, n_blocks_q;
-    const int nb = BN / Lseg;
-    if (nb >= 2 && B >= 2) {             // pack nb clips per block
+    // clips packed per block: columns enumerate (clip, q) densely (Q per clip), the staged patch holds Lseg virtual
+    // positions per clip
+    int nb = BN / Q;
+    while (nb >= 2 && patch_width(nb * Lseg, stride, K, dil) > RTG_PW_MAX) --nb;
+    if ((nb < 2 || B < 2) && patch_width(BN, stride, K, dil) > RTG_PW_MAX) continue;
+    if (nb >= 2 && B >= 2) {
       c.seg_len = Lseg;
       c.seg_nb = nb < B ? nb : B;
       const int zb = rtg_ceil_div(B, c.seg_nb);
@@ -265,7 +269,7 @@ static int conv_plan(const RtgConv1dDesc* d, const float* x1, const float* x2, c
   if (c.MT == 0) return d->tile_cfg ? RTG_EINVAL : RTG_ERANGE;   // unknown shape / even the smallest patch exceeds RTG_PW_MAX
   a.WM = c.WM; a.WN = c.WN;
   const int BN = c.WN * c.NT * TM;
-  a.PW = patch_width(BN, d->stride, d->K, d->dil);
+  a.PW = patch_width(c.seg_len > 0 ? c.seg_nb * c.seg_len : BN, d->stride, d->K, d->dil);
   a.seg_len = c.seg_len; a.seg_nb = c.seg_nb;
   a.seg_pitch = c.seg_len > 0 ? c.seg_len * d->stride : 1;
   a.seg_pw = patch_width(d->Q, d->stride, d->K, d->dil);

@@ -4,7 +4,6 @@
 #pragma once
 #include <cstdio>
 #include <cstdlib>
-#include <type_traits>
 
 #include "rtg_common.h"
 
@@ -360,6 +359,16 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a, const unsign
   // ---- operand addressing
   const int n_lane = lane & (TM - 1), kk = lane / TM;
   const int bbase = kk * a.ROW + wn * NT * TM + n_lane;
+  // packed clips: the block's columns enumerate (clip, q) densely — column n is output q = n % Q of clip n / Q — while a
+  // clip's patch occupies seg_len virtual positions in LDS (its outputs plus the halo gap): pcol[j] is the LDS position
+  // of this lane's column in tile j (junk columns past the last clip read position 0 and are dropped in the epilogue)
+  int pcol[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int n = (wn * NT + j) * TM + n_lane;
+    const int seg = packed ? n / a.Q : 0;
+    pcol[j] = kk * a.ROW + (seg < a.seg_nb ? seg * a.seg_len + (n - seg * a.Q) : 0);
+  }
   const float* wptr[MT];
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
@@ -405,9 +414,12 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a, const unsign
     stage(0);
     swrite_bf(lds);
     __syncthreads();
-    int sK = a.K, sDil = a.dil, sStride = a.stride, sPH = a.PH, sBuf = bufsz, sROW = a.ROW;
-    asm volatile("" : "+s"(sK), "+s"(sDil), "+s"(sStride), "+s"(sPH), "+s"(sBuf), "+s"(sROW));
+    int sK = a.K, sDil = a.dil, sStride = a.stride, sPH = a.PH, sBuf = bufsz, sROW = a.ROW, sPacked = a.seg_len;
+    asm volatile("" : "+s"(sK), "+s"(sDil), "+s"(sStride), "+s"(sPH), "+s"(sBuf), "+s"(sROW), "+s"(sPacked));
     const int colbase = wn * NT * TM + n_lane;
+    int pcb[NT];                                   // bf16 rows are 4-channel groups: no kk * ROW term in the column
+#pragma unroll
+    for (int j = 0; j < NT; ++j) pcb[j] = pcol[j] - kk * a.ROW;
     int cc = 0, tap = 0, tq = 0, tph = 0;
     auto step_bf = [&](int step, bf4 (&cur)[MT][NMF], bf4 (&nxt)[MT][NMF]) __attribute__((always_inline)) {
       const u32x2* buf = reinterpret_cast<const u32x2*>(lds + (cc & 1) * sBuf);
@@ -426,7 +438,7 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a, const unsign
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
           const int c4 = TM == 32 ? 2 * mf + kk : kk;
-          bfr[mf][j] = __builtin_bit_cast(bf4, buf[c4 * sROW + colbase + j * TM + tapoff]);
+          bfr[mf][j] = __builtin_bit_cast(bf4, buf[c4 * sROW + (sPacked ? pcb[j] : colbase + j * TM) + tapoff]);
         }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -494,8 +506,10 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a, const unsign
   // segment inside the loop: an s_load + s_waitcnt lgkmcnt(0) per step also drains the LDS reads in flight), the LDS
   // word offset of every k-step row per lane, and the tap offset of strided layers tracked incrementally
   // (tap * dil = q * stride + ph) instead of divided out every step.
-  int sK = a.K, sDil = a.dil, sStride = a.stride, sPH = a.PH, sBuf = bufsz, sTapm = a.tapmajor;
-  asm volatile("" : "+s"(sK), "+s"(sDil), "+s"(sStride), "+s"(sPH), "+s"(sBuf), "+s"(sTapm));
+  int sK = a.K, sDil = a.dil, sStride = a.stride, sPH = a.PH, sBuf = bufsz, sTapm = a.tapmajor, sPacked = a.seg_len;
+  asm volatile("" : "+s"(sK), "+s"(sDil), "+s"(sStride), "+s"(sPH), "+s"(sBuf), "+s"(sTapm), "+s"(sPacked));
+  int sRowStep = KK * a.ROW;
+  asm volatile("" : "+s"(sRowStep));
   int brow[CPN];
 #pragma unroll
   for (int cp = 0; cp < CPN; ++cp) brow[cp] = bbase + cp * KK * a.ROW;
@@ -531,11 +545,25 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a, const unsign
       int boff[CPN];
 #pragma unroll
       for (int cp = 0; cp < CPN; ++cp) boff[cp] = tab[(tap * CPN + cp) * KK + kk];
-      const float* b0p = buf + wn * NT * TM + n_lane;
+      if (sPacked) {
 #pragma unroll
-      for (int cp = 0; cp < CPN; ++cp)
+        for (int cp = 0; cp < CPN; ++cp)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) bf[cp][j] = b0p[boff[cp] + j * TM];
+          for (int j = 0; j < NT; ++j) bf[cp][j] = buf[boff[cp] + pcol[j] - kk * a.ROW];
+      } else {
+        const float* b0p = buf + wn * NT * TM + n_lane;
+#pragma unroll
+        for (int cp = 0; cp < CPN; ++cp)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) bf[cp][j] = b0p[boff[cp] + j * TM];
+      }
+    } else if (sPacked) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const float* bj = bp + pcol[j];
+#pragma unroll
+        for (int cp = 0; cp < CPN; ++cp) bf[cp][j] = bj[cp * sRowStep];
+      }
     } else {
 #pragma unroll
       for (int cp = 0; cp < CPN; ++cp)
@@ -607,8 +635,8 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a, const unsign
         int b = b0;
         bool ok = true;
         if (packed) {
-          const int seg = q / a.seg_len;
-          q -= seg * a.seg_len;
+          const int seg = q / a.Q;
+          q -= seg * a.Q;
           b = b0 + seg;
           ok = seg < a.seg_nb && b < a.B;
         }
@@ -662,6 +690,9 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a, const unsign
   }
 
   // ---- epilogue, general path (polyphase shuffle store, concat-split store, 2-D outputs)
+#ifdef RTG_EXP_NOGENERAL
+  return;                                 // ablation: code-size experiment (results of the general path are dropped)
+#endif
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     if (mt0 + i >= a.n_mt) continue;
@@ -671,8 +702,8 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a, const unsign
       int b = b0;
       int seg = 0;
       if (packed) {
-        seg = q / a.seg_len;
-        q -= seg * a.seg_len;
+        seg = q / a.Q;
+        q -= seg * a.Q;
         b = b0 + seg;
         if (seg >= a.seg_nb || (cls_mode ? seg >= rc.cnt : b >= a.B)) continue;
       }
