@@ -605,10 +605,13 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a, const unsign
   }
   RTG_STAMP(3);
 
-  // ---- epilogue, fast path (plain store): 32-bit element offsets through buffer descriptors, invalid rows / columns
-  // loaded from / stored to an out-of-range offset (returned as 0 / dropped by the hardware): no per-element branches,
-  // all loads of a tile in flight together, stores issue back to back
-  if (a.shuf_S == 1 && a.out_split == 0 && !a.two_d) {
+  // ---- epilogue, fast path (plain and polyphase "shuffle" stores): 32-bit element offsets through buffer descriptors,
+  // invalid rows / columns loaded from / stored to an out-of-range offset (returned as 0 / dropped by the hardware): no
+  // per-element branches, all loads of a tile in flight together, stores issue back to back.  Row m of the GEMM is
+  // output channel ch = m / S at phase m % S (S = shuf_S, 1 for a plain conv): element (m, q) lands at position
+  // q * S + phase - shuf_P of channel ch; the per-row part (ch, phase: one division per accumulator row) is computed
+  // once per m tile, the per-column part once per column tile, an element costs an add, a range check and a select.
+  if (a.out_split == 0) {
     const int out_bytes = a.B * a.out_C * a.out_L * 4;
     const rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, out_bytes, 0x00020000);
     const rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(a.bias ? a.bias : a.out), 0, a.bias ? a.out_C * 4 : 0,
@@ -619,37 +622,62 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a, const unsign
                                                         0x00020000);
     const rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, a.accumulate ? out_bytes : 0, 0x00020000);
     const float mslope = a.mask ? a.mask_slope : 1.f;
+    const int S = a.shuf_S;
+    const float invS = 1.0f / (float)S;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       if (mt0 + i >= a.n_mt) continue;
       const int mbase = (mt0 + i) * TM;
       float bv[M::NREG];
+      unsigned rowoff[M::NREG];          // (ch * out_L + phase - shuf_P) * 4, modulo 2^32 (the column part makes it >= 0)
+      int rowph[M::NREG];                // phase - shuf_P; far negative for rows past Mg (fails every range check)
 #pragma unroll
       for (int r = 0; r < M::NREG; ++r) {
         const int m = mbase + M::row(lane, r);
-        bv[r] = buf_load(rb, m < a.Mg ? (unsigned)(g * a.Mg + m) * 4u : RTG_OOB);
+        const int mrow = g * a.Mg + m;
+        int ch = mrow, ph = 0;
+        if (S != 1) {                    // mrow / S through the float reciprocal (mrow < 2^24), one correction step
+          ch = (int)((float)mrow * invS);
+          ph = mrow - ch * S;
+          if (ph < 0) { --ch; ph += S; }
+          else if (ph >= S) { ++ch; ph -= S; }
+          ph -= a.shuf_P;
+        }
+        const bool rok = m < a.Mg;
+        rowoff[r] = (unsigned)(ch * a.h_n * a.out_L + ph) * 4u;          // h_n == 1 in 1-D
+        rowph[r] = rok ? ph : -(1 << 28);
+        bv[r] = buf_load(rb, rok ? (unsigned)ch * 4u : RTG_OOB);
       }
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         int q = q_blk + (wn * NT + j) * TM + n_lane;
         int b = b0;
         bool ok = true;
+        int seg = 0;
         if (packed) {
-          const int seg = q / a.Q;
+          seg = q / a.Q;
           q -= seg * a.Q;
           b = b0 + seg;
-          ok = seg < a.seg_nb && b < a.B;
+          ok = seg < a.seg_nb && (cls_mode ? seg < rc.cnt : b < a.B);
         }
         ok = ok && q < a.Q;
-        const unsigned col = ok ? ((unsigned)(b * a.out_C + g * a.Mg + mbase) * (unsigned)a.out_L + (unsigned)q) * 4u
-                                : RTG_OOB;
+        int hh = 0;
+        if (a.two_d) {                     // clip -> (batch item, output row)
+          int item = b / a.h_n;
+          hh = b - item * a.h_n;
+          if (cls_mode) {
+            item = rc.item;
+            hh = rc.first + (rc.j0 + seg) * a.h_stride;
+          }
+          b = item;
+        }
+        const int qs = ok ? q * S : -(1 << 28);
+        const unsigned col = ((unsigned)(b * a.out_C * a.h_n + hh) * (unsigned)a.out_L + (unsigned)(q * S)) * 4u;
         unsigned off[M::NREG];
         float mv[M::NREG], rv[M::NREG], av[M::NREG];
 #pragma unroll
-        for (int r = 0; r < M::NREG; ++r) {
-          const int row = M::row(lane, r);
-          off[r] = (mbase + row < a.Mg) ? (col + (unsigned)row * (unsigned)a.out_L * 4u) | (col & RTG_OOB) : RTG_OOB;
-        }
+        for (int r = 0; r < M::NREG; ++r)
+          off[r] = ((unsigned)(qs + rowph[r]) < (unsigned)a.out_L) ? col + rowoff[r] : RTG_OOB;
         // optional operands: uniform branches per tile (an absent operand costs no load instructions at all; a load
         // through a zero-record descriptor would still occupy the address unit for a full wave)
         if (a.mask) {
@@ -689,7 +717,7 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a, const unsign
     return;
   }
 
-  // ---- epilogue, general path (polyphase shuffle store, concat-split store, 2-D outputs)
+  // ---- epilogue, general path (concat-split store)
 #ifdef RTG_EXP_NOGENERAL
   return;                                 // ablation: code-size experiment (results of the general path are dropped)
 #endif
