@@ -93,6 +93,7 @@ class BankedModel(nn.Module):
 import os
 
 _FORK_STREAMS = {}
+_FORK_MAX = int(os.environ.get('RTG_FORK_MAX', '0'))
 _FORK_PATH = [()]
 if hasattr(torch.autograd.graph, 'set_warn_on_accumulate_grad_stream_mismatch'):
     # leaves are accumulated on the stream of their first use while forked branches run elsewhere: intended
@@ -123,18 +124,21 @@ def fork_join(fns):
     main = torch.cuda.current_stream()
     path = _FORK_PATH[0]
     pool = _FORK_STREAMS.setdefault((main.device, path), [])
-    while len(pool) < len(fns):
+    n_str = len(fns) if _FORK_MAX <= 0 else min(len(fns), _FORK_MAX)   # RTG_FORK_MAX: branches share streams round-robin
+    while len(pool) < n_str:
         pool.append(torch.cuda.Stream(device=main.device))
     outs = []
     try:
-        for i, (f, s) in enumerate(zip(fns, pool)):
-            s.wait_stream(main)
+        for i, f in enumerate(fns):
+            s = pool[i % n_str]
+            if i < n_str:
+                s.wait_stream(main)
             _FORK_PATH[0] = path + (i,)
             with torch.cuda.stream(s):
                 outs.append(f())
     finally:
         _FORK_PATH[0] = path
-    for s in pool[:len(fns)]:
+    for s in pool[:n_str]:
         main.wait_stream(s)
     _record(outs, main)          # produced on a side stream, consumed (and later freed) on the main one
     return outs
