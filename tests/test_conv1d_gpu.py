@@ -248,3 +248,79 @@ def test_thin_kernels_match_the_mfma_path(case):
     mfma = run_conv(dict(desc, tile_cfg=111), x, wp, bias=bias, mask=mask, res=res, out_shape=(B, Cout, L_out))
     assert lib.rtg_conv1d_variant(C.byref(Conv1dDesc(**dict(desc, tile_cfg=111)))) >= 100
     np.testing.assert_allclose(thin.numpy(), mfma.numpy(), rtol=2e-5, atol=2e-5)
+
+
+PACKED_CASES = [
+    # B, C_in, C_out, L, K, stride, dil, pad, groups, tile_m — rows much shorter than a block tile: clips are packed
+    (37, 64, 64, 10, 5, 1, 1, 2, 1, 32),         # MPD tail, clip count not a multiple of the clips per block
+    (5, 32, 64, 21, 5, 1, 1, 2, 1, 32),
+    (9, 48, 32, 34, 5, 1, 1, 2, 1, 32),          # channels not a multiple of the chunk
+    (7, 32, 32, 1, 3, 1, 1, 1, 1, 32),           # one position per clip
+    (11, 32, 32, 2, 5, 1, 1, 2, 1, 32),          # rows shorter than the kernel
+    (6, 32, 32, 16, 3, 1, 9, 9, 1, 32),          # dilation wider than the row
+    (13, 32, 64, 61, 5, 3, 1, 2, 1, 32),         # strided, packed (phase-de-interleaved patch)
+    (10, 32, 64, 28, 5, 3, 1, 2, 1, 32),
+    (12, 64, 64, 40, 41, 4, 1, 20, 8, 16),       # grouped k41 s4 (tile_m 16), short rows
+    (3, 32, 32, 63, 7, 1, 1, 3, 1, 32),          # just under half / a full tile
+    (3, 32, 32, 65, 7, 1, 1, 3, 1, 32),
+    (2, 32, 32, 127, 3, 1, 1, 1, 1, 32),
+]
+
+
+@pytest.mark.parametrize('case', PACKED_CASES)
+def test_packed_short_clips_every_block_shape(case):
+    """Packed clips (rtg_conv1d_kernel.h: columns enumerate (clip, q) densely, the staged patch keeps a halo gap per
+    clip): every block shape against torch, with bias, mask, residual and activation in the epilogue."""
+    from rtg.lib import lib, Conv1dDesc
+    B, Cin, Cout, L, K, s, d, p, g, TM = case
+    gen = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    x = torch.randn(B, Cin, L, generator=gen)
+    w = torch.randn(Cout, Cin // g, K, generator=gen) / np.sqrt(Cin // g * K)
+    bias = torch.randn(Cout, generator=gen)
+    ref = F.conv1d(F.leaky_relu(x, 0.15).double(), w.double(), bias.double(), s, p, d, g)
+    L_out = ref.shape[-1]
+    res = torch.randn(B, Cout, L_out, generator=gen)
+    mask = torch.randn(B, Cout, L_out, generator=gen)
+    ref = ref * torch.where(mask > 0, 1.0, 0.15).double()
+    ref = F.leaky_relu((ref + res.double()) * 0.5, 0.01).float()
+    wp = packref.pack_logical(packref.logical_fwd(w.numpy(), g), TM)
+    desc = base_desc(B, Cin, 0, L, g, Cin // g, Cout // g, K, s, d, p, L_out, Cout, L_out, TM,
+                     pre_mode=1, pre_slope=0.15, mask_slope=0.15, out_scale=0.5, act=1, act_slope=0.01)
+    cands = (C.c_int * 16)()
+    n = lib.rtg_conv1d_tile_candidates(C.byref(Conv1dDesc(**desc)), cands, 16)
+    assert n >= 1
+    first = None
+    for c in cands[:n]:
+        out = run_conv(dict(desc, tile_cfg=c), x, wp, bias=bias, mask=mask, res=res, out_shape=(B, Cout, L_out))
+        np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=1e-4, atol=2e-5, err_msg=f'tile_cfg {c}')
+        if first is None:
+            first = out
+        assert torch.equal(out, first), f'tile_cfg {c}: bits differ between block shapes'
+
+
+@pytest.mark.parametrize('case', [(13, 32, 64, 61, 5, 3, 2, 1, 32), (37, 64, 64, 30, 5, 3, 2, 1, 32),
+                                  (9, 64, 128, 40, 41, 4, 20, 8, 16), (5, 16, 32, 17, 7, 4, 3, 1, 32)])
+def test_packed_polyphase_dgrad_every_block_shape(case):
+    """Backward-data of strided convs on short rows: packed clips + polyphase shuffle store + lrelu' mask through the
+    descriptor-based epilogue, every block shape."""
+    from rtg.lib import lib, Conv1dDesc
+    B, Cin, Cout, L, K, s, p, g, TM = case
+    gen = torch.Generator().manual_seed(29)
+    x = torch.randn(B, Cin, L, generator=gen, dtype=torch.float64, requires_grad=True)
+    w = (torch.randn(Cout, Cin // g, K, generator=gen) / np.sqrt(Cin // g * K))
+    y = F.conv1d(F.leaky_relu(x, 0.15), w.double(), None, s, p, 1, g)
+    dy = torch.randn(y.shape, generator=gen)
+    y.backward(dy.double())
+    Lo = y.shape[-1]
+    nt = -(-K // s)
+    wp = packref.pack_logical(packref.logical_dgrad_poly(w.numpy(), g, s), TM)
+    NQ = (L - 1 + p) // s + 1
+    desc = base_desc(B, Cout, 0, Lo, g, Cout // g, (Cin // g) * s, nt, 1, 1, nt - 1, NQ, Cin, L, TM,
+                     shuf_S=s, shuf_P=p, mask_slope=0.15)
+    mask = x.detach().float()                       # d lrelu(x) / dx = 1 for x > 0, 0.15 otherwise
+    cands = (C.c_int * 16)()
+    n = lib.rtg_conv1d_tile_candidates(C.byref(Conv1dDesc(**desc)), cands, 16)
+    assert n >= 1
+    for c in cands[:n]:
+        out = run_conv(dict(desc, tile_cfg=c), dy, wp, mask=mask, out_shape=(B, Cin, L))
+        np.testing.assert_allclose(out.numpy(), x.grad.float().numpy(), rtol=1e-4, atol=2e-5, err_msg=f'tile_cfg {c}')
