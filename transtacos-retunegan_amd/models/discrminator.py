@@ -132,10 +132,38 @@ def _split(t, B):
     return r, g
 
 
+# Generator step (D frozen): real and generated clips of a sub-discriminator run as ONE 2B-clip launch per layer
+# (ops.PairConvFn), the backward-data only over the generated half.  RTG_PAIR=0: two separate passes (A/B knob).
+PAIRED = os.environ.get('RTG_PAIR', '1') == '1'
+
+
+def _pairable(d):
+    return (hasattr(d, 'pre') and hasattr(d, 'post') and
+            all(c._layer is not None and c._layer.kind == 'conv' for c in list(d.convs) + [d.conv_post]))
+
+
+def _run_pair(d, tok, x_real, x_fake):
+    B = x_fake.shape[0]
+    with torch.no_grad():
+        xr = d.pre(x_real)
+    hr, hg = ops.pair_entry(xr, d.pre(x_fake))
+    fr, fg = [], []
+    for li, c in enumerate(d.convs):
+        hr, hg = ops.pair_conv(tok, c._layer, hr, hg, pre_slope=LRELU_SLOPE if li > 0 else 1.0)
+        fr.append(hr)
+        fg.append(hg)
+    lr, lg = ops.pair_conv(tok, d.conv_post._layer, hr, hg, pre_slope=LRELU_SLOPE)
+    lr, fr = d.post(lr, fr, B)
+    lg, fg = d.post(lg, fg, B)
+    return lr, lg, fr, fg
+
+
 def _sub_runner(d, tok, inp, frozen):
     """closure running one sub-discriminator on (real, fake): separately when D is frozen (real half without autograd),
     as one 2B batch otherwise.  Returns (logit_r, logit_g, fmap_r, fmap_g)."""
     def run():
+        if frozen and PAIRED and _pairable(d):
+            return _run_pair(d, tok, inp[0], inp[1])
         if frozen:
             with torch.no_grad():
                 lr, fr = d.run(tok, inp[0])

@@ -353,6 +353,86 @@ def _launch_group(descs, ptr_rows, flops, label, what):
     return True
 
 
+class PairEntryFn(torch.autograd.Function):
+    """(x_const, x_grad) -> the two halves of ONE [2B, ...] buffer (x_const first), so that the convs of a frozen stack
+    can run both as a single 2B-clip launch (PairConvFn).  Gradient flows to x_grad only."""
+
+    @staticmethod
+    def forward(ctx, x_const, x_grad):
+        _need_cuda(x_const, x_grad)
+        assert x_const.shape == x_grad.shape
+        B = x_const.shape[0]
+        buf = torch.empty((2 * B,) + tuple(x_const.shape[1:]), device=x_const.device, dtype=torch.float32)
+        buf[:B].copy_(x_const)
+        buf[B:].copy_(x_grad)
+        o_c, o_g = buf[:B], buf[B:]
+        ctx.mark_non_differentiable(o_c)
+        ctx.set_materialize_grads(False)
+        return o_c, o_g
+
+    @staticmethod
+    def backward(ctx, d_c, d_g):
+        return None, d_g
+
+
+def _adjacent(a, b):
+    return (a.is_contiguous() and b.is_contiguous() and a.shape == b.shape and
+            b.data_ptr() == a.data_ptr() + a.numel() * a.element_size())
+
+
+class PairConvFn(torch.autograd.Function):
+    """The generator step runs every (frozen) discriminator on the real and on the generated clips; only the generated
+    half carries a gradient.  Forward: ONE launch over both halves (they are the two halves of one buffer: same work per
+    launch as the discriminator step's 2B batch instead of two half-filled grids).  Backward: backward-data of the
+    generated half alone; the real half's output is non-differentiable, D's weights get no gradient here (the reference
+    discards them: train.py:133)."""
+
+    @staticmethod
+    def forward(ctx, token, ly, pre_slope, x_c, x_g):
+        _need_cuda(x_c, x_g)
+        assert _adjacent(x_c, x_g), 'PairConvFn needs the halves of one buffer (PairEntryFn)'
+        assert ly.kind == 'conv'
+        bank = token._rtg_bank
+        B, C1, L_in = x_c.shape
+        assert C1 == ly.cin
+        d, L_out = _fwd_desc(ly, 2 * B, C1, L_in, pre_slope)
+        out = torch.empty(2 * B, ly.cout, L_out, device=x_c.device, dtype=torch.float32)
+        _run_conv(d, (_p(x_c), None, None, bank.fwd_ptr(ly), bank.bias_ptr(ly), None, None, _p(out), None, _stream()),
+                  _conv_flop(ly, 2 * B, L_out), f'fwd {ly.name} B{2 * B} L{L_in}', f'conv1d fwd {ly.name}')
+        o_c, o_g = out[:B], out[B:]
+        ctx.ly, ctx.bank, ctx.pre_slope = ly, bank, pre_slope
+        ctx.save_for_backward(x_g)
+        ctx.mark_non_differentiable(o_c)
+        ctx.set_materialize_grads(False)
+        return o_c, o_g
+
+    @staticmethod
+    def backward(ctx, d_c, d_g):
+        if ctx.needs_input_grad[0]:
+            raise L.RtgError('PairConvFn is for frozen stacks: no weight gradient path')
+        if d_g is None or not ctx.needs_input_grad[4]:
+            return None, None, None, None, None
+        ly, bank, pre_slope = ctx.ly, ctx.bank, ctx.pre_slope
+        x_g, = ctx.saved_tensors
+        d_g = _c(d_g)
+        B, C1, L_in = x_g.shape
+        L_out = d_g.shape[-1]
+        dx = torch.empty_like(x_g)
+        d = _dgrad_desc(ly, B, L_in, L_out, pre_slope)
+        _run_conv(d, (_p(d_g), None, None, bank.bwd_ptr(ly), None, _p(x_g) if pre_slope != 1.0 else None, None, _p(dx),
+                      None, _stream()),
+                  _conv_flop(ly, B, L_out), f'dgrad {ly.name} B{B} L{L_in}', f'conv1d bwd-data {ly.name}')
+        return None, None, None, None, dx
+
+
+def pair_entry(x_const, x_grad):
+    return PairEntryFn.apply(x_const, x_grad)
+
+
+def pair_conv(token, ly, x_c, x_g, pre_slope=1.0):
+    return PairConvFn.apply(token, ly, float(pre_slope), x_c, x_g)
+
+
 class GroupConvFn(torch.autograd.Function):
     """outs[i] = conv_i(leaky_relu(xs[i], pre_slope)) + bias_i for the same layer position of n sub-discriminators (same
     bank): forward and backward-data are ONE launch each for the whole group, the weight gradients go through the
