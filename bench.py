@@ -240,6 +240,11 @@ def main():
         data = synthetic_batch(batch, T, hp.randseed + rank, device)
         next_batch = lambda: data  # noqa: E731
 
+    # set-up, outside warm-up and timing: the first train step of a Trainer also times the candidate block shapes of
+    # every conv / weight-gradient launch and keeps the fastest per problem (rtg/tune.py) — part of building the step,
+    # like compiling a kernel; with it here --warmup 0 still times tuned steps only
+    tr.train_step(*next_batch())
+    torch.cuda.synchronize()
     for _ in range(a.warmup):
         tr.train_step(*next_batch())
     torch.cuda.synchronize()
