@@ -127,8 +127,8 @@ __global__ __launch_bounds__(RTG_THREADS) void pack_kernel(const RtgPackJob* job
 }
 
 // One block per (layer, row).  Every thread owns the elements tid, tid + 256, ... of the row and sums their split
-// partials itself, splits in ascending order (bitwise reproducible, no cross-wave combine), eight independent loads in
-// flight per element group: the kernel is a pure stream over the partial buffers (0.3 GB per model and pass) and lives on
+// partials itself, splits in ascending order (bitwise reproducible, no cross-wave combine), 32 independent loads in
+// flight per thread: the kernel is a pure stream over the partial buffers (0.3 GB per model and pass) and lives on
 // memory-level parallelism.  The row sum is parked in LDS for the second pass (the weight-norm chain rule needs
 // <dW_row, v_row> before any element of dv can be written).
 __global__ __launch_bounds__(RTG_THREADS) void wn_bwd_kernel(const RtgWnBwdJob* jobs, const float* params,
@@ -141,20 +141,56 @@ __global__ __launch_bounds__(RTG_THREADS) void wn_bwd_kernel(const RtgWnBwdJob* 
     const float* v = params + j.v_off + (size_t)r * j.inner;
     const float* p0 = partials + j.part_off + (size_t)r * j.inner;
     float dot = 0.f;
-    for (int i = threadIdx.x; i < j.inner; i += RTG_THREADS) {
-      const float* p = p0 + i;
-      float s = 0.f;
-      int sp = 0;
-      for (; sp + 8 <= j.splits; sp += 8) {
-        float t[8];
+    // 32 loads in flight per thread: two elements x 16 splits, or (rows no longer than the block) one element x 32
+    // splits — the dependent chain of a row is splits / 32 memory latencies, whatever the split count (the narrow
+    // generator layers have 256 splits, the big discriminator layers 6 .. 11).  A short last batch re-reads the last
+    // split (cached) and drops the value.
+    if (j.inner <= RTG_THREADS) {
+      const int i = threadIdx.x;
+      if (i < j.inner) {
+        const float* pa = p0 + i;
+        float sa = 0.f;
+        for (int sp = 0; sp < j.splits; sp += 32) {
+          float ta[32];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) t[u] = p[(size_t)(sp + u) * j.part_stride];
+          for (int u = 0; u < 32; ++u) {
+            const int q = sp + u < j.splits ? sp + u : j.splits - 1;
+            ta[u] = pa[(size_t)q * j.part_stride];
+          }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) s += t[u];
+          for (int u = 0; u < 32; ++u) sa += (sp + u < j.splits) ? ta[u] : 0.f;
+        }
+        dw[i] = sa;
+        dot += sa * v[i];
       }
-      for (; sp < j.splits; ++sp) s += p[(size_t)sp * j.part_stride];
-      dw[i] = s;
-      dot += s * v[i];
+    } else {
+      for (int i = threadIdx.x; i < j.inner; i += 2 * RTG_THREADS) {
+        const bool two = i + RTG_THREADS < j.inner;
+        const float* pa = p0 + i;
+        const float* pb = p0 + (two ? i + RTG_THREADS : i);
+        float sa = 0.f, sb = 0.f;
+        for (int sp = 0; sp < j.splits; sp += 16) {
+          float ta[16], tb[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) {
+            const int q = sp + u < j.splits ? sp + u : j.splits - 1;
+            ta[u] = pa[(size_t)q * j.part_stride];
+            tb[u] = pb[(size_t)q * j.part_stride];
+          }
+#pragma unroll
+          for (int u = 0; u < 16; ++u) {
+            const bool ok = sp + u < j.splits;
+            sa += ok ? ta[u] : 0.f;
+            sb += ok ? tb[u] : 0.f;
+          }
+        }
+        dw[i] = sa;
+        dot += sa * v[i];
+        if (two) {
+          dw[i + RTG_THREADS] = sb;
+          dot += sb * v[i + RTG_THREADS];
+        }
+      }
     }
     dot = rtg_block_sum(dot, red);
     const float scale = scales[j.scale_off + r], inv_n = scales[j.scale_off + j.rows + r];
