@@ -475,11 +475,22 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a, const unsign
   } else {
   // two named A-fragment register sets used alternately (no loop-carried copy: with a copy at the end of the tap the
   // compiler waits for the JUST-issued prefetch in the middle of the MFMA phase, one exposed L2 latency per tap)
-  float a0[MT][CPN], a1[MT][CPN];
+  // One-tile waves (MT * NT == 1) multiply for only 8 x 64 cycles per step — less than an L2 round trip — and the small
+  // problems that pick this shape often run one wave per SIMD: their fragments are requested TWO steps ahead (three sets).
+  constexpr int PD = (MT * NT == 1 && !cls_mode) ? 2 : 1;     // prefetch distance in (chunk, tap) steps
+  float a0[MT][CPN], a1[MT][CPN], a2[PD == 2 ? MT : 1][CPN];
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int cp = 0; cp < CPN; ++cp) a0[i][cp] = wptr[i][wofs + cp * 64];
+  if constexpr (PD == 2) {
+    if (n_steps > 1) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int cp = 0; cp < CPN; ++cp) a1[i][cp] = wptr[i][wstep + cp * 64];
+    }
+  }
 
   int* tab = reinterpret_cast<int*>(lds + a.tab_off);
   if (a.tapmajor) {
@@ -517,15 +528,15 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a, const unsign
   // one (chunk, tap) step: prefetch the next step's A fragments into `nxt`, multiply with `cur`
   auto do_step = [&](int step, float (&cur)[MT][CPN], float (&nxt)[MT][CPN]) __attribute__((always_inline)) {
     const float* buf = lds + (cc & 1) * sBuf;
-    if (step + 1 < n_steps) {
-      // weight offset of the next step: the next tap of this chunk, or (once per chunk) tap 0 of the next walked chunk
+    if (step + PD < n_steps) {
+      // weight offset of the step PD ahead: the next tap of this chunk, or (once per chunk) tap 0 of the next walked chunk
       size_t nofs;
       if constexpr (cls_mode) {
         if (tap + 1 == sK) wofs = (size_t)real_cc(cc + 1) * a.K * wstep;
         else wofs += wstep;
         nofs = wofs;
       } else {
-        nofs = (size_t)(step + 1) * wstep;       // all chunks walked in order: a plain running offset
+        nofs = (size_t)(step + PD) * wstep;      // all chunks walked in order: a plain running offset
       }
 #pragma unroll
       for (int i = 0; i < MT; ++i)
@@ -597,11 +608,21 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a, const unsign
     }
   };
   int step = 0;
-  for (; step + 1 < n_steps; step += 2) {
-    do_step(step, a0, a1);
-    do_step(step + 1, a1, a0);
+  if constexpr (PD == 2) {
+    for (; step + 2 < n_steps; step += 3) {
+      do_step(step, a0, a2);                     // multiply with set k % 3, request step k + 2 into set (k + 2) % 3
+      do_step(step + 1, a1, a0);
+      do_step(step + 2, a2, a1);
+    }
+    if (step < n_steps) do_step(step, a0, a2);
+    if (step + 1 < n_steps) do_step(step + 1, a1, a0);
+  } else {
+    for (; step + 1 < n_steps; step += 2) {
+      do_step(step, a0, a1);
+      do_step(step + 1, a1, a0);
+    }
+    if (step < n_steps) do_step(step, a0, a1);
   }
-  if (step < n_steps) do_step(step, a0, a1);
   }
   RTG_STAMP(3);
 
