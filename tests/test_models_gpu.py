@@ -313,3 +313,66 @@ def test_discriminators_on_lengths_that_are_not_multiples_of_anything(nets, onet
     for a, b in zip([f for fl in fr + fg for f in fl], [f for fl in ofr + ofg for f in fl]):
         assert a.shape == b.shape
         np.testing.assert_allclose(a.cpu().numpy(), b.numpy(), rtol=1e-3, atol=5e-4)
+
+
+def test_full_size_batch_is_the_concatenation_of_its_clips(nets):
+    """BASELINE configs[1] size (32 clips x 8192 samples), a size-independent property: every clip of the batch gets the
+    result it gets in a batch of two (other block shapes, packing and grid: fp32 summation order only) — generator
+    output, all MSD / MPD logits and feature maps."""
+    gnet, msd, mpd = nets
+    B, T = 32, 8192
+    gen = torch.Generator().manual_seed(321)
+    x = torch.randn(B, 80, T // 256, generator=gen).abs().to(DEV)
+    y_tmpl = (torch.rand(B, 1, T, generator=gen) * 2 - 1).to(DEV)
+    y = (torch.rand(B, 1, T, generator=gen) * 2 - 1).to(DEV)
+    with torch.no_grad():
+        full = gnet(x, y_tmpl)
+        assert full.shape == (B, 1, T) and torch.isfinite(full).all()
+        for b0 in (0, 14, 30):
+            part = gnet(x[b0:b0 + 2].contiguous(), y_tmpl[b0:b0 + 2].contiguous())
+            np.testing.assert_allclose(part.cpu().numpy(), full[b0:b0 + 2].cpu().numpy(), atol=2e-5, rtol=0)
+        for d in (msd, mpd):
+            lr, lg, fr, fg = d(y, full)
+            b0 = 17
+            plr, plg, pfr, pfg = d(y[b0:b0 + 2].contiguous(), full[b0:b0 + 2].contiguous())
+            for a, p in zip(lr + lg, plr + plg):
+                np.testing.assert_allclose(p.cpu().numpy(), a[b0:b0 + 2].cpu().numpy(), rtol=1e-3, atol=2e-4)
+            for a, p in zip([f for fl in fr + fg for f in fl], [f for fl in pfr + pfg for f in fl]):
+                np.testing.assert_allclose(p.cpu().numpy(), a[b0:b0 + 2].cpu().numpy(), rtol=1e-3, atol=5e-4)
+
+
+def test_full_size_generator_side_gradient_is_per_clip(nets):
+    """Same size, the backward side of the generator step: with the discriminators frozen (one 2B-clip launch per layer
+    for real + generated clips, backward-data over the generated half only: ops.PairConvFn), d loss / d y_hat of a clip
+    does not depend on the other clips of the batch."""
+    from models.loss import generator_loss, feature_loss
+    _, msd, mpd = nets
+    B, T = 32, 8192
+    gen = torch.Generator().manual_seed(654)
+    y = (torch.rand(B, 1, T, generator=gen) * 2 - 1).to(DEV)
+    yh = (torch.rand(B, 1, T, generator=gen) * 2 - 1).to(DEV)
+
+    def grad_of(y_, yh_):
+        yh_ = yh_.clone().requires_grad_(True)
+        n = yh_.shape[0]
+        total = 0.0
+        params = [p for d in (msd, mpd) for p in d.parameters()]
+        for p in params:
+            p.requires_grad_(False)
+        try:
+            for d in (msd, mpd):
+                lr, lg, fr, fg = d(y_, yh_)
+                # batch-mean losses: scaled by the batch size, a clip's gradient is comparable across batch sizes
+                total = total + (generator_loss(lg, lr) + feature_loss(fr, fg)) * n
+            total.backward()
+        finally:
+            for p in params:
+                p.requires_grad_(True)
+        return yh_.grad.detach()
+
+    full = grad_of(y, yh)
+    assert torch.isfinite(full).all() and full.abs().max() > 0
+    b0 = 9
+    part = grad_of(y[b0:b0 + 2].contiguous(), yh[b0:b0 + 2].contiguous())
+    scale = full.abs().max().item()
+    np.testing.assert_allclose(part.cpu().numpy(), full[b0:b0 + 2].cpu().numpy(), atol=2e-4 * scale, rtol=1e-3)
