@@ -694,43 +694,49 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a, const unsign
         }
         const int qs = ok ? q * S : -(1 << 28);
         const unsigned col = ((unsigned)(b * a.out_C * a.h_n + hh) * (unsigned)a.out_L + (unsigned)(q * S)) * 4u;
-        unsigned off[M::NREG];
-        float mv[M::NREG], rv[M::NREG], av[M::NREG];
+        // eight accumulator rows at a time: their operand loads are in flight together, and the epilogue's registers
+        // (offsets + three optional operands) stay below the main loop's — the block shape's occupancy is set there
+        constexpr int RH = M::NREG > 8 ? 8 : M::NREG;
 #pragma unroll
-        for (int r = 0; r < M::NREG; ++r)
-          off[r] = ((unsigned)(qs + rowph[r]) < (unsigned)a.out_L) ? col + rowoff[r] : RTG_OOB;
-        // optional operands: uniform branches per tile (an absent operand costs no load instructions at all; a load
-        // through a zero-record descriptor would still occupy the address unit for a full wave)
-        if (a.mask) {
+        for (int r0 = 0; r0 < M::NREG; r0 += RH) {
+          unsigned off[RH];
+          float mv[RH], rv[RH], av[RH];
 #pragma unroll
-          for (int r = 0; r < M::NREG; ++r) mv[r] = buf_load(rm, off[r]);
-        } else {
+          for (int r = 0; r < RH; ++r)
+            off[r] = ((unsigned)(qs + rowph[r0 + r]) < (unsigned)a.out_L) ? col + rowoff[r0 + r] : RTG_OOB;
+          // optional operands: uniform branches per tile (an absent operand costs no load instructions at all; a load
+          // through a zero-record descriptor would still occupy the address unit for a full wave)
+          if (a.mask) {
 #pragma unroll
-          for (int r = 0; r < M::NREG; ++r) mv[r] = 1.f;
-        }
-        if (a.res) {
+            for (int r = 0; r < RH; ++r) mv[r] = buf_load(rm, off[r]);
+          } else {
 #pragma unroll
-          for (int r = 0; r < M::NREG; ++r) rv[r] = buf_load(rr, off[r]);
-        } else {
+            for (int r = 0; r < RH; ++r) mv[r] = 1.f;
+          }
+          if (a.res) {
 #pragma unroll
-          for (int r = 0; r < M::NREG; ++r) rv[r] = 0.f;
-        }
-        if (a.accumulate) {
+            for (int r = 0; r < RH; ++r) rv[r] = buf_load(rr, off[r]);
+          } else {
 #pragma unroll
-          for (int r = 0; r < M::NREG; ++r) av[r] = buf_load(ra, off[r]);
-        } else {
+            for (int r = 0; r < RH; ++r) rv[r] = 0.f;
+          }
+          if (a.accumulate) {
 #pragma unroll
-          for (int r = 0; r < M::NREG; ++r) av[r] = 0.f;
-        }
+            for (int r = 0; r < RH; ++r) av[r] = buf_load(ra, off[r]);
+          } else {
 #pragma unroll
-        for (int r = 0; r < M::NREG; ++r) {
-          float v = acc[i][j][r] + bv[r];
-          v *= (mv[r] > 0.f ? 1.f : mslope);
-          v = (v + rv[r]) * a.out_scale;
-          if (a.act == RTG_ACT_LRELU) v = rtg_lrelu(v, a.act_slope);
-          else if (a.act == RTG_ACT_TANH) v = tanhf(v);
-          v += av[r];
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ro, off[r], 0, 0);
+            for (int r = 0; r < RH; ++r) av[r] = 0.f;
+          }
+#pragma unroll
+          for (int r = 0; r < RH; ++r) {
+            float v = acc[i][j][r0 + r] + bv[r0 + r];
+            v *= (mv[r] > 0.f ? 1.f : mslope);
+            v = (v + rv[r]) * a.out_scale;
+            if (a.act == RTG_ACT_LRELU) v = rtg_lrelu(v, a.act_slope);
+            else if (a.act == RTG_ACT_TANH) v = tanhf(v);
+            v += av[r];
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ro, off[r], 0, 0);
+          }
         }
       }
     }
