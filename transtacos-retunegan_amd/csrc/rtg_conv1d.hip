@@ -53,6 +53,8 @@ namespace {
 struct TileCfg {
   int MT, NT, WM, WN;
   int seg_len, seg_nb;   // > 0: clips packed per block
+  int dense;             // packed, and the block's columns are a window of the dense (clip, q) sequence: clips may
+                         // straddle blocks (seg_nb = segments a block stages, partial clips included)
 };
 
 // Patch width (floats per channel) for a block covering BN output positions.
@@ -66,14 +68,14 @@ inline int segment_len(int Q, int stride, int K, int dil) {
 }
 
 // Scores every block shape valid for the problem (score <= 0: not applicable); returns the number of shapes.
-constexpr int kMaxTileCfgs = 16;
+constexpr int kMaxTileCfgs = 32;
 struct ScoredCfg {
   TileCfg c;
   double score;
 };
-inline int tile_code(const TileCfg& c) { return c.MT * 100 + c.NT * 10 + c.WM; }
+inline int tile_code(const TileCfg& c) { return c.dense * 1000 + c.MT * 100 + c.NT * 10 + c.WM; }
 
-int score_tiles(int TM, int n_mt, int Q, int B, int groups, int stride, int K, int dil, ScoredCfg* out) {
+int score_tiles(int TM, int n_mt, int Q, int B, int groups, int stride, int K, int dil, bool one_d, ScoredCfg* out) {
   static const int c32[][4] = {{2, 2, 1, 4}, {2, 2, 2, 2}, {2, 2, 4, 1}, {1, 2, 1, 4}, {1, 2, 2, 2}, {1, 2, 4, 1},
                                {1, 4, 1, 4}, {1, 4, 2, 2}, {2, 1, 1, 4}, {2, 1, 2, 2}, {2, 1, 4, 1}, {1, 1, 1, 4},
                                {1, 1, 2, 2}, {1, 1, 4, 1}};
@@ -84,7 +86,7 @@ int score_tiles(int TM, int n_mt, int Q, int B, int groups, int stride, int K, i
   const int Lseg = segment_len(Q, stride, K, dil);
   int cnt = 0;
   for (int i = 0; i < n; ++i) {
-    TileCfg c = {cs[i][0], cs[i][1], cs[i][2], cs[i][3], 0, 0};
+    TileCfg c = {cs[i][0], cs[i][1], cs[i][2], cs[i][3], 0, 0, 0};
     const int BN = c.WN * c.NT * TM;
     const int mrows = c.WM * c.MT;
     const int m_blocks = rtg_ceil_div(n_mt, mrows);
@@ -112,15 +114,34 @@ int score_tiles(int TM, int n_mt, int Q, int B, int groups, int stride, int K, i
     out[cnt].c = c;
     out[cnt].score = eff * fill * (0.6 + 0.4 * (reuse > 1.0 ? 1.0 : reuse)) + 1e-9;
     ++cnt;
+    // the same shape over the dense (clip, q) column sequence: no column is lost to whole-clip quantisation, a block
+    // stages every clip its window touches (1-D only; rows shorter than the tile; the wider patch must still fit)
+    if (one_d && B >= 2 && Q < BN && cnt < kMaxTileCfgs) {
+      const int segs0 = (Q - 1 + BN - 1) / Q + 1;
+      const int segs = segs0 < B ? segs0 : B;
+      const long long cols = (long long)B * Q;
+      const long long zb = (cols + BN - 1) / BN;
+      const double eff_d = (double)cols / ((double)zb * BN);
+      if (patch_width(segs * Lseg, stride, K, dil) <= RTG_PW_MAX && eff_d > eff_q + 0.02) {
+        TileCfg cd = c;
+        cd.dense = 1; cd.seg_len = Lseg; cd.seg_nb = segs;
+        const double blocks_d = (double)m_blocks * zb * groups;
+        const double fill_d = blocks_d >= 512.0 ? 1.0 : blocks_d / 512.0;
+        out[cnt].c = cd;
+        out[cnt].score = ((double)n_mt / (m_blocks * mrows)) * eff_d * fill_d * (0.6 + 0.4 * (reuse > 1.0 ? 1.0 : reuse)) *
+                             0.97 + 1e-9;      // more staging per block than the whole-clip packing of equal efficiency
+        ++cnt;
+      }
+    }
   }
   return cnt;
 }
 
 // forced: a RtgConv1dDesc.tile_cfg code, or 0 for the best score.  MT == 0 in the result: nothing applicable.
-TileCfg pick_tiles(int TM, int n_mt, int Q, int B, int groups, int stride, int K, int dil, int forced) {
+TileCfg pick_tiles(int TM, int n_mt, int Q, int B, int groups, int stride, int K, int dil, bool one_d, int forced) {
   ScoredCfg sc[kMaxTileCfgs];
-  const int n = score_tiles(TM, n_mt, Q, B, groups, stride, K, dil, sc);
-  TileCfg best = {0, 0, 0, 0, 0, 0};
+  const int n = score_tiles(TM, n_mt, Q, B, groups, stride, K, dil, one_d, sc);
+  TileCfg best = {0, 0, 0, 0, 0, 0, 0};
   double best_score = -1.0;
   for (int i = 0; i < n; ++i) {
     if (forced ? tile_code(sc[i].c) == forced : sc[i].score > best_score) {
@@ -146,6 +167,7 @@ extern "C" int rtg_conv1d_variant(const RtgConv1dDesc* d) {
     return RTG_EINVAL;
   if (d->tile_cfg == 0 && rtg_thin_kind(d)) return rtg_thin_kind(d);
   const TileCfg c = pick_tiles(d->tile_m, rtg_ceil_div(d->Mg, d->tile_m), d->Q, d->B, d->groups, d->stride, d->K, d->dil,
+                               !(d->h_k > 1 || d->h_n > 1),
                                d->tile_cfg);
   if (c.MT == 0) return d->tile_cfg ? RTG_EINVAL : RTG_ERANGE;
   return d->tile_m * 100 + c.MT * 10 + c.NT;
@@ -161,7 +183,8 @@ extern "C" int rtg_conv1d_tile_candidates(const RtgConv1dDesc* d, int* cfgs, int
     return 1;
   }
   ScoredCfg sc[kMaxTileCfgs];
-  const int n = score_tiles(d->tile_m, rtg_ceil_div(d->Mg, d->tile_m), d->Q, d->B, d->groups, d->stride, d->K, d->dil, sc);
+  const int n = score_tiles(d->tile_m, rtg_ceil_div(d->Mg, d->tile_m), d->Q, d->B, d->groups, d->stride, d->K, d->dil,
+                            !(d->h_k > 1 || d->h_n > 1), sc);
   // best-guess first (selection sort by score; n <= 14)
   int cnt = 0;
   for (int k = 0; k < n && cnt < max; ++k) {
@@ -265,12 +288,12 @@ static int conv_plan(const RtgConv1dDesc* d, const float* x1, const float* x2, c
     a.K = tapmajor_groups(d->Cg, d->K, TM);     // the kernel's step loop walks groups of CPN k-steps
   }
 
-  const TileCfg c = pick_tiles(TM, a.n_mt, d->Q, d->B, d->groups, d->stride, d->K, d->dil, d->tile_cfg);
+  const TileCfg c = pick_tiles(TM, a.n_mt, d->Q, d->B, d->groups, d->stride, d->K, d->dil, !two_d, d->tile_cfg);
   if (c.MT == 0) return d->tile_cfg ? RTG_EINVAL : RTG_ERANGE;   // unknown shape / even the smallest patch exceeds RTG_PW_MAX
   a.WM = c.WM; a.WN = c.WN;
   const int BN = c.WN * c.NT * TM;
   a.PW = patch_width(c.seg_len > 0 ? c.seg_nb * c.seg_len : BN, d->stride, d->K, d->dil);
-  a.seg_len = c.seg_len; a.seg_nb = c.seg_nb;
+  a.seg_len = c.seg_len; a.seg_nb = c.seg_nb; a.seg_dense = c.dense;
   a.seg_pitch = c.seg_len > 0 ? c.seg_len * d->stride : 1;
   a.seg_pw = patch_width(d->Q, d->stride, d->K, d->dil);
   int row;
@@ -284,6 +307,7 @@ static int conv_plan(const RtgConv1dDesc* d, const float* x1, const float* x2, c
   a.ROW = ((row + 15) / 32) * 32 + 16;          // == 16 (mod 32), >= row
   a.m_blocks = rtg_ceil_div(a.n_mt, c.WM * c.MT);
   int gz = c.seg_len > 0 ? rtg_ceil_div(d->B, c.seg_nb) : d->B;
+  if (c.dense) gz = (int)(((long long)d->B * d->Q + BN - 1) / BN);
   if (two_d && d->h_mode == 1 && d->h_stride > 1 && c.seg_len > 0) {
     // class-pure blocks of packed rows (rtg_conv1d_kernel.h, RowClass): per batch item, per residue class of the rows,
     // ceil(rows of the class / seg_nb) blocks

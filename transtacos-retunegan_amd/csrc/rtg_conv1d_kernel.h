@@ -29,6 +29,7 @@ struct ConvArgs {
   int accumulate;
   int n_cc, n_mt, WM, WN, PW, PH, ROW, m_blocks;
   int seg_len, seg_pitch, seg_nb, seg_pw;   // segment packing (seg_len == 0: one clip per block column)
+  int seg_dense;                            // packed: the block's columns are a window of the dense (clip, q) sequence
   // 2-D mode (h_k > 1 or h_n > 1): a "clip" is one (batch item, output row) pair and a "channel" one (channel, kernel
   // row) pair; the kernel row picks which input row of the [items, C, h_in, L_in] tensor the patch row comes from
   int two_d, h_in, h_k, h_stride, h_pad, h_n, h_mode;
@@ -235,7 +236,13 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a, const unsign
   const int mt0 = (mb * a.WM + wm) * MT;
   const int BN = a.WN * NT * TM;
   const bool packed = a.seg_len > 0;
-  const int b0 = packed ? bz * a.seg_nb : bz;   // first clip of this block
+  int b0 = packed ? bz * a.seg_nb : bz;         // first clip of this block
+  int q0 = 0;                                   // dense window: position of the block's first column within clip b0
+  if (packed && a.seg_dense) {
+    const int c0 = bz * BN;
+    b0 = c0 / a.Q;
+    q0 = c0 - b0 * a.Q;
+  }
   constexpr bool cls_mode = CLS;        // host: two_d && h_mode == 1 && h_stride > 1
   RowClass rc = {0, 0, 0, 0, 0};
   if (cls_mode) {
@@ -365,7 +372,7 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a, const unsign
   int pcol[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
-    const int n = (wn * NT + j) * TM + n_lane;
+    const int n = q0 + (wn * NT + j) * TM + n_lane;
     const int seg = packed ? n / a.Q : 0;
     pcol[j] = kk * a.ROW + (seg < a.seg_nb ? seg * a.seg_len + (n - seg * a.Q) : 0);
   }
@@ -671,7 +678,7 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a, const unsign
       }
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
-        int q = q_blk + (wn * NT + j) * TM + n_lane;
+        int q = q_blk + q0 + (wn * NT + j) * TM + n_lane;
         int b = b0;
         bool ok = true;
         int seg = 0;
@@ -753,7 +760,7 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a, const unsign
     if (mt0 + i >= a.n_mt) continue;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      int q = q_blk + (wn * NT + j) * TM + n_lane;
+      int q = q_blk + q0 + (wn * NT + j) * TM + n_lane;
       int b = b0;
       int seg = 0;
       if (packed) {

@@ -52,8 +52,8 @@ def conv_cfg(d, launch):
         return cfg
     if not (ENABLED and ACTIVE):
         return _miss()
-    cands = (C.c_int * 16)()
-    n = lib.rtg_conv1d_tile_candidates(C.byref(d), cands, 16)
+    cands = (C.c_int * 32)()
+    n = lib.rtg_conv1d_tile_candidates(C.byref(d), cands, 32)
     best, best_t = 0, None
     for c in cands[:max(n, 0)]:
         d.tile_cfg = c
@@ -104,8 +104,8 @@ def group_cfg(darr, n, launch):
         return cfg
     lists = []
     for i in range(n):
-        cands = (C.c_int * 16)()
-        k = lib.rtg_conv1d_tile_candidates(C.byref(darr[i]), cands, 16)
+        cands = (C.c_int * 32)()
+        k = lib.rtg_conv1d_tile_candidates(C.byref(darr[i]), cands, 32)
         lists.append([c for c in cands[:max(k, 0)] if c != 0])
     common = [c for c in lists[0] if all(c in l for l in lists[1:])]
     if not common:
