@@ -152,3 +152,67 @@ def test_stft_backward_through_log_magnitude_and_phase(oracle, gold):
         ((o * cs.double()).sum() + (M * cm.double()).sum()).backward()
         err = (yh.grad.cpu().double() - y64.grad).norm().item() / y64.grad.norm().item()
         assert err < 5e-3, (n_fft, err)      # fp32 vs float64: d angle / dD ~ 1/|D| amplifies rounding at weak bins
+
+
+@pytest.mark.parametrize('case', [CASES[1], CASES[3], CASES[4], (2, 32, 64, 9, 65, (3, 9), (1, 1), (1, 4))])
+def test_conv2d_every_block_shape(case, monkeypatch):
+    """2-D layers through every block shape the library lists for their forward and backward-data problems (whole-clip
+    packing and the dense windows over the (item, row, q) column sequence): all agree with torch and with each other."""
+    import ctypes as C
+    from models.layers import WNConv, BankedModel, conv
+    from rtg import tune
+    from rtg.lib import lib
+    B, Cin, Cout, H, W, k, s, p = case
+
+    class Net(BankedModel):
+        def __init__(self):
+            super().__init__()
+            self.c = WNConv('conv2d', Cin, Cout, k, stride=s, pad=p)
+
+        def forward(self, x):
+            return conv(self.token(), self.c, x, pre_slope=0.15)
+
+    torch.manual_seed(11)
+    net = Net()
+    x = torch.randn(B, Cin, H, W)
+    v = net.c.weight_v.detach().double()
+    g = net.c.weight_g.detach().double()
+    w = g * v / v.flatten(1).norm(dim=1).reshape(-1, 1, 1, 1)
+    xr = x.double().requires_grad_(True)
+    y = F.conv2d(F.leaky_relu(xr, 0.15), w, net.c.bias.detach().double(), s, p)
+    dy = torch.randn(y.shape, generator=torch.Generator().manual_seed(12))
+    y.backward(dy.double())
+    net.to(DEV)
+
+    # candidate lists of the forward and the backward-data problem: record the descriptors of one ordinary pass
+    seen = []
+    monkeypatch.setattr(tune, 'conv_cfg', lambda d, launch: (seen.append(bytes(d)), 0)[1])
+    xg = x.to(DEV).requires_grad_(True)
+    net(xg).backward(dy.to(DEV))
+    assert len(seen) == 2
+    from rtg.lib import Conv1dDesc
+    lists = []
+    for raw in seen:
+        d = Conv1dDesc.from_buffer_copy(raw)
+        cands = (C.c_int * 32)()
+        n = lib.rtg_conv1d_tile_candidates(C.byref(d), cands, 32)
+        assert n >= 1
+        lists.append(list(cands[:n]))
+    outs, dxs = [], []
+    for i in range(max(len(lists[0]), len(lists[1]))):
+        pick = [lists[0][min(i, len(lists[0]) - 1)], lists[1][min(i, len(lists[1]) - 1)]]
+        calls = []
+        monkeypatch.setattr(tune, 'conv_cfg', lambda d, launch: (calls.append(1), pick[len(calls) - 1])[1])
+        xg = x.to(DEV).requires_grad_(True)
+        out = net(xg)
+        out.backward(dy.to(DEV))
+        torch.cuda.synchronize()
+        for got, ref, name in ((out, y.detach(), 'out'), (xg.grad, xr.grad, 'dx')):
+            err = (got.detach().cpu().double() - ref).abs().max().item()
+            assert err <= 2e-4 * ref.abs().max().item() + 1e-5, (name, pick, err)
+        outs.append(out.detach().cpu())
+        dxs.append(xg.grad.detach().cpu())
+    if W == 65:       # rows of 65 positions: half of a 128-column tile would be lost to whole-clip packing
+        assert any(c >= 1000 for l in lists for c in l), 'no dense-window candidate exercised'
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])

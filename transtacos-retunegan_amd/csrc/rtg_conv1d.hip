@@ -75,7 +75,7 @@ struct ScoredCfg {
 };
 inline int tile_code(const TileCfg& c) { return c.dense * 1000 + c.MT * 100 + c.NT * 10 + c.WM; }
 
-int score_tiles(int TM, int n_mt, int Q, int B, int groups, int stride, int K, int dil, bool one_d, ScoredCfg* out) {
+int score_tiles(int TM, int n_mt, int Q, int B, int groups, int stride, int K, int dil, bool windows, ScoredCfg* out) {
   static const int c32[][4] = {{2, 2, 1, 4}, {2, 2, 2, 2}, {2, 2, 4, 1}, {1, 2, 1, 4}, {1, 2, 2, 2}, {1, 2, 4, 1},
                                {1, 4, 1, 4}, {1, 4, 2, 2}, {2, 1, 1, 4}, {2, 1, 2, 2}, {2, 1, 4, 1}, {1, 1, 1, 4},
                                {1, 1, 2, 2}, {1, 1, 4, 1}};
@@ -115,8 +115,9 @@ int score_tiles(int TM, int n_mt, int Q, int B, int groups, int stride, int K, i
     out[cnt].score = eff * fill * (0.6 + 0.4 * (reuse > 1.0 ? 1.0 : reuse)) + 1e-9;
     ++cnt;
     // the same shape over the dense (clip, q) column sequence: no column is lost to whole-clip quantisation, a block
-    // stages every clip its window touches (1-D only; rows shorter than the tile; the wider patch must still fit)
-    if (one_d && B >= 2 && Q < BN && cnt < kMaxTileCfgs) {
+    // stages every clip its window touches (not for the class-pure blocks of strided 2-D backward-data; rows shorter
+    // than the tile; the wider patch must still fit)
+    if (windows && B >= 2 && Q < BN && cnt < kMaxTileCfgs) {
       const int segs0 = (Q - 1 + BN - 1) / Q + 1;
       const int segs = segs0 < B ? segs0 : B;
       const long long cols = (long long)B * Q;
@@ -138,9 +139,9 @@ int score_tiles(int TM, int n_mt, int Q, int B, int groups, int stride, int K, i
 }
 
 // forced: a RtgConv1dDesc.tile_cfg code, or 0 for the best score.  MT == 0 in the result: nothing applicable.
-TileCfg pick_tiles(int TM, int n_mt, int Q, int B, int groups, int stride, int K, int dil, bool one_d, int forced) {
+TileCfg pick_tiles(int TM, int n_mt, int Q, int B, int groups, int stride, int K, int dil, bool windows, int forced) {
   ScoredCfg sc[kMaxTileCfgs];
-  const int n = score_tiles(TM, n_mt, Q, B, groups, stride, K, dil, one_d, sc);
+  const int n = score_tiles(TM, n_mt, Q, B, groups, stride, K, dil, windows, sc);
   TileCfg best = {0, 0, 0, 0, 0, 0, 0};
   double best_score = -1.0;
   for (int i = 0; i < n; ++i) {
@@ -167,7 +168,7 @@ extern "C" int rtg_conv1d_variant(const RtgConv1dDesc* d) {
     return RTG_EINVAL;
   if (d->tile_cfg == 0 && rtg_thin_kind(d)) return rtg_thin_kind(d);
   const TileCfg c = pick_tiles(d->tile_m, rtg_ceil_div(d->Mg, d->tile_m), d->Q, d->B, d->groups, d->stride, d->K, d->dil,
-                               !(d->h_k > 1 || d->h_n > 1),
+                               !((d->h_k > 1 || d->h_n > 1) && d->h_mode == 1 && d->h_stride > 1),
                                d->tile_cfg);
   if (c.MT == 0) return d->tile_cfg ? RTG_EINVAL : RTG_ERANGE;
   return d->tile_m * 100 + c.MT * 10 + c.NT;
@@ -184,7 +185,7 @@ extern "C" int rtg_conv1d_tile_candidates(const RtgConv1dDesc* d, int* cfgs, int
   }
   ScoredCfg sc[kMaxTileCfgs];
   const int n = score_tiles(d->tile_m, rtg_ceil_div(d->Mg, d->tile_m), d->Q, d->B, d->groups, d->stride, d->K, d->dil,
-                            !(d->h_k > 1 || d->h_n > 1), sc);
+                            !((d->h_k > 1 || d->h_n > 1) && d->h_mode == 1 && d->h_stride > 1), sc);
   // best-guess first (selection sort by score; n <= 14)
   int cnt = 0;
   for (int k = 0; k < n && cnt < max; ++k) {
@@ -288,7 +289,8 @@ static int conv_plan(const RtgConv1dDesc* d, const float* x1, const float* x2, c
     a.K = tapmajor_groups(d->Cg, d->K, TM);     // the kernel's step loop walks groups of CPN k-steps
   }
 
-  const TileCfg c = pick_tiles(TM, a.n_mt, d->Q, d->B, d->groups, d->stride, d->K, d->dil, !two_d, d->tile_cfg);
+  const TileCfg c = pick_tiles(TM, a.n_mt, d->Q, d->B, d->groups, d->stride, d->K, d->dil,
+                               !(two_d && d->h_mode == 1 && d->h_stride > 1), d->tile_cfg);
   if (c.MT == 0) return d->tile_cfg ? RTG_EINVAL : RTG_ERANGE;   // unknown shape / even the smallest patch exceeds RTG_PW_MAX
   a.WM = c.WM; a.WN = c.WN;
   const int BN = c.WN * c.NT * TM;
