@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define RTG_ABI_VERSION 1
+#define RTG_ABI_VERSION 2
 
 #define RTG_OK 0
 #define RTG_EINVAL (-1)   /* inconsistent descriptor               */
@@ -299,9 +299,12 @@ int rtg_strip_mirror_bwd(const float* y, int rows, int L, float w, const float* 
  * rtg_adamw — torch.optim.AdamW step (train.py:80-81,160,193) over a flat fp32 parameter buffer:
  * decoupled weight decay, bias correction from the device-resident step counter state[0] (float),
  * skipped entirely (counter included) when *loss_flag is NaN (NaN guard of train.py:158,191 made device-side).
+ * Hyper-parameters are doubles, as torch holds them: the scalar factors (1 - beta^t, lr / bc1, 1 - lr*wd) are formed in
+ * double and the element arithmetic runs in fp32 in torch's order (m = lerp(m, g, 1-b1), ...).  grads are read as
+ * grads[i] * grad_scale (1 / world size under data parallelism: the all-reduce sums).
  * ------------------------------------------------------------------------------------------------------------ */
 int rtg_adamw(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n, float* step_state,
-              const float* loss_flag, float lr, float beta1, float beta2, float eps, float weight_decay,
+              const float* loss_flag, double lr, double beta1, double beta2, double eps, double weight_decay,
               float grad_scale, void* stream);
 
 /* library self-description */

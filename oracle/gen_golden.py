@@ -61,6 +61,9 @@ def main():
         gold[f'init_{tag}_count'] = np.array(sum(p.numel() for p in m.parameters()))
         gold[f'init_{tag}_keys'] = np.array(sorted(m.state_dict().keys()))
         gold[f'init_{tag}_stats'] = np.stack([stats(p) for _, p in sorted(m.named_parameters())])
+        # registration order of the parameters: torch.optim state dicts index their entries by it (train.py:263-273
+        # saves optim_g / optim_d that way), so a drop-in must reproduce it, not only the key set
+        gold[f'init_{tag}_param_order'] = np.array([n for n, _ in m.named_parameters()])
 
     # ------------------------------------------------------------------ deterministic fill + golden inputs
     for m in (g, msd, mpd, mtd):
@@ -100,6 +103,14 @@ def main():
         gold[f'{tag}_d_loss'] = np.array(M.discriminator_loss(lr, lg).item())
         gold[f'{tag}_g_loss'] = np.array(M.generator_loss(lg, lr).item())
         gold[f'{tag}_fm_loss'] = np.array(M.feature_loss(fr, fg).item())
+
+    # frame 0 of the centred, reflect-padded STFT is symmetric: its spectrum is real up to rounding and the sign of the
+    # reference's angle() (+pi or -pi) there is rounding noise of THIS run.  The MTD values above were computed from it,
+    # so the branch the reference took is part of the fixture (tests put GPU phases that sit on the cut on this branch).
+    for j, spec_list in enumerate(zip(S, Sg)):
+        n_fft = hp.multi_stft_params[j][0]
+        gold[f'stft{n_fft}_frame0_phase_r'] = spec_list[0][:, 1, :, 0].numpy().copy()
+        gold[f'stft{n_fft}_frame0_phase_g'] = spec_list[1][:, 1, :, 0].numpy().copy()
 
     # ------------------------------------------------------------------ waveform / spectral losses
     gold['loss_mstft'] = np.array(M.multi_stft_loss(y, yd, ret_loss=True).item())

@@ -45,6 +45,7 @@ def main():
     gold['full_count'] = np.array(sum(p.numel() for p in g.parameters()))
     gold['full_keys'] = np.array(sorted(g.state_dict().keys()))
     gold['full_init_stats'] = np.stack([stats(p) for _, p in sorted(g.named_parameters())])
+    gold['full_param_order'] = np.array([n for n, _ in g.named_parameters()])      # optimizer state index order
     # ---------------------------------------------------------------- forward / backward on the golden inputs
     O.det_fill(g)
     g.train()

@@ -60,9 +60,12 @@ class WNConv(nn.Module):
         fan_in = shape[1] * int(np.prod(ks))
         bound = 1.0 / math.sqrt(fan_in)
         b = torch.empty(cout).uniform_(-bound, bound)
+        # registration order of torch.nn.utils.weight_norm(Conv*): the conv registers (weight, bias), weight_norm deletes
+        # `weight` and appends weight_g, weight_v -> bias, weight_g, weight_v.  torch.optim state dicts index their
+        # entries by this order (checkpoints `do_*`, train.py:263-273), so it is part of the drop-in contract.
+        self.bias = nn.Parameter(b)
         self.weight_g = nn.Parameter(v.flatten(1).norm(dim=1).reshape((shape[0],) + (1,) * (len(shape) - 1)))
         self.weight_v = nn.Parameter(v)
-        self.bias = nn.Parameter(b)
 
     def burn_init_rng(self):
         """`init_weights` (utils.py:26-29) run after weight_norm only overwrites the derived .weight, which the

@@ -30,18 +30,20 @@ def _setup():
             sys.path.insert(0, p)
 
 
-def _make_trainer():
+def _make_trainer(full=False):
+    """full: the whole stack with MTD and d_train_times = 2 (BASELINE configs[3] per rank): the MTD -> MPD -> MSD flush
+    order and two D reductions per step are exercised"""
     import rtg_oracle as O
     from train import Trainer
     torch.manual_seed(5)
-    tr = Trainer(use_mpd=True, use_mtd=False, d_train_times=1, dev='cuda:0')
-    for m in (tr.generator, tr.msd, tr.mpd):
+    tr = Trainer(use_mpd=True, use_mtd=full, d_train_times=2 if full else 1, dev='cuda:0')
+    for m in (tr.generator, *tr.discs):
         O.det_fill(m)
     return tr, O
 
 
 def _params(tr):
-    return torch.cat([tr.generator.bank().flat, tr.msd.bank().flat, tr.mpd.bank().flat]).cpu()
+    return torch.cat([m.bank().flat for m in (tr.generator, *tr.discs)]).cpu()
 
 
 def _noise(batch):
@@ -50,12 +52,13 @@ def _noise(batch):
     return [torch.rand(batch, *s, generator=g) for s in shapes]
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, full=False):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     _setup()
     dist.init_process_group('gloo', rank=rank, world_size=world)
-    tr, O = _make_trainer()
+    tr, O = _make_trainer(full)
     assert tr.dp.enabled and tr.dp.world == 2
+    assert tr.generator.noise.rank in (None, rank)
     x, y_tmpl, y = O.golden_inputs(batch=2)
     sl = slice(rank, rank + 1)
     noise = [n[sl].cuda() for n in _noise(2)]
@@ -66,9 +69,10 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_ranks_match_single_process_step():
+@pytest.mark.parametrize('full', [False, True])
+def test_two_ranks_match_single_process_step(full):
     _setup()
-    tr, O = _make_trainer()
+    tr, O = _make_trainer(full)
     x, y_tmpl, y = O.golden_inputs(batch=2)
     noise = [n.cuda() for n in _noise(2)]
     before = _params(tr).clone()
@@ -81,7 +85,7 @@ def test_two_ranks_match_single_process_step():
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, full)) for r in range(2)]
     for p in procs:
         p.start()
     got = {}
@@ -98,6 +102,8 @@ def test_two_ranks_match_single_process_step():
     move_ref, move_dp = ref - before.numpy(), got[0][0] - before.numpy()
     assert np.abs(move_ref).max() > 1e-5
     frac_bad = np.mean(np.abs(move_dp - move_ref) > 0.2 * 2e-4)
-    assert frac_bad < 2e-3, frac_bad
+    # with MTD the phase input is discontinuous in y_hat (+-pi branch of frame 0): a rank's 1-clip forward and the
+    # 2-clip forward differ by fp32 summation order, some phases flip, and the gradients downstream differ visibly
+    assert frac_bad < (5e-2 if full else 2e-3), frac_bad
     # mean of per-rank generator losses = single-process loss on the global batch
-    np.testing.assert_allclose(0.5 * (got[0][1] + got[1][1]), gl['gen_all'].item(), rtol=2e-3)
+    np.testing.assert_allclose(0.5 * (got[0][1] + got[1][1]), gl['gen_all'].item(), rtol=1e-2 if full else 2e-3)

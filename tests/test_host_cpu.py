@@ -78,18 +78,76 @@ def test_mel_filterbank_and_stft_plan(oracle, gold):
     np.testing.assert_array_equal(t["window"].numpy(), torch.hann_window(1024, periodic=True).numpy())
 
 
-def test_exponential_lr_and_loss_switches():
+def test_parameter_registration_order_is_the_references(oracle, gold, gold4):
+    """torch.optim state dicts (the `do_*` checkpoints, train.py:263-273) index their entries by parameter position:
+    the modules must yield their parameters in the order the reference's modules do (bias, weight_g, weight_v per
+    weight-normed conv; module registration order of the constructors).  The order lists come from the real reference
+    modules (oracle/gen_golden.py, gen_golden_f4.py)."""
+    import models as M
+    torch.manual_seed(0)
+    for tag, prod, orc in (('g', M.Generator_RefineGAN_small, oracle.Generator), ('msd', M.MultiScaleDiscriminator, oracle.MSD),
+                           ('mpd', M.MultiPeriodDiscriminator, oracle.MPD), ('mtd', M.MultiStftDiscriminator, oracle.MTD)):
+        ref = list(gold[f'init_{tag}_param_order'])
+        assert [n for n, _ in prod().named_parameters()] == ref, tag
+        assert [n for n, _ in orc().named_parameters()] == ref, tag
+    ref = list(gold4['full_param_order'])
+    assert [n for n, _ in M.Generator_RefineGAN().named_parameters()] == ref
+    assert [n for n, _ in oracle.GeneratorFull().named_parameters()] == ref
+
+
+def test_mel_filterbank_known_answer_from_librosa_docs():
+    """A pin outside the shared restatement: the docstring example of librosa.filters.mel (librosa 0.8.1,
+    `melfb = librosa.filters.mel(22050, 2048)`) prints `[[0., 0.016, ..., 0., 0.], [0., 0., ..., 0., 0.], ...]`:
+    128 Slaney bands over 0..11025 Hz, element [0, 1] = 0.016 at 3 decimals, first and last columns zero."""
+    from audio import mel_filterbank
+    fb = mel_filterbank(22050, 2048, 128, 0.0, 11025.0)
+    assert fb.shape == (128, 1025)
+    assert np.round(fb[0, 1], 3) == np.float32(0.016)
+    assert fb[0, 0] == 0 and fb[0, -1] == 0 and fb[0, -2] == 0 and fb[1, 0] == 0 and fb[1, 1] == 0
+    assert fb[-1, 0] == 0 and fb[-1, -1] == 0
+    # Slaney area normalisation: every band integrates to ~1 over frequency (bin width sr / n_fft), up to sampling
+    area = fb.astype(np.float64).sum(1) * 22050 / 2048
+    assert np.all(np.abs(area - 1.0) < 0.25) and abs(area.mean() - 1.0) < 0.01
+    # the band edges follow the Slaney scale: linear below 1 kHz (200/3 Hz per mel), log above (step ln(6.4)/27)
+    peak_hz = fb.argmax(1) * 22050 / 2048
+    mel = np.where(peak_hz < 1000, peak_hz / (200 / 3), 15 + np.log(np.maximum(peak_hz, 1e-9) / 1000) / (np.log(6.4) / 27))
+    step = np.diff(mel)
+    assert np.all(np.abs(step - step.mean()) < 0.5 * step.mean() + 0.2)
+
+
+def test_exponential_lr_matches_torch_fresh_and_resumed():
+    """train.py:87-88: ExponentialLR(optim, gamma, last_epoch=-1) for a fresh run, last_epoch=<saved epoch> on resume.
+    Compared against torch's own scheduler on a torch AdamW, including the extra step torch's constructor performs."""
     import train
     import hparam as hp
+    from torch.optim.lr_scheduler import ExponentialLR as TorchLR
 
-    class FakeOpt:
-        initial_lr = 2e-4
-        param_groups = [{'lr': 2e-4}]
-
-    sch = train.ExponentialLR(FakeOpt(), gamma=hp.lr_decay)
+    w = torch.nn.Parameter(torch.zeros(3))
+    topt = torch.optim.AdamW([w], hp.learning_rate_d, betas=[hp.adam_b1, hp.adam_b2])
+    tsch = TorchLR(topt, gamma=hp.lr_decay, last_epoch=-1)
+    opt = train.AdamW([], hp.learning_rate_d, betas=[hp.adam_b1, hp.adam_b2])
+    sch = train.ExponentialLR(opt, gamma=hp.lr_decay)
+    assert sch.get_last_lr() == tsch.get_last_lr() == [hp.learning_rate_d] and sch.last_epoch == tsch.last_epoch == 0
     for _ in range(3):
-        sch.step()
-    assert sch.get_last_lr()[0] == pytest.approx(2e-4 * 0.999 ** 3)
+        topt.step(); tsch.step(); sch.step()
+    assert sch.get_last_lr()[0] == tsch.get_last_lr()[0] == opt.param_groups[0]['lr']
+    assert sch.get_last_lr()[0] == pytest.approx(2e-4 * 0.999 ** 3, rel=1e-12)
+    # resume at epoch 3 from the saved optimizer state (param_groups carry lr and initial_lr)
+    sd = topt.state_dict()
+    topt2 = torch.optim.AdamW([w], hp.learning_rate_d, betas=[hp.adam_b1, hp.adam_b2])
+    topt2.load_state_dict(sd)
+    tsch2 = TorchLR(topt2, gamma=hp.lr_decay, last_epoch=3)
+    opt2 = train.AdamW([], hp.learning_rate_d, betas=[hp.adam_b1, hp.adam_b2])
+    opt2.load_state_dict({'state': {}, 'param_groups': sd['param_groups']})
+    sch2 = train.ExponentialLR(opt2, gamma=hp.lr_decay, last_epoch=3)
+    assert sch2.last_epoch == tsch2.last_epoch == 4
+    assert sch2.get_last_lr()[0] == tsch2.get_last_lr()[0] == opt2.param_groups[0]['lr']
+    topt2.step(); tsch2.step(); sch2.step()
+    assert sch2.get_last_lr()[0] == tsch2.get_last_lr()[0]
+    assert opt2.initial_lr == hp.learning_rate_d
+
+
+def test_loss_switches_refuse_cpu():
     from models import envelope_loss, strip_mirror_loss
     from rtg.lib import RtgError
     with pytest.raises(RtgError):

@@ -1,0 +1,464 @@
+"""The real step sequence of retunegan/train.py:121-193 on the HIP path against the fixtures the REFERENCE produced
+(oracle/gen_golden.py `run_steps`): two complete iterations — generator forward, `d_train_times` discriminator updates
+(the second one sees the first one's weights), generator update through the frozen discriminators, AdamW — for BASELINE
+configs 1, 2 and 4 at batch 2; the MTD generator-side gradient fixture; the AdamW kernel against torch.optim.AdamW; and
+the full-size workloads of BASELINE configs[2..4] through size-independent properties (a batch-mean loss and its
+gradients are the mean over the batch's clip pairs).  GPU only."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+NOISE_SHAPES = [(128, 256), (128, 256), (64, 2048), (64, 2048), (32, 8192), (32, 8192)]
+
+
+def stats(t):
+    t = t.detach().double().cpu()
+    return np.array([t.sum().item(), t.abs().mean().item()])
+
+
+def _param_stats(m):
+    return np.stack([stats(p) for _, p in sorted(m.named_parameters())])
+
+
+def _numels(m):
+    return np.array([p.numel() for _, p in sorted(m.named_parameters())])
+
+
+def _reference_noise(oracle, n_steps, batch=2):
+    """The rand_like draws of the reference run (gen_golden.run_steps): torch.manual_seed(1234), construction of the four
+    reference modules (the oracle's constructors consume the identical RNG stream: tests/test_oracle_golden.py
+    test_construction_matches_reference), then six draws per generator forward."""
+    torch.manual_seed(1234)
+    oracle.Generator(), oracle.MSD(), oracle.MPD(), oracle.MTD()
+    return [[torch.rand((batch,) + s) for s in NOISE_SHAPES] for _ in range(n_steps)]
+
+
+@pytest.mark.parametrize('name,cfg', [('cfg1', (False, False, 1)), ('cfg2', (True, False, 2)), ('cfg4', (True, True, 2))])
+def test_two_train_steps_match_the_reference_fixture(oracle, gold, name, cfg):
+    """Trainer.train_step x 2 against gold['step_<cfg>_*'] (losses of the last D update and of the G update per step,
+    parameter statistics of every tensor of G and of each discriminator after the second step).
+    Tolerances: losses rtol 2e-4 without MTD; with MTD 3e-3 — frame 0 of the centred STFT is symmetric, its spectrum is
+    real up to rounding, and the reference's own angle() there is +-pi by rounding noise (tests/test_conv2d_gpu.py), which
+    moves the MTD terms by ~1e-3.  Parameters: |mean| and sum of every tensor as in tests/test_oracle_golden.py; with MTD
+    only to a fraction of lr * updates (AdamW turns the sign of a ~0 gradient into a +-lr move)."""
+    from train import Trainer
+    use_mpd, use_mtd, d_times = cfg
+    torch.manual_seed(3)
+    tr = Trainer(use_mpd=use_mpd, use_mtd=use_mtd, d_train_times=d_times, dev='cuda:0')
+    for m in (tr.generator, *tr.discs):
+        oracle.det_fill(m)
+    x, y_tmpl, y = [t.to(DEV) for t in oracle.golden_inputs()]
+    noise = _reference_noise(oracle, 2)
+    rec = []
+    for step in range(2):
+        dl, gl = tr.train_step(x, y_tmpl, y, noise_list=[n.to(DEV) for n in noise[step]])
+        rec.append([dl['disc_all'].item(), gl['gen_all'].item()])
+    torch.cuda.synchronize()
+    ref = gold[f'step_{name}_losses']
+    np.testing.assert_allclose(np.array(rec), ref, rtol=3e-3 if use_mtd else 2e-4)
+
+    def check(mod, key):
+        got, want, ne = _param_stats(mod), gold[key], _numels(mod)
+        assert got.shape == want.shape
+        if use_mtd:
+            lr_steps = 2e-4 * 2 * d_times
+            assert np.all(np.abs(got[:, 1] - want[:, 1]) <= 0.25 * lr_steps), key
+            assert np.all(np.abs(got[:, 0] - want[:, 0]) <= 0.25 * lr_steps * ne + 5e-3), key
+            return
+        # two AdamW updates move every element by at most ~2 lr per update; elements whose gradient is ~0 (sign decided
+        # by fp32 summation order) move by +-lr either way: mean |p| is pinned to 2 % of lr * updates, the plain sum to
+        # the same per element
+        lr_steps = 2e-4 * 2 * d_times
+        assert np.all(np.abs(got[:, 1] - want[:, 1]) <= 0.02 * lr_steps + 2e-6 * want[:, 1]), \
+            (key, np.abs(got[:, 1] - want[:, 1]).max())
+        assert np.all(np.abs(got[:, 0] - want[:, 0]) <= 0.05 * lr_steps * ne + 1e-3), key
+
+    check(tr.generator, f'step_{name}_g_stats')
+    for tag, d in (('msd', tr.msd), ('mpd', tr.mpd), ('mtd', tr.mtd)):
+        if d is not None:
+            check(d, f'step_{name}_{tag}_stats')
+
+
+def test_second_discriminator_update_sees_the_first_ones_weights(oracle, gold):
+    """train.py:132-160 with d_train_times = 2: the loss of the second D update differs from the first (same inputs, new
+    weights), and the last one is what the fixture recorded — run with d_train_times 1 and 2 and compare both."""
+    from train import Trainer
+    x, y_tmpl, y = [t.to(DEV) for t in oracle.golden_inputs()]
+    out = {}
+    for d_times in (1, 2):
+        torch.manual_seed(3)
+        tr = Trainer(use_mpd=True, use_mtd=False, d_train_times=d_times, dev='cuda:0')
+        for m in (tr.generator, *tr.discs):
+            oracle.det_fill(m)
+        dl, _ = tr.train_step(x, y_tmpl, y)
+        out[d_times] = dl['disc_all'].item()
+    ref = gold['step_cfg2_losses'][0, 0]
+    np.testing.assert_allclose(out[2], ref, rtol=2e-4)
+    assert abs(out[1] - out[2]) > 1e-3 * abs(ref)          # the first update's loss is a different number
+
+
+def _on_reference_branch(spec, ref_phase0):
+    """[log|D|, phase/PI] from the HIP kernel with the phases of frame 0 that sit on the +-1 branch cut put on the side the
+    REFERENCE run took (gold['stft<n_fft>_frame0_phase_{r,g}']): frame 0 of the centred, reflect-padded STFT is symmetric,
+    its spectrum is real up to rounding, and the sign of angle() for a negative real part is rounding noise of the
+    machine that ran it (the CPU oracle on another host takes other branches than the fixture run did).  Straight-through:
+    the gradient of the returned tensor flows to `spec` unchanged."""
+    ref = torch.from_numpy(ref_phase0).to(spec.device)
+    ph = spec[:, 1, :, 0].detach()
+    cut = (ph.abs() > 1 - 1e-3) & (ref.abs() > 1 - 1e-3) & (torch.sign(ph) != torch.sign(ref))
+    delta = torch.zeros_like(spec)
+    delta[:, 1, :, 0] = torch.where(cut, ref - ph, torch.zeros_like(ph))
+    return spec + delta, cut.float().mean().item()
+
+
+def _mtd(oracle):
+    from models import MultiStftDiscriminator
+    torch.manual_seed(1)
+    mtd = MultiStftDiscriminator()
+    oracle.det_fill(mtd)
+    return mtd.to(DEV).train()
+
+
+def test_mtd_losses_against_the_reference_fixture_on_its_branch(oracle, gold):
+    """MTD logits and d / g / feature losses against the reference's own values (gold['mtd_*']) at rtol 1e-3, the spectra
+    computed by the HIP STFT kernel, frame-0 phases on the branch cut put on the reference run's side (what the 2e-2 of
+    tests/test_conv2d_gpu.py absorbed)."""
+    from models import multi_stft_loss, discriminator_loss, generator_loss, feature_loss
+    mtd = _mtd(oracle)
+    _, _, y = oracle.golden_inputs()
+    yd = torch.from_numpy(gold['y_hat'])
+    S, Sg = multi_stft_loss(y.to(DEV), yd.to(DEV), ret_specs=True)
+    fixed, frac = [], []
+    for j, (n_fft, _, _) in enumerate(oracle.STFT_PARAMS):
+        for lst, tag in ((S, 'r'), (Sg, 'g')):
+            f, fr_ = _on_reference_branch(lst[j], gold[f'stft{n_fft}_frame0_phase_{tag}'])
+            fixed.append(f); frac.append(fr_)
+    assert 0.05 < max(frac) < 0.5                            # about half of the negative-real bins of frame 0
+    with torch.no_grad():
+        lr, lg, fr, fg = mtd(fixed[0::2], fixed[1::2])
+        np.testing.assert_allclose(discriminator_loss(lr, lg).item(), gold['mtd_d_loss'], rtol=1e-3)
+        np.testing.assert_allclose(generator_loss(lg, lr).item(), gold['mtd_g_loss'], rtol=1e-3)
+        np.testing.assert_allclose(feature_loss(fr, fg).item(), gold['mtd_fm_loss'], rtol=1e-3)
+    for i, (r, g_) in enumerate(zip(lr, lg)):
+        np.testing.assert_allclose(r.cpu().numpy(), gold[f'mtd_logit_r{i}'], rtol=2e-3, atol=5e-4)
+        np.testing.assert_allclose(g_.cpu().numpy(), gold[f'mtd_logit_g{i}'], rtol=2e-3, atol=5e-4)
+    ne = np.array([f.numel() for fl in fg for f in fl])
+    got = np.stack([stats(f) for fl in fg for f in fl])
+    np.testing.assert_allclose(got[:, 1], gold['mtd_fmap_g_stats'][:, 1], rtol=1e-3, atol=2e-5)
+    assert np.all(np.abs(got[:, 0] - gold['mtd_fmap_g_stats'][:, 0]) <= 2e-4 * ne * gold['mtd_fmap_g_stats'][:, 1] + 1e-3)
+
+
+def test_mtd_generator_side_gradient_fixture(oracle, gold):
+    """gold['grad_mtd_yhat'] (gen_golden.py): d(generator_loss + 2 feature_loss)/d y_hat through the frozen MTD, log|D|
+    and angle(D) of the three STFT resolutions, down to the wave — 2-D backward-data + STFT backward kernel.  Phases of
+    frame 0 on the reference's branch (see _on_reference_branch); relative L2 over the wave."""
+    from models import multi_stft_loss, generator_loss, feature_loss
+    mtd = _mtd(oracle)
+    for p in mtd.parameters():
+        p.requires_grad_(False)
+    _, _, y = oracle.golden_inputs()
+    yh = torch.from_numpy(gold['y_hat']).to(DEV).requires_grad_(True)
+    S, Sgh = multi_stft_loss(y.to(DEV), yh, ret_specs=True)
+    Sf = [_on_reference_branch(s, gold[f'stft{n}_frame0_phase_r'])[0] for s, (n, _, _) in zip(S, oracle.STFT_PARAMS)]
+    Sgf = [_on_reference_branch(s, gold[f'stft{n}_frame0_phase_g'])[0] for s, (n, _, _) in zip(Sgh, oracle.STFT_PARAMS)]
+    lr, lg, fr, fg = mtd(Sf, Sgf)
+    (generator_loss(lg, lr) + 2 * feature_loss(fr, fg)).backward()
+    got, ref = yh.grad.cpu().numpy(), gold['grad_mtd_yhat']
+    assert got.shape == ref.shape
+    rel = np.linalg.norm(got - ref) / np.linalg.norm(ref)
+    print('grad_mtd_yhat: relative L2 %.3e' % rel)
+    assert rel < 5e-3         # d angle / d D ~ 1/|D| amplifies fp32 rounding at weak bins (tests/test_conv2d_gpu.py: 5e-3)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# rtg_adamw against torch.optim.AdamW (train.py:80-81,158-160,191-193)
+# ---------------------------------------------------------------------------------------------------------------
+def _adamw_launch(p, g, m, v, step, flag, lr, gscale=1.0, b1=0.8, b2=0.99, eps=1e-8, wd=0.01):
+    from rtg.lib import lib, check, current_stream_ptr
+    ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    check(lib.rtg_adamw(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), ptr(step), ptr(flag), lr, b1, b2, eps, wd, gscale,
+                        current_stream_ptr()), 'adamw')
+
+
+def test_adamw_kernel_matches_torch_adamw():
+    """random flat parameters / gradients, 5 steps, against torch.optim.AdamW(lr, betas=(0.8, 0.99), eps=1e-8,
+    weight_decay=0.01) on the CPU at rtol 1e-6: gradients spanning 12 orders of magnitude (|g| << eps .. >> 1), a
+    learning-rate change between steps (ExponentialLR), grad_scale = 1/2 (data-parallel averaging of a summed gradient)."""
+    n = 1 << 20
+    gen = torch.Generator().manual_seed(17)
+    p0 = torch.randn(n, generator=gen)
+    ref_p = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([ref_p], 2e-4, betas=(0.8, 0.99), eps=1e-8, weight_decay=0.01)
+    p = p0.clone().to(DEV)
+    m, v, step = torch.zeros_like(p), torch.zeros_like(p), torch.zeros(1, device=DEV)
+    lr = 2e-4
+    for it in range(5):
+        mag = 10.0 ** (torch.rand(n, generator=gen) * 12 - 10)
+        g = torch.randn(n, generator=gen) * mag
+        ref_p.grad = g.clone()
+        opt.param_groups[0]['lr'] = lr
+        opt.step()
+        _adamw_launch(p, (2 * g).to(DEV), m, v, step, None, lr, gscale=0.5)
+        lr *= 0.999
+    torch.cuda.synchronize()
+    assert step.item() == 5
+    st = opt.state[ref_p]
+    np.testing.assert_allclose(p.cpu().numpy(), ref_p.detach().numpy(), rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(m.cpu().numpy(), st['exp_avg'].numpy(), rtol=2e-6, atol=1e-30)
+    np.testing.assert_allclose(v.cpu().numpy(), st['exp_avg_sq'].numpy(), rtol=2e-6, atol=1e-36)
+    # the size of the LAST update alone (p moved by ~lr per step: a wrong bias correction or weight decay shows here)
+    upd = (p.cpu() - p0).numpy()
+    ref_upd = (ref_p.detach() - p0).numpy()
+    np.testing.assert_allclose(upd, ref_upd, rtol=2e-3, atol=2.5e-7)       # p - p0 cancels: 2 ulp of |p| ~ 1
+
+
+def test_adamw_nan_flag_skips_update_moments_and_counter():
+    """train.py:158,191 `if not torch.isnan(loss): loss.backward()` made device-side: a NaN loss flag leaves parameters,
+    both moments and the step counter untouched; a finite flag updates as usual."""
+    n = 4096 + 37
+    gen = torch.Generator().manual_seed(5)
+    p = torch.randn(n, generator=gen).to(DEV)
+    g = torch.randn(n, generator=gen).to(DEV)
+    m, v = torch.rand(n, generator=gen).to(DEV), torch.rand(n, generator=gen).to(DEV)
+    step = torch.full((1,), 3.0, device=DEV)
+    before = [t.clone() for t in (p, m, v, step)]
+    _adamw_launch(p, g, m, v, step, torch.full((1,), float('nan'), device=DEV), 2e-4)
+    torch.cuda.synchronize()
+    for a, b in zip((p, m, v, step), before):
+        assert torch.equal(a, b)
+    _adamw_launch(p, g, m, v, step, torch.full((1,), 1.25, device=DEV), 2e-4)
+    torch.cuda.synchronize()
+    assert step.item() == 4 and not torch.equal(p, before[0]) and not torch.equal(m, before[1])
+    # against torch from the same state (step 3 -> 4)
+    rp = torch.nn.Parameter(before[0].cpu().clone())
+    opt = torch.optim.AdamW([rp], 2e-4, betas=(0.8, 0.99), eps=1e-8, weight_decay=0.01)
+    opt.state[rp] = {'step': torch.tensor(3.0), 'exp_avg': before[1].cpu().clone(), 'exp_avg_sq': before[2].cpu().clone()}
+    rp.grad = g.cpu().clone()
+    opt.step()
+    np.testing.assert_allclose(p.cpu().numpy(), rp.detach().numpy(), rtol=1e-6, atol=1e-9)
+
+
+def test_nan_loss_in_the_trainer_skips_the_update(oracle):
+    """the guard through Trainer: a NaN in the real wave makes both totals NaN; no parameter, moment or counter moves"""
+    from train import Trainer
+    torch.manual_seed(3)
+    tr = Trainer(use_mpd=True, use_mtd=False, d_train_times=1, dev='cuda:0')
+    x, y_tmpl, y = [t.to(DEV) for t in oracle.golden_inputs(batch=1)]
+    tr.train_step(x, y_tmpl, y)                       # a normal step first: moments exist
+    snap = [m.bank().flat.clone() for m in (tr.generator, *tr.discs)]
+    steps = [tr.optim_g.step_tensor(tr.generator).item()] + [tr.optim_d.step_tensor(d).item() for d in tr.discs]
+    y_bad = y.clone()
+    y_bad[0, 0, 100] = float('nan')
+    dl, gl = tr.train_step(x, y_tmpl, y_bad)
+    torch.cuda.synchronize()
+    assert torch.isnan(dl['disc_all']) and torch.isnan(gl['gen_all'])
+    for m, s in zip((tr.generator, *tr.discs), snap):
+        assert torch.equal(m.bank().flat, s)
+    assert steps == [tr.optim_g.step_tensor(tr.generator).item()] + [tr.optim_d.step_tensor(d).item() for d in tr.discs]
+
+
+def test_one_step_from_checkpointed_moments_matches_oracle_elementwise(oracle):
+    """one HIP step from non-trivial AdamW moments against the oracle's torch.optim.AdamW step: parameters element-wise
+    wherever |grad| >> eps (elements whose update is decided by the sign of a ~0 gradient are excluded), in units of the
+    learning rate."""
+    from train import Trainer
+    og, omsd, ompd = oracle.Generator(), oracle.MSD(), oracle.MPD()
+    for m in (og, omsd, ompd):
+        oracle.det_fill(m)
+    oog, ood = oracle.make_optimizers(og, [omsd, ompd])
+    x, y_tmpl, y = oracle.golden_inputs(batch=1)
+    oracle.train_step(og, oog, ood, x, y_tmpl, y, omsd, ompd, None, 1)
+    torch.manual_seed(3)
+    tr = Trainer(use_mpd=True, use_mtd=False, d_train_times=1, dev='cuda:0')
+    tr.generator.load_state_dict(og.state_dict())
+    tr.msd.load_state_dict(omsd.state_dict())
+    tr.mpd.load_state_dict(ompd.state_dict())
+    tr.optim_g.load_state_dict(oog.state_dict())
+    tr.optim_d.load_state_dict(ood.state_dict())
+    with torch.no_grad():
+        tr.generator.noise.w.zero_(); og.noise.w.zero_()
+    tr.train_step(x.to(DEV), y_tmpl.to(DEV), y.to(DEV))
+    oracle.train_step(og, oog, ood, x, y_tmpl, y, omsd, ompd, None, 1)
+    torch.cuda.synchronize()
+    n_checked = 0
+    for mod, omod, lr in ((tr.generator, og, 1.8e-4), (tr.msd, omsd, 2e-4), (tr.mpd, ompd, 2e-4)):
+        op = dict(omod.named_parameters())
+        for name, p in mod.named_parameters():
+            if name == 'noise.w':
+                continue
+            ref, grad = op[name].detach(), op[name].grad
+            big = grad.abs() > 1e-4 * grad.abs().max() + 1e-7
+            got = p.detach().cpu()
+            n_checked += int(big.sum())
+            # what the kernels determine is the update (~lr per element): m / (sqrt(v) + eps) follows the gradient, and
+            # the HIP gradients carry ~1e-3 of relative noise through 57 layers (leaky-relu branch flips,
+            # tests/test_models_gpu.py), so an element's update is pinned to a few % of lr, the bulk far tighter
+            err = ((got - ref).abs() / lr)[big]
+            assert err.mean().item() < 5e-3, (name, err.mean().item())
+            n_bad = int((err >= 0.05).sum())
+            assert n_bad <= max(2, 0.005 * err.numel()), (name, n_bad, err.numel())
+            # (|m / sqrt(v)| <= (1 - b1) / sqrt(1 - b2) = 2: a single element whose second-step gradient disagrees in sign
+            # can differ by a few lr; a wrong bias correction or decay would move EVERY element, caught by the mean)
+            assert err.max().item() < 4.0, (name, err.max().item())
+    assert n_checked > 5_000_000
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# full-size workloads (BASELINE configs[2..4]): size-independent properties
+# ---------------------------------------------------------------------------------------------------------------
+def _pairs_property(tr, x, y_tmpl, y, tol_out, tol_d, tol_dy, tol_g):
+    """Every loss of the step is a batch mean and clips do not interact.  At the same generated wave (a leaf):
+      * the generator output of a clip pair equals the pair's rows of the full batch;
+      * D step: the flat D gradients of the full batch equal the mean over its clip pairs (d_step(apply=False));
+      * G step through the frozen D's + STFT / dynamic losses: d loss / d y_hat of the full batch, row by row, equals
+        2/B times that of the pair alone;
+      * generator backward: the flat G gradients of the full batch under that cotangent equal the sum over pairs.
+    (Evaluating the pair's losses at the pair's OWN forward instead would compare different branches of angle(): the
+    MTD's phase input is discontinuous in y_hat and a 1e-5 change of the wave flips frame-0 phases, as in the reference.)"""
+    from models.loss import stft_cache
+    B = x.shape[0]
+    n_pairs = B // 2
+    sl = [slice(b0, b0 + 2) for b0 in range(0, B, 2)]
+
+    def d_grads(ys, yh):
+        with stft_cache():
+            dl = tr.d_step(ys, yh, apply=False)
+        return dl['disc_all'].item(), [d.bank().gflat.clone() for d in tr.discs]
+
+    def g_cotangent(ys, yh):
+        leaf = yh.clone().requires_grad_(True)
+        with stft_cache():
+            gl = tr.g_step(ys, leaf, apply=False)
+        return gl['gen_all'].item(), leaf.grad.detach()
+
+    def g_grads(xs, ts, cot):
+        tr.optim_g.zero_grad()
+        out = tr.generator(xs, ts)
+        out.backward(cot)
+        tr.generator.bank().sync_grads()
+        return out.detach(), tr.generator.bank().gflat.clone()
+
+    with torch.no_grad():
+        y_hat = tr.generator(x, y_tmpl)
+    assert torch.isfinite(y_hat).all()
+    dlf, dgf = d_grads(y, y_hat)
+    glf, cot = g_cotangent(y, y_hat)
+    _, ggf = g_grads(x, y_tmpl, cot)
+    assert np.isfinite([dlf, glf]).all() and torch.isfinite(cot).all() and cot.abs().max() > 0
+    acc_d, acc_g, dls, gls = [torch.zeros_like(t) for t in dgf], torch.zeros_like(ggf), [], []
+    scale_y, scale_c = y_hat.abs().max().item(), cot.abs().max().item()
+    for s_ in sl:
+        xs, ts, ys, yh = x[s_].contiguous(), y_tmpl[s_].contiguous(), y[s_].contiguous(), y_hat[s_].contiguous()
+        dlp, dgp = d_grads(ys, yh)
+        glp, cp = g_cotangent(ys, yh)
+        assert (cp * (2.0 / B) - cot[s_]).abs().max().item() <= tol_dy * scale_c, (s_, 'd loss / d y_hat')
+        yp, ggp = g_grads(xs, ts, cot[s_].contiguous())
+        assert (yp - y_hat[s_]).abs().max().item() <= tol_out * scale_y, (s_, 'generator output')
+        for a_, t_ in zip(acc_d, dgp):
+            a_ += t_
+        acc_g += ggp
+        dls.append(dlp); gls.append(glp)
+    np.testing.assert_allclose(dlf, np.mean(dls), rtol=tol_d[0])
+    np.testing.assert_allclose(glf, np.mean(gls), rtol=tol_d[0])
+    for full, acc, d in zip(dgf, acc_d, tr.discs):
+        rel = ((full - acc / n_pairs).norm() / full.norm()).item()
+        assert rel < tol_d[1], (type(d).__name__, rel)
+    # (the slot of noise.w is excluded: its gradient is sum(u * dy) with the device noise field u of each call)
+    keep = torch.ones_like(ggf, dtype=torch.bool)
+    for name, p_, off in tr.generator.bank().extra:
+        keep[off:off + p_.numel()] = False
+    rel = ((ggf - acc_g)[keep].norm() / ggf[keep].norm()).item()
+    assert rel < tol_g, rel
+    return dlf, glf
+
+
+def _full_stack_trainer(oracle, B, T, seed):
+    from train import Trainer
+    torch.manual_seed(seed)
+    tr = Trainer(use_mpd=True, use_mtd=True, d_train_times=2, dev='cuda:0')
+    with torch.no_grad():
+        tr.generator.noise.w.zero_()          # the device noise field depends on the call counter, not on the clip
+    x, y_tmpl, y = [t.to(DEV) for t in oracle.synthetic_batch(B, T, seed)]
+    return tr, x, y_tmpl, y
+
+
+def _finite_step(tr, x, y_tmpl, y):
+    before = tr.generator.bank().flat.clone()
+    dl, gl = tr.train_step(x, y_tmpl, y)
+    torch.cuda.synchronize()
+    assert torch.isfinite(dl['disc_all']) and torch.isfinite(gl['gen_all'])
+    for m in (tr.generator, *tr.discs):
+        assert torch.isfinite(m.bank().flat).all()
+    moved = (tr.generator.bank().flat - before).abs()
+    assert 0 < moved.max().item() <= 4 * 1.8e-4
+
+
+def test_config4_full_stack_step_at_32x8192(oracle):
+    """BASELINE configs[3] per GPU: full stack (G + MSD + MPD + MTD), 32 clips x 8192 samples, fp32."""
+    tr, x, y_tmpl, y = _full_stack_trainer(oracle, 32, 8192, 41)
+    _pairs_property(tr, x, y_tmpl, y, tol_out=2e-5, tol_d=(1e-4, 2e-3), tol_dy=1e-3, tol_g=2e-3)
+    _finite_step(tr, x, y_tmpl, y)
+
+
+def test_config5_full_stack_step_at_16x22016(oracle):
+    """BASELINE configs[4] per GPU: full stack at the finetune shape, 16 clips x 22016 samples (86 frames), fp32."""
+    tr, x, y_tmpl, y = _full_stack_trainer(oracle, 16, 22016, 42)
+    _pairs_property(tr, x, y_tmpl, y, tol_out=2e-5, tol_d=(1e-4, 2e-3), tol_dy=1e-3, tol_g=2e-3)
+    _finite_step(tr, x, y_tmpl, y)
+
+
+def test_config3_full_stack_bf16_step_at_32x16384(oracle):
+    """BASELINE configs[2]: full stack, 32 clips x 16384 samples, bf16 operands with fp32 accumulation and fp32 losses.
+    bf16 rounds the operands per element, independent of the batch: the same properties hold at bf16 summation noise."""
+    import hparam as hp
+    hp.compute_dtype = 'bf16'
+    try:
+        tr, x, y_tmpl, y = _full_stack_trainer(oracle, 32, 16384, 43)
+        assert any(ly.fwd_bf for ly in tr.generator.bank().layers) and any(ly.fwd_bf for ly in tr.mtd.bank().layers)
+        _pairs_property(tr, x, y_tmpl, y, tol_out=2e-2, tol_d=(2e-3, 2e-2), tol_dy=2e-2, tol_g=2e-2)
+        _finite_step(tr, x, y_tmpl, y)
+    finally:
+        hp.compute_dtype = 'fp32'
+
+
+def test_bf16_two_steps_against_the_bf16_rounding_oracle(oracle):
+    """cfg2-shaped run (G + MSD + MPD, d_train_times 2, two steps) in bf16 against the oracle with bf16-rounded operands
+    in exactly the layers the product runs in bf16: losses within 1 % (bf16 keeps 8 significant bits; the rounding
+    decisions of two evaluations diverge after a few layers), and closer to the bf16 oracle than the fp32 oracle is."""
+    import hparam as hp
+    from train import Trainer
+    hp.compute_dtype = 'bf16'
+    try:
+        torch.manual_seed(3)
+        tr = Trainer(use_mpd=True, use_mtd=False, d_train_times=2, dev='cuda:0')
+        nets = {'bf16': (oracle.Generator(), oracle.MSD(), oracle.MPD()), 'fp32': (oracle.Generator(), oracle.MSD(), oracle.MPD())}
+        for m in (tr.generator, *tr.discs):
+            oracle.det_fill(m)
+        for ms in nets.values():
+            for m in ms:
+                oracle.det_fill(m)
+        for prod, om in zip((tr.generator, tr.msd, tr.mpd), nets['bf16']):
+            flags = {ly.name: ly.fwd_bf for ly in prod.bank().layers}
+            for name, mod in om.named_modules():
+                if name in flags:
+                    mod.bf16 = bool(flags[name])
+        x, y_tmpl, y = oracle.golden_inputs()
+        rec = {k: [] for k in ('hip', 'bf16', 'fp32')}
+        opts = {k: oracle.make_optimizers(ms[0], list(ms[1:])) for k, ms in nets.items()}
+        for _ in range(2):
+            dl, gl = tr.train_step(x.to(DEV), y_tmpl.to(DEV), y.to(DEV))
+            rec['hip'].append([dl['disc_all'].item(), gl['gen_all'].item()])
+            for k, (g_, msd, mpd) in nets.items():
+                odl, ogl = oracle.train_step(g_, *opts[k], x, y_tmpl, y, msd, mpd, None, 2)
+                rec[k].append([sum(odl.values()).item(), ogl['total'].item()])
+        hip, b16, f32 = (np.array(rec[k]) for k in ('hip', 'bf16', 'fp32'))
+        print('bf16 steps: hip', hip.tolist(), 'oracle_bf16', b16.tolist(), 'oracle_fp32', f32.tolist())
+        np.testing.assert_allclose(hip, b16, rtol=1e-2)
+        assert np.abs(hip - b16).max() <= np.abs(b16 - f32).max() + 1e-3 * np.abs(f32).max()
+    finally:
+        hp.compute_dtype = 'fp32'

@@ -297,22 +297,28 @@ __global__ __launch_bounds__(RTG_THREADS) void dyn_kernel(const float* __restric
 // ---------------------------------------------------------------------------------------------------------------
 // AdamW over a flat buffer
 // ---------------------------------------------------------------------------------------------------------------
+// torch.optim.AdamW, single-tensor form, in torch's own order of operations (torch/optim/adamw.py / adam.py
+// _single_tensor_adam): scalar factors (bias corrections, step size, decay factor) in double like the Python side
+// computes them, element math in fp32: p *= 1 - lr*wd; m = lerp(m, g, 1-b1); v = v*b2 + (1-b2)*g*g;
+// p -= step_size * m / (sqrt(v) / sqrt(bc2) + eps).
 __global__ __launch_bounds__(RTG_THREADS) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                             float* __restrict__ m, float* __restrict__ v, long long n,
                                                             const float* __restrict__ step_state,
-                                                            const float* __restrict__ loss_flag, float lr, float b1,
-                                                            float b2, float eps, float wd, float gscale) {
+                                                            const float* __restrict__ loss_flag, double lr, double b1,
+                                                            double b2, double eps_d, double wd, float gscale) {
   if (loss_flag && isnan(*loss_flag)) return;
-  const float t = step_state[0] + 1.f;
-  const float bc1 = 1.f - powf(b1, t), bc2 = 1.f - powf(b2, t);
-  const float step_size = lr / bc1, rs2 = 1.f / sqrtf(bc2), decay = 1.f - lr * wd;
+  const double t = (double)step_state[0] + 1.0;
+  const double bc1 = 1.0 - pow(b1, t), bc2 = 1.0 - pow(b2, t);
+  const float step_size = (float)(lr / bc1), bc2s = (float)sqrt(bc2), decay = (float)(1.0 - lr * wd);
+  const float w1 = (float)(1.0 - b1), fb2 = (float)b2, w2 = (float)(1.0 - b2), eps = (float)eps_d;
   for (long long i = (long long)blockIdx.x * RTG_THREADS + threadIdx.x; i < n; i += (long long)gridDim.x * RTG_THREADS) {
     const float gi = g[i] * gscale;
-    const float mi = b1 * m[i] + (1.f - b1) * gi;
-    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    const float m0 = m[i];
+    const float mi = m0 + w1 * (gi - m0);
+    const float vi = v[i] * fb2 + w2 * gi * gi;
     m[i] = mi;
     v[i] = vi;
-    p[i] = p[i] * decay - step_size * (mi / (sqrtf(vi) * rs2 + eps));
+    p[i] = p[i] * decay - step_size * mi / (sqrtf(vi) / bc2s + eps);
   }
 }
 
@@ -561,8 +567,8 @@ extern "C" int rtg_strip_mirror_bwd(const float* y, int rows, int L, float w, co
 }
 
 extern "C" int rtg_adamw(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n,
-                         float* step_state, const float* loss_flag, float lr, float beta1, float beta2, float eps,
-                         float weight_decay, float grad_scale, void* stream) {
+                         float* step_state, const float* loss_flag, double lr, double beta1, double beta2, double eps,
+                         double weight_decay, float grad_scale, void* stream) {
   RTG_REQ(params && grads && exp_avg && exp_avg_sq && step_state);
   if (n < 1) return RTG_EINVAL;
   RTG_KLAUNCH(adamw_kernel, dim3(grid_for(n)), dim3(RTG_THREADS), 0, (hipStream_t)stream, params, grads, exp_avg,

@@ -12,6 +12,7 @@
 // Both kernels read the weights from the SAME packed buffers the MFMA kernels use (rtg_weights_pack), so callers see
 // no difference: rtg_conv1d dispatches here (rtg_conv1d.hip).
 #include "rtg_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -45,7 +46,7 @@ __device__ __forceinline__ long long packed_index(int m, int c, int tap, int Cg,
 }
 
 __device__ __forceinline__ float thin_act(float v, int act, float slope) {
-  if (act == RTG_ACT_LRELU) return fmaf(fminf(v, 0.f), slope, fmaxf(v, 0.f));
+  if (act == RTG_ACT_LRELU) return v > 0.f ? v : v * slope;     // (a NaN stays a NaN: the step's NaN guard relies on it)
   if (act == RTG_ACT_TANH) return tanhf(v);
   return v;
 }
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(RTG_THREADS) void thin_cin1_kernel(const ThinArgs a
     float v = 0.f;
     if (j < a.K && pos >= 0 && pos < a.L_in) {
       v = xr[pos];
-      if (a.pre_mode == RTG_PRE_LRELU) v = fmaf(fminf(v, 0.f), a.pre_slope, fmaxf(v, 0.f));
+      if (a.pre_mode == RTG_PRE_LRELU) v = v > 0.f ? v : v * a.pre_slope;
       else if (a.pre_mode == RTG_PRE_MUL_DLRELU) v *= (ar[pos] > 0.f ? 1.f : a.pre_slope);
       else if (a.pre_mode == RTG_PRE_MUL_DTANH) v *= fmaf(-ar[pos], ar[pos], 1.f);
     }
@@ -103,7 +104,7 @@ constexpr int kCoutWaves = 8;
 using rsrc_t = __amdgpu_buffer_rsrc_t;
 
 __global__ __launch_bounds__(64 * kCoutWaves) void thin_cout1_kernel(const ThinArgs a) {
-  extern __shared__ float sm[];                 // [C*K] weights in logical order, then [waves][64] partial sums
+  extern __shared__ __attribute__((aligned(16))) float sm[];                 // [C*K] weights in logical order, then [waves][64] partial sums
   float* w = sm;
   float* part = sm + a.C * a.K;
   for (int e = threadIdx.x; e < a.C * a.K; e += 64 * kCoutWaves) {
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(64 * kCoutWaves) void thin_cout1_kernel(const ThinA
     const unsigned off = ok ? clip_off + (unsigned)c * row_bytes + (unsigned)pos * 4u : 0x80000000u;
     float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, off, 0, 0));
     if (a.pre_mode == RTG_PRE_LRELU) {
-      v = fmaf(fminf(v, 0.f), a.pre_slope, fmaxf(v, 0.f));
+      v = v > 0.f ? v : v * a.pre_slope;
     } else if (a.pre_mode >= RTG_PRE_MUL_DLRELU) {
       const float av = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra, off, 0, 0));
       v *= (a.pre_mode == RTG_PRE_MUL_DTANH) ? fmaf(-av, av, 1.f) : fmaf(1.f - a.pre_slope, (float)(av > 0.f), a.pre_slope);
@@ -160,6 +161,412 @@ __global__ __launch_bounds__(64 * kCoutWaves) void thin_cout1_kernel(const ThinA
   }
 }
 
+
+// =====================================================================================================================
+// Tile-staged bandwidth kernels (round 2).  The two kernels above fetch every tap with its own dword load and work on
+// 64..256 positions per block; measured 405 GB/s (one output channel) and 1 047 GB/s (one input channel).  The
+// kernels below move every input byte ONCE with wide coalesced loads into LDS (activation applied on the way), take
+// the K taps from LDS, and write 16 bytes per lane.  They serve the shapes the train step actually has; anything else
+// (aux operand on the one-output-channel shape, rows beyond the staging limits) falls back to the kernels above.
+// =====================================================================================================================
+struct TileGeo {
+  int PT, TP, tp_shift, R, NG, CH, W, Wp, tiles, w_floats, vec;
+  int TPRow, tprow_shift, unit, shift;
+  int RB;                      // one-input-channel kernels: output rows per block
+  int chunks;                  // flat kernel: chunks of kFlatChunk outputs per clip
+};
+
+__device__ __forceinline__ float thin_pre(float v, const ThinArgs& a) {
+  return a.pre_mode == RTG_PRE_LRELU ? (v > 0.f ? v : v * a.pre_slope) : v;
+}
+
+// ---- one output channel, long rows.  Block = (clip, tile of PT positions); the C input rows are staged CH at a time as
+// [CH][window of the tile] — float4 loads from 16-byte aligned row addresses (VEC) or dword loads, no integer division
+// (thread = column q of row rr, rows rr, rr + RP, ...), up to 8 loads in flight per thread — with the activation applied
+// on the way and the window start at LDS column 0 of each row.  Compute: thread = (4 consecutive positions, channel
+// group); for stride 1 / dilation 1 the 4 + K - 1 inputs of a channel come from aligned 16-byte LDS reads and live in
+// registers (K weights + 4K multiply-adds per 3..5 LDS reads); other strides take scalar LDS reads.  The NG partial sums
+// of a position meet in LDS and are added in fixed order.
+template <bool VEC, int KT>
+__global__ __launch_bounds__(RTG_THREADS) void cout1_long_kernel(const ThinArgs a, const TileGeo g) {
+  const int K = KT > 0 ? KT : a.K;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* wl = sm;                                     // [C][Kp]
+  float* xs = sm + g.w_floats;                        // [CH][Wp]
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x / g.tiles, tile = blockIdx.x - b * g.tiles;
+  // g.shift: the tile grid starts `shift` outputs left of output 0 so that (stride 1) every window starts on a 16-byte
+  // boundary of the input row: m == 0, aligned 16-byte LDS writes and reads
+  const int t0 = tile * g.PT - g.shift;
+  const int g0 = t0 * a.stride - a.pad;
+  const int a0 = VEC ? (g0 & ~3) : g0;               // floor to a multiple of 4 (also for negative g0)
+  const int m = g0 - a0;
+  const int Kp = (K + 3) & ~3;
+  for (int e = tid; e < a.C * Kp; e += RTG_THREADS) {
+    const int c = e / Kp, j = e - c * Kp;
+    wl[e] = j < K ? a.wp[packed_index(0, c, j, a.C, K, a.tile_m, a.tap_major)] : 0.f;
+  }
+  const float* xb = a.x + (size_t)b * a.C * a.L_in;
+  const int pl = tid & (g.TP - 1), cg = tid >> g.tp_shift;
+  const int NQ = VEC ? ((m + g.W + 3) >> 2) : g.W;   // load columns per row (float4 / dword)
+  // staging: thread = column qcol (+ TPRow * pass) of rows rr, rr + RP, ...; everything that does not depend on the row
+  // is computed once, the row loop advances two pointers
+  const int qcol = tid & (g.TPRow - 1), rr = tid >> g.tprow_shift;
+  const int RP = RTG_THREADS >> g.tprow_shift;
+  const int ncp = (NQ + g.TPRow - 1) >> g.tprow_shift;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int c0 = 0; c0 < a.C; c0 += g.CH) {
+    const int chc = min(g.CH, a.C - c0);
+    __syncthreads();
+    for (int cp = 0; cp < ncp; ++cp) {
+      const int q = qcol + (cp << g.tprow_shift);
+      const int pos = VEC ? a0 + 4 * q : g0 + q;
+      const bool col_ok = q < NQ;
+      const bool in_row = col_ok && pos >= 0 && pos < a.L_in;
+      const int col = VEC ? 4 * q - m : q;           // LDS column of the first loaded float (window start = column 0)
+      const float* src = xb + (size_t)(c0 + rr) * a.L_in + pos;
+      float* dst = xs + rr * g.Wp + col;
+      const size_t src_step = (size_t)RP * a.L_in;
+      const int dst_step = RP * g.Wp;
+      for (int c = rr; c < chc; c += 8 * RP) {
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (in_row && c + u * RP < chc) {
+            if (VEC) v[u] = *reinterpret_cast<const f32x4*>(src + u * src_step);
+            else v[u].x = src[u * src_step];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (!col_ok || c + u * RP >= chc) continue;
+          float* d_ = dst + u * dst_step;
+          if (VEC && m == 0) {
+            f32x4 t = v[u];
+            t.x = thin_pre(t.x, a); t.y = thin_pre(t.y, a); t.z = thin_pre(t.z, a); t.w = thin_pre(t.w, a);
+            *reinterpret_cast<f32x4*>(d_) = t;
+          } else if (VEC) {
+            const float t4[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)               // the floats left of the window (first float4 of a row) are dropped
+              if (col + e >= 0) d_[e] = thin_pre(t4[e], a);
+          } else {
+            d_[0] = thin_pre(v[u].x, a);
+          }
+        }
+        src += 8 * src_step;
+        dst += 8 * dst_step;
+      }
+    }
+    __syncthreads();
+    if (g.unit) {
+      for (int c = cg; c < chc; c += g.NG) {
+        const f32x4* row4 = reinterpret_cast<const f32x4*>(xs + c * g.Wp) + pl;
+        const f32x4* w4 = reinterpret_cast<const f32x4*>(wl + (c0 + c) * Kp);
+        float xw[20], w[16];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+          if (4 * q < 3 + K) {
+            const f32x4 t = row4[q];
+            xw[4 * q] = t.x; xw[4 * q + 1] = t.y; xw[4 * q + 2] = t.z; xw[4 * q + 3] = t.w;
+          } else {
+            xw[4 * q] = xw[4 * q + 1] = xw[4 * q + 2] = xw[4 * q + 3] = 0.f;
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (4 * q < K) {
+            const f32x4 t = w4[q];
+            w[4 * q] = t.x; w[4 * q + 1] = t.y; w[4 * q + 2] = t.z; w[4 * q + 3] = t.w;
+          } else {
+            w[4 * q] = w[4 * q + 1] = w[4 * q + 2] = w[4 * q + 3] = 0.f;
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < kMaxTaps; ++j) {
+          if (j < K) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = fmaf(w[j], xw[i + j], acc[i]);
+          }
+        }
+      }
+    } else {
+      for (int c = cg; c < chc; c += g.NG) {
+        const float* row = xs + c * g.Wp + 4 * pl * a.stride;
+        const float* wr = wl + (c0 + c) * Kp;
+        for (int j = 0; j < K; ++j) {
+          const float w = wr[j];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[i] = fmaf(w, row[i * a.stride + j * a.dil], acc[i]);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  float* part = xs;                                   // [NG][PT]
+#pragma unroll
+  for (int i = 0; i < 4; ++i) part[cg * g.PT + 4 * pl + i] = acc[i];
+  __syncthreads();
+  for (int e = tid; e < g.PT; e += RTG_THREADS) {
+    const int t = t0 + e;
+    if (t < 0 || t >= a.Q) continue;
+    float v = part[e];
+    for (int k = 1; k < g.NG; ++k) v += part[k * g.PT + e];                          // fixed order
+    if (a.bias) v += a.bias[0];
+    const size_t o = (size_t)b * a.out_L + t;
+    if (a.mask) v *= (a.mask[o] > 0.f ? 1.f : a.mask_slope);
+    if (a.res) v += a.res[o];
+    a.out[o] = thin_act(v * a.out_scale, a.act, a.act_slope);
+  }
+}
+
+// ---- one output channel, short rows (the whole row of <= 256 outputs is one tile): the [CH, L_in] input rows of a clip
+// are one contiguous run in memory and are copied flat (16-byte loads when the run is aligned), zero padding is a
+// predicate in the tap loop.  512 threads = (position, channel group); the loads of chunk i+1 are in flight while chunk i
+// is computed (one block per clip: there are only B blocks, so the overlap has to happen inside the block).
+constexpr int kShortThreads = 512;
+constexpr int kShortRegs = 6;                         // float4 (or dword x 4) registers of the prefetch per thread
+template <bool VEC>
+__global__ __launch_bounds__(kShortThreads) void cout1_short_kernel(const ThinArgs a, const TileGeo g) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* wl = sm;                                     // [C][K]
+  float* xs = sm + g.w_floats;                        // [CH][L_in] flat
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x;
+  for (int e = tid; e < a.C * a.K; e += kShortThreads) {
+    const int c = e / a.K, j = e - c * a.K;
+    wl[e] = a.wp[packed_index(0, c, j, a.C, a.K, a.tile_m, a.tap_major)];
+  }
+  const float* xb = a.x + (size_t)b * a.C * a.L_in;
+  const int pl = tid & (g.TP - 1), cg = tid >> g.tp_shift;
+  const int p0 = pl * a.stride - a.pad;
+  float acc = 0.f;
+  f32x4 v[kShortRegs];
+  auto issue = [&](int c0) __attribute__((always_inline)) {
+    const int n = min(g.CH, a.C - c0) * a.L_in;
+    const float* src = xb + (size_t)c0 * a.L_in;
+#pragma unroll
+    for (int u = 0; u < kShortRegs; ++u) {
+      const int f = tid + u * kShortThreads;
+      v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (VEC) {
+        if (4 * f < n) v[u] = reinterpret_cast<const f32x4*>(src)[f];
+      } else {
+        if (4 * f < n) v[u].x = src[4 * f];
+        if (4 * f + 1 < n) v[u].y = src[4 * f + 1];
+        if (4 * f + 2 < n) v[u].z = src[4 * f + 2];
+        if (4 * f + 3 < n) v[u].w = src[4 * f + 3];
+      }
+    }
+  };
+  issue(0);
+  for (int c0 = 0; c0 < a.C; c0 += g.CH) {
+    const int chc = min(g.CH, a.C - c0);
+    __syncthreads();                                  // (first pass: the weights; later: the previous chunk is consumed)
+#pragma unroll
+    for (int u = 0; u < kShortRegs; ++u) {
+      const int f = tid + u * kShortThreads;
+      if (4 * f < chc * a.L_in) {                     // (a partial last float4 is zero-filled; xs has the slack)
+        f32x4 t = v[u];
+        t.x = thin_pre(t.x, a); t.y = thin_pre(t.y, a); t.z = thin_pre(t.z, a); t.w = thin_pre(t.w, a);
+        reinterpret_cast<f32x4*>(xs)[f] = t;
+      }
+    }
+    __syncthreads();
+    if (c0 + g.CH < a.C) issue(c0 + g.CH);
+    if (pl < a.Q) {
+      for (int c = cg; c < chc; c += g.NG) {
+        const float* row = xs + c * a.L_in;
+        const float* wr = wl + (c0 + c) * a.K;
+        for (int j = 0; j < a.K; ++j) {
+          const int pos = p0 + j * a.dil;
+          if (pos >= 0 && pos < a.L_in) acc = fmaf(wr[j], row[pos], acc);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  float* part = xs;                                   // [NG][TP]
+  part[cg * g.TP + pl] = acc;
+  __syncthreads();
+  if (tid < a.Q) {
+    float s_ = part[tid];
+    for (int k = 1; k < g.NG; ++k) s_ += part[k * g.TP + tid];                      // fixed order
+    if (a.bias) s_ += a.bias[0];
+    const size_t o = (size_t)b * a.out_L + tid;
+    if (a.mask) s_ *= (a.mask[o] > 0.f ? 1.f : a.mask_slope);
+    if (a.res) s_ += a.res[o];
+    a.out[o] = thin_act(s_ * a.out_scale, a.act, a.act_slope);
+  }
+}
+
+// stage the input window [g0, g0 + W) of clip b (one channel) into xs, pre-activation and aux factors applied
+__device__ __forceinline__ void cin1_stage(const ThinArgs& a, int b, int g0, int W, float* xs) {
+  const float* xr = a.x + (size_t)b * a.L_in;
+  const float* ar = a.aux ? a.aux + (size_t)b * a.L_in : nullptr;
+  for (int i0 = threadIdx.x; i0 < W; i0 += 4 * RTG_THREADS) {
+    float v[4], av[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int pos = g0 + i0 + u * RTG_THREADS;
+      const bool ok = i0 + u * RTG_THREADS < W && pos >= 0 && pos < a.L_in;
+      v[u] = ok ? xr[pos] : 0.f;
+      av[u] = (ok && ar) ? ar[pos] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * RTG_THREADS;
+      if (i >= W) continue;
+      float t = v[u];
+      if (a.pre_mode == RTG_PRE_LRELU) t = t > 0.f ? t : t * a.pre_slope;
+      else if (a.pre_mode == RTG_PRE_MUL_DLRELU) t *= (av[u] > 0.f ? 1.f : a.pre_slope);
+      else if (a.pre_mode == RTG_PRE_MUL_DTANH) t *= fmaf(-av[u], av[u], 1.f);
+      xs[i] = t;
+    }
+  }
+}
+
+// ---- one input channel, long rows (out_L % 4 == 0): block = (clip, 1024 positions) x RB output rows; a thread keeps the
+// 4 x K input values of its four consecutive positions in registers and walks the rows: K broadcast weight reads, 4K
+// multiply-adds and ONE 16-byte store per row.
+constexpr int kRowTile = 4 * RTG_THREADS;
+template <int KT>
+__global__ __launch_bounds__(RTG_THREADS) void cin1_rows_kernel(const ThinArgs a, const TileGeo g) {
+  const int K = KT > 0 ? KT : a.K;
+  constexpr int KR = KT > 0 ? KT : kMaxTaps;         // taps kept in registers
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* wl = sm;                                     // [RB][kMaxTaps]
+  float* bl = wl + g.RB * kMaxTaps;                   // [RB]
+  float* xs = bl + g.RB;                              // [W]
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x / g.tiles, tile = blockIdx.x - b * g.tiles;
+  const int t0 = tile * kRowTile;
+  const int m0 = blockIdx.y * g.RB;
+  const int rows = min(g.RB, a.M - m0);
+  for (int e = tid; e < rows * kMaxTaps; e += RTG_THREADS) {
+    const int r = e / kMaxTaps, j = e - r * kMaxTaps;
+    wl[e] = j < K ? a.wp[packed_index(m0 + r, 0, j, 1, K, a.tile_m, a.tap_major)] : 0.f;
+  }
+  for (int r = tid; r < rows; r += RTG_THREADS) bl[r] = a.bias ? a.bias[m0 + r] : 0.f;
+  cin1_stage(a, b, t0 * a.stride - a.pad, g.W, xs);
+  __syncthreads();
+  const int t = t0 + 4 * tid;
+  if (t >= a.Q) return;
+  float xv[4][KR];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < KR; ++j) xv[i][j] = j < K ? xs[(4 * tid + i) * a.stride + j * a.dil] : 0.f;
+  const float mslope = a.mask_slope;
+  for (int r = 0; r < rows; ++r) {
+    const f32x4* w4 = reinterpret_cast<const f32x4*>(wl + r * kMaxTaps);
+    float w[kMaxTaps];
+#pragma unroll
+    for (int q = 0; q < (KR + 3) / 4; ++q) {
+      const f32x4 t4 = w4[q];
+      w[4 * q] = t4.x; w[4 * q + 1] = t4.y; w[4 * q + 2] = t4.z; w[4 * q + 3] = t4.w;
+    }
+    float acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float s_ = bl[r];
+#pragma unroll
+      for (int j = 0; j < KR; ++j)
+        if (j < K) s_ = fmaf(w[j], xv[i][j], s_);
+      acc[i] = s_;
+    }
+    const size_t o = ((size_t)b * a.M + m0 + r) * a.out_L + t;
+    if (t + 3 < a.Q) {
+      f32x4 v{acc[0], acc[1], acc[2], acc[3]};
+      if (a.mask) {
+        const f32x4 mk = *reinterpret_cast<const f32x4*>(a.mask + o);
+        v.x *= mk.x > 0.f ? 1.f : mslope; v.y *= mk.y > 0.f ? 1.f : mslope;
+        v.z *= mk.z > 0.f ? 1.f : mslope; v.w *= mk.w > 0.f ? 1.f : mslope;
+      }
+      if (a.res) {
+        const f32x4 rs = *reinterpret_cast<const f32x4*>(a.res + o);
+        v.x += rs.x; v.y += rs.y; v.z += rs.z; v.w += rs.w;
+      }
+      v.x = thin_act(v.x * a.out_scale, a.act, a.act_slope); v.y = thin_act(v.y * a.out_scale, a.act, a.act_slope);
+      v.z = thin_act(v.z * a.out_scale, a.act, a.act_slope); v.w = thin_act(v.w * a.out_scale, a.act, a.act_slope);
+      *reinterpret_cast<f32x4*>(a.out + o) = v;
+    } else {
+      for (int i = 0; i < 4 && t + i < a.Q; ++i) {
+        float v = acc[i];
+        if (a.mask) v *= (a.mask[o + i] > 0.f ? 1.f : mslope);
+        if (a.res) v += a.res[o + i];
+        a.out[o + i] = thin_act(v * a.out_scale, a.act, a.act_slope);
+      }
+    }
+  }
+}
+
+// ---- one input channel, any row length: the [M, Q] outputs of a clip are one contiguous run; block = (clip, chunk of
+// kFlatChunk flat outputs), thread = 4 consecutive flat outputs per pass (16-byte stores when the run allows it), each
+// output looks up its row's taps and its K inputs in LDS (the clip's whole input row is staged once per block).
+constexpr int kFlatChunk = 32 * RTG_THREADS;
+__global__ __launch_bounds__(RTG_THREADS) void cin1_flat_kernel(const ThinArgs a, const TileGeo g) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* wl = sm;                                     // [rows of this chunk][K]
+  float* bl = wl + g.RB * a.K;                        // [rows of this chunk]
+  float* xs = bl + g.RB;                              // [W], W = (Q-1)*stride + (K-1)*dil + 1 from position -pad
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x / g.chunks, chunk = blockIdx.x - b * g.chunks;
+  const int n_out = a.M * a.Q;
+  const int e_lo = chunk * kFlatChunk, e_hi = min(n_out, e_lo + kFlatChunk);
+  const int m_lo = e_lo / a.Q, rows = (e_hi - 1) / a.Q - m_lo + 1;
+  for (int e = tid; e < rows * a.K; e += RTG_THREADS) {
+    const int r = e / a.K, j = e - r * a.K;
+    wl[e] = a.wp[packed_index(m_lo + r, 0, j, 1, a.K, a.tile_m, a.tap_major)];
+  }
+  for (int r = tid; r < rows; r += RTG_THREADS) bl[r] = a.bias ? a.bias[m_lo + r] : 0.f;
+  cin1_stage(a, b, -a.pad, g.W, xs);
+  __syncthreads();
+  const size_t base = (size_t)b * n_out;
+  for (int it = 0; it < kFlatChunk / (4 * RTG_THREADS); ++it) {
+    const int e0 = e_lo + it * 4 * RTG_THREADS + 4 * tid;
+    if (e0 >= n_out) break;
+    float v[4];
+    int mrow = e0 / a.Q, t = e0 - mrow * a.Q;
+    mrow -= m_lo;
+    const bool full = g.vec && e0 + 3 < n_out;
+    float mk[4] = {1.f, 1.f, 1.f, 1.f}, rs[4] = {0.f, 0.f, 0.f, 0.f};
+    if (full) {
+      if (a.mask) { const f32x4 t4 = *reinterpret_cast<const f32x4*>(a.mask + base + e0); mk[0] = t4.x; mk[1] = t4.y; mk[2] = t4.z; mk[3] = t4.w; }
+      if (a.res) { const f32x4 t4 = *reinterpret_cast<const f32x4*>(a.res + base + e0); rs[0] = t4.x; rs[1] = t4.y; rs[2] = t4.z; rs[3] = t4.w; }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (e0 + i < n_out && a.mask) mk[i] = a.mask[base + e0 + i];
+        if (e0 + i < n_out && a.res) rs[i] = a.res[base + e0 + i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float s_ = 0.f;
+      if (e0 + i < n_out) {
+        s_ = bl[mrow];
+        const float* wr = wl + mrow * a.K;
+        const float* xp = xs + t * a.stride;
+        for (int j = 0; j < a.K; ++j) s_ = fmaf(wr[j], xp[j * a.dil], s_);
+        if (a.mask) s_ *= (mk[i] > 0.f ? 1.f : a.mask_slope);
+        s_ += rs[i];
+        s_ = thin_act(s_ * a.out_scale, a.act, a.act_slope);
+      }
+      v[i] = s_;
+      if (++t == a.Q) { t = 0; ++mrow; }
+    }
+    if (g.vec && e0 + 3 < n_out) {
+      *reinterpret_cast<f32x4*>(a.out + base + e0) = f32x4{v[0], v[1], v[2], v[3]};
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (e0 + i < n_out) a.out[base + e0 + i] = v[i];
+    }
+  }
+}
+
 }  // namespace
 
 // 0: not a thin shape (use the MFMA kernel), 1: one input channel, 2: one output channel
@@ -169,6 +576,71 @@ int rtg_thin_kind(const RtgConv1dDesc* d) {
   if (d->Cg == 1 && d->K <= kMaxTaps) return 1;
   if (d->Mg == 1 && (long long)d->Cg * d->K <= 12288 && (long long)d->B * d->Cg * d->L_in * 4 < (1ll << 31)) return 2;
   return 0;
+}
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+static inline int round4(int v) { return (v + 3) & ~3; }
+constexpr int kLdsFloats = 12288;    // 48 KB per block: three blocks per CU overlap their load and compute phases
+
+static inline int pow2_at_least(int v, int lo, int hi) {
+  int p = lo;
+  while (p < v && p < hi) p <<= 1;
+  return p;
+}
+static inline int log2i(int p) {
+  int s = 0;
+  while ((1 << s) < p) ++s;
+  return s;
+}
+
+// geometry of cout1_long_kernel for descriptor d; false: not served (fallback kernel)
+static bool cout1_long_geo(const RtgConv1dDesc* d, bool vec, TileGeo* g) {
+  const int Q = d->Q, B = d->B;
+  if (d->K > kMaxTaps) return false;
+  g->PT = 256;
+  for (int pt = 512; pt >= 256; pt >>= 1)
+    if ((long long)B * rtg_ceil_div(Q, pt) >= 768) { g->PT = pt; break; }
+  g->R = 4; g->TP = g->PT / 4; g->NG = RTG_THREADS / g->TP;
+  g->tp_shift = log2i(g->TP);
+  g->unit = (d->stride == 1 && d->dil == 1) ? 1 : 0;
+  g->shift = (vec && d->stride == 1) ? ((4 - (d->pad & 3)) & 3) : 0;
+  g->tiles = rtg_ceil_div(Q + g->shift, g->PT);
+  g->W = (g->PT - 1) * d->stride + (d->K - 1) * d->dil + 1;
+  // pitch: the window plus what the aligned 16-byte reads of the last lane touch (4 * (TP - 1) + 20 floats), a multiple of 4
+  const int need = g->unit ? 4 * (g->TP - 1) + 20 : g->W;
+  g->Wp = round4((need > g->W ? need : g->W) + 4);
+  const int Kp = round4(d->K);
+  g->w_floats = round4(d->Cg * Kp);
+  const int budget = kLdsFloats - g->w_floats;
+  if (budget < g->NG * g->PT) return false;
+  int ch = budget / g->Wp;
+  if (ch > d->Cg) ch = d->Cg;
+  ch -= ch % g->NG;
+  if (ch < g->NG) return false;
+  g->CH = ch;
+  const int nq = vec ? (g->W + 3 + 3) / 4 : g->W;
+  g->TPRow = pow2_at_least(nq, 32, RTG_THREADS);
+  g->tprow_shift = log2i(g->TPRow);
+  return true;
+}
+
+static bool cout1_short_geo(const RtgConv1dDesc* d, TileGeo* g) {
+  if (d->Q > 256 || d->L_in > 1024) return false;
+  g->TP = pow2_at_least(d->Q, 64, 256);
+  g->tp_shift = log2i(g->TP);
+  g->NG = kShortThreads / g->TP;
+  g->R = 1; g->PT = g->TP; g->tiles = 1;
+  g->w_floats = round4(d->Cg * d->K);
+  int budget = kLdsFloats - g->w_floats - 4;
+  if (budget > 4 * kShortRegs * kShortThreads) budget = 4 * kShortRegs * kShortThreads;   // what the prefetch holds
+  if (budget < kShortThreads) return false;
+  int ch = budget / d->L_in;
+  if (ch > d->Cg) ch = d->Cg;
+  const int mult = g->NG > 4 ? g->NG : 4;           // a multiple of 4 keeps every chunk 16-byte aligned (VEC)
+  if (ch < d->Cg) ch -= ch % mult;
+  if (ch < 1) return false;
+  g->CH = ch;
+  return true;
 }
 
 int rtg_thin_launch(int kind, const RtgConv1dDesc* d, const float* x, const float* aux, const float* wp,
@@ -181,6 +653,88 @@ int rtg_thin_launch(int kind, const RtgConv1dDesc* d, const float* x, const floa
   a.mask_slope = d->mask_slope; a.out_scale = d->out_scale; a.act = d->act; a.act_slope = d->act_slope;
   a.tile_m = d->tile_m; a.tap_major = d->tap_major ? 1 : 0;
   a.n_pos = (long long)d->B * d->Q;
+  const bool legacy = getenv("RTG_THIN_LEGACY") != nullptr;       // A/B knob: the round-1 kernels
+  TileGeo g = {};
+  if (kind == 1 && !legacy && d->Q == d->out_L) {
+    const long long wq = (long long)(d->Q - 1) * d->stride + (long long)(d->K - 1) * d->dil + 1;
+    const bool vec_io = d->out_L % 4 == 0 && aligned16(out) && (!mask || aligned16(mask)) && (!res || aligned16(res));
+    if (vec_io && d->Q >= 256) {
+      g.tiles = rtg_ceil_div(d->Q, kRowTile);
+      g.W = (kRowTile - 1) * d->stride + (d->K - 1) * d->dil + 1;
+      const long long bx = (long long)d->B * g.tiles;
+      int rb = d->Mg;
+      if (bx < 1024) {
+        const int want = rtg_ceil_div(1024, bx);
+        rb = rtg_ceil_div(d->Mg, want);
+        if (rb < 8) rb = 8;
+        if (rb > d->Mg) rb = d->Mg;
+      }
+      g.RB = rb;
+      const size_t lds = ((size_t)rb * (kMaxTaps + 1) + g.W) * sizeof(float);
+      const int gy = rtg_ceil_div(d->Mg, rb);
+      if (bx <= 0x7fffffffLL && gy <= 65535 && lds <= 48 * 1024) {
+#define RTG_C1R(KT) RTG_KLAUNCH((cin1_rows_kernel<KT>), dim3((unsigned)bx, gy), dim3(RTG_THREADS), lds, s, a, g)
+        switch (d->K) {
+          case 3: RTG_C1R(3); break;
+          case 5: RTG_C1R(5); break;
+          case 7: RTG_C1R(7); break;
+          case 15: RTG_C1R(15); break;
+          default: RTG_C1R(0);
+        }
+#undef RTG_C1R
+        return rtg_launch_status();
+      }
+    }
+    const long long n_out = (long long)d->Mg * d->Q;
+    int rows_max = kFlatChunk / d->Q + 2;              // output rows a chunk can touch
+    if (rows_max > d->Mg) rows_max = d->Mg;
+    const size_t lds = ((size_t)rows_max * (d->K + 1) + wq) * sizeof(float);
+    if (lds <= 48 * 1024 && n_out < (1ll << 30)) {
+      g.W = (int)wq;
+      g.RB = rows_max;
+      g.chunks = rtg_ceil_div(n_out, kFlatChunk);
+      g.vec = (n_out % 4 == 0 && aligned16(out) && (!mask || aligned16(mask)) && (!res || aligned16(res))) ? 1 : 0;
+      const long long bx = (long long)d->B * g.chunks;
+      if (bx <= 0x7fffffffLL) {
+        RTG_KLAUNCH(cin1_flat_kernel, dim3((unsigned)bx), dim3(RTG_THREADS), lds, s, a, g);
+        return rtg_launch_status();
+      }
+    }
+  }
+  if (kind == 2 && !legacy && !a.aux) {
+    const bool short_ok = d->Q <= 256 && d->Q == d->out_L;
+    const bool vec_s = ((long long)d->Cg * d->L_in) % 4 == 0 && aligned16(x);
+    if (short_ok && cout1_short_geo(d, &g)) {
+      size_t body = round4(g.CH * d->L_in) + 4;
+      if (body < (size_t)kShortThreads) body = kShortThreads;
+      const size_t lds = (g.w_floats + body) * sizeof(float);
+      const bool v = vec_s && (g.CH % 4 == 0 || g.CH == d->Cg);
+      if (v) RTG_KLAUNCH(cout1_short_kernel<true>, dim3((unsigned)d->B), dim3(kShortThreads), lds, s, a, g);
+      else RTG_KLAUNCH(cout1_short_kernel<false>, dim3((unsigned)d->B), dim3(kShortThreads), lds, s, a, g);
+      return rtg_launch_status();
+    }
+    const bool vec_l = d->L_in % 4 == 0 && aligned16(x);
+    if (cout1_long_geo(d, vec_l, &g)) {
+      const long long bx = (long long)d->B * g.tiles;
+      const size_t body = (size_t)g.CH * g.Wp > (size_t)g.NG * g.PT ? (size_t)g.CH * g.Wp : (size_t)g.NG * g.PT;
+      const size_t lds = (g.w_floats + body) * sizeof(float);
+      if (bx <= 0x7fffffffLL) {
+#define RTG_C1L(V, KT) RTG_KLAUNCH((cout1_long_kernel<V, KT>), dim3((unsigned)bx), dim3(RTG_THREADS), lds, s, a, g)
+        if (vec_l) {
+          switch (d->K) {
+            case 3: RTG_C1L(true, 3); break;
+            case 7: RTG_C1L(true, 7); break;
+            case 15: RTG_C1L(true, 15); break;
+            default: RTG_C1L(true, 0);
+          }
+        } else {
+          RTG_C1L(false, 0);
+        }
+#undef RTG_C1L
+        return rtg_launch_status();
+      }
+    }
+  }
   if (kind == 1) {
     const long long gx = (a.n_pos + RTG_THREADS - 1) / RTG_THREADS;
     const int gy = rtg_ceil_div(d->Mg, kRowsPerBlock);

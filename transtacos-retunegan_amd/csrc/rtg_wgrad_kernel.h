@@ -315,7 +315,7 @@ __global__ __launch_bounds__(RTG_THREADS) void wgrad_kernel(const WgArgs a) {
   };
   // branch-free leaky ReLU (slope 1 = identity): selects on loaded values tend to come back as exec-mask branches
   auto lrelu = [](float v, float slope) __attribute__((always_inline)) {
-    return fmaf(fminf(v, 0.f), slope, fmaxf(v, 0.f));
+    return v > 0.f ? v : v * slope;
   };
   auto swrite = [&]() __attribute__((always_inline)) {
 #pragma unroll

@@ -15,6 +15,12 @@ from .layers import WNConv, BankedModel, conv, fork_join, ACT_LRELU, ACT_TANH
 device = 'cuda' if torch.cuda.is_available() else 'cpu'
 
 
+def noise_seed(seed, rank, calls):
+    """64-bit counter-RNG key of one GaussianNoise call: the run seed, the data-parallel rank (a
+    different stream per rank — the reference draws independent noise per sample) and the per-process call counter."""
+    return ((seed * 0x9E3779B1 + calls) ^ (rank * 0x632BE59BD9B4E019)) & (2 ** 63 - 1)
+
+
 class GaussianNoise(nn.Module):
     """generator.py:19-30: x + U[0,1)*w followed by leaky_relu(0.15); one shared trainable scalar w = 1e-6."""
 
@@ -22,13 +28,16 @@ class GaussianNoise(nn.Module):
         super().__init__()
         self.w = nn.Parameter(torch.FloatTensor([1e-6]), requires_grad=True)
         self.seed = hp.randseed
+        self.rank = None          # data-parallel rank, mixed into the seed: every rank draws its own noise field
         self.calls = 0
         self.salt = None          # optional device word mixed into the seed (changes every optimizer step)
 
     def forward(self, x, u=None):
         self.calls += 1
-        return ops.NoiseFn.apply(x, self.w, u, LRELU_SLOPE, (self.seed * 0x9E3779B1 + self.calls) & (2 ** 63 - 1),
-                                 self.salt)
+        if self.rank is None:
+            import torch.distributed as dist
+            self.rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+        return ops.NoiseFn.apply(x, self.w, u, LRELU_SLOPE, noise_seed(self.seed, self.rank, self.calls), self.salt)
 
 
 class _Seq(nn.Module):

@@ -33,9 +33,12 @@ class WNConv(nn.Module):
         nn.init.kaiming_uniform_(v, a=math.sqrt(5))            # torch's default conv init (reset_parameters)
         bound = 1.0 / math.sqrt(shape[1] * int(np.prod(ks)))
         b = torch.empty(cout).uniform_(-bound, bound)
+        # registration order of torch.nn.utils.weight_norm(Conv*): the conv registers (weight, bias), weight_norm deletes
+        # `weight` and appends weight_g, weight_v -> bias, weight_g, weight_v.  torch.optim state dicts index their
+        # entries by this order (checkpoints `do_*`, train.py:263-273), so it is part of the drop-in contract.
+        self.bias = nn.Parameter(b)
         self.weight_g = nn.Parameter(v.flatten(1).norm(dim=1).reshape((shape[0],) + (1,) * (len(shape) - 1)))
         self.weight_v = nn.Parameter(v)
-        self.bias = nn.Parameter(b)
         self._layer = None      # rtg.bank.ConvLayer, set when the owning model builds its bank
 
     def burn_init_rng(self):
@@ -73,6 +76,12 @@ class BankedModel(nn.Module):
         if dev.type != 'cuda':
             raise RtgError(f'{type(self).__name__}: parameters are on {dev}; the RetuneGAN hot path runs on the HIP '
                            'kernels only — call .to("cuda") (there is no CPU fallback)')
+        if dev.index is not None and dev.index != torch.cuda.current_device():
+            # librtg launches on the current stream of the CURRENT device (rtg/lib.py:current_stream_ptr); a model on
+            # another device would be computed on by kernels queued to the wrong device's stream
+            raise RtgError(f'{type(self).__name__} lives on {dev} but the current device is cuda:'
+                           f'{torch.cuda.current_device()}: call torch.cuda.set_device({dev.index}) first (one process '
+                           'per GPU; train.Trainer does it for its `dev`)')
         if self._bank is None or self._bank.device != dev or not self._bank.check_views():
             layers = [(n, m) for n, m in self.named_modules() if isinstance(m, WNConv)]
             self._bank = WeightBank(layers, self._extra_bank_params(), dev)

@@ -70,8 +70,9 @@ CK = 16
 LOSS_L1, LOSS_L1_L1LOG, LOSS_MSE_TARGET, LOSS_MSE_REL = 0, 1, 2, 3
 MAX_LOSS_JOBS = 48
 
+ABI_VERSION = 2            # RTG_ABI_VERSION of include/rtg.h these struct layouts / prototypes were written for
 _P = C.c_void_p
-_I, _F, _LL, _ULL = C.c_int, C.c_float, C.c_longlong, C.c_ulonglong
+_I, _F, _D, _LL, _ULL = C.c_int, C.c_float, C.c_double, C.c_longlong, C.c_ulonglong
 
 # name -> (restype, argtypes); must list every symbol include/rtg.h declares (checked by tests/test_abi.py)
 PROTOTYPES = {
@@ -108,7 +109,7 @@ PROTOTYPES = {
     'rtg_env_loss_bwd': (_I, [_P, _P, _I, _I, _I, _F, _P, _P, _P]),
     'rtg_strip_mirror_fwd': (_I, [_P, _I, _I, _F, _P, _P, _P, _P]),
     'rtg_strip_mirror_bwd': (_I, [_P, _I, _I, _F, _P, _P, _P, _P]),
-    'rtg_adamw': (_I, [_P, _P, _P, _P, _LL, _P, _P, _F, _F, _F, _F, _F, _F, _P]),
+    'rtg_adamw': (_I, [_P, _P, _P, _P, _LL, _P, _P, _D, _D, _D, _D, _D, _F, _P]),
     'rtg_abi_version': (_I, []),
     'rtg_build_info': (C.c_char_p, []),
 }
@@ -135,6 +136,9 @@ class _Lib:
                         continue
                     raise
                 fn.restype, fn.argtypes = res, args
+            if hasattr(dll, 'rtg_abi_version') and dll.rtg_abi_version() != ABI_VERSION:
+                raise RtgError(f'{LIB_PATH} has ABI version {dll.rtg_abi_version()}, these bindings are for '
+                               f'{ABI_VERSION}: stale build — run `python transtacos-retunegan_amd/build.py`')
             self._dll = dll
         return self._dll
 

@@ -118,35 +118,52 @@ class AdamW:
         return {'state': state, 'param_groups': [g]}
 
     def load_state_dict(self, sd):
+        """Accepts what torch.optim.AdamW.state_dict() of the reference wrote (train.py:84-85): entries indexed by
+        parameter position, which is why the models register their parameters in the reference's order."""
         idx = 0
         for m in self.models:
             s = self._st(m)
             base = s['bank'].flat.data_ptr()
-            for p in m.parameters():
+            for name, p in m.named_parameters():
                 e = sd['state'].get(idx)
                 if e is not None:
+                    for key in ('exp_avg', 'exp_avg_sq'):
+                        if tuple(e[key].shape) != tuple(p.shape):
+                            raise RtgError(f'AdamW.load_state_dict: state {idx} ({name}) has {key} of shape '
+                                           f'{tuple(e[key].shape)}, the parameter is {tuple(p.shape)}: the checkpoint '
+                                           'was written for another parameter order or architecture')
                     off = (p.data_ptr() - base) // 4
                     s['exp_avg'][off:off + p.numel()].copy_(e['exp_avg'].reshape(-1))
                     s['exp_avg_sq'][off:off + p.numel()].copy_(e['exp_avg_sq'].reshape(-1))
                     s['step'].fill_(float(e['step']))
                 idx += 1
-        self.param_groups[0]['lr'] = sd['param_groups'][0]['lr']
+        g = sd['param_groups'][0]
+        self.param_groups[0]['lr'] = float(g['lr'])
+        if 'initial_lr' in g:
+            self.initial_lr = self.param_groups[0]['initial_lr'] = float(g['initial_lr'])
 
 
 class ExponentialLR:
-    """torch.optim.lr_scheduler.ExponentialLR(optim, gamma, last_epoch) as used at train.py:87-88,326-327."""
+    """torch.optim.lr_scheduler.ExponentialLR(optim, gamma, last_epoch) as used at train.py:87-88,326-327, with the
+    semantics of the torch this package runs on (2.x; tests/test_host_cpu.py compares with torch's own class): the
+    constructor counts one step without touching the learning rate — a fresh run (last_epoch=-1) ends at last_epoch 0
+    with lr = initial_lr, a resumed run (last_epoch=e, lr loaded from the checkpoint's param_groups) at e+1 with the
+    loaded lr — and every step() multiplies the CURRENT lr by gamma (the chainable form).  (torch 1.8, which the
+    reference pins, multiplied once more inside the constructor on resume.)"""
 
     def __init__(self, optimizer, gamma, last_epoch=-1):
         self.optimizer, self.gamma = optimizer, gamma
-        self.last_epoch = max(last_epoch, 0)
-        self._apply()
-
-    def _apply(self):
-        self.optimizer.param_groups[0]['lr'] = self.optimizer.initial_lr * self.gamma ** self.last_epoch
+        group = optimizer.param_groups[0]
+        if last_epoch == -1:
+            group.setdefault('initial_lr', group['lr'])
+        elif 'initial_lr' not in group:
+            raise KeyError("param 'initial_lr' is not specified in param_groups[0] when resuming an optimizer")
+        self.base_lrs = [group['initial_lr']]
+        self.last_epoch = last_epoch + 1          # the constructor's initial step
 
     def step(self):
         self.last_epoch += 1
-        self._apply()
+        self.optimizer.param_groups[0]['lr'] = self.optimizer.param_groups[0]['lr'] * self.gamma
 
     def get_last_lr(self):
         return [self.optimizer.param_groups[0]['lr']]
@@ -216,7 +233,11 @@ class Trainer:
 
     def __init__(self, generator=None, msd=None, mpd=None, mtd=None, use_mpd=True, use_mtd=True, d_train_times=None,
                  dev=None, process_group=None):
-        dev = dev or device
+        dev = torch.device(dev or device)
+        if dev.type == 'cuda':
+            # librtg launches on the current stream of the CURRENT device (rtg/lib.py:current_stream_ptr): make the
+            # trainer's device that device, as one process per GPU does anyway
+            torch.cuda.set_device(dev if dev.index is not None else torch.cuda.current_device())
         Generator = globals().get(f'Generator_{hp.generator_ver}')
         self.generator = (generator or Generator()).to(dev)
         self.msd = (msd or MultiScaleDiscriminator()).to(dev)
@@ -480,4 +501,8 @@ class Trainer:
         self.optim_g.load_state_dict(sd['optim_g'])
         self.optim_d.load_state_dict(sd['optim_d'])
         self.steps = sd['steps']
+        # train.py:87-88: the schedulers are rebuilt on the loaded optimizers with last_epoch = the saved epoch
+        self.scheduler_g = ExponentialLR(self.optim_g, gamma=hp.lr_decay, last_epoch=sd['epoch'])
+        self.scheduler_d = ExponentialLR(self.optim_d, gamma=hp.lr_decay, last_epoch=sd['epoch'])
+        self._graphs = None            # the learning rate is baked into captured AdamW launches
         return sd['epoch']
