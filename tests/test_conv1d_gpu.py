@@ -324,3 +324,77 @@ def test_packed_polyphase_dgrad_every_block_shape(case):
     for c in cands[:n]:
         out = run_conv(dict(desc, tile_cfg=c), dy, wp, mask=mask, out_shape=(B, Cin, L))
         np.testing.assert_allclose(out.numpy(), x.grad.float().numpy(), rtol=1e-4, atol=2e-5, err_msg=f'tile_cfg {c}')
+
+
+RESCONV_CASES = [
+    # B, C, L, K, dil — the stride-1 "same" convolutions of ResBlock3 / ResidualStack (generator.py:33-77,133-155)
+    (3, 32, 1000, 7, 9),         # ragged length: the last tile of a clip is partial
+    (2, 32, 8192, 3, 1),
+    (2, 32, 2048, 5, 3),
+    (2, 64, 2048, 5, 3),
+    (2, 64, 260, 7, 9),
+    (5, 64, 256, 3, 9),
+    (7, 32, 36, 3, 3),           # rows shorter than a tile
+]
+
+
+@pytest.mark.parametrize('mode', ['resblock_fwd', 'resblock_dgrad', 'stack_fwd_act', 'mask_and_res'])
+@pytest.mark.parametrize('case', RESCONV_CASES)
+def test_resconv_kernel_matches_general_kernel_bitwise_and_torch(case, mode):
+    """rtg_resconv.hip (block-shape codes 7001 / 7002: weights in registers, double-buffered raw window, activation on
+    the read side, residual from LDS) against torch in float64 and bit for bit against the general MFMA kernel: same
+    accumulation order, same epilogue arithmetic."""
+    from rtg.lib import lib, Conv1dDesc, check
+    B, Cc, L, K, d = case
+    p = (K * d - d) // 2
+    gen = torch.Generator().manual_seed(L + K)
+    x = torch.randn(B, Cc, L, generator=gen)
+    w = torch.randn(Cc, Cc, K, generator=gen) / np.sqrt(Cc * K)
+    bias = torch.randn(Cc, generator=gen)
+    other = torch.randn(B, Cc, L, generator=gen)
+    msk = torch.randn(B, Cc, L, generator=gen)
+    dev = 'cuda'
+    xd, od, md, bd = x.to(dev), other.to(dev), msk.to(dev), bias.to(dev)
+    xw, ww = x.double(), w.double()
+    if mode == 'resblock_fwd':
+        ref = F.conv1d(F.leaky_relu(xw, 0.15), ww, bias.double(), 1, p, d) + xw
+        wp = packref.pack_logical(packref.logical_fwd(w.numpy(), 1), 32)
+        kw = dict(pre_mode=1, pre_slope=0.15)
+        ptrs = dict(bias=bd, mask=None, res=xd)
+    elif mode == 'resblock_dgrad':
+        # x plays dy; `msk` the forward input whose leaky-relu derivative masks the conv branch; residual gradient = dy
+        gin = torch.nn.grad.conv1d_input(xw.shape, ww, xw, 1, p, d)
+        ref = gin * torch.where(msk.double() > 0, 1.0, 0.15) + xw
+        wp = packref.pack_logical(packref.logical_dgrad_s1(w.numpy(), 1), 32)
+        kw = dict(mask_slope=0.15)
+        ptrs = dict(bias=None, mask=md, res=xd)
+    elif mode == 'stack_fwd_act':
+        ref = F.leaky_relu(F.conv1d(F.leaky_relu(xw, 0.01), ww, bias.double(), 1, p, d) + other.double(), 0.15)
+        wp = packref.pack_logical(packref.logical_fwd(w.numpy(), 1), 32)
+        kw = dict(pre_mode=1, pre_slope=0.01, act=1, act_slope=0.15)
+        ptrs = dict(bias=bd, mask=None, res=od)
+    else:
+        ref = (F.conv1d(xw, ww, bias.double(), 1, p, d) * torch.where(msk.double() > 0, 1.0, 0.3) + other.double()) * 0.5
+        wp = packref.pack_logical(packref.logical_fwd(w.numpy(), 1), 32)
+        kw = dict(mask_slope=0.3, out_scale=0.5)
+        ptrs = dict(bias=bd, mask=md, res=od)
+    pad = p if mode != 'resblock_dgrad' else (K - 1) * d - p
+    desc = base_desc(B, Cc, 0, L, 1, Cc, Cc, K, 1, d, pad, L, Cc, L, 32, **kw)
+    cands = (C.c_int * 32)()
+    n = lib.rtg_conv1d_tile_candidates(C.byref(Conv1dDesc(**desc)), cands, 32)
+    codes = [c for c in cands[:n] if c > 7000]
+    assert codes == ([7002, 7001] if Cc == 32 else [7001]), list(cands[:n])
+    wp_d = torch.from_numpy(wp).to(dev)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    outs = {}
+    for code in [0] + codes:
+        dd = Conv1dDesc(**dict(desc, tile_cfg=code))
+        assert lib.rtg_conv1d_variant(C.byref(dd)) == (code if code else lib.rtg_conv1d_variant(C.byref(dd)))
+        out = torch.full((B, Cc, L), float('nan'), device=dev)
+        check(lib.rtg_conv1d(C.byref(dd), _ptr(xd), None, None, _ptr(wp_d), _ptr(ptrs['bias']), _ptr(ptrs['mask']),
+                             _ptr(ptrs['res']), _ptr(out), None, st), f'rtg_conv1d cfg {code}')
+        torch.cuda.synchronize()
+        outs[code] = out.cpu()
+    np.testing.assert_allclose(outs[0].numpy(), ref.float().numpy(), rtol=1e-4, atol=2e-5)
+    for code in codes:
+        assert torch.equal(outs[code], outs[0]), (code, (outs[code] - outs[0]).abs().max().item())

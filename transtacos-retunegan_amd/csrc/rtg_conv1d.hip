@@ -161,8 +161,17 @@ int rtg_thin_kind(const RtgConv1dDesc* d);
 int rtg_thin_launch(int kind, const RtgConv1dDesc* d, const float* x, const float* aux, const float* wp,
                     const float* bias, const float* mask, const float* res, float* out, hipStream_t s);
 
+// rtg_resconv.hip: weights-in-registers kernel for the stride-1 "same" convolutions of the UNet-G residual blocks
+// (block-shape codes 7001 / 7002 = 32 / 64 positions per wave)
+int rtg_resconv_variants(const RtgConv1dDesc* d);
+int rtg_resconv_launch(const RtgConv1dDesc* d, int nt, const float* x, const float* wp, const float* bias,
+                       const float* mask, const float* res, float* out, hipStream_t s);
+#define RTG_RESCONV_CODE 7000
+
 extern "C" int rtg_conv1d_variant(const RtgConv1dDesc* d) {
   if (!d) return RTG_ENULL;
+  if (d->tile_cfg > RTG_RESCONV_CODE && d->tile_cfg <= RTG_RESCONV_CODE + 2)
+    return (rtg_resconv_variants(d) & (1 << (d->tile_cfg - RTG_RESCONV_CODE - 1))) ? d->tile_cfg : RTG_EINVAL;
   if ((d->tile_m != 32 && d->tile_m != 16) || d->Mg < 1 || d->Q < 1 || d->B < 1 || d->groups < 1 || d->stride < 1 ||
       d->K < 1 || d->dil < 1)
     return RTG_EINVAL;
@@ -196,6 +205,9 @@ extern "C" int rtg_conv1d_tile_candidates(const RtgConv1dDesc* d, int* cfgs, int
     cfgs[cnt++] = tile_code(sc[bi].c);
     sc[bi].score = -1.0;
   }
+  const int rv = rtg_resconv_variants(d);
+  for (int nt = 2; nt >= 1; --nt)
+    if ((rv & (1 << (nt - 1))) && cnt < max) cfgs[cnt++] = RTG_RESCONV_CODE + nt;
   return cnt;
 }
 
@@ -354,6 +366,8 @@ extern "C" int rtg_conv1d(const RtgConv1dDesc* d, const float* x1, const float* 
       return rtg_thin_launch(thin, d, x1, aux, wp, bias, mask, res, out, (hipStream_t)stream);
     }
   }
+  if (d->tile_cfg > RTG_RESCONV_CODE && d->tile_cfg <= RTG_RESCONV_CODE + 2)
+    return rtg_resconv_launch(d, d->tile_cfg - RTG_RESCONV_CODE, x1, wp, bias, mask, res, out, (hipStream_t)stream);
   ConvPlan pl;
   const int st = conv_plan(d, x1, x2, aux, wp, bias, mask, res, out, out2, &pl);
   if (st != RTG_OK) return st;

@@ -737,8 +737,9 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a, const unsign
 #pragma unroll
           for (int r = 0; r < RH; ++r) {
             float v = acc[i][j][r0 + r] + bv[r0 + r];
-            v *= (mv[r] > 0.f ? 1.f : mslope);
-            v = (v + rv[r]) * a.out_scale;
+            // (one explicit fused multiply-add: every kernel that serves a layer rounds this step the same way,
+            // rtg_resconv.hip included, whatever the compiler would contract)
+            v = __builtin_fmaf(v, mv[r] > 0.f ? 1.f : mslope, rv[r]) * a.out_scale;
             if (a.act == RTG_ACT_LRELU) v = rtg_lrelu(v, a.act_slope);
             else if (a.act == RTG_ACT_TANH) v = tanhf(v);
             v += av[r];
