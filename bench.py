@@ -131,6 +131,21 @@ def cpu_baseline(budget_s=12.0):
                       f'at batch 2); oracle/rtg_oracle.py'}
 
 
+def _src_digest():
+    """digest of the kernel sources of this build (csrc/*.hip, *.h + include/rtg.h): tools/pmc_summary.py stores it in the
+    PMC summary, so a committed PMC pass that describes other code than the one benchmarked is flagged"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(REPO, 'transtacos-retunegan_amd', 'csrc', '*.hip')) +
+                   glob.glob(os.path.join(REPO, 'transtacos-retunegan_amd', 'csrc', '*.h')) +
+                   [os.path.join(REPO, 'include', 'rtg.h')])
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, 'rb').read())
+    return h.hexdigest()[:16]
+
+
 def _pmc_for(prefix):
     """launch-weighted HBM bytes and matrix-pipe busy fraction of the kernels whose name starts with `prefix`, from the
     newest profiles/*_pmc.json"""
@@ -138,7 +153,9 @@ def _pmc_for(prefix):
     files = sorted(glob.glob(os.path.join(REPO, 'profiles', '*_pmc.json')))
     if not files:
         return None
-    ks = json.load(open(files[-1]))['kernels']
+    doc = json.load(open(files[-1]))
+    ks = doc['kernels']
+    stale = doc.get('src_digest') != _src_digest()
     n = b = m = 0.0
     for name, e in ks.items():
         if name.startswith(prefix):
@@ -147,7 +164,8 @@ def _pmc_for(prefix):
             m += e['launches'] * e.get('mfma_busy_frac', 0.0)
     if n == 0:
         return None
-    return {'traffic': round(b / n), 'mfma_busy': round(m / n, 3), 'source': 'profiles/' + os.path.basename(files[-1])}
+    return {'traffic': round(b / n), 'mfma_busy': round(m / n, 3), 'source': 'profiles/' + os.path.basename(files[-1]),
+            'stale': bool(stale)}
 
 
 def roofline(trainer, batch, bf16=False):
@@ -158,7 +176,15 @@ def roofline(trainer, batch, bf16=False):
     torch.cuda.synchronize()
     rec, ops.PROFILE = ops.PROFILE, None
     agg = {}
+    bw = {}
     for kernel, variant, flop, e0, e1, _label, nbytes in rec:
+        # bandwidth kernels: the weight-norm / optimizer / STFT launches (ops.timed_bw) and the 1-channel conv shapes
+        name = kernel[3:] if kernel.startswith('bw:') else ({1: 'thin_cin1', 2: 'thin_cout1'}.get(variant) if kernel == 'conv1d' else None)
+        if name:
+            e = bw.setdefault(name, [0, 0.0, 0.0])
+            e[0] += 1; e[1] += e0.elapsed_time(e1) * 1e-3; e[2] += nbytes
+        if kernel.startswith('bw:'):
+            continue
         k = (kernel, variant)
         a = agg.setdefault(k, [0, 0.0, 0.0, 0.0])
         a[0] += 1
@@ -176,7 +202,8 @@ def roofline(trainer, batch, bf16=False):
     out = {'bound': 'mfma', 'achieved': round(achieved, 3), 'peak': PEAK_FP32_MATRIX_TFLOPS, 'unit': 'TFLOP/s',
            'frac': round(achieved / PEAK_FP32_MATRIX_TFLOPS, 4), 'traffic': None, 'kernel': name,
            'launches_per_step': n, 'avg_launch_us': round(secs / n * 1e6, 2),
-           'algorithmic_gflop_per_launch': round(flop / n / 1e9, 4)}
+           'algorithmic_gflop_per_launch': round(flop / n / 1e9, 4),
+           'algorithmic_bytes_per_launch': round(nbytes / n) if nbytes else None}
     # HBM traffic and matrix-pipe occupancy of that kernel from the committed PMC passes (rocprofv3 --pmc cannot run inside
     # this process): profiles/*_pmc.json, written by tools/pmc_pass.sh + tools/pmc_summary.py from this same command
     pmc = _pmc_for(f'conv1d_mfma_group_kernel<{variant // 100}, {variant // 10 % 10}, {variant % 10},' if kernel == 'conv1d'
@@ -186,9 +213,11 @@ def roofline(trainer, batch, bf16=False):
         out['traffic_unit'] = 'bytes/launch (HBM read + write, PMC FETCH_SIZE x2 + WRITE_SIZE)'
         out['mfma_busy_frac_pmc'] = pmc['mfma_busy']
         out['pmc_source'] = pmc['source']
+        out['pmc_stale'] = pmc['stale']      # True: the committed PMC pass was taken on other kernel sources than this build
     # the UNet-G conv stack alone (north-star target: >= 30 % of the fp32 matrix peak)
-    g_flop = sum(f for k_, v_, f, e0, e1, lb, _nb in rec if not lb.split()[1].startswith('discriminators'))
-    g_s = sum(e0.elapsed_time(e1) * 1e-3 for k_, v_, f, e0, e1, lb, _nb in rec if not lb.split()[1].startswith('discriminators'))
+    conv_rec = [r for r in rec if not r[0].startswith('bw:')]
+    g_flop = sum(f for k_, v_, f, e0, e1, lb, _nb in conv_rec if not lb.split()[1].startswith('discriminators'))
+    g_s = sum(e0.elapsed_time(e1) * 1e-3 for k_, v_, f, e0, e1, lb, _nb in conv_rec if not lb.split()[1].startswith('discriminators'))
     if g_s > 0:
         out['unet_g_conv_stack'] = {'tflops': round(g_flop / g_s / 1e12, 3),
                                     'frac': None if bf16 else round(g_flop / g_s / 1e12 / PEAK_FP32_MATRIX_TFLOPS, 4),
@@ -209,6 +238,11 @@ def roofline(trainer, batch, bf16=False):
                                'gflop_per_step': round(total_flop / 1e9, 2)}
     out['by_kernel'] = {(f'{k[0]}:{k[1]}'): {'n': v[0], 'ms': round(v[1] * 1e3, 3),
                                              'tflops': round(v[2] / v[1] / 1e12, 2)} for k, v in sorted(agg.items())}
+    # HBM-bound kernels: algorithmic bytes (every operand once) / event-timed duration against the 8 TB/s spec
+    out['bandwidth_kernels'] = {
+        name: {'n': n_, 'ms': round(s_ * 1e3, 3), 'algorithmic_MB_per_launch': round(b_ / n_ / 1e6, 2),
+               'GBps': round(b_ / s_ / 1e9, 1), 'frac_of_hbm_peak': round(b_ / s_ / 1e9 / PEAK_HBM_GBS, 4)}
+        for name, (n_, s_, b_) in sorted(bw.items()) if s_ > 0}
     return out
 
 
@@ -247,17 +281,20 @@ def main():
     # set-up, outside warm-up and timing: the first train step of a Trainer also times the candidate block shapes of
     # every conv / weight-gradient launch and keeps the fastest per problem (rtg/tune.py) — part of building the step,
     # like compiling a kernel; with it here --warmup 0 still times tuned steps only
+    # RTG_GRAPH=1: the step replayed from HIP graphs (Trainer.train_step_graphed) — same kernels, issued by the graph
+    # executor; for hosts whose cores cannot feed 8 ranks x ~900 launches per step (tools/scale.sh)
+    step = tr.train_step_graphed if os.environ.get('RTG_GRAPH') == '1' else tr.train_step
     tr.train_step(*next_batch())
     torch.cuda.synchronize()
     for _ in range(a.warmup):
-        tr.train_step(*next_batch())
+        step(*next_batch())
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        dl, gl = tr.train_step(*next_batch())
+        dl, gl = step(*next_batch())
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -24,8 +24,12 @@ class _FakeBank:
     def __init__(self, n, seed):
         g = torch.Generator().manual_seed(seed)
         self.flat = torch.randn(n, generator=g)
-        self.gflat = torch.zeros(n)
+        self.n_params = n
+        self.gflat = torch.zeros(n + 1)                    # gradients + the loss flag slot (rtg/bank.py)
         self.on_flush = None
+
+    def flag(self):
+        return self.gflat[self.n_params:]
 
 
 class _FakeModel:
@@ -51,18 +55,21 @@ def _worker(rank, world, port, out):
     ref = _FakeBank(1000, 10).flat
     assert torch.equal(m.bank().flat, ref)                # everyone now holds rank 0's parameters
     # per-rank gradient = rank-dependent; all-reduce (async) sums them
-    m.bank().gflat.copy_(torch.arange(1000, dtype=torch.float32) * (rank + 1))
+    m.bank().gflat[:1000].copy_(torch.arange(1000, dtype=torch.float32) * (rank + 1))
+    m.bank().flag().fill_(1.5)                             # the loss of the step rides in the last slot
     dp.reduce_async(m.bank().gflat)
     dp.wait()
     expect = torch.arange(1000, dtype=torch.float32) * sum(r + 1 for r in range(world))
-    assert torch.equal(m.bank().gflat, expect)
-    # collective NaN guard: only rank 1 sees a NaN loss, every rank must skip
-    flag = torch.tensor([float('nan') if rank == 1 else 1.0])
-    dp.reduce_flag(flag)
-    assert torch.isnan(flag).all()
-    flag = torch.tensor([1.5])
-    dp.reduce_flag(flag)
-    assert flag.item() == pytest.approx(1.5 * world)
+    assert torch.equal(m.bank().gflat[:1000], expect)
+    assert m.bank().flag().item() == pytest.approx(1.5 * world)
+    # collective NaN guard without a collective of its own: only rank 1 sees a NaN loss, the summed flag is NaN on every
+    # rank (rtg_adamw then skips the update everywhere), the gradients are still the plain sums
+    m.bank().gflat[:1000].copy_(torch.arange(1000, dtype=torch.float32) * (rank + 1))
+    m.bank().flag().fill_(float('nan') if rank == 1 else 1.0)
+    dp.reduce_async(m.bank().gflat)
+    dp.wait()
+    assert torch.isnan(m.bank().flag()).all()
+    assert torch.equal(m.bank().gflat[:1000], expect)
     if rank == 0:
         out.put('ok')
     dist.barrier()

@@ -1,0 +1,27 @@
+#!/bin/bash
+# 1/2/4/8-GPU weak-scaling sweep of the train step on ONE node (one process per GPU, RCCL over xGMI):
+#     tools/scale.sh [workload=config4] [steps=20] [warmup=5]
+# prints audio-s/s per N and the efficiency against N x the 1-GPU value.  Needs as many visible GPUs as the largest N
+# (the build's gpurun boxes expose one: the driver runs this sweep on an 8-GPU node at round end).
+# RTG_GRAPH=1 replays the step from HIP graphs (train.Trainer.train_step_graphed): for hosts whose cores cannot issue
+# the ~900 launches of a step for 8 ranks at once.
+set -e
+WL=${1:-config4}; STEPS=${2:-20}; WARM=${3:-5}
+cd "$(dirname "$0")/.."
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+NGPU=$(python3 -c 'import torch; print(torch.cuda.device_count())')
+base=""
+for N in 1 2 4 8; do
+  if [ "$N" -gt "$NGPU" ]; then echo "N=$N: only $NGPU GPU(s) visible, skipped"; continue; fi
+  if [ "$N" -eq 1 ]; then
+    out=$(python3 bench.py --gpus 1 --steps $STEPS --warmup $WARM --workload $WL --no-cpu-baseline --no-roofline)
+  else
+    out=$(python3 -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port $((29500 + N)) \
+          bench.py --gpus $N --steps $STEPS --warmup $WARM --workload $WL --no-cpu-baseline --no-roofline | tail -1)
+  fi
+  val=$(echo "$out" | python3 -c 'import sys, json; d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d["value"], d["ms_per_step"])')
+  v=${val% *}; ms=${val#* }
+  [ -z "$base" ] && base=$v
+  eff=$(python3 -c "print(round($v / ($N * $base), 3))")
+  echo "N=$N  $v audio-s/s  $ms ms/step  efficiency $eff"
+done

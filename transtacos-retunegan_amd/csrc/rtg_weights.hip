@@ -145,7 +145,47 @@ __global__ __launch_bounds__(RTG_THREADS) void wn_bwd_kernel(const RtgWnBwdJob* 
     // splits — the dependent chain of a row is splits / 32 memory latencies, whatever the split count (the narrow
     // generator layers have 256 splits, the big discriminator layers 6 .. 11).  A short last batch re-reads the last
     // split (cached) and drops the value.
-    if (j.inner <= RTG_THREADS) {
+    // bias column (one partial per split): requested first, 32 splits in flight, summed in ascending order by thread 0
+    float bsum = 0.f;
+    if (threadIdx.x == 0 && j.b_off >= 0) {
+      const float* pb = partials + j.part_off + (size_t)j.rows * j.inner + r;
+      for (int sp = 0; sp < j.splits; sp += 32) {
+        float tb[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) tb[u] = pb[(size_t)(sp + u < j.splits ? sp + u : j.splits - 1) * j.part_stride];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) bsum += (sp + u < j.splits) ? tb[u] : 0.f;
+      }
+    }
+    // (rows of fewer than 1024 elements keep one element per thread: more splits in flight per row)
+    const bool vec = j.inner >= 4 * RTG_THREADS && (j.inner & 3) == 0 && (j.part_off & 3) == 0 && (j.part_stride & 3) == 0;
+    if (vec) {
+      // 16-byte loads of the partials (the bulk of the traffic: splits x the row), four consecutive elements per thread,
+      // 8 splits in flight; every element still sums its splits in ascending order (the same bits as the scalar path)
+      const int n4 = j.inner >> 2;
+      for (int i4 = threadIdx.x; i4 < n4; i4 += RTG_THREADS) {
+        const f32x4* pa = reinterpret_cast<const f32x4*>(p0) + i4;
+        const size_t st4 = (size_t)(j.part_stride >> 2);
+        f32x4 sa = {0.f, 0.f, 0.f, 0.f};
+        for (int sp = 0; sp < j.splits; sp += 8) {
+          f32x4 ta[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) ta[u] = pa[(size_t)(sp + u < j.splits ? sp + u : j.splits - 1) * st4];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            if (sp + u < j.splits) { sa.x += ta[u].x; sa.y += ta[u].y; sa.z += ta[u].z; sa.w += ta[u].w; }
+          }
+        }
+        const int i = 4 * i4;
+        dw[i] = sa.x; dw[i + 1] = sa.y; dw[i + 2] = sa.z; dw[i + 3] = sa.w;
+        // (the scalar path adds this thread's elements i, i + 256, ... in that order; here the thread owns 4i4 .. 4i4+3:
+        // the block-wide dot product is summed in another order — rounding-level difference in d g and the k2 term)
+        dot += sa.x * v[i];
+        dot += sa.y * v[i + 1];
+        dot += sa.z * v[i + 2];
+        dot += sa.w * v[i + 3];
+      }
+    } else if (j.inner <= RTG_THREADS) {
       const int i = threadIdx.x;
       if (i < j.inner) {
         const float* pa = p0 + i;
@@ -199,12 +239,7 @@ __global__ __launch_bounds__(RTG_THREADS) void wn_bwd_kernel(const RtgWnBwdJob* 
     for (int i = threadIdx.x; i < j.inner; i += RTG_THREADS) dv[i] += scale * dw[i] - k2 * v[i];   // own elements only
     if (threadIdx.x == 0) {
       grads[j.g_off + r] += dot * inv_n;
-      if (j.b_off >= 0) {
-        const float* pb = partials + j.part_off + (size_t)j.rows * j.inner + r;
-        float s = 0.f;
-        for (int sp = 0; sp < j.splits; ++sp) s += pb[(size_t)sp * j.part_stride];
-        grads[j.b_off + r] += s;
-      }
+      if (j.b_off >= 0) grads[j.b_off + r] += bsum;
     }
     __syncthreads();
   }

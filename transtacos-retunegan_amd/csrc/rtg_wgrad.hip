@@ -217,8 +217,11 @@ extern "C" int rtg_conv1d_wgrad(const RtgWgradDesc* d, const float* x1, const fl
   a.ones_off = a.xbuf_sz + rows * ROWD;
   const size_t lds_bytes = (size_t)(a.ones_off + TT * d->stride + 8) * sizeof(float);
   const long long gy = (long long)d->groups * g.m_blocks * g.n_cchunk;
-  if (gy > 65535) return RTG_ERANGE;
-  dim3 grid(d->splits, (unsigned)gy, 1);
+  const long long n_items = gy * d->splits;
+  if (n_items > (1ll << 28)) return RTG_ERANGE;
+  a.gy = (int)gy; a.n_items = (int)n_items;
+  a.per_xcd = (int)((n_items + 7) / 8);
+  dim3 grid((unsigned)(8 * a.per_xcd), 1, 1);
   hipStream_t s = (hipStream_t)stream;
   switch ((g.cont ? 1 : 0) | (two_d ? 2 : 0) | (d->bf16 ? 4 : 0)) {
     case 0: return rtg_wgrad_launch_m0(g.TM, g.shape, g.maxit, a, grid, lds_bytes, s);

@@ -148,7 +148,10 @@ class WeightBank:
             off += p.numel()
         self.n_params = off
         self.flat = torch.empty(off, device=self.device, dtype=torch.float32)
-        self.gflat = torch.zeros(off, device=self.device, dtype=torch.float32)
+        # one slot past the gradients holds the step's loss value ("flag"): it travels inside the data-parallel
+        # all-reduce of the buffer (a NaN on any rank makes the sum NaN on every rank) and is what rtg_adamw tests for
+        # the NaN guard of train.py:158,191 — no separate collective, no host round trip
+        self.gflat = torch.zeros(off + 1, device=self.device, dtype=torch.float32)
         self.scales = torch.empty(soff, device=self.device, dtype=torch.float32)
         poff = 0
         for ly in self.layers:
@@ -233,10 +236,12 @@ class WeightBank:
     # ------------------------------------------------------------------ forward-side refresh
     def _run_prep(self):
         st = _stream()
-        check(lib.rtg_weightnorm_scales(_p(self.norm_table), len(self.layers), self.max_rows, _p(self.flat),
-                                        _p(self.scales), st), 'weightnorm_scales')
-        check(lib.rtg_weights_pack(_p(self.pack_table), self.n_pack, self.max_pack, _p(self.flat), _p(self.scales),
-                                   _p(self.packed), st), 'weights_pack')
+        from . import ops
+        check(ops.timed_bw('wn_scales', 4 * self.n_params, lambda: lib.rtg_weightnorm_scales(
+            _p(self.norm_table), len(self.layers), self.max_rows, _p(self.flat), _p(self.scales), st)), 'weightnorm_scales')
+        check(ops.timed_bw('wn_pack', 4 * (self.n_params + self.packed.numel()), lambda: lib.rtg_weights_pack(
+            _p(self.pack_table), self.n_pack, self.max_pack, _p(self.flat), _p(self.scales), _p(self.packed), st)),
+              'weights_pack')
 
     def prepare(self):
         """Refresh the packed weights from the current parameters; returns the autograd token for this forward."""
@@ -248,6 +253,15 @@ class WeightBank:
         tok._rtg_id = tid
         tok._rtg_bank = self
         return tok
+
+    def flag(self):
+        return self.gflat[self.n_params:]
+
+    def set_flag(self, loss):
+        """store the (device scalar) loss of the step being differentiated in the flag slot"""
+        src = loss.detach().reshape(1)
+        check(lib.rtg_axpby(_p(src), None, C.c_void_p(self.gflat.data_ptr() + 4 * self.n_params), 1, 1.0, 0.0, 0,
+                            _stream()), 'set_flag')
 
     def fwd_ptr(self, ly):
         return C.c_void_p(self.packed.data_ptr() + 4 * ly.fwd_off)
@@ -309,9 +323,14 @@ class WeightBank:
         else:
             tab = _table([self._job(ly, ly.part, ly.splits, base) for ly in owned], self.device)
             self._keep.append(tab)
-        check(lib.rtg_weightnorm_backward(_p(tab), len(owned), self.max_rows, self.max_inner, _p(self.flat),
-                                          _p(self.scales), _p(self.flat), _p(self.gflat), _stream()),
-              'weightnorm_backward')
+        from . import ops
+        # algorithmic bytes: the weight gradient once + v, g once + d g, d v, d bias once = 12 B per parameter; what the
+        # split-K design moves on top is the partials: sum(splits * rows * (inner + 1)) floats read
+        n_par = sum(ly.rows * (ly.inner + 1) + ly.cout for ly in owned)
+        part_bytes = 4 * sum(ly.splits * ly.rows * (ly.inner + 1) for ly in owned)
+        check(ops.timed_bw('wn_bwd', 12 * n_par, lambda: lib.rtg_weightnorm_backward(
+            _p(tab), len(owned), self.max_rows, self.max_inner, _p(self.flat), _p(self.scales), _p(self.flat),
+            _p(self.gflat), _stream()), f'{len(owned)} layers, partials {part_bytes / 1e6:.1f} MB'), 'weightnorm_backward')
         for ly in owned:
             self._owner[ly.lid] = None
         if self.on_flush is not None:

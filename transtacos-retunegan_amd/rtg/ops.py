@@ -44,6 +44,12 @@ def _timed(kernel, variant, flop, launch, label='', nbytes=0):
     return r
 
 
+def timed_bw(name, nbytes, launch, label=''):
+    """bench.py's live timing of a bandwidth kernel (PROFILE on): recorded as ('bw:<name>', 0, 0, e0, e1, label, bytes),
+    bytes = the ALGORITHMIC HBM bytes of the launch (every operand once)."""
+    return _timed('bw:' + name, 0, 0.0, launch, label, nbytes)
+
+
 def _conv_bytes(d, args):
     """algorithmic HBM bytes of one rtg_conv1d launch: every operand tensor once (fp32), weights once"""
     two_d = d.h_k > 1 or d.h_n > 1
@@ -720,9 +726,10 @@ class StftFn(torch.autograd.Function):
         re = torch.empty(B, frames, F, device=dev) if need_bwd else None
         im = torch.empty(B, frames, F, device=dev) if need_bwd else None
         d = L.StftDesc(B, T, plan.n_fft, plan.win, plan.hop, frames, plan.n_mel)
-        check(lib.rtg_stft_forward(C.byref(d), _p(y), _p(t['window']), _p(t['twiddle']), _p(t['mel_lo']),
-                                   _p(t['mel_len']), _p(t['mel_woff']), _p(t['mel_w']), _p(mel), _p(spec), _p(re),
-                                   _p(im), _stream()), 'stft fwd')
+        nbytes = 4 * (y.numel() + mel.numel() + (spec.numel() if want_spec else 0) + (2 * re.numel() if need_bwd else 0))
+        check(timed_bw('stft_fwd', nbytes, lambda: lib.rtg_stft_forward(
+            C.byref(d), _p(y), _p(t['window']), _p(t['twiddle']), _p(t['mel_lo']), _p(t['mel_len']), _p(t['mel_woff']),
+            _p(t['mel_w']), _p(mel), _p(spec), _p(re), _p(im), _stream()), f'n_fft {plan.n_fft} B{B} T{T}'), 'stft fwd')
         ctx.plan, ctx.shape = plan, (B, T, frames)
         ctx.save_for_backward(re, im)
         ctx.set_materialize_grads(False)
@@ -740,7 +747,10 @@ class StftFn(torch.autograd.Function):
         dy = torch.zeros(B, T, device=dev)
         ws = torch.empty(B * frames * plan.win, device=dev)
         d = L.StftDesc(B, T, plan.n_fft, plan.win, plan.hop, frames, plan.n_mel)
-        check(lib.rtg_stft_backward(C.byref(d), _p(re), _p(im), _p(_c(dmel)), _p(_c(dspec)), _p(t['window']),
-                                    _p(t['twiddle']), _p(t['binmel_idx']), _p(t['binmel_w']), _p(ws), _p(dy),
-                                    _stream()), 'stft bwd')
+        dmel_c, dspec_c = _c(dmel), _c(dspec)
+        nbytes = 4 * (2 * re.numel() + (dmel_c.numel() if dmel_c is not None else 0) +
+                      (dspec_c.numel() if dspec_c is not None else 0) + dy.numel())
+        check(timed_bw('stft_bwd', nbytes, lambda: lib.rtg_stft_backward(
+            C.byref(d), _p(re), _p(im), _p(dmel_c), _p(dspec_c), _p(t['window']), _p(t['twiddle']), _p(t['binmel_idx']),
+            _p(t['binmel_w']), _p(ws), _p(dy), _stream()), f'n_fft {plan.n_fft} B{B} T{T}'), 'stft bwd')
         return dy, None, None

@@ -86,17 +86,21 @@ class AdamW:
         for m in self.models:
             m.bank().zero_grad()
 
-    def step(self, loss_flag=None):
+    def step(self, loss_flag=None, use_bank_flag=False):
         """loss_flag: optional device scalar; if it is NaN the update (and the step counter) is skipped on the device
-        — the reference's `if not torch.isnan(loss): loss.backward()` guard without a host round trip."""
+        — the reference's `if not torch.isnan(loss): loss.backward()` guard without a host round trip.
+        use_bank_flag: test the flag slot of each model's gradient buffer instead (WeightBank.set_flag: the loss value
+        rides the data-parallel all-reduce of the gradients, so the guard is collective without a collective of its own)."""
         lr = self.param_groups[0]['lr']
         for m in self.models:
             s = self._st(m)
             bank = s['bank']
             bank.sync_grads()
-            check(lib.rtg_adamw(_p(bank.flat), _p(bank.gflat), _p(s['exp_avg']), _p(s['exp_avg_sq']), bank.n_params,
-                                _p(s['step']), _p(loss_flag), lr, self.betas[0], self.betas[1], self.eps,
-                                self.weight_decay, self.grad_scale, _stream()), 'adamw')
+            from rtg import ops
+            check(ops.timed_bw('adamw', 28 * bank.n_params, lambda: lib.rtg_adamw(
+                _p(bank.flat), _p(bank.gflat), _p(s['exp_avg']), _p(s['exp_avg_sq']), bank.n_params, _p(s['step']),
+                _p(bank.flag() if use_bank_flag else loss_flag), lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.grad_scale,
+                _stream()), type(m).__name__), 'adamw')
 
     def step_tensor(self, m=None):
         return self._st(m or self.models[0])['step']
@@ -214,11 +218,6 @@ class DataParallel:
         if self.comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
 
-    def reduce_flag(self, flag):
-        """NaN guard made collective: a NaN on any rank makes every rank skip the update."""
-        if self.enabled:
-            dist.all_reduce(flag, op=dist.ReduceOp.SUM, group=self.group)
-        return flag
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -286,6 +285,8 @@ class Trainer:
             losses[tag] = discriminator_loss(r, g)
         total = sum(losses.values())
         losses['disc_all'] = total
+        for d in self.discs:                 # before the backward: the flush hooks all-reduce the buffers, flag included
+            d.bank().set_flag(total)
         total.backward()
         losses = _detached(losses)           # nobody differentiates them again: let the autograd graph go now
         if not apply:
@@ -293,7 +294,7 @@ class Trainer:
                 d.bank().sync_grads()
             return losses
         self._d_reduce()
-        self.optim_d.step(self.dp.reduce_flag(total.detach().clone().reshape(1)))
+        self.optim_d.step(use_bank_flag=True)
         return losses
 
     def _d_reduce(self):
@@ -331,6 +332,7 @@ class Trainer:
                 losses['fm_' + tag] = feature_loss(fr, fg)
                 total = total + losses['gen_' + tag] + losses['fm_' + tag] * hp.w_loss_fm
             losses['gen_all'] = total
+            self.generator.bank().set_flag(total)
             total.backward()
         finally:
             self._freeze(False)
@@ -339,7 +341,7 @@ class Trainer:
             self.generator.bank().sync_grads()
             return losses
         self._g_reduce()
-        self.optim_g.step(self.dp.reduce_flag(total.detach().clone().reshape(1)))
+        self.optim_g.step(use_bank_flag=True)
         return losses
 
     def _g_reduce(self):
@@ -422,7 +424,7 @@ class Trainer:
 
         def seg_d(i):
             def run():
-                self.optim_d.step(state['flag'])
+                self.optim_d.step(use_bank_flag=True)
                 if i < n_d:
                     state['dl'] = self.d_step(sy, state['y_hat'].detach(), apply=False)
                 else:
@@ -431,26 +433,18 @@ class Trainer:
             return run
 
         def seg_last():
-            self.optim_g.step(state['flag'])
-
-        def flag_of(key):
-            def run():
-                state['flag'] = state[key]['disc_all' if key == 'dl' else 'gen_all'].detach().clone().reshape(1)
-            return run
+            self.optim_g.step(use_bank_flag=True)
 
         def after_d():
             self._d_reduce()
-            self.dp.reduce_flag(state['flag'])
 
         def after_g():
             self._g_reduce()
-            self.dp.reduce_flag(state['flag'])
 
-        segs = [(lambda: (seg_first(), flag_of('dl')()), after_d)]
+        segs = [(seg_first, after_d)]
         for i in range(1, n_d + 1):
             last_d = i == n_d
-            segs.append((lambda i=i, last_d=last_d: (seg_d(i)(), flag_of('gl' if last_d else 'dl')()),
-                         after_g if last_d else after_d))
+            segs.append((seg_d(i), after_g if last_d else after_d))
         segs.append((seg_last, None))
         graphs = []
         try:
