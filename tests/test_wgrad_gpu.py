@@ -35,6 +35,39 @@ CASES = [
 
 @pytest.mark.parametrize('case', CASES)
 def test_wgrad_and_weightnorm_backward(case):
+    _check_case(case)
+
+
+THIN_CASES = [
+    (2, 1, 16, 1024, 7, 1, 1, 3, 1),         # conv_pre
+    (3, 1, 32, 5000, 15, 1, 1, 7, 1),        # MSD conv0, several tiles per clip, ragged
+    (6, 1, 32, 911, 5, 3, 1, 2, 1),          # MPD conv0: stride 3, period folded into the batch
+    (2, 32, 1, 8192, 7, 1, 1, 3, 1),         # G conv_post
+    (5, 32, 1, 1500, 7, 1, 1, 3, 1),
+    (10, 512, 1, 21, 3, 1, 1, 1, 1),         # D conv_post, short rows
+    (7, 512, 1, 128, 3, 1, 1, 1, 1),
+    (3, 300, 1, 10, 3, 1, 1, 1, 1),          # channels not a multiple of the block
+]
+
+
+@pytest.mark.parametrize('act', ['lrelu', 'tanh', 'none'])
+@pytest.mark.parametrize('case', THIN_CASES)
+def test_thin_wgrad_kernels(case, act):
+    """rtg_wgrad_thin.hip (shape code 7): weight / bias gradients of the one-input-channel and one-output-channel layers
+    on the bandwidth kernels, through the weight-norm chain, against torch autograd; listed as a candidate for exactly
+    these shapes."""
+    from rtg.lib import lib, WgradDesc
+    B, Cin, Cout, L, K, s, d, p, g = case
+    Lo = (L + 2 * p - d * (K - 1) - 1) // s + 1
+    probe = WgradDesc(B=B, C1=Cin, C2=0, L_in=L, groups=g, Cg=Cin // g, Mg=Cout // g, K=K, stride=s, dil=d, pad=p, Q=Lo,
+                      dy_L=Lo, pre_mode=1, pre_slope=0.15, gy_mode=0, gy_slope=1.0, gy_scale=1.0, splits=1, part_stride=0)
+    cands = (C.c_int * 8)()
+    n = lib.rtg_wgrad_shape_candidates(C.byref(probe), cands, 8)
+    assert 7 in list(cands[:n])
+    _check_case(case, shape_cfg=7, act=act)
+
+
+def _check_case(case, shape_cfg=0, act='lrelu'):
     from rtg.lib import lib, WgradDesc, WnBwdJob, NormJob, check
     B, Cin, Cout, L, K, s, d, p, g = case
     gen = torch.Generator().manual_seed(abs(hash(case)) % (2 ** 31))
@@ -43,7 +76,8 @@ def test_wgrad_and_weightnorm_backward(case):
     gg = (1 + 0.1 * torch.randn(Cout, 1, 1, generator=gen, dtype=torch.float64)).requires_grad_(True)
     bias = torch.zeros(Cout, dtype=torch.float64, requires_grad=True)
     w = gg * v / v.flatten(1).norm(dim=1).reshape(-1, 1, 1)
-    y = F.leaky_relu(F.conv1d(F.leaky_relu(x.double(), 0.15), w, bias, s, p, d, g), 0.2)
+    pre = F.conv1d(F.leaky_relu(x.double(), 0.15), w, bias, s, p, d, g)
+    y = F.leaky_relu(pre, 0.2) if act == 'lrelu' else (torch.tanh(pre) if act == 'tanh' else pre)
     dy = torch.randn(y.shape, generator=gen)
     y.backward(dy.double())
     Lo = y.shape[-1]
@@ -60,7 +94,8 @@ def test_wgrad_and_weightnorm_backward(case):
 
     check(lib.rtg_weightnorm_scales(_ptr(table(NormJob(0, rows, 0, rows, inner))), 1, rows, _ptr(flat), _ptr(scales), st))
     wd = WgradDesc(B=B, C1=Cin, C2=0, L_in=L, groups=g, Cg=Cin // g, Mg=Cout // g, K=K, stride=s, dil=d, pad=p, Q=Lo,
-                   dy_L=Lo, pre_mode=1, pre_slope=0.15, gy_mode=2, gy_slope=0.2, gy_scale=1.0, splits=1, part_stride=0)
+                   dy_L=Lo, pre_mode=1, pre_slope=0.15, gy_mode={'lrelu': 2, 'tanh': 3, 'none': 0}[act], gy_slope=0.2,
+                   gy_scale=1.0, splits=1, part_stride=0, shape_cfg=shape_cfg)
     splits = lib.rtg_wgrad_splits(C.byref(wd))
     assert splits >= 1
     stride = rows * (inner + 1)

@@ -74,14 +74,16 @@ __global__ __launch_bounds__(RTG_THREADS) void pack_kernel(const RtgPackJob* job
   const RtgPackJob j = jobs[blockIdx.y];
   const int TM = j.tile_m, KK = 64 / TM, CPN = RTG_CK / KK;
   const int n_mt = (j.Mg + TM - 1) / TM, n_cc = (j.Cg + RTG_CK - 1) / RTG_CK;
-  for (long long e = (long long)blockIdx.x * RTG_THREADS + threadIdx.x; e < j.dst_size;
-       e += (long long)gridDim.x * RTG_THREADS) {
+  // (32-bit index arithmetic: dst_size < 2^31, checked on the host — the 64-bit divisions of the index decode were most of
+  // this kernel's time)
+  const unsigned n_e = (unsigned)j.dst_size;
+  for (unsigned e = blockIdx.x * RTG_THREADS + threadIdx.x; e < n_e; e += gridDim.x * RTG_THREADS) {
     if (j.bf16) {
       // two bf16 per 32-bit slot: elements (2e, 2e+1) of [g][mt][cc][tap][mfma][lane][4]
       const int NMF = TM == 32 ? 2 : 1;
       unsigned bits = 0;
       for (int h = 0; h < 2; ++h) {
-        long long t2 = 2 * e + h;
+        unsigned t2 = 2 * e + h;
         const int el = (int)(t2 % 4); t2 /= 4;
         const int ln = (int)(t2 % 64); t2 /= 64;
         const int mf = (int)(t2 % NMF); t2 /= NMF;
@@ -98,7 +100,7 @@ __global__ __launch_bounds__(RTG_THREADS) void pack_kernel(const RtgPackJob* job
       packed[j.dst_off + e] = __builtin_bit_cast(float, bits);
       continue;
     }
-    long long t = e;
+    unsigned t = e;
     const int m = (int)(t % TM); t /= TM;
     const int kk = (int)(t % KK); t /= KK;
     const int cp = (int)(t % CPN); t /= CPN;
@@ -260,6 +262,7 @@ extern "C" int rtg_weights_pack(const RtgPackJob* jobs_dev, int n_jobs, long lon
                                 const float* scales, float* packed, void* stream) {
   if (!jobs_dev || !params || !scales || !packed) return RTG_ENULL;
   if (n_jobs < 1 || n_jobs > 65535 || max_dst_size < 1) return RTG_EINVAL;
+  if (max_dst_size >= (1ll << 30)) return RTG_ERANGE;          // 32-bit index decode in the kernel (2e + 1 must fit)
   long long gx = (max_dst_size + RTG_THREADS * 4 - 1) / (RTG_THREADS * 4);
   if (gx > 4096) gx = 4096;
   dim3 grid((unsigned)gx, n_jobs);

@@ -29,8 +29,15 @@ int rtg_wgrad_launch_m5(int, int, int, const rtg_wg::WgArgs&, dim3, size_t, hipS
 int rtg_wgrad_launch_m6(int, int, int, const rtg_wg::WgArgs&, dim3, size_t, hipStream_t);
 int rtg_wgrad_launch_m7(int, int, int, const rtg_wg::WgArgs&, dim3, size_t, hipStream_t);
 
+// rtg_wgrad_thin.hip: bandwidth kernels for the one-input-channel / one-output-channel shapes (shape code kThinShape)
+int rtg_wgrad_thin_kind(const RtgWgradDesc* d);
+int rtg_wgrad_thin_splits(const RtgWgradDesc* d);
+int rtg_wgrad_thin_launch(const RtgWgradDesc* d, const float* x, const float* dy, const float* aux, float* part,
+                          hipStream_t s);
+
 namespace {
 using namespace rtg_wg;
+constexpr int kThinShape = 7;
 
 struct Shape {
   int MTW, NTW, WM;
@@ -104,7 +111,7 @@ int validate(const RtgWgradDesc* d) {
   if (d->C1 + d->C2 != d->groups * d->Cg) return RTG_EINVAL;
   if (d->groups > 1 && d->C2 != 0) return RTG_EINVAL;
   if (d->stride > 8) return RTG_ERANGE;
-  if (d->shape_cfg < 0 || d->shape_cfg > kNumShapes) return RTG_EINVAL;
+  if (d->shape_cfg < 0 || (d->shape_cfg > kNumShapes && d->shape_cfg != kThinShape)) return RTG_EINVAL;
   const bool two_d = d->h_k > 1 || d->h_n > 1;
   if (two_d) {
     if (d->h_in < 1 || d->h_k < 1 || d->h_stride < 1 || d->h_pad < 0 || d->h_n < 1) return RTG_EINVAL;
@@ -124,6 +131,7 @@ extern "C" int rtg_wgrad_splits(const RtgWgradDesc* d) {
   if (!d) return RTG_ENULL;
   int st = validate(d);
   if (st) return st;
+  if (d->shape_cfg == kThinShape) return rtg_wgrad_thin_splits(d);
   WgGeom g;
   st = geometry(d, &g);
   if (st) return st;
@@ -173,6 +181,7 @@ extern "C" int rtg_wgrad_shape_candidates(const RtgWgradDesc* d, int* cfgs, int 
     WgGeom gs;
     if (geometry(&t, &gs) == RTG_OK) cfgs[cnt++] = s + 1;
   }
+  if (rtg_wgrad_thin_kind(d) > 0 && cnt < max) cfgs[cnt++] = kThinShape;
   return cnt;
 }
 
@@ -187,6 +196,7 @@ extern "C" int rtg_conv1d_wgrad(const RtgWgradDesc* d, const float* x1, const fl
   if (d->splits < 1 || d->splits > 65535) return RTG_EINVAL;
   const long long need = (long long)d->groups * d->Mg * ((long long)d->Cg * d->K + 1);
   if (d->splits > 1 && d->part_stride < need) return RTG_EINVAL;
+  if (d->shape_cfg == kThinShape) return rtg_wgrad_thin_launch(d, x1, dy, gy_aux, part, (hipStream_t)stream);
   WgGeom g;
   st = geometry(d, &g);
   if (st) return st;
