@@ -143,14 +143,14 @@ def test_single_layer_bf16_is_exact_on_rounded_operands(bf16_mode, cin, cout, k,
 
 def test_mtd_forward_backward_bf16(oracle, gold, bf16_mode):
     """the 2-D stack (MTD) in bf16: forward against the bf16-rounding oracle on the same spectra; gradients against the
-    fp32 oracle gradients at bf16 noise level (strided 2-D backward-data stays fp32, the rest is bf16)"""
+    fp32 oracle gradients at bf16 noise level (every layer's backward-data in bf16, the class-pure strided 2-D one too)"""
     from models import MultiStftDiscriminator, multi_stft_loss, discriminator_loss
     mtd, omtd = MultiStftDiscriminator(), oracle.MTD()
     oracle.det_fill(mtd); oracle.det_fill(omtd)
     mtd.to(DEV).train()
     n, tot = _mirror_flags(mtd, omtd)
     assert n >= tot - 3                                   # all but the three 1-output-channel conv_post layers
-    assert any(ly.bwd_bf for ly in mtd.bank().layers) and not all(ly.bwd_bf for ly in mtd.bank().layers)
+    assert all(ly.bwd_bf for ly in mtd.bank().layers)       # the class-pure strided 2-D backward-data included (round 2)
     _, _, y = oracle.golden_inputs()
     yd = torch.from_numpy(gold['y_hat'])
     S, Sg = multi_stft_loss(y.to(DEV), yd.to(DEV), ret_specs=True)

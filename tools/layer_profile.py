@@ -25,6 +25,8 @@ ops.PROFILE = []
 tr.train_step(*data)
 torch.cuda.synchronize()
 rec, ops.PROFILE = ops.PROFILE, None
+bw = [r for r in rec if r[0].startswith('bw:')]
+rec = [r for r in rec if not r[0].startswith('bw:')]
 agg = {}
 for kernel, variant, flop, e0, e1, label, _nb in rec:
     a = agg.setdefault((label, variant), [0, 0.0, 0.0])
@@ -55,3 +57,9 @@ for k in sorted(tot):
 for m in ('G', 'MSD', 'MPD'):
     ms = sum(v[0] for k, v in tot.items() if k[0] == m); fl = sum(v[1] for k, v in tot.items() if k[0] == m)
     print(f'{m}: {ms:.2f} ms {fl / 1e9:.0f} GFLOP {fl / ms / 1e9:.1f} TF/s')
+print('---- bandwidth kernels')
+agg_bw = {}
+for kernel, variant, flop, e0, e1, label, nb in bw:
+    a = agg_bw.setdefault(kernel[3:], [0, 0.0, 0.0]); a[0] += 1; a[1] += e0.elapsed_time(e1); a[2] += nb
+for k, (n, ms, nb) in sorted(agg_bw.items()):
+    print(f'{k:10s} n={n:3d} {ms:7.3f} ms  {nb / ms / 1e6:8.1f} GB/s')

@@ -414,11 +414,14 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a, const unsign
       wpb[i] = reinterpret_cast<const u32x2*>(a.wp) + ((size_t)(g * a.n_mt + mt) * a.n_cc) * a.K * (NMF * 64) + lane;
     }
     bf4 A0[MT][NMF], A1[MT][NMF];
+    // offset (in 8-byte fragments) of the step whose A fragments were requested last; class-pure blocks (strided 2-D
+    // backward-data) walk only the chunks of their kernel-row class: virtual chunk v -> real_cc(v)
+    size_t wcur = (size_t)real_cc(0) * a.K * (NMF * 64);
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-      for (int mf = 0; mf < NMF; ++mf) A0[i][mf] = __builtin_bit_cast(bf4, wpb[i][mf * 64]);
-    stage(0);
+      for (int mf = 0; mf < NMF; ++mf) A0[i][mf] = __builtin_bit_cast(bf4, wpb[i][wcur + mf * 64]);
+    stage(real_cc(0));
     swrite_bf(lds);
     __syncthreads();
     int sK = a.K, sDil = a.dil, sStride = a.stride, sPH = a.PH, sBuf = bufsz, sROW = a.ROW, sPacked = a.seg_len;
@@ -431,13 +434,20 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a, const unsign
     auto step_bf = [&](int step, bf4 (&cur)[MT][NMF], bf4 (&nxt)[MT][NMF]) __attribute__((always_inline)) {
       const u32x2* buf = reinterpret_cast<const u32x2*>(lds + (cc & 1) * sBuf);
       if (step + 1 < n_steps) {
+        size_t nofs;
+        if constexpr (cls_mode) {
+          if (tap + 1 == sK) wcur = (size_t)real_cc(cc + 1) * a.K * (NMF * 64);
+          else wcur += NMF * 64;
+          nofs = wcur;
+        } else {
+          nofs = (size_t)(step + 1) * (NMF * 64);
+        }
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
-          for (int mf = 0; mf < NMF; ++mf)
-            nxt[i][mf] = __builtin_bit_cast(bf4, wpb[i][(size_t)(step + 1) * (NMF * 64) + mf * 64]);
+          for (int mf = 0; mf < NMF; ++mf) nxt[i][mf] = __builtin_bit_cast(bf4, wpb[i][nofs + mf * 64]);
       }
-      if (tap == 0 && cc + 1 < n_cc) stage(cc + 1);
+      if (tap == 0 && cc + 1 < n_cc) stage(real_cc(cc + 1));
       const int tapoff = tph * sPH + tq;
       bf4 bfr[NMF][NT];
 #pragma unroll
@@ -854,7 +864,8 @@ int launch_group_it(const GroupArgs& ga, size_t lds_bytes, int bf, hipStream_t s
   if (bf) {
     for (int i = 0; i < ga.n; ++i)
       if (ga.p[i].tapmajor) return RTG_EINVAL;
-    return cls ? RTG_EINVAL : launch_group_cls<TM, MT, NT, MAXIT, false, true>(ga, lds_bytes, s);
+    return cls ? launch_group_cls<TM, MT, NT, MAXIT, true, true>(ga, lds_bytes, s)
+               : launch_group_cls<TM, MT, NT, MAXIT, false, true>(ga, lds_bytes, s);
   }
   return cls ? launch_group_cls<TM, MT, NT, MAXIT, true, false>(ga, lds_bytes, s)
              : launch_group_cls<TM, MT, NT, MAXIT, false, false>(ga, lds_bytes, s);

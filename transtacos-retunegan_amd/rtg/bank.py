@@ -97,7 +97,7 @@ class ConvLayer:
             return bool(want_bf and not tap and op[2] > 1 and op[3] > 1)
         self.fwd_bf = int(ok(self.fwd_op, self.fwd_tap))
         self.wgrad_bf = int(want_bf)          # the weight-gradient kernel has one K order: every layer
-        self.bwd_bf = int(ok(self.bwd_op, self.bwd_tap) and not (self.kind == 'conv2d' and getattr(self, 'sh', 1) > 1))
+        self.bwd_bf = int(ok(self.bwd_op, self.bwd_tap))     # (the class-pure strided 2-D backward-data included)
         # filled by the bank
         self.g_off = self.v_off = self.b_off = self.scale_off = 0
         self.fwd_off = self.bwd_off = 0
