@@ -51,73 +51,57 @@ __global__ __launch_bounds__(RTG_THREADS) void stft_fwd_kernel(RtgStftDesc d, co
                                                                const int* __restrict__ mel_len,
                                                                const int* __restrict__ mel_woff,
                                                                const float* __restrict__ mel_w, float* mel, float* spec,
-                                                               float* re_out, float* im_out, int FT) {
+                                                               float* re_out, float* im_out) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int N = d.n_fft, F = N / 2 + 1;
   cpx* A = reinterpret_cast<cpx*>(smem);
   cpx* Bf = A + N;
   float* S = reinterpret_cast<float*>(Bf + N);          // F magnitudes
-  // spectrum output [B][2][F][frames] has the frame index innermost: a block transforms FT consecutive frames and parks
-  // their log-magnitudes / phases in an LDS tile [2][F][FT], so that the final store writes FT consecutive floats per
-  // frequency row (one frame per block wrote every 4-byte value to its own cache line)
-  float* tile = S + ((F + 3) & ~3);
-  const int b = blockIdx.y, f0 = blockIdx.x * FT;
+  const int frame = blockIdx.x, b = blockIdx.y;
   const int lpad = (N - d.win) / 2;
   const float* yb = y + (size_t)b * d.T;
 
-  for (int j = 0; j < FT; ++j) {
-    const int frame = f0 + j;
-    if (frame >= d.frames) break;                        // (uniform)
-    if (j) __syncthreads();                              // the previous frame's S / FFT buffers are consumed
-    for (int i = threadIdx.x; i < N; i += RTG_THREADS) {
-      float v = 0.f;
-      const int n = i - lpad;
-      if (n >= 0 && n < d.win) {
-        int t = frame * d.hop + i - N / 2;               // centre=True: padded index - n_fft/2
-        if (t < 0) t = -t;
-        if (t >= d.T) t = 2 * (d.T - 1) - t;
-        v = yb[t] * window[n];
-      }
-      A[i].x = v;
-      A[i].y = 0.f;
+  for (int i = threadIdx.x; i < N; i += RTG_THREADS) {
+    float v = 0.f;
+    const int n = i - lpad;
+    if (n >= 0 && n < d.win) {
+      int t = frame * d.hop + i - N / 2;                 // centre=True: padded index - n_fft/2
+      if (t < 0) t = -t;
+      if (t >= d.T) t = 2 * (d.T - 1) - t;
+      v = yb[t] * window[n];
     }
-    __syncthreads();
-    const cpx* X = fft_stockham(A, Bf, N, twiddle, twiddle + N / 2);
+    A[i].x = v;
+    A[i].y = 0.f;
+  }
+  __syncthreads();
+  const cpx* X = fft_stockham(A, Bf, N, twiddle, twiddle + N / 2);
 
-    const size_t fo = ((size_t)b * d.frames + frame) * F;  // [B][frames][F] scratch layout for the backward
-    for (int f = threadIdx.x; f < F; f += RTG_THREADS) {
-      // DC and Nyquist of a real-input transform are exactly real: a real-to-complex FFT (torch.stft / pocketfft)
-      // returns imag = +0.0 there, so angle() is exactly 0 or +pi; rounding noise of a complex FFT would flip it to -pi
-      const float re = X[f].x, im = (f == 0 || f == N / 2) ? 0.f : X[f].y;
-      const float rr = re + 1e-9f;
-      const float mag = sqrtf(rr * rr + im * im);
-      S[f] = mag;
-      if (re_out) {
-        re_out[fo + f] = re;
-        im_out[fo + f] = im;
-      }
-      if (spec) {
-        tile[f * FT + j] = logf(mag);
-        tile[(F + f) * FT + j] = atan2f(im, re) / RTG_PI_REF;
-      }
+  const size_t fo = ((size_t)b * d.frames + frame) * F;  // [B][frames][F] scratch layout for the backward
+  for (int f = threadIdx.x; f < F; f += RTG_THREADS) {
+    // DC and Nyquist of a real-input transform are exactly real: a real-to-complex FFT (torch.stft / pocketfft) returns
+    // imag = +0.0 there, so angle() is exactly 0 or +pi; rounding noise of a complex FFT would flip it to -pi at random
+    const float re = X[f].x, im = (f == 0 || f == N / 2) ? 0.f : X[f].y;
+    const float rr = re + 1e-9f;
+    const float mag = sqrtf(rr * rr + im * im);
+    S[f] = mag;
+    if (re_out) {
+      re_out[fo + f] = re;
+      im_out[fo + f] = im;
     }
-    __syncthreads();
-    if (mel) {
-      for (int m = threadIdx.x; m < d.n_mel; m += RTG_THREADS) {
-        const int lo = mel_lo[m], len = mel_len[m];
-        const float* w = mel_w + mel_woff[m];
-        float acc = 0.f;
-        for (int i = 0; i < len; ++i) acc += w[i] * S[lo + i];
-        mel[((size_t)b * d.n_mel + m) * d.frames + frame] = acc;
-      }
+    if (spec) {
+      const size_t so = (((size_t)b * 2) * F + f) * d.frames + frame;
+      spec[so] = logf(mag);
+      spec[so + (size_t)F * d.frames] = atan2f(im, re) / RTG_PI_REF;
     }
   }
-  if (spec) {
-    __syncthreads();
-    const int nf = min(FT, d.frames - f0);
-    for (int idx = threadIdx.x; idx < 2 * F * FT; idx += RTG_THREADS) {
-      const int row = idx / FT, j = idx - row * FT;      // row = plane * F + f
-      if (j < nf) spec[((size_t)b * 2 * F + row) * d.frames + f0 + j] = tile[idx];
+  __syncthreads();
+  if (mel) {
+    for (int m = threadIdx.x; m < d.n_mel; m += RTG_THREADS) {
+      const int lo = mel_lo[m], len = mel_len[m];
+      const float* w = mel_w + mel_woff[m];
+      float acc = 0.f;
+      for (int i = 0; i < len; ++i) acc += w[i] * S[lo + i];
+      mel[((size_t)b * d.n_mel + m) * d.frames + frame] = acc;
     }
   }
 }
@@ -130,66 +114,56 @@ __global__ __launch_bounds__(RTG_THREADS) void stft_bwd_frame_kernel(RtgStftDesc
                                                                      const float* __restrict__ twiddle,
                                                                      const int* __restrict__ binmel_idx,
                                                                      const float* __restrict__ binmel_w,
-                                                                     float* __restrict__ frame_ws, int FT) {
+                                                                     float* __restrict__ frame_ws) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int N = d.n_fft, F = N / 2 + 1;
   cpx* A = reinterpret_cast<cpx*>(smem);
   cpx* Bf = A + N;
   float* dm = reinterpret_cast<float*>(Bf + N);          // n_mel cotangents of this frame
-  float* tile = dm + 256;                                // [2][F][FT] cotangents of the spectrum (frame innermost in HBM)
-  const int b = blockIdx.y, f0 = blockIdx.x * FT;
+  const int frame = blockIdx.x, b = blockIdx.y;
   const int lpad = (N - d.win) / 2;
-  const int nf = min(FT, d.frames - f0);
-  if (dspec) {
-    for (int idx = threadIdx.x; idx < 2 * F * FT; idx += RTG_THREADS) {
-      const int row = idx / FT, j = idx - row * FT;
-      tile[idx] = j < nf ? dspec[((size_t)b * 2 * F + row) * d.frames + f0 + j] : 0.f;
-    }
-  }
-  for (int j = 0; j < nf; ++j) {
-    const int frame = f0 + j;
-    __syncthreads();                                     // tile loaded / the previous frame's buffers consumed
-    if (dmel)
-      for (int m = threadIdx.x; m < d.n_mel; m += RTG_THREADS)
-        dm[m] = dmel[((size_t)b * d.n_mel + m) * d.frames + frame];
-    __syncthreads();
-    const size_t fo = ((size_t)b * d.frames + frame) * F;
-    for (int f = threadIdx.x; f < N; f += RTG_THREADS) {
-      float gr = 0.f, gi = 0.f;
-      if (f < F) {
-        const float re = re_in[fo + f], im = im_in[fo + f];
-        const float rr = re + 1e-9f;
-        const float mag = sqrtf(rr * rr + im * im);
-        float dS = 0.f;
-        if (dmel) {
-          const int i0 = binmel_idx[2 * f], i1 = binmel_idx[2 * f + 1];
-          if (i0 >= 0) dS += binmel_w[2 * f] * dm[i0];
-          if (i1 >= 0) dS += binmel_w[2 * f + 1] * dm[i1];
-        }
-        float dP = 0.f;
-        if (dspec) {
-          dS += tile[f * FT + j] / mag;                       // d log S
-          dP = tile[(F + f) * FT + j] / RTG_PI_REF;
-        }
-        if (mag > 0.f) {
-          gr = dS * rr / mag;
-          gi = dS * im / mag;
-        }
-        const float r2 = re * re + im * im;
-        if (dP != 0.f && r2 > 0.f) {
-          gr += dP * (-im / r2);
-          gi += dP * (re / r2);
-        }
-        if (f == 0 || f == N / 2) gi = 0.f;               // structurally-zero imaginary parts carry no gradient
+
+  if (dmel)
+    for (int m = threadIdx.x; m < d.n_mel; m += RTG_THREADS)
+      dm[m] = dmel[((size_t)b * d.n_mel + m) * d.frames + frame];
+  __syncthreads();
+  const size_t fo = ((size_t)b * d.frames + frame) * F;
+  for (int f = threadIdx.x; f < N; f += RTG_THREADS) {
+    float gr = 0.f, gi = 0.f;
+    if (f < F) {
+      const float re = re_in[fo + f], im = im_in[fo + f];
+      const float rr = re + 1e-9f;
+      const float mag = sqrtf(rr * rr + im * im);
+      float dS = 0.f;
+      if (dmel) {
+        const int i0 = binmel_idx[2 * f], i1 = binmel_idx[2 * f + 1];
+        if (i0 >= 0) dS += binmel_w[2 * f] * dm[i0];
+        if (i1 >= 0) dS += binmel_w[2 * f + 1] * dm[i1];
       }
-      A[f].x = gr;                                        // conj(G): adjoint of the forward DFT = Re FFT(conj G)
-      A[f].y = -gi;
+      float dP = 0.f;
+      if (dspec) {
+        const size_t so = (((size_t)b * 2) * F + f) * d.frames + frame;
+        dS += dspec[so] / mag;                            // d log S
+        dP = dspec[so + (size_t)F * d.frames] / RTG_PI_REF;
+      }
+      if (mag > 0.f) {
+        gr = dS * rr / mag;
+        gi = dS * im / mag;
+      }
+      const float r2 = re * re + im * im;
+      if (dP != 0.f && r2 > 0.f) {
+        gr += dP * (-im / r2);
+        gi += dP * (re / r2);
+      }
+      if (f == 0 || f == N / 2) gi = 0.f;                 // structurally-zero imaginary parts carry no gradient
     }
-    __syncthreads();
-    const cpx* Z = fft_stockham(A, Bf, N, twiddle, twiddle + N / 2);
-    float* out = frame_ws + ((size_t)b * d.frames + frame) * d.win;
-    for (int n = threadIdx.x; n < d.win; n += RTG_THREADS) out[n] = Z[lpad + n].x * window[n];
+    A[f].x = gr;                                          // conj(G): adjoint of the forward DFT = Re FFT(conj G)
+    A[f].y = -gi;
   }
+  __syncthreads();
+  const cpx* Z = fft_stockham(A, Bf, N, twiddle, twiddle + N / 2);
+  float* out = frame_ws + ((size_t)b * d.frames + frame) * d.win;
+  for (int n = threadIdx.x; n < d.win; n += RTG_THREADS) out[n] = Z[lpad + n].x * window[n];
 }
 
 // dy[b,t] += sum over the (<= 3) padded positions that alias to t of the frames covering them.
@@ -220,11 +194,6 @@ __global__ __launch_bounds__(RTG_THREADS) void stft_ola_kernel(RtgStftDesc d, co
   dy[(size_t)b * d.T + t] += acc;
 }
 
-// frames a block transforms when the [.., F, frames] spectrum is written / read (LDS tile 2 * F * FT floats): 16-byte
-// (n_fft 2048) .. 32-byte runs along the frame axis instead of isolated 4-byte accesses, while the grid still has
-// frames / FT * B >= 256 blocks at the train-step sizes
-static int stft_frames_per_block(int n_fft) { return n_fft >= 2048 ? 4 : 8; }
-
 int validate(const RtgStftDesc* d) {
   if (d->B < 1 || d->T < 2 || d->hop < 1 || d->n_mel < 1 || d->n_mel > 256) return RTG_EINVAL;
   if (d->n_fft != 512 && d->n_fft != 1024 && d->n_fft != 2048 && d->n_fft != 256 && d->n_fft != 4096) return RTG_ERANGE;
@@ -245,14 +214,11 @@ extern "C" int rtg_stft_forward(const RtgStftDesc* d, const float* y, const floa
   if (st) return st;
   if (mel && (!mel_lo || !mel_len || !mel_woff || !mel_w)) return RTG_ENULL;
   if ((re == nullptr) != (im == nullptr)) return RTG_EINVAL;
-  const int F = d->n_fft / 2 + 1;
-  const int FT = spec ? stft_frames_per_block(d->n_fft) : 1;
-  const size_t lds = (size_t)d->n_fft * 2 * sizeof(cpx) + (size_t)((F + 3) & ~3) * sizeof(float) +
-                     (spec ? (size_t)2 * F * FT * sizeof(float) : 0);
+  const size_t lds = (size_t)d->n_fft * 2 * sizeof(cpx) + (size_t)(d->n_fft / 2 + 1) * sizeof(float);
   if (lds > 64 * 1024)
-    hipFuncSetAttribute((const void*)stft_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  RTG_KLAUNCH(stft_fwd_kernel, dim3(rtg_ceil_div(d->frames, FT), d->B), dim3(RTG_THREADS), lds, (hipStream_t)stream, *d,
-                     y, window, twiddle, mel_lo, mel_len, mel_woff, mel_w, mel, spec, re, im, FT);
+    hipFuncSetAttribute((const void*)stft_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  RTG_KLAUNCH(stft_fwd_kernel, dim3(d->frames, d->B), dim3(RTG_THREADS), lds, (hipStream_t)stream, *d, y, window,
+                     twiddle, mel_lo, mel_len, mel_woff, mel_w, mel, spec, re, im);
   return rtg_launch_status();
 }
 
@@ -263,14 +229,11 @@ extern "C" int rtg_stft_backward(const RtgStftDesc* d, const float* re, const fl
   int st = validate(d);
   if (st) return st;
   if (dmel && (!binmel_idx || !binmel_w)) return RTG_ENULL;
-  const int F = d->n_fft / 2 + 1;
-  const int FT = dspec ? stft_frames_per_block(d->n_fft) : 1;
-  const size_t lds = (size_t)d->n_fft * 2 * sizeof(cpx) + 256 * sizeof(float) +
-                     (dspec ? (size_t)2 * F * FT * sizeof(float) : 0);
+  const size_t lds = (size_t)d->n_fft * 2 * sizeof(cpx) + 256 * sizeof(float);
   if (lds > 64 * 1024)
-    hipFuncSetAttribute((const void*)stft_bwd_frame_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  RTG_KLAUNCH(stft_bwd_frame_kernel, dim3(rtg_ceil_div(d->frames, FT), d->B), dim3(RTG_THREADS), lds,
-                     (hipStream_t)stream, *d, re, im, dmel, dspec, window, twiddle, binmel_idx, binmel_w, frame_ws, FT);
+    hipFuncSetAttribute((const void*)stft_bwd_frame_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  RTG_KLAUNCH(stft_bwd_frame_kernel, dim3(d->frames, d->B), dim3(RTG_THREADS), lds, (hipStream_t)stream, *d, re,
+                     im, dmel, dspec, window, twiddle, binmel_idx, binmel_w, frame_ws);
   int e = rtg_launch_status();
   if (e) return e;
   RTG_KLAUNCH(stft_ola_kernel, dim3(rtg_ceil_div(d->T, RTG_THREADS), d->B), dim3(RTG_THREADS), 0,
