@@ -75,7 +75,7 @@ def main():
             e['lds_bank_conflict_frac'] = round(a['SQ_LDS_BANK_CONFLICT'] / wc, 4)
         table[k] = e
     table = dict(sorted(table.items(), key=lambda kv: -kv[1]['avg_us'] * kv[1]['launches']))
-    import os, sys
+    import os
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
     json.dump({'source': 'rocprofv3 --pmc (3 separate passes: SQ, FETCH_SIZE+GRBM, WRITE_SIZE+TCC) over bench.py',

@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'librtg.so')
 STAMP = os.path.join(HERE, 'csrc', '.build_stamp')
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-comment', '-Wno-unused-result']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-comment', '-Wno-unused-result'] + os.environ.get('RTG_EXTRA_FLAGS', '').split()
 JOBS = max(1, min(8, os.cpu_count() or 1))
 
 

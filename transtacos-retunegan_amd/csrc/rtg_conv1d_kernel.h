@@ -193,6 +193,10 @@ struct MfmaBf;
 template <>
 struct MfmaBf<32> {
   static __device__ __forceinline__ f32x16 run(bf4 a, bf4 b, f32x16 c) {
+#ifdef RTG_EXP_NOMFMA_BF
+    c[0] += (float)(a.x + b.x);      // ablation: operands stay live, no matrix instruction
+    return c;
+#endif
     return __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a, b, c, 0, 0, 0);
   }
 };

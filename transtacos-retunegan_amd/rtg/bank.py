@@ -88,9 +88,10 @@ class ConvLayer:
         if want_bf and os.environ.get('RTG_BF16_NOTAP', '1') == '1':
             # at bf16 matrix rates padding 8 channels per group to a 16-channel chunk costs less than staying on the
             # fp32 tap-major path: the grouped MSD layers run channel-major in bf16
-            if self.fwd_tap and self.fwd_op[3] >= 8:
+            min_c = int(os.environ.get('RTG_BF16_NOTAP_MINC', '8'))
+            if self.fwd_tap and self.fwd_op[3] >= min_c:
                 self.fwd_tap = 0
-            if self.bwd_tap and self.bwd_op[3] >= 8:
+            if self.bwd_tap and self.bwd_op[3] >= min_c:
                 self.bwd_tap = 0
 
         def ok(op, tap):
