@@ -67,6 +67,31 @@ def test_thin_wgrad_kernels(case, act):
     _check_case(case, shape_cfg=7, act=act)
 
 
+RES_CASES = [
+    (3, 32, 32, 1000, 7, 1, 9, 27, 1),       # ragged: the last tile of a clip is partial
+    (2, 32, 32, 8192, 3, 1, 1, 1, 1),
+    (2, 32, 32, 2048, 5, 1, 3, 6, 1),
+    (2, 64, 64, 2048, 5, 1, 3, 6, 1),
+    (5, 64, 64, 260, 5, 1, 3, 6, 1),
+    (9, 64, 64, 256, 3, 1, 9, 9, 1),
+    (300, 32, 32, 128, 3, 1, 1, 1, 1),       # more tiles than blocks: several tiles per block
+]
+
+
+@pytest.mark.parametrize('case', RES_CASES)
+def test_reswgrad_kernel(case):
+    """rtg_reswgrad.hip (shape code 8): the weight / bias gradients of the stride-1 'same' convs of ResBlock3 /
+    ResidualStack as a streaming reduction, through the weight-norm chain, against torch autograd."""
+    from rtg.lib import lib, WgradDesc
+    B, Cin, Cout, L, K, s, d, p, g = case
+    probe = WgradDesc(B=B, C1=Cin, C2=0, L_in=L, groups=g, Cg=Cin // g, Mg=Cout // g, K=K, stride=s, dil=d, pad=p, Q=L,
+                      dy_L=L, pre_mode=1, pre_slope=0.15, gy_mode=0, gy_slope=1.0, gy_scale=1.0, splits=1, part_stride=0)
+    cands = (C.c_int * 8)()
+    n = lib.rtg_wgrad_shape_candidates(C.byref(probe), cands, 8)
+    assert 8 in list(cands[:n])
+    _check_case(case, shape_cfg=8, act='none')
+
+
 def _check_case(case, shape_cfg=0, act='lrelu'):
     from rtg.lib import lib, WgradDesc, WnBwdJob, NormJob, check
     B, Cin, Cout, L, K, s, d, p, g = case

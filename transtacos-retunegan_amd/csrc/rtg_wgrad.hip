@@ -35,9 +35,15 @@ int rtg_wgrad_thin_splits(const RtgWgradDesc* d);
 int rtg_wgrad_thin_launch(const RtgWgradDesc* d, const float* x, const float* dy, const float* aux, float* part,
                           hipStream_t s);
 
+// rtg_reswgrad.hip: streaming reduction for the stride-1 "same" convs of the UNet-G residual blocks (shape code kResShape)
+int rtg_reswgrad_ok(const RtgWgradDesc* d);
+int rtg_reswgrad_splits(const RtgWgradDesc* d);
+int rtg_reswgrad_launch(const RtgWgradDesc* d, const float* x, const float* dy, float* part, hipStream_t s);
+
 namespace {
 using namespace rtg_wg;
 constexpr int kThinShape = 7;
+constexpr int kResShape = 8;
 
 struct Shape {
   int MTW, NTW, WM;
@@ -111,7 +117,8 @@ int validate(const RtgWgradDesc* d) {
   if (d->C1 + d->C2 != d->groups * d->Cg) return RTG_EINVAL;
   if (d->groups > 1 && d->C2 != 0) return RTG_EINVAL;
   if (d->stride > 8) return RTG_ERANGE;
-  if (d->shape_cfg < 0 || (d->shape_cfg > kNumShapes && d->shape_cfg != kThinShape)) return RTG_EINVAL;
+  if (d->shape_cfg < 0 || (d->shape_cfg > kNumShapes && d->shape_cfg != kThinShape && d->shape_cfg != kResShape))
+    return RTG_EINVAL;
   const bool two_d = d->h_k > 1 || d->h_n > 1;
   if (two_d) {
     if (d->h_in < 1 || d->h_k < 1 || d->h_stride < 1 || d->h_pad < 0 || d->h_n < 1) return RTG_EINVAL;
@@ -132,6 +139,7 @@ extern "C" int rtg_wgrad_splits(const RtgWgradDesc* d) {
   int st = validate(d);
   if (st) return st;
   if (d->shape_cfg == kThinShape) return rtg_wgrad_thin_splits(d);
+  if (d->shape_cfg == kResShape) return rtg_reswgrad_splits(d);
   WgGeom g;
   st = geometry(d, &g);
   if (st) return st;
@@ -182,6 +190,7 @@ extern "C" int rtg_wgrad_shape_candidates(const RtgWgradDesc* d, int* cfgs, int 
     if (geometry(&t, &gs) == RTG_OK) cfgs[cnt++] = s + 1;
   }
   if (rtg_wgrad_thin_kind(d) > 0 && cnt < max) cfgs[cnt++] = kThinShape;
+  if (rtg_reswgrad_ok(d) && cnt < max) cfgs[cnt++] = kResShape;
   return cnt;
 }
 
@@ -197,6 +206,7 @@ extern "C" int rtg_conv1d_wgrad(const RtgWgradDesc* d, const float* x1, const fl
   const long long need = (long long)d->groups * d->Mg * ((long long)d->Cg * d->K + 1);
   if (d->splits > 1 && d->part_stride < need) return RTG_EINVAL;
   if (d->shape_cfg == kThinShape) return rtg_wgrad_thin_launch(d, x1, dy, gy_aux, part, (hipStream_t)stream);
+  if (d->shape_cfg == kResShape) return rtg_reswgrad_launch(d, x1, dy, part, (hipStream_t)stream);
   WgGeom g;
   st = geometry(d, &g);
   if (st) return st;

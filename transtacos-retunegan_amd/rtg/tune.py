@@ -74,8 +74,8 @@ def wgrad_cfg(wd, run):
         return cfg
     if not (ENABLED and ACTIVE):
         return _miss()
-    cands = (C.c_int * 8)()
-    n = lib.rtg_wgrad_shape_candidates(C.byref(wd), cands, 8)
+    cands = (C.c_int * 12)()
+    n = lib.rtg_wgrad_shape_candidates(C.byref(wd), cands, 12)
     need = wd.groups * wd.Mg * (wd.Cg * wd.K + 1)
     best, best_t = 0, None
     for c in cands[:max(n, 0)]:
