@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define RTG_ABI_VERSION 2
+#define RTG_ABI_VERSION 3
 
 #define RTG_OK 0
 #define RTG_EINVAL (-1)   /* inconsistent descriptor               */
@@ -306,6 +306,30 @@ int rtg_strip_mirror_bwd(const float* y, int rows, int L, float w, const float* 
 int rtg_adamw(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n, float* step_state,
               const float* loss_flag, double lr, double beta1, double beta2, double eps, double weight_decay,
               float grad_scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * rtg_resstack_* — a whole ResidualStack (generator.py:33-77: three times r = conv_d(lrelu(x)), x = x + conv_1(lrelu(r)),
+ * k = 3, d = 1, 3, 9; optional leaky-relu on the final x) in ONE launch per direction, for the stacks whose clips fit in
+ * LDS: (C, L) = (128, 32) and (64, 256).  Replaces the 6 Conv1d forward and 6 backward-data launches of a stack.
+ *   forward   x [B,C,L]; wp / bias: the 6 layers' packed forward weights (RTG_PACK_FWD, tile_m 32) and biases in execution
+ *             order; outs: the 6 results r1, x1, r2, x2, r3, y (y = the final x, activated when final_act)
+ *   backward  dy [B,C,L] (cotangent of y), y (for the activation's derivative when final_act); wpb: the packed
+ *             backward-data weights (RTG_PACK_DGRAD_S1) of the layers in REVERSE order; masks: the forward tensors whose
+ *             sign masks each step: r3, x2, r2, x1, r1, x0; gouts: g_r3, g_x2, g_r2, g_x1, g_r1, dx0 — the first five are
+ *             the output cotangents the weight-gradient launches of the layers need.
+ * rtg_resstack_ok: 1 when the shape is served.
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct RtgResStackDesc {
+  int B, C, L;
+  int dil[6];                  /* dilation (= padding) of the layers in execution order                          */
+  float pre_slope;             /* leaky-relu slope of every conv input (0.01)                                       */
+  int final_act; float act_slope;
+} RtgResStackDesc;
+int rtg_resstack_ok(const RtgResStackDesc* d);
+int rtg_resstack_forward(const RtgResStackDesc* d, const float* x, const float* const* wp, const float* const* bias,
+                         float* const* outs, void* stream);
+int rtg_resstack_backward(const RtgResStackDesc* d, const float* dy, const float* y, const float* const* wpb,
+                          const float* const* masks, float* const* gouts, void* stream);
 
 /* library self-description */
 int rtg_abi_version(void);

@@ -59,6 +59,14 @@ class LossJob(C.Structure):
                 ('w', C.c_float), ('target', C.c_float)]
 
 
+class ResStackDesc(C.Structure):
+    _fields_ = [('B', C.c_int), ('C', C.c_int), ('L', C.c_int), ('dil', C.c_int * 6), ('pre_slope', C.c_float),
+                ('final_act', C.c_int), ('act_slope', C.c_float)]
+
+
+PtrArray6 = C.c_void_p * 6
+
+
 class StftDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in ('B', 'T', 'n_fft', 'win', 'hop', 'frames', 'n_mel')]
 
@@ -70,7 +78,7 @@ CK = 16
 LOSS_L1, LOSS_L1_L1LOG, LOSS_MSE_TARGET, LOSS_MSE_REL = 0, 1, 2, 3
 MAX_LOSS_JOBS = 48
 
-ABI_VERSION = 2            # RTG_ABI_VERSION of include/rtg.h these struct layouts / prototypes were written for
+ABI_VERSION = 3            # RTG_ABI_VERSION of include/rtg.h these struct layouts / prototypes were written for
 _P = C.c_void_p
 _I, _F, _D, _LL, _ULL = C.c_int, C.c_float, C.c_double, C.c_longlong, C.c_ulonglong
 
@@ -110,6 +118,9 @@ PROTOTYPES = {
     'rtg_strip_mirror_fwd': (_I, [_P, _I, _I, _F, _P, _P, _P, _P]),
     'rtg_strip_mirror_bwd': (_I, [_P, _I, _I, _F, _P, _P, _P, _P]),
     'rtg_adamw': (_I, [_P, _P, _P, _P, _LL, _P, _P, _D, _D, _D, _D, _D, _F, _P]),
+    'rtg_resstack_ok': (_I, [C.POINTER(ResStackDesc)]),
+    'rtg_resstack_forward': (_I, [C.POINTER(ResStackDesc), _P, C.POINTER(PtrArray6), C.POINTER(PtrArray6), C.POINTER(PtrArray6), _P]),
+    'rtg_resstack_backward': (_I, [C.POINTER(ResStackDesc), _P, _P, C.POINTER(PtrArray6), C.POINTER(PtrArray6), C.POINTER(PtrArray6), _P]),
     'rtg_abi_version': (_I, []),
     'rtg_build_info': (C.c_char_p, []),
 }

@@ -244,6 +244,103 @@ class ConvFn(torch.autograd.Function):
         return None, dx1, dx2, dres, None, None, None, None, None, None
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# ResidualStack in one launch per direction (rtg_resstack.hip)
+# ---------------------------------------------------------------------------------------------------------------
+import os as _os
+
+RESSTACK = _os.environ.get('RTG_RESSTACK', '1') == '1'          # A/B knob: 0 = six conv launches per direction
+
+
+def _stack_desc(lys, B, Lx, pre_slope, final_act_slope, reverse=False):
+    dils = [ly.dil for ly in (reversed(lys) if reverse else lys)]
+    return L.ResStackDesc(B, lys[0].cin, Lx, (C.c_int * 6)(*dils), pre_slope, int(final_act_slope is not None),
+                          float(final_act_slope or 1.0))
+
+
+def resstack_ok(lys, x):
+    """the six convs of a ResidualStack (execution order) can run as one fused launch on input x"""
+    if not (RESSTACK and len(lys) == 6 and x.is_cuda and x.dim() == 3):
+        return False
+    c = lys[0].cin
+    for ly in lys:
+        if (ly.kind != 'conv' or ly.cin != c or ly.cout != c or ly.k != 3 or ly.stride != 1 or ly.groups != 1 or
+                ly.pad != ly.dil or ly.fwd_bf or ly.bwd_bf or ly.fwd_tap or ly.bwd_tap or ly.fwd_tm != 32 or ly.bwd_tm != 32):
+            return False
+    if x.shape[1] != c:
+        return False
+    B, _, Lx = x.shape
+    d = L.ResStackDesc(B, c, Lx, (C.c_int * 6)(*[ly.dil for ly in lys]), 0.01, 0, 1.0)
+    return lib.rtg_resstack_ok(C.byref(d)) == 1
+
+
+class ResStackFn(torch.autograd.Function):
+    """y = ResidualStack(x) (retunegan/models/generator.py:33-77), optionally followed by leaky_relu(final_act_slope):
+    forward and backward-data of the six convs in ONE launch each; the six weight gradients run as usual on the tensors
+    the fused launches leave in HBM."""
+
+    @staticmethod
+    def forward(ctx, token, x, lys, pre_slope, final_act_slope):
+        _need_cuda(x)
+        bank = token._rtg_bank
+        x = _c(x)
+        B, Cc, Lx = x.shape
+        d = _stack_desc(lys, B, Lx, pre_slope, final_act_slope)
+        outs = [torch.empty_like(x) for _ in range(6)]
+        wp = L.PtrArray6(*[bank.fwd_ptr(ly).value for ly in lys])
+        bias = L.PtrArray6(*[bank.bias_ptr(ly).value for ly in lys])
+        op = L.PtrArray6(*[o.data_ptr() for o in outs])
+        flop = sum(_conv_flop(ly, B, Lx) for ly in lys)
+        st = _stream()
+        check(_timed('conv1d', 7100, flop, lambda: lib.rtg_resstack_forward(C.byref(d), _p(x), C.byref(wp), C.byref(bias),
+                                                                           C.byref(op), st),
+                     f'fwd {lys[0].name}..stack B{B} L{Lx}', 4 * 7 * x.numel()), 'resstack fwd')
+        ctx.lys, ctx.bank, ctx.tok_id = lys, bank, token._rtg_id
+        ctx.cfg = (pre_slope, final_act_slope)
+        ctx.save_for_backward(x, *outs)
+        ctx.set_materialize_grads(False)
+        return outs[5]
+
+    @staticmethod
+    def backward(ctx, dy):
+        if dy is None:
+            return None, None, None, None, None
+        lys, bank = ctx.lys, ctx.bank
+        pre_slope, final_act_slope = ctx.cfg
+        x0, r1, x1, r2, x2, r3, y = ctx.saved_tensors
+        dy = _c(dy)
+        B, Cc, Lx = x0.shape
+        d = _stack_desc(lys, B, Lx, pre_slope, final_act_slope, reverse=True)
+        gouts = [torch.empty_like(x0) for _ in range(6)]          # g_r3, g_x2, g_r2, g_x1, g_r1, dx0
+        wpb = L.PtrArray6(*[bank.bwd_ptr(ly).value for ly in reversed(lys)])
+        masks = L.PtrArray6(*[t.data_ptr() for t in (r3, x2, r2, x1, r1, x0)])
+        gp = L.PtrArray6(*[g.data_ptr() for g in gouts])
+        st = _stream()
+        flop = sum(_conv_flop(ly, B, Lx) for ly in lys)
+        check(_timed('conv1d', 7100, flop, lambda: lib.rtg_resstack_backward(C.byref(d), _p(dy), _p(y), C.byref(wpb),
+                                                                            C.byref(masks), C.byref(gp), st),
+                     f'dgrad {lys[0].name}..stack B{B} L{Lx}', 4 * 14 * x0.numel()), 'resstack bwd')
+        if ctx.needs_input_grad[0]:
+            ins = (x0, r1, x1, r2, x2, r3)
+            dys = (gouts[4], gouts[3], gouts[2], gouts[1], gouts[0], dy)
+            for i, ly in enumerate(lys):
+                last = i == 5 and final_act_slope is not None
+                wd = L.WgradDesc(B=B, C1=Cc, C2=0, L_in=Lx, groups=1, Cg=Cc, Mg=Cc, K=3, stride=1, dil=ly.dil, pad=ly.pad,
+                                 Q=Lx, dy_L=Lx, pre_mode=L.PRE_LRELU, pre_slope=pre_slope,
+                                 gy_mode=L.PRE_MUL_DLRELU if last else L.PRE_NONE,
+                                 gy_slope=final_act_slope if last else 1.0, gy_scale=1.0, splits=1, part_stride=0)
+                part, splits, immediate = _run_wgrad(wd, (_p(ins[i]), None, _p(dys[i]), _p(y) if last else None), st, bank,
+                                                     ly, ctx.tok_id, _conv_flop(ly, B, Lx), f'wgrad {ly.name} B{B} L{Lx}',
+                                                     f'conv1d wgrad {ly.name}')
+                if immediate:
+                    bank.flush_one(ly, part, splits)
+        return None, (gouts[5] if ctx.needs_input_grad[1] else None), None, None, None
+
+
+def resstack(token, lys, x, pre_slope, final_act_slope=None):
+    return ResStackFn.apply(token, x, tuple(lys), float(pre_slope), None if final_act_slope is None else float(final_act_slope))
+
+
 def conv(token, ly, x1, x2=None, res=None, pre_slope=1.0, act=L.ACT_NONE, act_slope=1.0, out_scale=1.0):
     if ly.kind == 'conv2d':
         assert x2 is None and res is None and act == L.ACT_NONE and out_scale == 1.0
