@@ -24,10 +24,10 @@ def _net(C):
 
 
 @pytest.mark.parametrize('final', [None, 0.15])
-@pytest.mark.parametrize('C,L,B', [(128, 32, 5), (64, 256, 3)])
+@pytest.mark.parametrize('C,L,B', [(128, 32, 5), (64, 256, 3), (64, 200, 2), (32, 2048, 2), (32, 500, 3)])
 def test_fused_residual_stack_matches_oracle_and_unfused(oracle, C, L, B, final, monkeypatch):
     from rtg import ops
-    monkeypatch.setenv('RTG_RESSTACK_ALL', '1')          # the (64, 256) instance is not served by default (slower)
+    monkeypatch.setenv('RTG_RESSTACK_KINDS', '7')        # the C = 32 instance is not served by default (not faster)
     torch.manual_seed(C + L)
     net = _net(C)
     ref = oracle.ResidualStack(C).double()
@@ -76,11 +76,11 @@ def test_fused_residual_stack_matches_oracle_and_unfused(oracle, C, L, B, final,
 
 
 def test_stack_shapes_that_are_not_served_fall_back(oracle):
-    """C = 32 at 2048 samples (a clip does not fit in LDS) keeps the six-launch path"""
+    """clips shorter than a tile (C = 32 below 128 samples) keep the six-launch path"""
     from rtg import ops
     net = _net(32).to(DEV)
     net.bank()
     lys = [getattr(blk, n)._layer for blk in (net.stack.res_1, net.stack.res_2, net.stack.res_3) for n in ('1', '3')]
-    assert not ops.resstack_ok(lys, torch.zeros(2, 32, 2048, device=DEV))
-    y = net(torch.randn(2, 32, 2048, device=DEV))
-    assert y.shape == (2, 32, 2048) and torch.isfinite(y).all()
+    assert not ops.resstack_ok(lys, torch.zeros(2, 32, 64, device=DEV))
+    y = net(torch.randn(2, 32, 64, device=DEV))
+    assert y.shape == (2, 32, 64) and torch.isfinite(y).all()

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.join(REPO, 'transtacos-retunegan_amd'))
 import torch
 from rtg import lib as L
 from rtg.lib import lib
-for Cc, Lx in ((128, 32), (64, 256)):
+for Cc, Lx in ((128, 32), (64, 256), (32, 2048)):
     B = 32
     d = L.ResStackDesc(B, Cc, Lx, (C.c_int * 6)(1, 1, 3, 1, 9, 1), 0.01, 1, 0.15)
     x = torch.randn(B, Cc, Lx, device='cuda')

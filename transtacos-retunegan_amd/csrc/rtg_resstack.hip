@@ -35,7 +35,7 @@ struct StackArgs {
   float mask_slope;
   int final_act;                // forward: leaky-relu on the last result; backward: its derivative in the prologue
   float act_slope;
-  int dbg;
+  int L, n_t;                   // clip length, position tiles per clip
 };
 
 __device__ __forceinline__ int mrow32(int lane, int r) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
@@ -43,33 +43,38 @@ __device__ __forceinline__ int mrow32(int lane, int r) { return (r & 3) + 8 * (r
 constexpr int kStackWaves = 8;
 constexpr int kHalo = 9;
 
-template <int C, int L>
+// C channels; a block computes a REGION of R positions of one clip and stores the CEN central ones (R - CEN = 32: the
+// stack's receptive field is 16 positions to each side; R == CEN: the whole clip, no neighbours).  Every layer is computed on
+// the whole region: what the halo misses only reaches 16 positions inward, never the centre.
+template <int C, int R, int CEN>
 __global__ __launch_bounds__(64 * kStackWaves) void resstack_kernel(const StackArgs a) {
   constexpr int NCC = C / RTG_CK;                 // 16-channel chunks
   constexpr int RT = C / 32;                      // row tiles
-  constexpr int NKS = C == 128 ? 2 : 1;           // K splits across waves
-  constexpr int CHP = NCC / NKS;                  // chunks per wave: 4
-  constexpr int NT = C == 128 ? 1 : 2;            // column tiles per wave
-  constexpr int NA = CHP * 3 * 8;                 // A fragments per wave and layer: 96
-  constexpr int LP = L + 2 * kHalo + 2;           // LDS row pitch (zero halo on both sides)
-  static_assert(CHP == 4 && RT * NKS * (L / 32 / NT) == kStackWaves, "wave decomposition");
+  constexpr int CT = R / 32;                      // column tiles of the region
+  constexpr int NKS = kStackWaves / (RT * CT);    // K splits across waves (C = 128: 2)
+  constexpr int CHP = NCC / NKS;                  // chunks per wave
+  constexpr int NA = CHP * 3 * 8;                 // A fragments per wave and layer
+  constexpr int LP = R + 2 * kHalo + 2;           // LDS row pitch (zero columns on both sides: the convs' zero padding)
+  constexpr int HL = (R - CEN) / 2;               // halo positions on each side of the centre
+  static_assert(RT * CT * NKS == kStackWaves && NCC % NKS == 0 && NKS <= 2, "wave decomposition");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* bufA = lds;
   float* bufB = lds + C * LP;
-  float* scr = lds + 2 * C * LP;                  // K-split meeting point (C = 128): [RT][32 x 32]
+  float* scr = lds + 2 * C * LP;                  // K-split meeting point: [RT][32 x 32]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kk = lane >> 5, n_lane = lane & 31;
   const int rt = wave % RT;
-  const int ks = C == 128 ? wave / RT : 0;
-  const int ct0 = C == 128 ? 0 : (wave / RT) * NT;
-  const int b = blockIdx.x;
+  const int ks = NKS == 2 ? wave / RT : 0;
+  const int ct = NKS == 2 ? 0 : wave / RT;
+  const int b = blockIdx.x / a.n_t, ti = blockIdx.x - b * a.n_t;
+  const int t0 = ti * CEN;                        // first central position
+  const int rs = t0 - HL;                         // clip position of region column 0
 
-  // ---- A fragments of a layer: ((chunk, tap), channel pair) -> 64 consecutive floats in the packed layout
-  // (C = 128: two register sets, the next layer's fragments are requested a layer ahead; C = 64 has two accumulator
-  // tiles per wave and no room for the second set: its fragments are requested at the top of the layer and waited for one
-  // by one as the MFMA loop reaches them)
-  constexpr bool DB = C == 128;
+  // ---- A fragments of a layer: ((chunk, tap), channel pair) -> 64 consecutive floats in the packed layout.  Two register
+  // sets where they fit (the next layer's fragments are requested a layer ahead), else requested at the top of the layer
+  // and waited for one by one as the MFMA loop reaches them.
+  constexpr bool DB = NA <= 96 && C != 64;
   float A0[NA], A1[DB ? NA : 1];
   auto aload = [&](int l, float (&Af)[NA]) __attribute__((always_inline)) {
     const float* w = a.wp[l] + ((size_t)(rt * NCC + ks * CHP) * 3) * 8 * 64 + lane;
@@ -78,15 +83,17 @@ __global__ __launch_bounds__(64 * kStackWaves) void resstack_kernel(const StackA
   };
   aload(0, A0);
 
-  // ---- buffers: zero (the halos stay zero: every conv sees zero padding), then the clip
+  // ---- buffers: zero (the edge columns stay zero), then the region of the clip (zeros outside the clip)
   for (int i = tid; i < 2 * C * LP; i += 64 * kStackWaves) lds[i] = 0.f;
   __syncthreads();
-  for (int i = tid; i < C * L; i += 64 * kStackWaves) {
-    const int c = i / L, t = i - c * L;
-    const size_t gi = ((size_t)b * C + c) * L + t;
+  for (int i = tid; i < C * R; i += 64 * kStackWaves) {
+    const int c = i / R, p = i - c * R;
+    const int t = rs + p;
+    if (t < 0 || t >= a.L) continue;
+    const size_t gi = ((size_t)b * C + c) * a.L + t;
     float v = a.in[gi];
     if (a.pro_aux && a.final_act) v *= (a.pro_aux[gi] > 0.f ? 1.f : a.act_slope);
-    bufA[c * LP + kHalo + t] = v;
+    bufA[c * LP + kHalo + p] = v;
   }
   __syncthreads();
 
@@ -101,64 +108,55 @@ __global__ __launch_bounds__(64 * kStackWaves) void resstack_kernel(const StackA
       if (l > 0) aload(l, Acur);
     }
     const int dil = a.dil[l];
-    f32x16 acc[NT];
+    f32x16 acc;
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-    const float* bp = in + (ks * CHP * RTG_CK + kk) * LP + kHalo + ct0 * 32 + n_lane - dil;
-    constexpr int NS = NA, PD = NT == 1 ? 4 : 2;    // B-fragment reads requested PD steps (>= 256 cycles of MFMAs) ahead
-    float vb[PD + 1][NT];
-    auto bload = [&](int s_, float (&dst)[NT]) __attribute__((always_inline)) {
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const float* bp = in + (ks * CHP * RTG_CK + kk) * LP + kHalo + ct * 32 + n_lane - dil;
+    constexpr int NS = NA, PD = 4;                 // B-fragment reads requested PD steps (256 cycles of MFMAs) ahead
+    float vb[PD + 1];
+    auto bload = [&](int s_) __attribute__((always_inline)) {
       const int cci = s_ / 24, tap = (s_ / 8) % 3, cp = s_ % 8;
-      const float* brow = bp + (cci * RTG_CK + cp * 2) * LP + tap * dil;
-#pragma unroll
-      for (int j = 0; j < NT; ++j) dst[j] = brow[j * 32];
+      return bp[(cci * RTG_CK + cp * 2) * LP + tap * dil];
     };
-    if (!(a.dbg & 1)) {
 #pragma unroll
-    for (int s_ = 0; s_ < PD; ++s_) bload(s_, vb[s_]);
+    for (int s_ = 0; s_ < PD; ++s_) vb[s_] = bload(s_);
 #pragma unroll
     for (int s_ = 0; s_ < NS; ++s_) {
-      if (s_ + PD < NS) bload(s_ + PD, vb[(s_ + PD) % (PD + 1)]);
+      if (s_ + PD < NS) vb[(s_ + PD) % (PD + 1)] = bload(s_ + PD);
       __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        float v = vb[s_ % (PD + 1)][j];
-        v = v > 0.f ? v : v * a.pre_slope;
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(Acur[s_], v, acc[j], 0, 0, 0);
-      }
+      float v = vb[s_ % (PD + 1)];
+      v = v > 0.f ? v : v * a.pre_slope;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Acur[s_], v, acc, 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-    }
     }
     if (NKS == 2) {                                // the upper channel half hands its sums to the lower one
       if (ks == 1) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) scr[rt * 1024 + r * 64 + lane] = acc[0][r];
+        for (int r = 0; r < 16; ++r) scr[rt * 1024 + r * 64 + lane] = acc[r];
       }
       __syncthreads();
       if (ks == 0) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[0][r] += scr[rt * 1024 + r * 64 + lane];
+        for (int r = 0; r < 16; ++r) acc[r] += scr[rt * 1024 + r * 64 + lane];
       }
     }
     __syncthreads();                               // every wave is done reading `in` (and, odd layers, may overwrite bufA)
-    if (ks == 0 && !(a.dbg & 2)) {
+    if (ks == 0) {
+      const int pos = ct * 32 + n_lane;            // region column
+      const int t = rs + pos;                      // clip position
+      const bool inside = t >= 0 && t < a.L;       // outside the clip the next layer must see zero padding
+      const bool central = inside && t >= t0 && t < t0 + CEN;
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const int pos = (ct0 + j) * 32 + n_lane;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = rt * 32 + mrow32(lane, r);
-          const size_t gi = ((size_t)b * C + m) * L + pos;
-          float v = acc[j][r] + (a.bias[l] ? a.bias[l][m] : 0.f);
-          const float mf = a.mask[l] ? (a.mask[l][gi] > 0.f ? 1.f : a.mask_slope) : 1.f;
-          const float rv = odd ? outb[m * LP + kHalo + pos] : 0.f;
-          v = __builtin_fmaf(v, mf, rv);
-          if (l < 5) outb[m * LP + kHalo + pos] = v;
-          if (l == 5 && a.final_act && !a.pro_aux) v = v > 0.f ? v : v * a.act_slope;
-          a.gout[l][gi] = v;
-        }
+      for (int r = 0; r < 16; ++r) {
+        const int m = rt * 32 + mrow32(lane, r);
+        const size_t gi = ((size_t)b * C + m) * a.L + (inside ? t : 0);
+        float v = acc[r] + (a.bias[l] ? a.bias[l][m] : 0.f);
+        const float mf = (a.mask[l] && inside) ? (a.mask[l][gi] > 0.f ? 1.f : a.mask_slope) : 1.f;
+        const float rv = odd ? outb[m * LP + kHalo + pos] : 0.f;
+        v = __builtin_fmaf(v, mf, rv);
+        if (l < 5) outb[m * LP + kHalo + pos] = inside ? v : 0.f;
+        if (l == 5 && a.final_act && !a.pro_aux) v = v > 0.f ? v : v * a.act_slope;
+        if (central) a.gout[l][gi] = v;
       }
     }
     __syncthreads();
@@ -180,24 +178,38 @@ __global__ __launch_bounds__(64 * kStackWaves) void resstack_kernel(const StackA
   }
 }
 
-template <int C, int L>
-int launch(const StackArgs& a, hipStream_t s) {
-  constexpr int LP = L + 2 * kHalo + 2;
-  const size_t lds_bytes = ((size_t)2 * C * LP + (C == 128 ? 4 * 1024 : 0)) * sizeof(float);
+template <int C, int R, int CEN>
+int launch(StackArgs a, int L, hipStream_t s) {
+  constexpr int LP = R + 2 * kHalo + 2;
+  constexpr int NKS = kStackWaves / ((C / 32) * (R / 32));
+  const size_t lds_bytes = ((size_t)2 * C * LP + (NKS == 2 ? 4 * 1024 : 0)) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&resstack_kernel<C, L>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&resstack_kernel<C, R, CEN>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return RTG_ERANGE;
     attr_set = true;
   }
-  RTG_KLAUNCH((resstack_kernel<C, L>), dim3(a.B), dim3(64 * kStackWaves), lds_bytes, s, a);
+  a.L = L;
+  a.n_t = (L + CEN - 1) / CEN;
+  RTG_KLAUNCH((resstack_kernel<C, R, CEN>), dim3((unsigned)(a.B * a.n_t)), dim3(64 * kStackWaves), lds_bytes, s, a);
   return rtg_launch_status();
 }
 
+// which instance serves (C, L): 1 = the whole clip of 32 positions (C = 128), 2 / 3 = position tiles with halo (C = 64 / 32)
+int stack_kind(const RtgResStackDesc* d) {
+  if (d->C == 128 && d->L == 32) return 1;
+  if (d->C == 64 && d->L >= 64) return 2;
+  if (d->C == 32 && d->L >= 128) return 3;
+  return 0;
+}
+
 int run(const RtgResStackDesc* d, const StackArgs& a, hipStream_t s) {
-  if (d->C == 128 && d->L == 32) return launch<128, 32>(a, s);
-  if (d->C == 64 && d->L == 256) return launch<64, 256>(a, s);
+  switch (stack_kind(d)) {
+    case 1: return launch<128, 32, 32>(a, d->L, s);
+    case 2: return launch<64, 128, 96>(a, d->L, s);
+    case 3: return launch<32, 256, 224>(a, d->L, s);
+  }
   return RTG_EINVAL;
 }
 
@@ -208,11 +220,14 @@ extern "C" int rtg_resstack_ok(const RtgResStackDesc* d) {
   if (d->B < 1 || d->B > 65535) return 0;
   for (int i = 0; i < 6; ++i)
     if (d->dil[i] < 1 || d->dil[i] > kHalo) return 0;
-  // (C, L) = (64, 256) is built and tested (RTG_RESSTACK_ALL=1) but not served by default: one block per clip is 32 blocks
-  // at batch 32, and its 1536 MFMAs per layer and block take longer on 32 CUs (126 / 166 us per stack and direction) than
-  // six launches of the general kernel spread over the chip (102 / 120 us); (128, 32): 66 / 71 against 150 / 170 us
-  if (d->C == 64 && d->L == 256) return getenv("RTG_RESSTACK_ALL") ? 1 : 0;
-  return (d->C == 128 && d->L == 32) ? 1 : 0;
+  if ((long long)d->B * ((d->L + 95) / 96) > (1 << 24)) return 0;
+  const int kind = stack_kind(d);
+  // RTG_RESSTACK_KINDS: bit mask of the served instances.  Measured at batch 32 inside the train step (us per stack, forward
+  // / backward, against six launches of the general kernel): (128, 32) 73 / 115 vs 150 / 170 — served; (64, 256) 79 / 113 vs
+  // 102 / 120 and (32, 2048) 93 / 130 vs 96 / 114 (stand-alone) — no gain: a block per clip (tile) leaves most of the chip
+  // idle or, tiled, moves 58-108 MB through 4-byte epilogue accesses.  Both are built and tested but not served.
+  const int served = getenv("RTG_RESSTACK_KINDS") ? atoi(getenv("RTG_RESSTACK_KINDS")) : 1;
+  return (kind > 0 && (served & (1 << (kind - 1)))) ? 1 : 0;
 }
 
 extern "C" int rtg_resstack_forward(const RtgResStackDesc* d, const float* x, const float* const* wp,
@@ -226,7 +241,6 @@ extern "C" int rtg_resstack_forward(const RtgResStackDesc* d, const float* x, co
     a.wp[i] = wp[i]; a.bias[i] = bias[i]; a.mask[i] = nullptr; a.gout[i] = outs[i]; a.dil[i] = d->dil[i];
   }
   a.B = d->B; a.pre_slope = d->pre_slope; a.mask_slope = 1.f; a.final_act = d->final_act; a.act_slope = d->act_slope;
-  a.dbg = getenv("RTG_RS_DBG") ? atoi(getenv("RTG_RS_DBG")) : 0;
   return run(d, a, (hipStream_t)stream);
 }
 
@@ -242,6 +256,5 @@ extern "C" int rtg_resstack_backward(const RtgResStackDesc* d, const float* dy, 
     a.wp[i] = wpb[i]; a.bias[i] = nullptr; a.mask[i] = masks[i]; a.gout[i] = gouts[i]; a.dil[i] = d->dil[i];
   }
   a.B = d->B; a.pre_slope = 1.f; a.mask_slope = d->pre_slope; a.final_act = d->final_act; a.act_slope = d->act_slope;
-  a.dbg = getenv("RTG_RS_DBG") ? atoi(getenv("RTG_RS_DBG")) : 0;
   return run(d, a, (hipStream_t)stream);
 }
