@@ -285,6 +285,31 @@ def test_grouped_launch_path_matches_forked_streams(nets, oracle, gold):
         assert ((ga - gb).norm() / ga.norm()).item() < 1e-5
 
 
+@pytest.mark.parametrize('mode', [1, 2])
+def test_grouped_resblock_branches_match_forked_streams(nets, oracle, mode):
+    """RTG_MRF_GROUP: the three parallel ResBlock3 branches of a decoder stage conv by conv through rtg_conv1d_group
+    (residual epilogue forward, dy + mask * convT(dy) backward) against each branch on its own stream.  mode 1 groups
+    the stages of >= 64 channels (the default), 2 all of them.  The block shape, and with it the accumulation order
+    inside a tile, is the tuner's choice in both: rounding-level differences only."""
+    from rtg import ops
+    x, y_tmpl, _ = oracle.golden_inputs()
+    g = nets[0]
+    res = []
+    old = ops.MRF_GROUP
+    try:
+        for m in (0, mode):
+            ops.MRF_GROUP = m
+            g.zero_grad()
+            out = g(x.to(DEV), y_tmpl.to(DEV))
+            (out * torch.linspace(-1, 1, out.numel(), device=DEV).view_as(out)).sum().backward()
+            torch.cuda.synchronize()
+            res.append((out.detach().clone(), g.bank().gflat[:-2].clone()))    # without noise.w (fresh noise per call) and the flag slot
+    finally:
+        ops.MRF_GROUP = old
+    assert ((res[0][0] - res[1][0]).abs().max() / res[0][0].abs().max()).item() < 1e-5
+    assert ((res[0][1] - res[1][1]).norm() / res[0][1].norm()).item() < 1e-5
+
+
 @pytest.mark.parametrize('B,T', [(1, 256 * 3), (3, 256 * 9), (2, 256 * 86)])
 def test_generator_other_lengths_and_batches(nets, onets, oracle, B, T):
     """ragged / minimum / finetune-sized inputs: any frame count and batch size the reference accepts (T = 256 x frames;

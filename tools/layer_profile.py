@@ -33,7 +33,9 @@ for kernel, variant, flop, e0, e1, label, _nb in rec:
     a[0] += 1; a[1] += e0.elapsed_time(e1); a[2] += flop
 tot = sum(a[1] for a in agg.values())
 print(f'total conv ms {tot:.2f}')
-for (label, variant), (n, ms, flop) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:int(os.environ.get("LP_TOP", "70"))]:
+only = os.environ.get('LP_ONLY')  # 'G': only the generator's layers
+items = [kv for kv in agg.items() if not only or (only == 'G') == ('discriminators' not in kv[0][0])]
+for (label, variant), (n, ms, flop) in sorted(items, key=lambda kv: -kv[1][1])[:int(os.environ.get("LP_TOP", "70"))]:
     print(f'{ms:8.3f} ms  n={n:2d}  {flop / ms / 1e9:7.2f} TF/s  v{variant:<5d} {label}')
 
 # ---- totals by (pass, model part)

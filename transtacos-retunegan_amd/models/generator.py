@@ -110,6 +110,19 @@ class ResBlock(nn.Module):
         return x
 
 
+def run_branches(tok, blocks, z):
+    """the parallel ResBlock branches of one decoder stage on the same input z (generator.py:776-778, 650-653): conv by
+    conv as grouped launches where that pays (ops.mrf_group_ok), else each branch on its own stream"""
+    n_conv = len(blocks[0].convs)
+    if all(len(b.convs) == n_conv for b in blocks) and \
+            all(ops.mrf_group_ok([b.convs[c]._layer for b in blocks], z) for c in range(n_conv)):
+        xs = [z] * len(blocks)
+        for c in range(n_conv):
+            xs = ops.group_conv(tok, [b.convs[c]._layer for b in blocks], xs, pre_slope=LRELU_SLOPE, res_self=True)
+        return xs
+    return fork_join([(lambda blk=blk, zz=z: blk.run(tok, zz)) for blk in blocks])
+
+
 class _Mean3(torch.autograd.Function):
     """(a + b + c) / 3 — the average of the three ResBlock3 branches (generator.py:776-778)."""
 
@@ -185,8 +198,7 @@ class Generator_RefineGAN_small(BankedModel):
             z = conv(tok, self.merge[i], z, o[self.n_layer - i - 1])               # cat([z, skip]) fused
             z = self.noise(z, nz(2 * i))
             nk = self.num_kernels
-            z = _Mean3.apply(*fork_join([(lambda blk=self.resblocks[i * nk + j], zz=z: blk.run(tok, zz))
-                                         for j in range(nk)]))
+            z = _Mean3.apply(*run_branches(tok, [self.resblocks[i * nk + j] for j in range(nk)], z))
             z = self.noise(z, nz(2 * i + 1))
         return conv(tok, self.conv_post, z, pre_slope=LRELU_SLOPE, act=ACT_TANH)
 
@@ -246,8 +258,7 @@ class Generator_RefineGAN(BankedModel):
             z = conv(tok, self.merge[i], z, o[self.n_layer - i - 1])
             z = self.noise(z, nz(2 * i))
             nk = self.num_kernels
-            z = _Mean3.apply(*fork_join([(lambda blk=self.resblocks[i * nk + j], zz=z: blk.run(tok, zz))
-                                         for j in range(nk)]))
+            z = _Mean3.apply(*run_branches(tok, [self.resblocks[i * nk + j] for j in range(nk)], z))
             z = self.noise(z, nz(2 * i + 1))
         return conv(tok, self.conv_post, z, pre_slope=LRELU_SLOPE, act=ACT_TANH)
 

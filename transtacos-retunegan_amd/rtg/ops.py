@@ -537,12 +537,13 @@ def pair_conv(token, ly, x_c, x_g, pre_slope=1.0):
 
 
 class GroupConvFn(torch.autograd.Function):
-    """outs[i] = conv_i(leaky_relu(xs[i], pre_slope)) + bias_i for the same layer position of n sub-discriminators (same
-    bank): forward and backward-data are ONE launch each for the whole group, the weight gradients go through the
-    per-layer wgrad kernels into the bank as usual."""
+    """outs[i] = conv_i(leaky_relu(xs[i], pre_slope)) + bias_i (+ xs[i] when res_self: a ResBlock conv) for the same layer
+    position of n sub-discriminators / of the parallel ResBlock branches of a UNet-G stage (same bank): forward and
+    backward-data are ONE launch each for the whole group, the weight gradients go through the per-layer wgrad kernels
+    into the bank as usual."""
 
     @staticmethod
-    def forward(ctx, token, lys, pre_slope, *xs):
+    def forward(ctx, token, lys, pre_slope, res_self, *xs):
         _need_cuda(*xs)
         bank = token._rtg_bank
         xs = [_c(x) for x in xs]
@@ -553,10 +554,11 @@ class GroupConvFn(torch.autograd.Function):
             d, L_out = _fwd_desc(ly, B, C1, L_in, pre_slope)
             out = torch.empty(B, ly.cout, L_out, device=x.device, dtype=torch.float32)
             descs.append(d); outs.append(out); flops.append(_conv_flop(ly, B, L_out))
-            rows.append((x, None, None, bank.fwd_ptr(ly).value, bank.bias_ptr(ly).value, None, None, out, None))
+            rows.append((x, None, None, bank.fwd_ptr(ly).value, bank.bias_ptr(ly).value, None, x if res_self else None, out,
+                         None))
         if not _launch_group(descs, rows, flops, f'fwd group {lys[0].name} x{len(lys)}', f'conv1d group fwd {lys[0].name}'):
             raise L.RtgError(f'no common block shape for the group of {lys[0].name}')
-        ctx.lys, ctx.bank, ctx.tok_id, ctx.pre_slope = lys, bank, token._rtg_id, pre_slope
+        ctx.lys, ctx.bank, ctx.tok_id, ctx.pre_slope, ctx.res_self = lys, bank, token._rtg_id, pre_slope, res_self
         ctx.save_for_backward(*xs)
         return tuple(outs)
 
@@ -566,7 +568,7 @@ class GroupConvFn(torch.autograd.Function):
         xs = ctx.saved_tensors
         dys = [_c(dy) for dy in dys]
         st = _stream()
-        need_x = any(ctx.needs_input_grad[3:])
+        need_x = any(ctx.needs_input_grad[4:])
         dxs = [None] * len(xs)
         if need_x:
             descs, rows, flops = [], [], []
@@ -576,7 +578,9 @@ class GroupConvFn(torch.autograd.Function):
                 dxs[i] = torch.empty_like(x)
                 descs.append(_dgrad_desc(ly, B, L_in, L_out, pre_slope))
                 flops.append(_conv_flop(ly, B, L_out))
-                rows.append((dy, None, None, bank.bwd_ptr(ly).value, None, x if pre_slope != 1.0 else None, None, dxs[i], None))
+                # res_self: dx = dy + lrelu'(x) * convT(dy), the residual branch rides the same epilogue
+                rows.append((dy, None, None, bank.bwd_ptr(ly).value, None, x if pre_slope != 1.0 else None,
+                             dy if ctx.res_self else None, dxs[i], None))
             if not _launch_group(descs, rows, flops, f'dgrad group {lys[0].name} x{len(lys)}',
                                  f'conv1d group bwd-data {lys[0].name}'):
                 raise L.RtgError(f'no common block shape for the dgrad group of {lys[0].name}')
@@ -599,12 +603,29 @@ class GroupConvFn(torch.autograd.Function):
                 return run
             for ly, x, dy in zip(lys, xs, dys):      # (forking these over streams measured slower: 43.9 vs 42.7 ms/step)
                 wgrad_of(ly, x, dy)()
-        return (None, None, None, *dxs)
+        return (None, None, None, None, *dxs)
 
 
-def group_conv(token, lys, xs, pre_slope=1.0):
+def group_conv(token, lys, xs, pre_slope=1.0, res_self=False):
     """lys: rtg.bank.ConvLayer of each group member (same position in sibling sub-discriminators); xs: their inputs"""
-    return list(GroupConvFn.apply(token, tuple(lys), float(pre_slope), *xs))
+    return list(GroupConvFn.apply(token, tuple(lys), float(pre_slope), bool(res_self), *xs))
+
+
+# RTG_MRF_GROUP: the parallel ResBlock branches of a UNet-G decoder stage (kernel sizes 3 / 5 / 7 on the same input) as
+# grouped launches, conv by conv.  1 (default): stages of >= 64 channels, where a branch alone is 256-1024 workgroups of
+# 25-50 us and three of them share one launch's fixed cost; the 32-channel stage is HBM-bound and keeps its
+# weights-in-registers kernel (rtg_resconv) per branch.  0: never (forked streams), 2: every stage.
+MRF_GROUP = int(_os.environ.get('RTG_MRF_GROUP', '1'))
+
+
+def mrf_group_ok(lys, x):
+    if MRF_GROUP == 0 or len(lys) < 2 or len(lys) > L.MAX_GROUP:
+        return False
+    c = lys[0].cin
+    if any(ly.kind != 'conv' or ly.stride != 1 or ly.groups != 1 or ly.cin != c or ly.cout != c or
+           2 * ly.pad != ly.dil * (ly.k - 1) for ly in lys):
+        return False
+    return c >= 64 or MRF_GROUP == 2
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -106,7 +106,7 @@ def group_cfg(darr, n, launch):
     for i in range(n):
         cands = (C.c_int * 32)()
         k = lib.rtg_conv1d_tile_candidates(C.byref(darr[i]), cands, 32)
-        lists.append([c for c in cands[:max(k, 0)] if c != 0])
+        lists.append([c for c in cands[:max(k, 0)] if 0 < c < 7000])     # 7001 / 7002: rtg_resconv, not a group member
     common = [c for c in lists[0] if all(c in l for l in lists[1:])]
     if not common:
         _group[key] = 0
