@@ -129,6 +129,9 @@ def _split(t, B):
     if base is not None:
         n = base.shape[0] // 2
         r._rtg_base, g._rtg_base = base[:n], base[n:]
+    # the halves remember the tensor they are halves of: discriminator_loss then runs as ONE node over the whole tensors
+    whole = base if base is not None else t
+    r._rtg_pair, g._rtg_pair = (whole, 0), (whole, 1)
     return r, g
 
 
@@ -148,11 +151,15 @@ def _run_pair(d, tok, x_real, x_fake):
         xr = d.pre(x_real)
     hr, hg = ops.pair_entry(xr, d.pre(x_fake))
     fr, fg = [], []
-    for li, c in enumerate(d.convs):
-        hr, hg = ops.pair_conv(tok, c._layer, hr, hg, pre_slope=LRELU_SLOPE if li > 0 else 1.0)
+    hr, hg = ops.pair_conv(tok, d.convs[0]._layer, hr, hg)
+    # every feature map has two readers, the next layer and the feature-matching loss: the loss reads the copy the next
+    # layer hands through (`tap`), so the two gradients meet in that layer's backward-data epilogue
+    for c in list(d.convs[1:]) + [d.conv_post]:
+        nr, ng, tap = ops.pair_conv(tok, c._layer, hr, hg, pre_slope=LRELU_SLOPE, tap=True)
         fr.append(hr)
-        fg.append(hg)
-    lr, lg = ops.pair_conv(tok, d.conv_post._layer, hr, hg, pre_slope=LRELU_SLOPE)
+        fg.append(tap)
+        hr, hg = nr, ng
+    lr, lg = hr, hg
     lr, fr = d.post(lr, fr, B)
     lg, fg = d.post(lg, fg, B)
     return lr, lg, fr, fg

@@ -10,7 +10,7 @@ import hparam as hp
 from audio import get_stft_torch, stft_mel_spec  # noqa: F401
 from utils import PI  # noqa: F401
 from rtg import ops
-from rtg.lib import LOSS_L1, LOSS_L1_L1LOG, LOSS_MSE_TARGET, LOSS_MSE_REL, RtgError  # noqa: F401
+from rtg.lib import LOSS_L1, LOSS_L1_L1LOG, LOSS_MSE_TARGET, LOSS_MSE_REL, MAX_LOSS_JOBS, RtgError  # noqa: F401
 
 _real_cache = {}
 
@@ -93,6 +93,10 @@ def _base(t):
 def discriminator_loss(disc_r, disc_g):
     """loss.py:102-125: sum_k mean((1 - dr_k)^2) + mean(dg_k^2); with hparam.relative_gan_loss the real term is
     mean((1 - (dr_k - dg_k.detach()))^2) (loss.py:116)."""
+    pr, pg = [getattr(d, '_rtg_pair', None) for d in disc_r], [getattr(d, '_rtg_pair', None) for d in disc_g]
+    if len(pr) == len(pg) and 2 * len(pr) <= MAX_LOSS_JOBS and \
+            all(a is not None and b is not None and a[0] is b[0] and (a[1], b[1]) == (0, 1) for a, b in zip(pr, pg)):
+        return ops.pair_loss([a[0] for a in pr], relative=hp.relative_gan_loss)
     rs, gs = [_base(d) for d in disc_r], [_base(d) for d in disc_g]
     if hp.relative_gan_loss:
         real = ops.multi_loss(LOSS_MSE_REL, rs, [g.detach() for g in gs], target=1.0)

@@ -491,7 +491,7 @@ class PairConvFn(torch.autograd.Function):
     discards them: train.py:133)."""
 
     @staticmethod
-    def forward(ctx, token, ly, pre_slope, x_c, x_g):
+    def forward(ctx, token, ly, pre_slope, tap, x_c, x_g):
         _need_cuda(x_c, x_g)
         assert _adjacent(x_c, x_g), 'PairConvFn needs the halves of one buffer (PairEntryFn)'
         assert ly.kind == 'conv'
@@ -507,14 +507,21 @@ class PairConvFn(torch.autograd.Function):
         ctx.save_for_backward(x_g)
         ctx.mark_non_differentiable(o_c)
         ctx.set_materialize_grads(False)
+        if tap:
+            # x_g again, as an output: whoever else reads this feature map (the feature-matching loss) reads it HERE, so
+            # that its gradient arrives in this node's backward and is added in the backward-data epilogue instead of by
+            # an autograd accumulation kernel per feature map
+            return o_c, o_g, x_g.view_as(x_g)
         return o_c, o_g
 
     @staticmethod
-    def backward(ctx, d_c, d_g):
+    def backward(ctx, d_c, d_g, d_tap=None):
         if ctx.needs_input_grad[0]:
             raise L.RtgError('PairConvFn is for frozen stacks: no weight gradient path')
-        if d_g is None or not ctx.needs_input_grad[4]:
-            return None, None, None, None, None
+        if not ctx.needs_input_grad[5] or (d_g is None and d_tap is None):
+            return None, None, None, None, None, None
+        if d_g is None:
+            return None, None, None, None, None, d_tap
         ly, bank, pre_slope = ctx.ly, ctx.bank, ctx.pre_slope
         x_g, = ctx.saved_tensors
         d_g = _c(d_g)
@@ -522,18 +529,20 @@ class PairConvFn(torch.autograd.Function):
         L_out = d_g.shape[-1]
         dx = torch.empty_like(x_g)
         d = _dgrad_desc(ly, B, L_in, L_out, pre_slope)
-        _run_conv(d, (_p(d_g), None, None, bank.bwd_ptr(ly), None, _p(x_g) if pre_slope != 1.0 else None, None, _p(dx),
+        res = _c(d_tap) if d_tap is not None else None            # dx = lrelu'(x) * convT(d_g) + d_tap
+        _run_conv(d, (_p(d_g), None, None, bank.bwd_ptr(ly), None, _p(x_g) if pre_slope != 1.0 else None, _p(res), _p(dx),
                       None, _stream()),
                   _conv_flop(ly, B, L_out), f'dgrad {ly.name} B{B} L{L_in}', f'conv1d bwd-data {ly.name}')
-        return None, None, None, None, dx
+        return None, None, None, None, None, dx
 
 
 def pair_entry(x_const, x_grad):
     return PairEntryFn.apply(x_const, x_grad)
 
 
-def pair_conv(token, ly, x_c, x_g, pre_slope=1.0):
-    return PairConvFn.apply(token, ly, float(pre_slope), x_c, x_g)
+def pair_conv(token, ly, x_c, x_g, pre_slope=1.0, tap=False):
+    """-> (out_const, out_grad) and, with tap, the input x_g passed through as a third output (see PairConvFn.forward)"""
+    return PairConvFn.apply(token, ly, float(pre_slope), bool(tap), x_c, x_g)
 
 
 class GroupConvFn(torch.autograd.Function):
@@ -759,6 +768,55 @@ class MultiLossFn(torch.autograd.Function):
             ent = [(a_list[i], b_list[i], da[i], db[i], weights[i], target) for i in idx[s:s + L.MAX_LOSS_JOBS]]
             check(lib.rtg_loss_bwd(kind, _jobs(ent), len(ent), _p(g), st), 'loss bwd')
         return (None, None, None, None, *da, *db)
+
+
+class PairLossFn(torch.autograd.Function):
+    """discriminator_loss over logits that are still the two halves (real, generated) of one 2B-clip tensor each:
+    sum_k mean((1 - r_k)^2) + mean(g_k^2), or with `relative` mean((1 - (r_k - g_k.detach()))^2) for the real term
+    (loss.py:102-125).  One node over the whole tensors: the backward writes both halves of the gradient in place, no
+    slice / zero-fill / add kernels per sub-discriminator."""
+
+    @staticmethod
+    def forward(ctx, relative, *parents):
+        ps = [_c(p) for p in parents]
+        _need_cuda(*ps)
+        assert all(p.shape[0] % 2 == 0 for p in ps) and 2 * len(ps) <= L.MAX_LOSS_JOBS
+        loss = torch.zeros(1, device=ps[0].device)
+        ws = torch.empty(64 * L.MAX_LOSS_JOBS, device=ps[0].device)
+        st = _stream()
+        halves = [(p[:p.shape[0] // 2], p[p.shape[0] // 2:]) for p in ps]
+        fake = [(g, None, None, None, 1.0, 0.0) for _, g in halves]
+        if relative:
+            real = [(r, g, None, None, 1.0, 1.0) for r, g in halves]
+            check(lib.rtg_loss_fwd(L.LOSS_MSE_REL, _jobs(real), len(real), _p(ws), _p(loss), st), 'loss fwd')
+            check(lib.rtg_loss_fwd(L.LOSS_MSE_TARGET, _jobs(fake), len(fake), _p(ws), _p(loss), st), 'loss fwd')
+        else:
+            ent = [(r, None, None, None, 1.0, 1.0) for r, _ in halves] + fake
+            check(lib.rtg_loss_fwd(L.LOSS_MSE_TARGET, _jobs(ent), len(ent), _p(ws), _p(loss), st), 'loss fwd')
+        ctx.relative = relative
+        ctx.save_for_backward(*ps)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        ps = ctx.saved_tensors
+        g = _c(g).reshape(1)
+        st = _stream()
+        dps = [torch.empty_like(p) for p in ps]
+        hv = [(p[:p.shape[0] // 2], p[p.shape[0] // 2:], d[:p.shape[0] // 2], d[p.shape[0] // 2:]) for p, d in zip(ps, dps)]
+        fake = [(gg, None, dg, None, 1.0, 0.0) for _, gg, _, dg in hv]
+        if ctx.relative:
+            real = [(r, gg, dr, None, 1.0, 1.0) for r, gg, dr, _ in hv]
+            check(lib.rtg_loss_bwd(L.LOSS_MSE_REL, _jobs(real), len(real), _p(g), st), 'loss bwd')
+            check(lib.rtg_loss_bwd(L.LOSS_MSE_TARGET, _jobs(fake), len(fake), _p(g), st), 'loss bwd')
+        else:
+            ent = [(r, None, dr, None, 1.0, 1.0) for r, _, dr, _ in hv] + fake
+            check(lib.rtg_loss_bwd(L.LOSS_MSE_TARGET, _jobs(ent), len(ent), _p(g), st), 'loss bwd')
+        return (None, *dps)
+
+
+def pair_loss(parents, relative=False):
+    return PairLossFn.apply(bool(relative), *parents)
 
 
 def multi_loss(kind, a_list, b_list=None, weights=None, target=0.0):
