@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define RTG_ABI_VERSION 3
+#define RTG_ABI_VERSION 4
 
 #define RTG_OK 0
 #define RTG_EINVAL (-1)   /* inconsistent descriptor               */
@@ -154,6 +154,17 @@ typedef struct RtgWgradDesc {
 
 int rtg_conv1d_wgrad(const RtgWgradDesc* d, const float* x1, const float* x2, const float* dy, const float* gy_aux,
                      float* part, void* stream);
+/* n <= RTG_WGRAD_MAX_GROUP problems in ONE launch (the parallel ResBlock branches of a UNet-G decoder stage,
+ * generator.py:776-778; the six convs of a ResidualStack, generator.py:33-77).  Every descriptor names the same general
+ * block shape (shape_cfg 1..6, as listed by rtg_wgrad_shape_candidates) and its own splits / part_stride; the members
+ * must share one kernel instance (fp32, 1-D, Mg >= 32, same tiling mode, patch width <= 128): RTG_EINVAL otherwise and
+ * the caller launches them one by one.  Bit-identical to the members' own rtg_conv1d_wgrad launches. */
+#define RTG_WGRAD_MAX_GROUP 6
+typedef struct RtgWgradPtrs {
+  const float *x1, *x2, *dy, *gy_aux;
+  float* part;
+} RtgWgradPtrs;
+int rtg_conv1d_wgrad_group(int n, const RtgWgradDesc* descs, const RtgWgradPtrs* ptrs, void* stream);
 /* suggested number of splits for a problem and its block shape (>= 1) */
 int rtg_wgrad_splits(const RtgWgradDesc* d);
 /* the block shapes (RtgWgradDesc.shape_cfg codes) valid for this problem, best-guess first; returns the count written */

@@ -175,3 +175,61 @@ def test_every_wgrad_block_shape_agrees(case):
         assert (got - ref).abs().max().item() <= 1e-4 * ref.abs().max().item(), f'shape_cfg {c}'
     probe.shape_cfg = 99
     assert lib.rtg_wgrad_splits(C.byref(probe)) < 0
+
+
+GROUPS = [
+    # members (C, L, K, dil) of one grouped launch; B = 3
+    [(128, 256, 3, 9), (128, 256, 5, 3), (128, 256, 7, 1)],                       # ResBlock3 branches of a decoder stage
+    [(128, 32, 3, 1), (128, 32, 3, 1), (128, 32, 3, 3), (128, 32, 3, 1), (128, 32, 3, 9), (128, 32, 3, 1)],   # ResidualStack
+    [(64, 300, 7, 1), (64, 177, 3, 3)],                                            # ragged, different lengths
+]
+
+
+@pytest.mark.parametrize('div', [1, 3])
+@pytest.mark.parametrize('members', GROUPS)
+def test_grouped_wgrad_is_bit_identical_to_the_members_own_launches(members, div):
+    """rtg_conv1d_wgrad_group: n weight-gradient problems of one kernel instance in one launch.  Every member's partials
+    (all splits, weight and bias columns) equal the partials of its own rtg_conv1d_wgrad launch bit for bit, for every
+    general block shape the members share; a group the kernel instance cannot serve is refused with RTG_EINVAL."""
+    from rtg.lib import lib, WgradDesc, WgradPtrs
+    B = 3
+    g = torch.Generator().manual_seed(len(members) * 10 + div)
+    descs, tens = [], []
+    for (Cc, L, K, dil) in members:
+        pad = dil * (K - 1) // 2
+        x = torch.randn(B, Cc, L, generator=g).cuda()
+        dy = torch.randn(B, Cc, L, generator=g).cuda()
+        d = WgradDesc(B=B, C1=Cc, C2=0, L_in=L, groups=1, Cg=Cc, Mg=Cc, K=K, stride=1, dil=dil, pad=pad, Q=L, dy_L=L,
+                      pre_mode=1, pre_slope=0.15, gy_mode=0, gy_slope=1.0, gy_scale=1.0, splits=1, part_stride=0)
+        descs.append(d)
+        tens.append((x, dy))
+    lists = []
+    for d in descs:
+        cands = (C.c_int * 12)()
+        k = lib.rtg_wgrad_shape_candidates(C.byref(d), cands, 12)
+        lists.append([c for c in cands[:k] if 1 <= c <= 6])
+    common = [c for c in lists[0] if all(c in l for l in lists[1:])]
+    assert common
+    n = len(members)
+    for shape in common:
+        singles, parts = [], []
+        darr, parr = (WgradDesc * n)(), (WgradPtrs * n)()
+        for i, (d, (x, dy)) in enumerate(zip(descs, tens)):
+            d.shape_cfg, d.splits, d.part_stride = shape, 1, 0
+            s = max(1, -(-lib.rtg_wgrad_splits(C.byref(d)) // div))
+            need = d.Mg * (d.Cg * d.K + 1)
+            d.splits, d.part_stride = s, need
+            one = torch.full((s * need,), float('nan'), device='cuda')
+            assert lib.rtg_conv1d_wgrad(C.byref(d), _ptr(x), None, _ptr(dy), None, _ptr(one), None) == 0
+            singles.append(one)
+            parts.append(torch.full((s * need,), float('nan'), device='cuda'))
+            darr[i] = d
+            parr[i] = WgradPtrs(x.data_ptr(), None, dy.data_ptr(), None, parts[-1].data_ptr())
+        assert lib.rtg_conv1d_wgrad_group(n, darr, parr, None) == 0
+        torch.cuda.synchronize()
+        for one, grp in zip(singles, parts):
+            assert torch.isfinite(one).all()
+            assert torch.equal(one, grp)
+    # refused: a member on a kernel of its own (shape 8), and a member whose rows use the 16-row tile
+    darr[0].shape_cfg = 8
+    assert lib.rtg_conv1d_wgrad_group(n, darr, parr, None) != 0

@@ -194,8 +194,19 @@ extern "C" int rtg_wgrad_shape_candidates(const RtgWgradDesc* d, int* cfgs, int 
   return cnt;
 }
 
-extern "C" int rtg_conv1d_wgrad(const RtgWgradDesc* d, const float* x1, const float* x2, const float* dy,
-                                const float* gy_aux, float* part, void* stream) {
+namespace {
+
+struct WgPlan {
+  WgArgs a;
+  WgGeom g;
+  unsigned blocks;
+  size_t lds_bytes;
+  int mode;                 // bit 0: continuous tiling, bit 1: second dimension, bit 2: bf16 operands
+};
+
+// checks + geometry + kernel arguments of one problem served by the general (matrix-core) kernel
+int wgrad_plan(const RtgWgradDesc* d, const float* x1, const float* x2, const float* dy, const float* gy_aux,
+               float* part, WgPlan* pl) {
   if (!d || !x1 || !dy || !part) return RTG_ENULL;
   int st = validate(d);
   if (st) return st;
@@ -205,14 +216,13 @@ extern "C" int rtg_conv1d_wgrad(const RtgWgradDesc* d, const float* x1, const fl
   if (d->splits < 1 || d->splits > 65535) return RTG_EINVAL;
   const long long need = (long long)d->groups * d->Mg * ((long long)d->Cg * d->K + 1);
   if (d->splits > 1 && d->part_stride < need) return RTG_EINVAL;
-  if (d->shape_cfg == kThinShape) return rtg_wgrad_thin_launch(d, x1, dy, gy_aux, part, (hipStream_t)stream);
-  if (d->shape_cfg == kResShape) return rtg_reswgrad_launch(d, x1, dy, part, (hipStream_t)stream);
-  WgGeom g;
+  if (d->shape_cfg == kThinShape || d->shape_cfg == kResShape) return RTG_EINVAL;     // kernels of their own
+  WgGeom& g = pl->g;
   st = geometry(d, &g);
   if (st) return st;
   const Shape sh = kShapes[g.shape];
 
-  WgArgs a;
+  WgArgs& a = pl->a;
   a.x1 = x1; a.x2 = x2; a.dy = dy; a.gy_aux = gy_aux; a.part = part;
   a.B = d->B; a.C1 = d->C1; a.C2 = d->C2; a.L_in = d->L_in; a.groups = d->groups; a.Cg = d->Cg; a.Mg = d->Mg;
   a.K = d->K; a.stride = d->stride; a.dil = d->dil; a.pad = d->pad; a.Q = d->Q; a.dy_L = d->dy_L;
@@ -235,15 +245,45 @@ extern "C" int rtg_conv1d_wgrad(const RtgWgradDesc* d, const float* x1, const fl
   a.xbuf_sz = xr_cap * g.ROW;                       // patch rows up to the staging capacity (rows past CKW unused)
   if (g.CKW < xr_cap) a.xbuf_sz = g.CKW * g.ROW;
   a.ones_off = a.xbuf_sz + rows * ROWD;
-  const size_t lds_bytes = (size_t)(a.ones_off + TT * d->stride + 8) * sizeof(float);
+  pl->lds_bytes = (size_t)(a.ones_off + TT * d->stride + 8) * sizeof(float);
   const long long gy = (long long)d->groups * g.m_blocks * g.n_cchunk;
   const long long n_items = gy * d->splits;
   if (n_items > (1ll << 28)) return RTG_ERANGE;
   a.gy = (int)gy; a.n_items = (int)n_items;
   a.per_xcd = (int)((n_items + 7) / 8);
-  dim3 grid((unsigned)(8 * a.per_xcd), 1, 1);
+  pl->blocks = (unsigned)(8 * a.per_xcd);
+  pl->mode = (g.cont ? 1 : 0) | (two_d ? 2 : 0) | (d->bf16 ? 4 : 0);
+  return RTG_OK;
+}
+
+}  // namespace
+
+int rtg_wgrad_launch_group_m0(int, const rtg_wg::WgGroupArgs&, size_t, hipStream_t);
+int rtg_wgrad_launch_group_m1(int, const rtg_wg::WgGroupArgs&, size_t, hipStream_t);
+
+extern "C" int rtg_conv1d_wgrad(const RtgWgradDesc* d, const float* x1, const float* x2, const float* dy,
+                                const float* gy_aux, float* part, void* stream) {
+  if (!d || !x1 || !dy || !part) return RTG_ENULL;
+  if (d->shape_cfg == kThinShape || d->shape_cfg == kResShape) {
+    int st = validate(d);
+    if (st) return st;
+    if ((d->gy_mode == RTG_PRE_MUL_DLRELU || d->gy_mode == RTG_PRE_MUL_DTANH) && !gy_aux) return RTG_ENULL;
+    if (d->pre_mode != RTG_PRE_NONE && d->pre_mode != RTG_PRE_LRELU) return RTG_EINVAL;
+    if (d->splits < 1 || d->splits > 65535) return RTG_EINVAL;
+    const long long need = (long long)d->groups * d->Mg * ((long long)d->Cg * d->K + 1);
+    if (d->splits > 1 && d->part_stride < need) return RTG_EINVAL;
+    if (d->shape_cfg == kThinShape) return rtg_wgrad_thin_launch(d, x1, dy, gy_aux, part, (hipStream_t)stream);
+    return rtg_reswgrad_launch(d, x1, dy, part, (hipStream_t)stream);
+  }
+  WgPlan pl;
+  const int st = wgrad_plan(d, x1, x2, dy, gy_aux, part, &pl);
+  if (st) return st;
+  const WgGeom& g = pl.g;
+  const WgArgs& a = pl.a;
+  const dim3 grid(pl.blocks, 1, 1);
+  const size_t lds_bytes = pl.lds_bytes;
   hipStream_t s = (hipStream_t)stream;
-  switch ((g.cont ? 1 : 0) | (two_d ? 2 : 0) | (d->bf16 ? 4 : 0)) {
+  switch (pl.mode) {
     case 0: return rtg_wgrad_launch_m0(g.TM, g.shape, g.maxit, a, grid, lds_bytes, s);
     case 1: return rtg_wgrad_launch_m1(g.TM, g.shape, g.maxit, a, grid, lds_bytes, s);
     case 2: return rtg_wgrad_launch_m2(g.TM, g.shape, g.maxit, a, grid, lds_bytes, s);
@@ -253,4 +293,35 @@ extern "C" int rtg_conv1d_wgrad(const RtgWgradDesc* d, const float* x1, const fl
     case 6: return rtg_wgrad_launch_m6(g.TM, g.shape, g.maxit, a, grid, lds_bytes, s);
     default: return rtg_wgrad_launch_m7(g.TM, g.shape, g.maxit, a, grid, lds_bytes, s);
   }
+}
+
+// n problems in ONE launch.  Every member names the same general block shape (shape_cfg 1..6: the caller fixes it, as
+// for rtg_conv1d_group) and must map to the same kernel instance: fp32 operands, 1-D rows, 32-row MFMA tiles (Mg >= 32),
+// the same tiling mode and a staged patch of at most 128 floats per channel.  RTG_EINVAL otherwise — the caller then
+// launches the members one by one.  Results are bit-identical to the members' own launches.
+extern "C" int rtg_conv1d_wgrad_group(int n, const RtgWgradDesc* descs, const RtgWgradPtrs* ptrs, void* stream) {
+  if (!descs || !ptrs) return RTG_ENULL;
+  if (n < 1 || n > RTG_WG_MAX_GROUP) return RTG_EINVAL;
+  rtg_wg::WgGroupArgs ga;
+  ga.n = n;
+  size_t lds_bytes = 0;
+  unsigned end = 0;
+  int shape = -1, mode = -1;
+  for (int i = 0; i < n; ++i) {
+    if (descs[i].shape_cfg < 1 || descs[i].shape_cfg > kNumShapes) return RTG_EINVAL;
+    WgPlan pl;
+    const RtgWgradPtrs& q = ptrs[i];
+    const int st = wgrad_plan(&descs[i], q.x1, q.x2, q.dy, q.gy_aux, q.part, &pl);
+    if (st) return st;
+    if (pl.g.TM != 32 || pl.g.maxit != 2 || (pl.mode & ~1) != 0) return RTG_EINVAL;
+    if (i == 0) { shape = pl.g.shape; mode = pl.mode; }
+    else if (pl.g.shape != shape || pl.mode != mode) return RTG_EINVAL;
+    ga.p[i] = pl.a;
+    end += pl.blocks;
+    ga.blk_end[i] = end;
+    lds_bytes = pl.lds_bytes > lds_bytes ? pl.lds_bytes : lds_bytes;
+  }
+  for (int i = n; i < RTG_WG_MAX_GROUP; ++i) ga.blk_end[i] = end;
+  hipStream_t s = (hipStream_t)stream;
+  return mode == 0 ? rtg_wgrad_launch_group_m0(shape, ga, lds_bytes, s) : rtg_wgrad_launch_group_m1(shape, ga, lds_bytes, s);
 }

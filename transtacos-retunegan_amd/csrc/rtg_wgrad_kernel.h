@@ -17,6 +17,8 @@ __device__ __forceinline__ float buf_load(rsrc_t r, unsigned off) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
 }
 
+#define RTG_WG_MAX_GROUP RTG_WGRAD_MAX_GROUP
+
 struct WgArgs {
   const float *x1, *x2, *dy, *gy_aux;
   float* part;
@@ -75,8 +77,10 @@ struct MfmaW<16> {
 };
 
 // block shapes: wave grid WM x WN (WM*WN = 4), register tile MTW x NTW
+// `bid`: the block's index within its problem (blockIdx.x of a plain launch; a grouped launch subtracts the first block of
+// the member, see wgrad_group_kernel)
 template <int TM, int MTW, int NTW, int WM, int MAXIT, int MODE>
-__global__ __launch_bounds__(RTG_THREADS) void wgrad_kernel(const WgArgs a) {
+__device__ __forceinline__ void wgrad_body(const WgArgs& a, const unsigned bid) {
   using M = MfmaW<TM>;
   constexpr bool CONT = (MODE & 1) != 0, TWO_D = (MODE & 2) != 0;   // compile-time addressing mode
   // bit 2: bf16 operands — the fp32 tiles in LDS are rounded to bf16 as they are read into fragments (a lane holds 4
@@ -105,7 +109,7 @@ __global__ __launch_bounds__(RTG_THREADS) void wgrad_kernel(const WgArgs a) {
   // contiguous item range [k * per_xcd, (k + 1) * per_xcd), so the blocks resident on an XCD at one time share their
   // operand tiles through that XCD's L2 (before: the split index ran fastest and neighbours shared nothing; PMC l2_hit
   // 0.06, 176-201 MB fetched per launch for 26 MB of operands).
-  const int item = (int)(blockIdx.x & 7) * a.per_xcd + (int)(blockIdx.x >> 3);
+  const int item = (int)(bid & 7u) * a.per_xcd + (int)(bid >> 3);
   if (item >= a.n_items) return;
   const int split = item / a.gy;
   int by = item - split * a.gy;
@@ -455,6 +459,52 @@ __global__ __launch_bounds__(RTG_THREADS) void wgrad_kernel(const WgArgs a) {
 }
 
 template <int TM, int MTW, int NTW, int WM, int MAXIT, int MODE>
+__global__ __launch_bounds__(RTG_THREADS) void wgrad_kernel(const WgArgs a) {
+  wgrad_body<TM, MTW, NTW, WM, MAXIT, MODE>(a, blockIdx.x);
+}
+
+// Several weight-gradient problems of ONE kernel instance in one launch (the parallel ResBlock branches of a UNet-G stage,
+// the six convs of a ResidualStack): a block finds its member by its index; every member's grid is a multiple of 8 blocks,
+// so the XCD a block runs on is the one its member's own launch would have given it.
+struct WgGroupArgs {
+  int n;
+  unsigned blk_end[RTG_WG_MAX_GROUP];
+  WgArgs p[RTG_WG_MAX_GROUP];
+};
+
+template <int TM, int MTW, int NTW, int WM, int MAXIT, int MODE>
+__global__ __launch_bounds__(RTG_THREADS) void wgrad_group_kernel(const WgGroupArgs ga) {
+  int pid = 0;
+  unsigned start = 0;
+  for (int i = 0; i + 1 < ga.n; ++i)
+    if (blockIdx.x >= ga.blk_end[i]) {
+      pid = i + 1;
+      start = ga.blk_end[i];
+    }
+  wgrad_body<TM, MTW, NTW, WM, MAXIT, MODE>(ga.p[pid], blockIdx.x - start);
+}
+
+template <int TM, int MTW, int NTW, int WM, int MODE>
+int launch_group(const WgGroupArgs& ga, size_t lds_bytes, hipStream_t s) {
+  auto k = wgrad_group_kernel<TM, MTW, NTW, WM, 2, MODE>;          // staging width of the members: PW <= 128 (host check)
+  if (lds_bytes > 64 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  RTG_KLAUNCH(k, dim3(ga.blk_end[ga.n - 1]), dim3(RTG_THREADS), lds_bytes, s, ga);
+  return rtg_launch_status();
+}
+
+template <int MODE>
+int launch_group_mode(int shape, const WgGroupArgs& ga, size_t lds_bytes, hipStream_t s) {
+  switch (shape) {                                                   // 32-row MFMA tiles only
+    case 0: return launch_group<32, 2, 2, 2, MODE>(ga, lds_bytes, s);
+    case 1: return launch_group<32, 2, 2, 1, MODE>(ga, lds_bytes, s);
+    case 2: return launch_group<32, 1, 2, 1, MODE>(ga, lds_bytes, s);
+    case 3: return launch_group<32, 1, 4, 1, MODE>(ga, lds_bytes, s);
+    case 4: return launch_group<32, 1, 1, 1, MODE>(ga, lds_bytes, s);
+    default: return launch_group<32, 1, 1, 4, MODE>(ga, lds_bytes, s);
+  }
+}
+
+template <int TM, int MTW, int NTW, int WM, int MAXIT, int MODE>
 int launch(const WgArgs& a, dim3 grid, size_t lds_bytes, hipStream_t s) {
   auto k = wgrad_kernel<TM, MTW, NTW, WM, MAXIT, MODE>;
   if (lds_bytes > 64 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -490,6 +540,11 @@ int launch_mode(int tm, int shape, int maxit, const WgArgs& a, dim3 grid, size_t
 }
 
 }  // namespace rtg_wg
+
+#define RTG_WGRAD_DEFINE_GROUP(N)                                                                                  \
+  int rtg_wgrad_launch_group_m##N(int shape, const rtg_wg::WgGroupArgs& ga, size_t lds_bytes, hipStream_t s) {      \
+    return rtg_wg::launch_group_mode<N>(shape, ga, lds_bytes, s);                                                    \
+  }
 
 #define RTG_WGRAD_DEFINE_MODE(N)                                                                                   \
   int rtg_wgrad_launch_m##N(int tm, int shape, int maxit, const rtg_wg::WgArgs& a, dim3 grid, size_t lds_bytes,     \

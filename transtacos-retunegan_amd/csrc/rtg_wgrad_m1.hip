@@ -2,3 +2,4 @@
 #include "rtg_wgrad_kernel.h"
 
 RTG_WGRAD_DEFINE_MODE(1)
+RTG_WGRAD_DEFINE_GROUP(1)

@@ -1,6 +1,7 @@
 """Autograd wrappers over the C ABI of librtg.so (include/rtg.h).  Every function here launches hand-written HIP
 kernels on the current torch stream; PyTorch only owns the memory and the autograd graph.  CPU tensors are refused."""
 import ctypes as C
+import os as _os
 
 import torch
 
@@ -80,8 +81,95 @@ def _run_wgrad(wd, ptrs, st, bank, ly, tok_id, flop, label, what):
     bank.note_backward_stream()
     wd.splits, wd.part_stride = splits, stride
     check(_timed('wgrad', 32 if wd.Mg >= 32 else 16, flop,
-                 lambda: lib.rtg_conv1d_wgrad(C.byref(wd), *ptrs, _p(part), st), f'{label} splits{splits}'), what)
+                 lambda: lib.rtg_conv1d_wgrad(C.byref(wd), *ptrs, _p(part), st), f'{label} splits{splits} s{wd.shape_cfg}'), what)
     return part, splits, immediate
+
+
+# RTG_WGRAD_GROUP=0: every weight gradient as its own launch (A/B knob)
+WGRAD_GROUP = _os.environ.get('RTG_WGRAD_GROUP', '1') == '1'
+
+
+def _run_wgrad_group(items, st, bank, tok_id, label):
+    """The weight gradients of several layers of one bank, as ONE launch where the tuner found that faster
+    (rtg_conv1d_wgrad_group: small problems that each leave most of the chip idle), else one by one.
+    items: [(wd, (x1, x2, dy, gy_aux), ly, flop, label, what)]."""
+    n = len(items)
+    wds = [it[0] for it in items]
+    code = 0
+    if WGRAD_GROUP and 2 <= n <= L.WGRAD_MAX_GROUP and all(w.Mg >= 32 and not getattr(it[2], 'wgrad_bf', 0)
+                                                            for w, it in zip(wds, items)):
+        for w in wds:
+            w.bf16, w.shape_cfg, w.splits, w.part_stride = 0, 0, 1, 0
+        need = [w.groups * w.Mg * (w.Cg * w.K + 1) for w in wds]
+
+        def set_cfg(c, parts):
+            """descriptor / pointer arrays of the group at code c into the partial buffers parts(i, splits) -> (ptr, stride)"""
+            darr, parr, spl = (L.WgradDesc * n)(), (L.WgradPtrs * n)(), []
+            for i, (w, it) in enumerate(zip(wds, items)):
+                w.shape_cfg, w.splits, w.part_stride = c & 15, 1, 0
+                s = lib.rtg_wgrad_splits(C.byref(w))
+                if s < 1:
+                    return None
+                if c & 16:
+                    s = max(1, -(-s // n))
+                ptr, stride = parts(i, s)
+                w.splits, w.part_stride = s, stride
+                darr[i] = w
+                x1, x2, dy, aux = it[1]
+                parr[i] = L.WgradPtrs(x1.value if x1 else None, x2.value if x2 else None, dy.value if dy else None,
+                                      aux.value if aux else None, ptr)
+                spl.append(s)
+            return darr, parr, spl
+
+        def reset():
+            for w in wds:
+                w.shape_cfg, w.splits, w.part_stride = 0, 1, 0
+
+        def run_group(c):
+            scratch = []
+
+            def parts(i, s):
+                scratch.append(torch.empty(s * need[i], device='cuda'))
+                return scratch[-1].data_ptr(), need[i]
+            r = set_cfg(c, parts)
+            if r is None:
+                return -1
+            return lib.rtg_conv1d_wgrad_group(n, r[0], r[1], st)
+
+        def run_singles():
+            for i, (w, it) in enumerate(zip(wds, items)):
+                cfg = tune.wgrad_cfg(w, lambda part, w=w, it=it: lib.rtg_conv1d_wgrad(C.byref(w), *it[1], _p(part), st))
+                w.shape_cfg, w.splits, w.part_stride = cfg, 1, 0
+                s = lib.rtg_wgrad_splits(C.byref(w))
+                if s < 1:
+                    return -1
+                part = torch.empty(s * need[i], device='cuda')
+                w.splits, w.part_stride = s, need[i]
+                rc = lib.rtg_conv1d_wgrad(C.byref(w), *it[1], _p(part), st)
+                if rc:
+                    return rc
+            return 0
+        reset()
+        code = tune.wgrad_group_cfg(wds, run_group, lambda: (run_singles(), reset())[0])
+        reset()
+    if code == 0:
+        out = []
+        for wd, ptrs, ly, flop, lab, what in items:
+            wd.shape_cfg, wd.splits, wd.part_stride = 0, 1, 0
+            out.append(_run_wgrad(wd, ptrs, st, bank, ly, tok_id, flop, lab, what))
+        return out
+    slots = []
+
+    def parts(i, s):
+        part, stride, immediate = bank.partial_slot(items[i][2], s, tok_id)
+        slots.append((part, s, immediate))
+        return part.data_ptr(), stride
+    darr, parr, spl = set_cfg(code, parts)
+    bank.note_backward_stream()
+    check(_timed('wgrad', 32, sum(it[3] for it in items),
+                 lambda: lib.rtg_conv1d_wgrad_group(n, darr, parr, st), f'wgrad group {label} x{n} s{code}'),
+          f'conv1d wgrad group {label}')
+    return slots
 
 
 def _conv_flop(ly, B, L_conv_out):
@@ -247,8 +335,6 @@ class ConvFn(torch.autograd.Function):
 # ---------------------------------------------------------------------------------------------------------------
 # ResidualStack in one launch per direction (rtg_resstack.hip)
 # ---------------------------------------------------------------------------------------------------------------
-import os as _os
-
 RESSTACK = _os.environ.get('RTG_RESSTACK', '1') == '1'          # A/B knob: 0 = six conv launches per direction
 
 
@@ -323,15 +409,17 @@ class ResStackFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             ins = (x0, r1, x1, r2, x2, r3)
             dys = (gouts[4], gouts[3], gouts[2], gouts[1], gouts[0], dy)
+            items = []
             for i, ly in enumerate(lys):
                 last = i == 5 and final_act_slope is not None
                 wd = L.WgradDesc(B=B, C1=Cc, C2=0, L_in=Lx, groups=1, Cg=Cc, Mg=Cc, K=3, stride=1, dil=ly.dil, pad=ly.pad,
                                  Q=Lx, dy_L=Lx, pre_mode=L.PRE_LRELU, pre_slope=pre_slope,
                                  gy_mode=L.PRE_MUL_DLRELU if last else L.PRE_NONE,
                                  gy_slope=final_act_slope if last else 1.0, gy_scale=1.0, splits=1, part_stride=0)
-                part, splits, immediate = _run_wgrad(wd, (_p(ins[i]), None, _p(dys[i]), _p(y) if last else None), st, bank,
-                                                     ly, ctx.tok_id, _conv_flop(ly, B, Lx), f'wgrad {ly.name} B{B} L{Lx}',
-                                                     f'conv1d wgrad {ly.name}')
+                items.append((wd, (_p(ins[i]), None, _p(dys[i]), _p(y) if last else None), ly, _conv_flop(ly, B, Lx),
+                              f'wgrad {ly.name} B{B} L{Lx}', f'conv1d wgrad {ly.name}'))
+            for ly, (part, splits, immediate) in zip(lys, _run_wgrad_group(items, st, bank, ctx.tok_id,
+                                                                             f'{lys[0].name}..stack')):
                 if immediate:
                     bank.flush_one(ly, part, splits)
         return None, (gouts[5] if ctx.needs_input_grad[1] else None), None, None, None
@@ -596,22 +684,21 @@ class GroupConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             pre_mode = L.PRE_LRELU if pre_slope != 1.0 else L.PRE_NONE
 
-            def wgrad_of(ly, x, dy):
-                def run():
-                    B, C1, L_in = x.shape
-                    L_out = dy.shape[-1]
-                    wd = L.WgradDesc(B=B, C1=C1, C2=0, L_in=L_in, groups=ly.groups, Cg=ly.cin // ly.groups,
-                                     Mg=ly.cout // ly.groups, K=ly.k, stride=ly.stride, dil=ly.dil, pad=ly.pad, Q=L_out,
-                                     dy_L=L_out, pre_mode=pre_mode, pre_slope=pre_slope, gy_mode=L.PRE_NONE, gy_slope=1.0,
-                                     gy_scale=1.0, splits=1, part_stride=0)
-                    part, splits, immediate = _run_wgrad(wd, (_p(x), None, _p(dy), None), _stream(), bank, ly, ctx.tok_id,
-                                                         _conv_flop(ly, B, L_out), f'wgrad {ly.name} B{B} L{L_in}',
-                                                         f'conv1d wgrad {ly.name}')
-                    if immediate:
-                        bank.flush_one(ly, part, splits)
-                return run
-            for ly, x, dy in zip(lys, xs, dys):      # (forking these over streams measured slower: 43.9 vs 42.7 ms/step)
-                wgrad_of(ly, x, dy)()
+            items = []
+            for ly, x, dy in zip(lys, xs, dys):
+                B, C1, L_in = x.shape
+                L_out = dy.shape[-1]
+                wd = L.WgradDesc(B=B, C1=C1, C2=0, L_in=L_in, groups=ly.groups, Cg=ly.cin // ly.groups,
+                                 Mg=ly.cout // ly.groups, K=ly.k, stride=ly.stride, dil=ly.dil, pad=ly.pad, Q=L_out,
+                                 dy_L=L_out, pre_mode=pre_mode, pre_slope=pre_slope, gy_mode=L.PRE_NONE, gy_slope=1.0,
+                                 gy_scale=1.0, splits=1, part_stride=0)
+                items.append((wd, (_p(x), None, _p(dy), None), ly, _conv_flop(ly, B, L_out),
+                              f'wgrad {ly.name} B{B} L{L_in}', f'conv1d wgrad {ly.name}'))
+            # one launch for the group where the tuner found that faster, else layer by layer
+            # (forking the layers over streams measured slower: 43.9 vs 42.7 ms/step)
+            for ly, (part, splits, immediate) in zip(lys, _run_wgrad_group(items, _stream(), bank, ctx.tok_id, lys[0].name)):
+                if immediate:
+                    bank.flush_one(ly, part, splits)
         return (None, None, None, None, *dxs)
 
 

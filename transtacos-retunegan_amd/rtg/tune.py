@@ -21,7 +21,7 @@ ENABLED = os.environ.get('RTG_TUNE', '1') != '0'
 ACTIVE = False
 MISSED = False
 REPS = 3
-_conv, _wgrad, _group = {}, {}, {}
+_conv, _wgrad, _group, _wgroup = {}, {}, {}, {}
 
 
 def _time(launch):
@@ -93,6 +93,32 @@ def wgrad_cfg(wd, run):
     return best
 
 
+def wgrad_group_cfg(wds, run_group, run_singles):
+    """How to run the weight gradients of n layers that may share one launch (rtg_conv1d_wgrad_group).  -> 0: one by
+    one (each with its own tuned shape), else shape_cfg + 16 * d with the members' split counts divided by n (d = 1) or
+    as for a lone launch (d = 0).  `run_group(code)` / `run_singles()` launch into scratch partials, return a status."""
+    key = b''.join(bytes(w) for w in wds)
+    cfg = _wgroup.get(key)
+    if cfg is not None:
+        return cfg
+    if not (ENABLED and ACTIVE):
+        return _miss()
+    lists = []
+    for w in wds:
+        cands = (C.c_int * 12)()
+        k = lib.rtg_wgrad_shape_candidates(C.byref(w), cands, 12)
+        lists.append([c for c in cands[:max(k, 0)] if 1 <= c <= 6])
+    common = [c for c in lists[0] if all(c in l for l in lists[1:])]
+    best, best_t = 0, _time(run_singles)
+    for c in common:
+        for d in (0, 1):
+            t = _time(lambda: run_group(c + 16 * d))
+            if t is not None and (best_t is None or t < best_t):
+                best, best_t = c + 16 * d, t
+    _wgroup[key] = best
+    return best
+
+
 def group_cfg(darr, n, launch):
     """common tile_cfg for the n descriptors of a grouped launch (ctypes array `darr`); `launch()` runs rtg_conv1d_group
     on it as it stands.  0: the members have no block shape in common."""
@@ -128,4 +154,4 @@ def group_cfg(darr, n, launch):
 
 
 def stats():
-    return {'conv_problems': len(_conv), 'wgrad_problems': len(_wgrad), 'group_problems': len(_group)}
+    return {'conv_problems': len(_conv), 'wgrad_problems': len(_wgrad), 'group_problems': len(_group), 'wgrad_group_problems': len(_wgroup)}
