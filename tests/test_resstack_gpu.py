@@ -37,8 +37,11 @@ def test_fused_residual_stack_matches_oracle_and_unfused(oracle, C, L, B, final,
     x = torch.randn(B, C, L, generator=gen)
     dy = torch.randn(B, C, L, generator=gen)
 
-    def run(fused):
-        ops.RESSTACK = fused
+    def run(mode):
+        # 'fused': one launch per direction; 'node': one autograd node, six launches per direction (residual gradient in
+        # the backward-data epilogue, grouped weight gradients); 'legacy': one autograd node per conv
+        ops.RESSTACK = mode != 'legacy'
+        monkeypatch.setenv('RTG_RESSTACK_KINDS', '7' if mode == 'fused' else '0')
         try:
             net.zero_grad()
             xg = x.to(DEV).requires_grad_(True)
@@ -48,31 +51,35 @@ def test_fused_residual_stack_matches_oracle_and_unfused(oracle, C, L, B, final,
             return y.detach().cpu(), xg.grad.cpu(), {n: p.grad.detach().cpu().clone() for n, p in net.named_parameters()}
         finally:
             ops.RESSTACK = True
+            monkeypatch.setenv('RTG_RESSTACK_KINDS', '7')
 
     lys = [getattr(blk, n)._layer for blk in (net.stack.res_1, net.stack.res_2, net.stack.res_3) for n in ('1', '3')] \
         if net._bank is not None else None
     net.bank()                                            # builds the layers
     lys = [getattr(blk, n)._layer for blk in (net.stack.res_1, net.stack.res_2, net.stack.res_3) for n in ('1', '3')]
     assert ops.resstack_ok(lys, x.to(DEV))
-    y1, dx1, g1 = run(True)
-    y0, dx0, g0 = run(False)
+    y1, dx1, g1 = run('fused')
+    y2, dx2, g2 = run('node')
+    y0, dx0, g0 = run('legacy')
+    assert torch.equal(y2, y0)                            # the same six forward launches
     xr = x.double().requires_grad_(True)
     yr = ref(xr)
     if final is not None:
         yr = F.leaky_relu(yr, final)
     yr.backward(dy.double())
     rp = dict(ref.named_parameters())
-    for got, name in ((y1, 'fused'), (y0, 'unfused')):
+    for got, name in ((y1, 'fused'), (y2, 'node'), (y0, 'legacy')):
         np.testing.assert_allclose(got.numpy(), yr.detach().float().numpy(), rtol=1e-4, atol=2e-5, err_msg=name)
-    for got, name in ((dx1, 'fused'), (dx0, 'unfused')):
+    for got, name in ((dx1, 'fused'), (dx2, 'node'), (dx0, 'legacy')):
         err = (got.double() - xr.grad).norm().item() / xr.grad.norm().item()
         assert err < 2e-4, (name, err)       # relative L2: a leaky-relu flip of an activation within rounding of 0 is local
     for n, g in g1.items():
         r = rp[n[len('stack.'):]].grad
         err = (g.double() - r).norm().item() / (r.norm().item() + 1e-30)
         assert err < 2e-4, (n, err)
-        err0 = (g - g0[n]).norm().item() / (g0[n].norm().item() + 1e-30)
-        assert err0 < 2e-4, (n, err0)
+        for other in (g0, g2):
+            err0 = (g - other[n]).norm().item() / (other[n].norm().item() + 1e-30)
+            assert err0 < 2e-4, (n, err0)
 
 
 def test_stack_shapes_that_are_not_served_fall_back(oracle):

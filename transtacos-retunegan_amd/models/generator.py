@@ -63,7 +63,7 @@ class ResidualStack(nn.Module):
     def run(self, tok, x, final_act_slope=None):
         blocks = (self.res_1, self.res_2, self.res_3)
         lys = [getattr(blk, n)._layer for blk in blocks for n in ('1', '3')]
-        if ops.resstack_ok(lys, x):          # clips that fit in LDS: the whole stack in one launch per direction
+        if ops.resstack_shape_ok(lys, x):    # one autograd node; clips that fit in LDS: one launch per direction
             return ops.resstack(tok, lys, x, 0.01, final_act_slope)
         for i, blk in enumerate(blocks):
             r = conv(tok, getattr(blk, '1'), x, pre_slope=0.01)

@@ -344,45 +344,64 @@ def _stack_desc(lys, B, Lx, pre_slope, final_act_slope, reverse=False):
                           float(final_act_slope or 1.0))
 
 
-def resstack_ok(lys, x):
-    """the six convs of a ResidualStack (execution order) can run as one fused launch on input x"""
+def resstack_shape_ok(lys, x):
+    """the six convs of a ResidualStack (execution order) on input x: what ResStackFn runs as one autograd node"""
     if not (RESSTACK and len(lys) == 6 and x.is_cuda and x.dim() == 3):
         return False
     c = lys[0].cin
-    for ly in lys:
-        if (ly.kind != 'conv' or ly.cin != c or ly.cout != c or ly.k != 3 or ly.stride != 1 or ly.groups != 1 or
-                ly.pad != ly.dil or ly.fwd_bf or ly.bwd_bf or ly.fwd_tap or ly.bwd_tap or ly.fwd_tm != 32 or ly.bwd_tm != 32):
-            return False
-    if x.shape[1] != c:
+    return x.shape[1] == c and all(ly.kind == 'conv' and ly.cin == c and ly.cout == c and ly.k == 3 and ly.stride == 1 and
+                                   ly.groups == 1 and ly.pad == ly.dil for ly in lys)
+
+
+def resstack_ok(lys, x):
+    """... and can run as ONE fused launch per direction (rtg_resstack.hip)"""
+    if not resstack_shape_ok(lys, x):
         return False
-    B, _, Lx = x.shape
+    if any(ly.fwd_bf or ly.bwd_bf or ly.fwd_tap or ly.bwd_tap or ly.fwd_tm != 32 or ly.bwd_tm != 32 for ly in lys):
+        return False
+    B, c, Lx = x.shape
     d = L.ResStackDesc(B, c, Lx, (C.c_int * 6)(*[ly.dil for ly in lys]), 0.01, 0, 1.0)
     return lib.rtg_resstack_ok(C.byref(d)) == 1
 
 
 class ResStackFn(torch.autograd.Function):
-    """y = ResidualStack(x) (retunegan/models/generator.py:33-77), optionally followed by leaky_relu(final_act_slope):
-    forward and backward-data of the six convs in ONE launch each; the six weight gradients run as usual on the tensors
-    the fused launches leave in HBM."""
+    """y = ResidualStack(x) (retunegan/models/generator.py:33-77), optionally followed by leaky_relu(final_act_slope), as
+    one autograd node.  fused: forward and backward-data of the six convs in ONE launch each (rtg_resstack.hip, clips
+    that fit in LDS); else six conv launches per direction, the residual gradient riding the backward-data epilogue
+    (no accumulation kernels).  Either way the six weight gradients run on the tensors left in HBM, as one grouped
+    launch where that is faster."""
 
     @staticmethod
-    def forward(ctx, token, x, lys, pre_slope, final_act_slope):
+    def forward(ctx, token, x, lys, pre_slope, final_act_slope, fused):
         _need_cuda(x)
         bank = token._rtg_bank
         x = _c(x)
         B, Cc, Lx = x.shape
-        d = _stack_desc(lys, B, Lx, pre_slope, final_act_slope)
-        outs = [torch.empty_like(x) for _ in range(6)]
-        wp = L.PtrArray6(*[bank.fwd_ptr(ly).value for ly in lys])
-        bias = L.PtrArray6(*[bank.bias_ptr(ly).value for ly in lys])
-        op = L.PtrArray6(*[o.data_ptr() for o in outs])
-        flop = sum(_conv_flop(ly, B, Lx) for ly in lys)
+        outs = [torch.empty_like(x) for _ in range(6)]            # r1, x1, r2, x2, r3, y
         st = _stream()
-        check(_timed('conv1d', 7100, flop, lambda: lib.rtg_resstack_forward(C.byref(d), _p(x), C.byref(wp), C.byref(bias),
-                                                                           C.byref(op), st),
-                     f'fwd {lys[0].name}..stack B{B} L{Lx}', 4 * 7 * x.numel()), 'resstack fwd')
+        if fused:
+            d = _stack_desc(lys, B, Lx, pre_slope, final_act_slope)
+            wp = L.PtrArray6(*[bank.fwd_ptr(ly).value for ly in lys])
+            bias = L.PtrArray6(*[bank.bias_ptr(ly).value for ly in lys])
+            op = L.PtrArray6(*[o.data_ptr() for o in outs])
+            flop = sum(_conv_flop(ly, B, Lx) for ly in lys)
+            check(_timed('conv1d', 7100, flop, lambda: lib.rtg_resstack_forward(C.byref(d), _p(x), C.byref(wp),
+                                                                               C.byref(bias), C.byref(op), st),
+                         f'fwd {lys[0].name}..stack B{B} L{Lx}', 4 * 7 * x.numel()), 'resstack fwd')
+        else:
+            ins = (x, *outs[:5])
+            for i, ly in enumerate(lys):
+                last = i == 5 and final_act_slope is not None
+                mode, g, mg, cg, k, s = ly.fwd_op
+                d = _desc(B=B, C1=Cc, C2=0, L_in=Lx, groups=g, Cg=cg, Mg=mg, K=k, stride=1, dil=ly.dil, pad=ly.pad, Q=Lx,
+                          out_C=Cc, out_L=Lx, pre_mode=L.PRE_LRELU, pre_slope=pre_slope,
+                          act=L.ACT_LRELU if last else L.ACT_NONE, act_slope=final_act_slope if last else 1.0,
+                          tile_m=ly.fwd_tm, tap_major=ly.fwd_tap, bf16=ly.fwd_bf)
+                res = ins[i - 1] if i % 2 else None           # x_{j+1} = x_j + conv3(lrelu(r_{j+1}))
+                _run_conv(d, (_p(ins[i]), None, None, bank.fwd_ptr(ly), bank.bias_ptr(ly), None, _p(res), _p(outs[i]), None,
+                              st), _conv_flop(ly, B, Lx), f'fwd {ly.name} B{B} L{Lx}', f'conv1d fwd {ly.name}')
         ctx.lys, ctx.bank, ctx.tok_id = lys, bank, token._rtg_id
-        ctx.cfg = (pre_slope, final_act_slope)
+        ctx.cfg = (pre_slope, final_act_slope, fused)
         ctx.save_for_backward(x, *outs)
         ctx.set_materialize_grads(False)
         return outs[5]
@@ -390,22 +409,38 @@ class ResStackFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         if dy is None:
-            return None, None, None, None, None
+            return None, None, None, None, None, None
         lys, bank = ctx.lys, ctx.bank
-        pre_slope, final_act_slope = ctx.cfg
+        pre_slope, final_act_slope, fused = ctx.cfg
         x0, r1, x1, r2, x2, r3, y = ctx.saved_tensors
         dy = _c(dy)
         B, Cc, Lx = x0.shape
-        d = _stack_desc(lys, B, Lx, pre_slope, final_act_slope, reverse=True)
         gouts = [torch.empty_like(x0) for _ in range(6)]          # g_r3, g_x2, g_r2, g_x1, g_r1, dx0
-        wpb = L.PtrArray6(*[bank.bwd_ptr(ly).value for ly in reversed(lys)])
-        masks = L.PtrArray6(*[t.data_ptr() for t in (r3, x2, r2, x1, r1, x0)])
-        gp = L.PtrArray6(*[g.data_ptr() for g in gouts])
+        masks_t = (r3, x2, r2, x1, r1, x0)
         st = _stream()
-        flop = sum(_conv_flop(ly, B, Lx) for ly in lys)
-        check(_timed('conv1d', 7100, flop, lambda: lib.rtg_resstack_backward(C.byref(d), _p(dy), _p(y), C.byref(wpb),
-                                                                            C.byref(masks), C.byref(gp), st),
-                     f'dgrad {lys[0].name}..stack B{B} L{Lx}', 4 * 14 * x0.numel()), 'resstack bwd')
+        if fused:
+            d = _stack_desc(lys, B, Lx, pre_slope, final_act_slope, reverse=True)
+            wpb = L.PtrArray6(*[bank.bwd_ptr(ly).value for ly in reversed(lys)])
+            masks = L.PtrArray6(*[t.data_ptr() for t in masks_t])
+            gp = L.PtrArray6(*[g.data_ptr() for g in gouts])
+            flop = sum(_conv_flop(ly, B, Lx) for ly in lys)
+            check(_timed('conv1d', 7100, flop, lambda: lib.rtg_resstack_backward(C.byref(d), _p(dy), _p(y), C.byref(wpb),
+                                                                                C.byref(masks), C.byref(gp), st),
+                         f'dgrad {lys[0].name}..stack B{B} L{Lx}', 4 * 14 * x0.numel()), 'resstack bwd')
+        else:
+            g_x = dy                                              # gradient of the block's output x_j
+            if final_act_slope is not None:
+                g_x = torch.empty_like(dy)
+                check(lib.rtg_lrelu_bwd(_p(dy), _p(y), _p(g_x), dy.numel(), final_act_slope, st), 'lrelu_bwd')
+            for j, ly in enumerate(reversed(lys)):
+                # odd j (a block's first conv): g_x_{j-1} = lrelu'(x) * convT(g_r) + g_x, the residual in the epilogue
+                d = _dgrad_desc(ly, B, Lx, Lx, pre_slope)
+                src = g_x if j % 2 == 0 else gouts[j - 1]
+                res = g_x if j % 2 else None
+                _run_conv(d, (_p(src), None, None, bank.bwd_ptr(ly), None, _p(masks_t[j]), _p(res), _p(gouts[j]), None, st),
+                          _conv_flop(ly, B, Lx), f'dgrad {ly.name} B{B} L{Lx}', f'conv1d bwd-data {ly.name}')
+                if j % 2:
+                    g_x = gouts[j]
         if ctx.needs_input_grad[0]:
             ins = (x0, r1, x1, r2, x2, r3)
             dys = (gouts[4], gouts[3], gouts[2], gouts[1], gouts[0], dy)
@@ -422,11 +457,12 @@ class ResStackFn(torch.autograd.Function):
                                                                              f'{lys[0].name}..stack')):
                 if immediate:
                     bank.flush_one(ly, part, splits)
-        return None, (gouts[5] if ctx.needs_input_grad[1] else None), None, None, None
+        return None, (gouts[5] if ctx.needs_input_grad[1] else None), None, None, None, None
 
 
 def resstack(token, lys, x, pre_slope, final_act_slope=None):
-    return ResStackFn.apply(token, x, tuple(lys), float(pre_slope), None if final_act_slope is None else float(final_act_slope))
+    return ResStackFn.apply(token, x, tuple(lys), float(pre_slope), None if final_act_slope is None else float(final_act_slope),
+                            resstack_ok(lys, x))
 
 
 def conv(token, ly, x1, x2=None, res=None, pre_slope=1.0, act=L.ACT_NONE, act_slope=1.0, out_scale=1.0):
