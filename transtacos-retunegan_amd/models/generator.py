@@ -154,6 +154,9 @@ class Generator_RefineGAN_small(BankedModel):
     """Zero-argument constructor, `forward(mel[B,80,T/256], wav_tmpl[B,1,T]) -> wav[B,1,T]`
     (retunegan/train.py:48,126)."""
 
+    # the backward is one serial chain of small launches: weight gradients run beside it (rtg.ops.wgrad_side)
+    wgrad_side = True
+
     def __init__(self):
         super().__init__()
         self.num_kernels = len(hp.resblock_kernel_sizes)
@@ -212,6 +215,9 @@ class Generator_RefineGAN(BankedModel):
     """The full-size RefineGAN (retunegan/models/generator.py:560-667; `hparam.generator_ver = 'RefineGAN'`): same UNet
     at twice the channels with 2-conv ResBlocks, the mel entering through its own conv_pre and the encoder output
     concatenated to it before the first upsampling.  Same constructor / forward signature and state-dict keys."""
+
+    # the backward is one serial chain of small launches: weight gradients run beside it (rtg.ops.wgrad_side)
+    wgrad_side = True
 
     def __init__(self):
         super().__init__()

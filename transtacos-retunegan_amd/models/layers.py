@@ -85,6 +85,7 @@ class BankedModel(nn.Module):
         if self._bank is None or self._bank.device != dev or not self._bank.check_views():
             layers = [(n, m) for n, m in self.named_modules() if isinstance(m, WNConv)]
             self._bank = WeightBank(layers, self._extra_bank_params(), dev)
+            self._bank.wgrad_side = bool(getattr(self, 'wgrad_side', False))
             for ly in self._bank.layers:
                 ly.module._layer = ly
         return self._bank

@@ -172,6 +172,7 @@ class WeightBank:
         self._keep = []          # tensors that must outlive the async kernels reading them within one flush
         self.on_flush = None     # optional callback(gflat) once a backward's weight gradients are complete (DP)
         self._bwd_streams = set()    # streams that ran weight-gradient kernels since the last flush
+        self.wgrad_side = False      # weight gradients on a side stream next to the backward-data chain (ops.wgrad_side)
         self._flush_stream = None    # stream the last flush (writes into gflat) was queued on
 
     # ------------------------------------------------------------------ parameters as views of the flat buffers

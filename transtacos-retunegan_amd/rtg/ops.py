@@ -85,6 +85,47 @@ def _run_wgrad(wd, ptrs, st, bank, ly, tok_id, flop, label, what):
     return part, splits, immediate
 
 
+# Weight gradients off the critical path.  The backward of a chain of layers is the chain of its backward-data launches;
+# a layer's weight gradient depends on that chain but nothing of the chain depends on it.  For a bank that asks for it
+# (`bank.wgrad_side`: the generator, whose layers are small launches that leave most of the chip idle, and whose backward
+# is one serial chain) the weight-gradient launches go to a side stream: they overlap the following backward-data
+# launches instead of delaying them.  The bank's flush waits for every stream that ran weight gradients
+# (note_backward_stream).  Not under the tuner or the per-launch profile (both time launches in isolation).
+# RTG_WGRAD_SIDE=0 turns it off (A/B knob).
+WGRAD_SIDE = _os.environ.get('RTG_WGRAD_SIDE', '1') == '1'
+_SIDE_STREAMS = {}
+
+
+class wgrad_side:
+    """context: the current stream becomes the side stream paired with it (ordered after everything queued so far);
+    `tensors` are the operands the launches inside read: the caching allocator must not recycle them before the side
+    stream is done with them"""
+
+    def __init__(self, bank, tensors):
+        self.on = WGRAD_SIDE and bank.wgrad_side and not tune.ACTIVE and PROFILE is None
+        self.tensors = tensors
+
+    def __enter__(self):
+        if not self.on:
+            return self
+        main = torch.cuda.current_stream()
+        side = _SIDE_STREAMS.get(main)
+        if side is None:
+            side = _SIDE_STREAMS[main] = torch.cuda.Stream(device=main.device)
+        side.wait_stream(main)
+        for t in self.tensors:
+            if t is not None:
+                t.record_stream(side)
+        self.ctx = torch.cuda.stream(side)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.ctx.__exit__(*exc)
+        return False
+
+
 # RTG_WGRAD_GROUP=0: every weight gradient as its own launch (A/B knob)
 WGRAD_GROUP = _os.environ.get('RTG_WGRAD_GROUP', '1') == '1'
 
@@ -321,14 +362,16 @@ class ConvFn(torch.autograd.Function):
                                  part_stride=0)
                 a1, a2, gyt, aux = dy, None, x1, None
             lc = L_out if ly.kind == 'conv' else L_in
-            part, splits, immediate = _run_wgrad(wd, (_p(a1), _p(a2), _p(gyt), _p(aux)), st, bank, ly, ctx.tok_id,
-                                                 _conv_flop(ly, B, lc), f'wgrad {ly.name} B{B} L{L_in}',
-                                                 f'conv1d wgrad {ly.name}')
-            if ly.kind == 'convT':   # bias gradient of a transposed conv: plain channel sum of dy
-                check(lib.rtg_channel_sum(_p(dy), C.c_void_p(bank.gflat.data_ptr() + 4 * ly.b_off), B, ly.cout, L_out,
-                                          st), 'channel_sum')
-            if immediate:
-                bank.flush_one(ly, part, splits)
+            with wgrad_side(bank, (a1, a2, gyt, aux, dy)):
+                st = _stream()
+                part, splits, immediate = _run_wgrad(wd, (_p(a1), _p(a2), _p(gyt), _p(aux)), st, bank, ly, ctx.tok_id,
+                                                     _conv_flop(ly, B, lc), f'wgrad {ly.name} B{B} L{L_in}',
+                                                     f'conv1d wgrad {ly.name}')
+                if ly.kind == 'convT':   # bias gradient of a transposed conv: plain channel sum of dy
+                    check(lib.rtg_channel_sum(_p(dy), C.c_void_p(bank.gflat.data_ptr() + 4 * ly.b_off), B, ly.cout, L_out,
+                                              st), 'channel_sum')
+                if immediate:
+                    bank.flush_one(ly, part, splits)
         return None, dx1, dx2, dres, None, None, None, None, None, None
 
 
@@ -453,10 +496,11 @@ class ResStackFn(torch.autograd.Function):
                                  gy_slope=final_act_slope if last else 1.0, gy_scale=1.0, splits=1, part_stride=0)
                 items.append((wd, (_p(ins[i]), None, _p(dys[i]), _p(y) if last else None), ly, _conv_flop(ly, B, Lx),
                               f'wgrad {ly.name} B{B} L{Lx}', f'conv1d wgrad {ly.name}'))
-            for ly, (part, splits, immediate) in zip(lys, _run_wgrad_group(items, st, bank, ctx.tok_id,
-                                                                             f'{lys[0].name}..stack')):
-                if immediate:
-                    bank.flush_one(ly, part, splits)
+            with wgrad_side(bank, (*ins, *gouts, dy, y)):
+                for ly, (part, splits, immediate) in zip(lys, _run_wgrad_group(items, _stream(), bank, ctx.tok_id,
+                                                                                 f'{lys[0].name}..stack')):
+                    if immediate:
+                        bank.flush_one(ly, part, splits)
         return None, (gouts[5] if ctx.needs_input_grad[1] else None), None, None, None, None
 
 
@@ -732,9 +776,11 @@ class GroupConvFn(torch.autograd.Function):
                               f'wgrad {ly.name} B{B} L{L_in}', f'conv1d wgrad {ly.name}'))
             # one launch for the group where the tuner found that faster, else layer by layer
             # (forking the layers over streams measured slower: 43.9 vs 42.7 ms/step)
-            for ly, (part, splits, immediate) in zip(lys, _run_wgrad_group(items, _stream(), bank, ctx.tok_id, lys[0].name)):
-                if immediate:
-                    bank.flush_one(ly, part, splits)
+            with wgrad_side(bank, (*xs, *dys)):
+                for ly, (part, splits, immediate) in zip(lys, _run_wgrad_group(items, _stream(), bank, ctx.tok_id,
+                                                                                 lys[0].name)):
+                    if immediate:
+                        bank.flush_one(ly, part, splits)
         return (None, None, None, None, *dxs)
 
 
