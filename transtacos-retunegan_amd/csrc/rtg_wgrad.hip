@@ -87,10 +87,16 @@ int geometry(const RtgWgradDesc* d, WgGeom* o) {
     }
   }
   if (o->shape < 0) return d->shape_cfg ? RTG_EINVAL : RTG_ERANGE;
-  // one virtual sequence over all clips: seg_len slots per clip (its Q outputs + the gap that separates patches)
-  const int extra = (d->K - 1) * d->dil + 1 - d->stride;
-  const int Lseg = d->Q + (extra > 0 ? (extra + d->stride - 1) / d->stride : 0);
+  // one virtual sequence over all clips: seg_len slots per clip (its Q outputs + the gap that separates patches).  A
+  // clip's patch is [left padding | L_in samples | right padding]; the right padding of one clip and the left padding of
+  // the next are both zeros, so consecutive patches may OVERLAP by min(left, right) positions: the slots a clip's last
+  // outputs read past its pitch are staged as the next clip's left padding (zero either way).  A "same" k5 conv on rows
+  // of 10 takes 12 slots per clip instead of 14 (reduction steps spent on the gap: 17 % instead of 29 %).
   o->seg_pw = (d->Q - 1) * d->stride + (d->K - 1) * d->dil + 1;
+  const int right = o->seg_pw - d->pad - d->L_in;            // zero slots after the clip's samples (< 0: samples unused)
+  const int overlap = right > 0 ? (right < d->pad ? right : d->pad) : 0;
+  int Lseg = (o->seg_pw - overlap + d->stride - 1) / d->stride;
+  if (Lseg < d->Q) Lseg = d->Q;
   o->seg_len = Lseg;
   if ((long long)d->B * Lseg * d->stride + RTG_PW_MAX >= (1ll << 24)) return RTG_ERANGE;   // float-reciprocal division
   const int per_clip = rtg_ceil_div(d->Q, TT);
