@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define RTG_ABI_VERSION 4
+#define RTG_ABI_VERSION 5
 
 #define RTG_OK 0
 #define RTG_EINVAL (-1)   /* inconsistent descriptor               */
@@ -154,6 +154,25 @@ typedef struct RtgWgradDesc {
 
 int rtg_conv1d_wgrad(const RtgWgradDesc* d, const float* x1, const float* x2, const float* dy, const float* gy_aux,
                      float* part, void* stream);
+/* ------------------------------------------------------------------------------------------------------------
+ * Thin-group strided convolutions on the vector ALUs (rtg_gconv.hip): the grouped k41 layers of DiscriminatorS
+ * (retunegan/models/discrminator.py:39-43: 4-8 input and 8-16 output channels per group, stride 2 / 4), whose groups
+ * are too small for the matrix-core tiles.
+ *   rtg_gconv_ok         1 when an instance serves the shape (K = 41; (Mg, Cg, stride) in (16, 8, 2), (16, 4, 4), (8, 8, 4))
+ *   rtg_gconv_workspace  floats of the layer's weight buffer w
+ *   rtg_gconv_prepare    w[group][ci][tap][oc] = v * scale from the weight-norm parameters (v [C_out][Cg][K], scale[r] =
+ *                        g[r] / ||v[r]|| as written by rtg_weightnorm_scales); once per weight update
+ *   rtg_gconv_forward    out = conv(leaky_relu(x, pre_slope)) + bias
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct RtgGconvDesc {
+  int B, groups, Cg, Mg, K, stride, pad, L_in, L_out;
+  float pre_slope;             /* 1 = no input activation */
+} RtgGconvDesc;
+int rtg_gconv_ok(const RtgGconvDesc* d);
+long long rtg_gconv_workspace(const RtgGconvDesc* d);
+int rtg_gconv_prepare(const RtgGconvDesc* d, const float* v, const float* scale, float* w, void* stream);
+int rtg_gconv_forward(const RtgGconvDesc* d, const float* x, const float* w, const float* bias, float* out, void* stream);
+
 /* n <= RTG_WGRAD_MAX_GROUP problems in ONE launch (the parallel ResBlock branches of a UNet-G decoder stage,
  * generator.py:776-778; the six convs of a ResidualStack, generator.py:33-77).  Every descriptor names the same general
  * block shape (shape_cfg 1..6, as listed by rtg_wgrad_shape_candidates) and its own splits / part_stride; the members

@@ -1,0 +1,69 @@
+"""rtg_gconv.hip: the thin-group k41 layers of DiscriminatorS on the vector ALUs, through the C ABI, against torch's
+grouped conv1d on the CPU (the same effective weights g * v / ||v||).  GPU only."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+CASES = [
+    # B, C_in, C_out, groups, stride, L_in, pre_slope          (discrminator.py:39-43 at the three MSD scales, ragged)
+    (3, 32, 64, 4, 2, 8192, 0.15),
+    (2, 64, 128, 8, 2, 4096, 0.15),
+    (2, 128, 512, 32, 4, 2048, 0.15),
+    (3, 512, 512, 64, 4, 512, 0.15),
+    (2, 512, 512, 64, 4, 128, 0.15),        # one partial tile per clip
+    (2, 128, 512, 32, 4, 1001, 1.0),        # ragged length, no input activation
+    (1, 64, 128, 8, 2, 37, 0.15),           # shorter than the kernel
+    (5, 32, 64, 4, 2, 3000, 0.15),
+]
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_gconv_forward_matches_torch(case):
+    from rtg.lib import lib, GconvDesc
+    B, Cin, Cout, g, s, L, slope = case
+    K, pad = 41, 20
+    Lo = (L + 2 * pad - (K - 1) - 1) // s + 1
+    gen = torch.Generator().manual_seed(Cin + L)
+    x = torch.randn(B, Cin, L, generator=gen)
+    v = torch.randn(Cout, Cin // g, K, generator=gen) * 0.2
+    gg = torch.rand(Cout, generator=gen) + 0.5
+    bias = torch.randn(Cout, generator=gen)
+    scale = gg / v.flatten(1).norm(dim=1)
+    w = v * scale[:, None, None]
+    ref = F.conv1d(F.leaky_relu(x.double(), slope) if slope != 1.0 else x.double(), w.double(), bias.double(), stride=s,
+                   padding=pad, groups=g)
+    d = GconvDesc(B, g, Cin // g, Cout // g, K, s, pad, L, Lo, slope)
+    assert lib.rtg_gconv_ok(C.byref(d)) == 1
+    xd, vd, sd, bd = x.cuda(), v.cuda(), scale.cuda(), bias.cuda()
+    out = torch.full((B, Cout, Lo), float('nan'), device='cuda')
+    n_w = lib.rtg_gconv_workspace(C.byref(d))
+    assert n_w >= v.numel()
+    wbuf = torch.full((n_w,), float('nan'), device='cuda')
+    assert lib.rtg_gconv_prepare(C.byref(d), _ptr(vd), _ptr(sd), _ptr(wbuf), None) == 0
+    # [group][ci][tap][oc] = the effective weights, re-ordered
+    wr = w.view(g, Cout // g, Cin // g, K).permute(0, 2, 3, 1).contiguous().flatten()
+    assert torch.allclose(wbuf.cpu()[:wr.numel()], wr, rtol=1e-6, atol=0)
+    assert lib.rtg_gconv_forward(C.byref(d), _ptr(xd), _ptr(wbuf), _ptr(bd), _ptr(out), None) == 0
+    torch.cuda.synchronize()
+    got = out.cpu().double()
+    assert torch.isfinite(got).all()
+    err = (got - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 2e-6, err
+
+
+def test_gconv_refuses_other_shapes():
+    from rtg.lib import lib, GconvDesc
+    assert lib.rtg_gconv_ok(C.byref(GconvDesc(2, 4, 8, 16, 41, 2, 20, 100, 50, 0.15))) == 1
+    assert lib.rtg_gconv_ok(C.byref(GconvDesc(2, 4, 8, 16, 5, 2, 2, 100, 50, 0.15))) == 0       # k5
+    assert lib.rtg_gconv_ok(C.byref(GconvDesc(2, 4, 16, 16, 41, 2, 20, 100, 50, 0.15))) == 0    # 16 channels per group
+    assert lib.rtg_gconv_ok(C.byref(GconvDesc(2, 4, 8, 16, 41, 2, 20, 100, 51, 0.15))) == 0     # wrong output length

@@ -172,6 +172,7 @@ class WeightBank:
         self._keep = []          # tensors that must outlive the async kernels reading them within one flush
         self.on_flush = None     # optional callback(gflat) once a backward's weight gradients are complete (DP)
         self._bwd_streams = set()    # streams that ran weight-gradient kernels since the last flush
+        self._gconv = {}             # layer id -> [weights for rtg_gconv, token id they were prepared for]
         self.wgrad_side = False      # weight gradients on a side stream next to the backward-data chain (ops.wgrad_side)
         self._flush_stream = None    # stream the last flush (writes into gflat) was queued on
 
@@ -264,6 +265,19 @@ class WeightBank:
         src = loss.detach().reshape(1)
         check(lib.rtg_axpby(_p(src), None, C.c_void_p(self.gflat.data_ptr() + 4 * self.n_params), 1, 1.0, 0.0, 0,
                             _stream()), 'set_flag')
+
+    def gconv_weights(self, ly, gd, tok_id):
+        """the layer's effective weights in the [group][ci][tap][oc] order of rtg_gconv.hip, refreshed once per forward
+        pass (token) from the raw weight-norm parameters and the scales the pass's prepare() wrote"""
+        ent = self._gconv.get(ly.lid)
+        if ent is None:
+            ent = self._gconv[ly.lid] = [torch.empty(lib.rtg_gconv_workspace(C.byref(gd)), device=self.device), -1]
+        if ent[1] != tok_id:
+            check(lib.rtg_gconv_prepare(C.byref(gd), C.c_void_p(self.flat.data_ptr() + 4 * ly.v_off),
+                                        C.c_void_p(self.scales.data_ptr() + 4 * ly.scale_off), _p(ent[0]), _stream()),
+                  'gconv_prepare')
+            ent[1] = tok_id
+        return ent[0]
 
     def fwd_ptr(self, ly):
         return C.c_void_p(self.packed.data_ptr() + 4 * ly.fwd_off)

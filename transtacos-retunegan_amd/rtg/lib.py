@@ -38,6 +38,11 @@ class WgradDesc(C.Structure):
                 ('part_stride', C.c_longlong)] + [(n, C.c_int) for n in ('h_in', 'h_k', 'h_stride', 'h_pad', 'h_n', 'shape_cfg', 'bf16')]
 
 
+class GconvDesc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ('B', 'groups', 'Cg', 'Mg', 'K', 'stride', 'pad', 'L_in', 'L_out')] + \
+               [('pre_slope', C.c_float)]
+
+
 class WgradPtrs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ('x1', 'x2', 'dy', 'gy_aux', 'part')]
 
@@ -83,7 +88,7 @@ CK = 16
 LOSS_L1, LOSS_L1_L1LOG, LOSS_MSE_TARGET, LOSS_MSE_REL = 0, 1, 2, 3
 MAX_LOSS_JOBS = 48
 
-ABI_VERSION = 4            # RTG_ABI_VERSION of include/rtg.h these struct layouts / prototypes were written for
+ABI_VERSION = 5            # RTG_ABI_VERSION of include/rtg.h these struct layouts / prototypes were written for
 _P = C.c_void_p
 _I, _F, _D, _LL, _ULL = C.c_int, C.c_float, C.c_double, C.c_longlong, C.c_ulonglong
 
@@ -99,6 +104,10 @@ PROTOTYPES = {
     'rtg_tapmajor_pays': (_I, [_I, _I, _I]),
     'rtg_conv1d_wgrad': (_I, [C.POINTER(WgradDesc), _P, _P, _P, _P, _P, _P]),
     'rtg_conv1d_wgrad_group': (_I, [_I, C.POINTER(WgradDesc), C.POINTER(WgradPtrs), _P]),
+    'rtg_gconv_ok': (_I, [C.POINTER(GconvDesc)]),
+    'rtg_gconv_workspace': (C.c_longlong, [C.POINTER(GconvDesc)]),
+    'rtg_gconv_prepare': (_I, [C.POINTER(GconvDesc), _P, _P, _P, _P]),
+    'rtg_gconv_forward': (_I, [C.POINTER(GconvDesc), _P, _P, _P, _P, _P]),
     'rtg_wgrad_splits': (_I, [C.POINTER(WgradDesc)]),
     'rtg_wgrad_shape_candidates': (_I, [C.POINTER(WgradDesc), C.POINTER(C.c_int), _I]),
     'rtg_weightnorm_scales': (_I, [_P, _I, _I, _P, _P, _P]),

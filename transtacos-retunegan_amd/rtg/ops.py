@@ -235,6 +235,31 @@ def _desc(**kw):
     return L.Conv1dDesc(**base)
 
 
+# RTG_GCONV=0: the thin-group MSD layers on the matrix cores only (A/B knob)
+GCONV = _os.environ.get('RTG_GCONV', '1') == '1'
+
+
+def _gconv_forward(ly, bank, tok_id, d, args, x_ptr, B, L_in, out, pre_slope, flop, label):
+    """The thin-group k41 layers of MSD (4-8 input, 8-16 output channels per group): matrix cores (tiles that are mostly
+    padding) or the vector ALUs (rtg_gconv.hip), whichever the tuner measured faster for this problem.  d / args: the
+    rtg_conv1d launch of the same plain forward (out = conv(lrelu(x)) + bias) on B clips at x_ptr.  True: ran on the
+    vector ALUs."""
+    if not (GCONV and ly.kind == 'conv' and ly.groups > 1 and ly.k == 41 and not ly.fwd_bf):
+        return False
+    gd = L.GconvDesc(B, ly.groups, ly.cin // ly.groups, ly.cout // ly.groups, ly.k, ly.stride, ly.pad, L_in, out.shape[-1],
+                     pre_slope)
+    if lib.rtg_gconv_ok(C.byref(gd)) != 1:
+        return False
+    d.tile_cfg = tune.conv_cfg(d, lambda: lib.rtg_conv1d(C.byref(d), *args))
+    gargs = (x_ptr, _p(bank.gconv_weights(ly, gd, tok_id)), bank.bias_ptr(ly), _p(out), _stream())
+    if tune.alt_choice(b'gconv' + bytes(gd), [lambda: lib.rtg_conv1d(C.byref(d), *args),
+                                             lambda: lib.rtg_gconv_forward(C.byref(gd), *gargs)]) != 1:
+        return False
+    check(_timed('conv1d', 7200, flop, lambda: lib.rtg_gconv_forward(C.byref(gd), *gargs), label,
+                 _conv_bytes(d, args) if PROFILE is not None else 0), f'gconv {label}')
+    return True
+
+
 class ConvFn(torch.autograd.Function):
     """out = act(out_scale * (conv(pre(xcat)) + bias + res)), conv being the layer's Conv1d or ConvTranspose1d."""
 
@@ -262,8 +287,11 @@ class ConvFn(torch.autograd.Function):
                       pre_slope=pre_slope, out_scale=out_scale, act=act, act_slope=act_slope, tile_m=ly.fwd_tm, tap_major=ly.fwd_tap,
                       bf16=ly.fwd_bf)
         lc = L_out if ly.kind == 'conv' else L_in
-        _run_conv(d, (_p(x1), _p(x2), None, bank.fwd_ptr(ly), bank.bias_ptr(ly), None, _p(res), _p(out), None, _stream()),
-                  _conv_flop(ly, B, lc), f'fwd {ly.name} B{B} L{L_in}', f'conv1d fwd {ly.name}')
+        args = (_p(x1), _p(x2), None, bank.fwd_ptr(ly), bank.bias_ptr(ly), None, _p(res), _p(out), None, _stream())
+        plain = x2 is None and res is None and act == L.ACT_NONE and out_scale == 1.0
+        if not (plain and _gconv_forward(ly, bank, token._rtg_id, d, args, _p(x1), B, L_in, out, pre_slope, _conv_flop(ly, B, lc),
+                                         f'fwd {ly.name} B{B} L{L_in}')):
+            _run_conv(d, args, _conv_flop(ly, B, lc), f'fwd {ly.name} B{B} L{L_in}', f'conv1d fwd {ly.name}')
         ctx.ly, ctx.bank, ctx.tok_id = ly, bank, token._rtg_id
         ctx.cfg = (pre_slope, act, act_slope, out_scale, res_is_input, res is not None)
         ctx.save_for_backward(x1, x2, out if act != L.ACT_NONE else None)
@@ -668,8 +696,10 @@ class PairConvFn(torch.autograd.Function):
         assert C1 == ly.cin
         d, L_out = _fwd_desc(ly, 2 * B, C1, L_in, pre_slope)
         out = torch.empty(2 * B, ly.cout, L_out, device=x_c.device, dtype=torch.float32)
-        _run_conv(d, (_p(x_c), None, None, bank.fwd_ptr(ly), bank.bias_ptr(ly), None, None, _p(out), None, _stream()),
-                  _conv_flop(ly, 2 * B, L_out), f'fwd {ly.name} B{2 * B} L{L_in}', f'conv1d fwd {ly.name}')
+        args = (_p(x_c), None, None, bank.fwd_ptr(ly), bank.bias_ptr(ly), None, None, _p(out), None, _stream())
+        if not _gconv_forward(ly, bank, token._rtg_id, d, args, _p(x_c), 2 * B, L_in, out, pre_slope, _conv_flop(ly, 2 * B, L_out),
+                              f'fwd {ly.name} B{2 * B} L{L_in}'):
+            _run_conv(d, args, _conv_flop(ly, 2 * B, L_out), f'fwd {ly.name} B{2 * B} L{L_in}', f'conv1d fwd {ly.name}')
         o_c, o_g = out[:B], out[B:]
         ctx.ly, ctx.bank, ctx.pre_slope = ly, bank, pre_slope
         ctx.save_for_backward(x_g)

@@ -21,7 +21,7 @@ ENABLED = os.environ.get('RTG_TUNE', '1') != '0'
 ACTIVE = False
 MISSED = False
 REPS = 3
-_conv, _wgrad, _group, _wgroup = {}, {}, {}, {}
+_conv, _wgrad, _group, _wgroup, _alt = {}, {}, {}, {}, {}
 
 
 def _time(launch):
@@ -116,6 +116,23 @@ def wgrad_group_cfg(wds, run_group, run_singles):
             if t is not None and (best_t is None or t < best_t):
                 best, best_t = c + 16 * d, t
     _wgroup[key] = best
+    return best
+
+
+def alt_choice(key, launches):
+    """index of the fastest of several complete ways to run one problem (`launches`: callables returning a status, each
+    already tuned in itself); 0 (the first) until timed"""
+    c = _alt.get(key)
+    if c is not None:
+        return c
+    if not (ENABLED and ACTIVE):
+        return _miss()
+    best, best_t = 0, None
+    for i, f in enumerate(launches):
+        t = _time(f)
+        if t is not None and (best_t is None or t < best_t):
+            best, best_t = i, t
+    _alt[key] = best
     return best
 
 
