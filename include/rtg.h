@@ -163,6 +163,10 @@ int rtg_conv1d_wgrad(const RtgWgradDesc* d, const float* x1, const float* x2, co
  *   rtg_gconv_prepare    w[group][ci][tap][oc] = v * scale from the weight-norm parameters (v [C_out][Cg][K], scale[r] =
  *                        g[r] / ||v[r]|| as written by rtg_weightnorm_scales); once per weight update
  *   rtg_gconv_forward    out = conv(leaky_relu(x, pre_slope)) + bias
+ *   rtg_gconv_prepare_bwd / rtg_gconv_backward_data
+ *                        dx = res + lrelu'(mask) * conv_transpose(dy) with w in [group][oc][tap][ci] order (mask / res
+ *                        NULL: none);
+ *                        d describes the FORWARD problem (L_in = length of dx, L_out = length of dy)
  * ------------------------------------------------------------------------------------------------------------ */
 typedef struct RtgGconvDesc {
   int B, groups, Cg, Mg, K, stride, pad, L_in, L_out;
@@ -172,6 +176,9 @@ int rtg_gconv_ok(const RtgGconvDesc* d);
 long long rtg_gconv_workspace(const RtgGconvDesc* d);
 int rtg_gconv_prepare(const RtgGconvDesc* d, const float* v, const float* scale, float* w, void* stream);
 int rtg_gconv_forward(const RtgGconvDesc* d, const float* x, const float* w, const float* bias, float* out, void* stream);
+int rtg_gconv_prepare_bwd(const RtgGconvDesc* d, const float* v, const float* scale, float* w, void* stream);
+int rtg_gconv_backward_data(const RtgGconvDesc* d, const float* dy, const float* w, const float* mask, const float* res,
+                            float* dx, void* stream);
 
 /* n <= RTG_WGRAD_MAX_GROUP problems in ONE launch (the parallel ResBlock branches of a UNet-G decoder stage,
  * generator.py:776-778; the six convs of a ResidualStack, generator.py:33-77).  Every descriptor names the same general

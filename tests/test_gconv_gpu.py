@@ -61,6 +61,42 @@ def test_gconv_forward_matches_torch(case):
     assert err < 2e-6, err
 
 
+@pytest.mark.parametrize('case', CASES)
+def test_gconv_backward_data_matches_torch(case):
+    """dx of out = conv(leaky_relu(x)) given dy: lrelu'(x) * conv_transpose(dy), against torch autograd in float64"""
+    from rtg.lib import lib, GconvDesc
+    B, Cin, Cout, g, s, L, slope = case
+    K, pad = 41, 20
+    Lo = (L + 2 * pad - (K - 1) - 1) // s + 1
+    gen = torch.Generator().manual_seed(Cin + L + 1)
+    x = torch.randn(B, Cin, L, generator=gen)
+    dy = torch.randn(B, Cout, Lo, generator=gen)
+    v = torch.randn(Cout, Cin // g, K, generator=gen) * 0.2
+    gg = torch.rand(Cout, generator=gen) + 0.5
+    scale = gg / v.flatten(1).norm(dim=1)
+    w = v * scale[:, None, None]
+    xr = x.double().requires_grad_(True)
+    out = F.conv1d(F.leaky_relu(xr, slope) if slope != 1.0 else xr, w.double(), None, stride=s, padding=pad, groups=g)
+    out.backward(dy.double())
+    ref = xr.grad
+    d = GconvDesc(B, g, Cin // g, Cout // g, K, s, pad, L, Lo, slope)
+    xd, dyd, vd, sd = x.cuda(), dy.cuda(), v.cuda(), scale.cuda()
+    wbuf = torch.full((lib.rtg_gconv_workspace(C.byref(d)),), float('nan'), device='cuda')
+    assert lib.rtg_gconv_prepare_bwd(C.byref(d), _ptr(vd), _ptr(sd), _ptr(wbuf), None) == 0
+    wr = w.view(g, Cout // g, Cin // g, K).permute(0, 1, 3, 2).contiguous().flatten()      # [group][oc][tap][ci]
+    assert torch.allclose(wbuf.cpu()[:wr.numel()], wr, rtol=1e-6, atol=0)
+    dx = torch.full((B, Cin, L), float('nan'), device='cuda')
+    res = torch.randn(B, Cin, L, generator=gen)            # a residual gradient riding the epilogue (B even: tested with it)
+    resd = res.cuda() if B % 2 == 0 else None
+    assert lib.rtg_gconv_backward_data(C.byref(d), _ptr(dyd), _ptr(wbuf), _ptr(xd) if slope != 1.0 else None, _ptr(resd),
+                                       _ptr(dx), None) == 0
+    torch.cuda.synchronize()
+    got = dx.cpu().double() - (res.double() if resd is not None else 0.0)
+    assert torch.isfinite(got).all()
+    err = (got - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 2e-6, err
+
+
 def test_gconv_refuses_other_shapes():
     from rtg.lib import lib, GconvDesc
     assert lib.rtg_gconv_ok(C.byref(GconvDesc(2, 4, 8, 16, 41, 2, 20, 100, 50, 0.15))) == 1

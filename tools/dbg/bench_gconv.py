@@ -12,6 +12,14 @@ from models import MultiScaleDiscriminator  # noqa: E402
 from rtg import ops, tune  # noqa: E402
 from rtg.lib import lib, GconvDesc  # noqa: E402
 
+def bank_v(ly):
+    return C.c_void_p(bank.flat.data_ptr() + 4 * ly.v_off)
+
+
+def bank_s(ly):
+    return C.c_void_p(bank.scales.data_ptr() + 4 * ly.scale_off)
+
+
 msd = MultiScaleDiscriminator().cuda()
 tok = msd.token()
 bank = msd.bank()
@@ -38,4 +46,21 @@ for sub, L0 in ((0, 8192), (1, 4096), (2, 2048)):
             fl = 2.0 * B * Lo * ly.cout * (ly.cin // ly.groups) * ly.k
             print(f'd{sub}.convs.{li} Cg{ly.cin // ly.groups} Mg{ly.cout // ly.groups} s{ly.stride} L{L}: mfma {t0 * 1e3:7.1f} us '
                   f'{fl / t0 / 1e9:6.1f} TF/s (cfg {d.tile_cfg})   valu {t1 * 1e3:7.1f} us {fl / t1 / 1e9:6.1f} TF/s')
+            # backward-data of the same layer
+            dy = torch.randn(B, ly.cout, Lo, device='cuda')
+            dx = torch.empty(B, ly.cin, L, device='cuda')
+            dd = ops._dgrad_desc(ly, B, L, Lo, 0.15)
+            dargs = (ops._p(dy), None, None, bank.bwd_ptr(ly), None, ops._p(x), None, ops._p(dx), None, None)
+            tune.ACTIVE = True
+            dd.tile_cfg = tune.conv_cfg(dd, lambda: lib.rtg_conv1d(C.byref(dd), *dargs))
+            tune.ACTIVE = False
+            wb = torch.empty(lib.rtg_gconv_workspace(C.byref(gd)), device='cuda')
+            lib.rtg_gconv_prepare_bwd(C.byref(gd), bank_v(ly), bank_s(ly), ops._p(wb), None)
+            bargs = (ops._p(dy), ops._p(wb), ops._p(x), None, ops._p(dx), None)
+            tune.REPS = 20
+            t0 = tune._time(lambda: lib.rtg_conv1d(C.byref(dd), *dargs)) / 20
+            t1 = tune._time(lambda: lib.rtg_gconv_backward_data(C.byref(gd), *bargs)) / 20
+            tune.REPS = 3
+            print(f'   dgrad: mfma {t0 * 1e3:7.1f} us {fl / t0 / 1e9:6.1f} TF/s (cfg {dd.tile_cfg})   valu {t1 * 1e3:7.1f} us '
+                  f'{fl / t1 / 1e9:6.1f} TF/s')
         L = Lo

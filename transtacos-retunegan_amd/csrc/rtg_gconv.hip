@@ -62,6 +62,16 @@ __global__ __launch_bounds__(RTG_THREADS) void gconv_prep_kernel(const float* __
   w[e] = v[(size_t)row * CK + r] * scale[row];
 }
 
+// backward-data order: w'[g][oc][t][ci] = v[g*MG + oc][ci][t] * scale[g*MG + oc]
+__global__ __launch_bounds__(RTG_THREADS) void gconv_prep_bwd_kernel(const float* __restrict__ v,
+                                                                     const float* __restrict__ scale, float* __restrict__ w,
+                                                                     int CG, int K, int total) {
+  const int e = blockIdx.x * RTG_THREADS + threadIdx.x;          // destination index
+  if (e >= total) return;
+  const int ci = e % CG, t = (e / CG) % K, row = e / (CG * K);
+  w[e] = v[((size_t)row * CG + ci) * K + t] * scale[row];
+}
+
 // A block of TB = 32 / MG taps (32 weights = four 8-register scalar loads): wait for its weights, request the next
 // block's into the other SGPR set, TB * P * MG / 2 packed FMAs.  Scalar loads return out of order, so the only safe wait
 // is lgkmcnt(0), which also covers whatever was requested last: requests are therefore made in blocks, right after the
@@ -208,13 +218,27 @@ __global__ __launch_bounds__(RTG_THREADS) void gconv_fwd_kernel(const float* __r
     // ---- store: P consecutive positions per (lane, output channel)
     if (clip < a.B) {
       float* orow = gout + ((size_t)clip * c_out + (size_t)g * MG) * a.L_out;
+      const bool vec = P % 4 == 0 && (a.L_out & 3) == 0 && (((size_t)gout) & 15) == 0;
 #pragma unroll
       for (int o = 0; o < MG / 2; ++o) {
+        if (vec) {                                    // 16-byte stores: L_out a multiple of 4, q0 a multiple of P
 #pragma unroll
-        for (int p = 0; p < P; ++p) {
-          if (q0 + p < a.L_out) {
-            orow[(size_t)(2 * o) * a.L_out + q0 + p] = acc[o][p].x;
-            orow[(size_t)(2 * o + 1) * a.L_out + q0 + p] = acc[o][p].y;
+          for (int p = 0; p + 3 < P; p += 4) {
+            if (q0 + p < a.L_out) {
+              f32x4 v0, v1;
+              v0.x = acc[o][p].x; v0.y = acc[o][p + 1].x; v0.z = acc[o][p + 2].x; v0.w = acc[o][p + 3].x;
+              v1.x = acc[o][p].y; v1.y = acc[o][p + 1].y; v1.z = acc[o][p + 2].y; v1.w = acc[o][p + 3].y;
+              *reinterpret_cast<f32x4*>(orow + (size_t)(2 * o) * a.L_out + q0 + p) = v0;
+              *reinterpret_cast<f32x4*>(orow + (size_t)(2 * o + 1) * a.L_out + q0 + p) = v1;
+            }
+          }
+        } else {
+#pragma unroll
+          for (int p = 0; p < P; ++p) {
+            if (q0 + p < a.L_out) {
+              orow[(size_t)(2 * o) * a.L_out + q0 + p] = acc[o][p].x;
+              orow[(size_t)(2 * o + 1) * a.L_out + q0 + p] = acc[o][p].y;
+            }
           }
         }
       }
@@ -248,9 +272,206 @@ int launch_fwd(const RtgGconvDesc* d, const float* x, const float* w, const floa
   return launch_lpc<MG, CG, S, P, 8>(d, x, w, bias, out, a, s);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// backward-data: dx[ci][i] = res[ci][i] + mask(x[ci][i]) * sum over (oc, tap t with (i + PAD - t) % S == 0) of
+// w[oc][ci][t] * dy[oc][(i + PAD - t) / S].  Same structure with the roles swapped: a lane owns P consecutive INPUT
+// positions (P a multiple of S, first position a multiple of S: which taps reach which position is then a compile-time
+// pattern) of all CG input channels of a group, the reduction runs over the MG output channels with the window of
+// dy[oc] in registers, the weights are [group][oc][tap][ci] (rtg_gconv_prepare_bwd) in blocks of 32 = 32 / CG taps.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int GPAD = 20;                    // padding of every layer this file serves
+
+template <int BI, int CG, int S, int P, int NW>
+__device__ __forceinline__ void tap_block_bwd(f32x2 (&acc)[CG / 2][P], const f32x2 (&win)[NW], f32x8 (&wq)[2][4],
+                                              const float* wrow) {
+  constexpr int TB = 32 / CG, NB = (GK + TB - 1) / TB;
+  constexpr int M0 = -((GK - 1 - GPAD + S - 1) / S);        // floor((GPAD - (GK - 1)) / S): first window element's offset
+#pragma unroll
+  for (int h = 0; h < 4; ++h) swait(wq[BI % 2][h]);
+  if (BI + 1 < NB) {
+#pragma unroll
+    for (int h = 0; h < 4; ++h) sload(wq[(BI + 1) % 2][h], wrow + (BI + 1) * 32 + 8 * h);
+  }
+#pragma unroll
+  for (int tb = 0; tb < TB; ++tb) {
+    const int t = BI * TB + tb;
+    if (t < GK) {
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        if ((p + GPAD - t + 64 * S) % S == 0) {            // tap t reaches position p of the lane
+          const int e = (p + GPAD - t + 64 * S) / S - 64 - M0;   // window element: dy position (p + GPAD - t) / S
+#pragma unroll
+          for (int c = 0; c < CG / 2; ++c) {
+            const int wi = tb * CG + 2 * c;
+            const f32x8 wv = wq[BI % 2][wi / 8];
+            f32x2 w2;
+            w2.x = wv[wi % 8]; w2.y = wv[wi % 8 + 1];
+            if (e & 1) pkfma_hi(acc[c][p], w2, win[e / 2]);
+            else pkfma_lo(acc[c][p], w2, win[e / 2]);
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int CG, int S, int P, int NW, int... BI>
+__device__ __forceinline__ void all_taps_bwd(f32x2 (&acc)[CG / 2][P], const f32x2 (&win)[NW], f32x8 (&wq)[2][4],
+                                             const float* wrow, std::integer_sequence<int, BI...>) {
+  (tap_block_bwd<BI, CG, S, P, NW>(acc, win, wq, wrow), ...);
+}
+
+template <int MG, int CG, int S, int P, int LPC>
+__global__ __launch_bounds__(RTG_THREADS) void gconv_bwd_kernel(const float* __restrict__ gdy, const float* __restrict__ gw,
+                                                                const float* __restrict__ gmask, const float* __restrict__ gres,
+                                                                float* __restrict__ gdx, const GcArgs a) {
+  static_assert(P % S == 0 && P % 4 == 0, "a lane's positions cover whole phase periods");
+  constexpr int CPW = 64 / LPC;
+  constexpr int M0 = -((GK - 1 - GPAD + S - 1) / S);
+  constexpr int WIN = (P - 1 + GPAD) / S - M0 + 1;          // dy samples a lane's P positions read per output channel
+  constexpr int WINP = (WIN + 3) & ~3;
+  constexpr int SPAN = LPC * P / S;                         // dy samples between consecutive tiles
+  constexpr int ROWF = ((SPAN + WINP) + 3) & ~3;
+  constexpr int NLD = (CPW * ROWF + 63) / 64;
+  __shared__ __attribute__((aligned(16))) float ys[4][2][CPW * ROWF];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int sub = lane / LPC, ll = lane - sub * LPC;
+  const int c_in = a.groups * CG, c_out = a.groups * MG;
+  const rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)gdy, 0, a.B * c_out * a.L_out * 4, 0x00020000);
+  for (int item = blockIdx.x * 4 + wave; item < a.n_items; item += gridDim.x * 4) {
+    const int per_g = a.csets * a.tiles;
+    const int g = item / per_g;
+    const int rest = item - g * per_g;
+    const int cset = rest / a.tiles, tile = rest - cset * a.tiles;
+    const int clip = cset * CPW + sub;
+    const int i0 = (tile * LPC + ll) * P;             // the lane's first input position (a multiple of S)
+    f32x2 acc[CG / 2][P];
+#pragma unroll
+    for (int c = 0; c < CG / 2; ++c)
+#pragma unroll
+      for (int p = 0; p < P; ++p) { acc[c][p].x = 0.f; acc[c][p].y = 0.f; }
+    const int q_tile = tile * SPAN + M0;              // dy index of the tile's first staged sample
+    const float* wg = gw + (size_t)g * (MG * GK * CG);
+    unsigned soff[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int j = lane + 64 * i;
+      const int sc = j / ROWF, w = j - sc * ROWF;
+      const int q = q_tile + w;
+      const int c = cset * CPW + sc;
+      const bool ok = j < CPW * ROWF && q >= 0 && q < a.L_out && c < a.B;
+      soff[i] = ok ? (unsigned)((c * c_out + g * MG) * a.L_out + q) * 4u : 0x80000000u;
+    }
+    float st[NLD];
+    auto fetch = [&](int oc) __attribute__((always_inline)) {
+      const unsigned coff = (unsigned)(oc * a.L_out) * 4u;
+#pragma unroll
+      for (int i = 0; i < NLD; ++i) st[i] = gload(ry, soff[i] + coff);
+    };
+    auto publish = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < NLD; ++i) {
+        const int j = lane + 64 * i;
+        if (j < CPW * ROWF) ys[wave][buf][j] = st[i];
+      }
+    };
+    fetch(0);
+    publish(0);
+#pragma unroll 1
+    for (int oc = 0; oc < MG; ++oc) {
+      if (oc + 1 < MG) fetch(oc + 1);
+      f32x2 win[WINP / 2];
+      const float* yw = &ys[wave][oc & 1][sub * ROWF + ll * (P / S)];
+#pragma unroll
+      for (int j = 0; j < WINP; j += 4) {
+        const f32x4 q = *reinterpret_cast<const f32x4*>(yw + j);
+        win[j / 2].x = q.x; win[j / 2].y = q.y; win[j / 2 + 1].x = q.z; win[j / 2 + 1].y = q.w;
+      }
+      const float* wrow = wg + oc * (GK * CG);
+      f32x8 wq[2][4];
+#pragma unroll
+      for (int h = 0; h < 4; ++h) sload(wq[0][h], wrow + 8 * h);
+      all_taps_bwd<CG, S, P, WINP / 2>(acc, win, wq, wrow, std::make_integer_sequence<int, (GK + 32 / CG - 1) / (32 / CG)>{});
+      if (oc + 1 < MG) publish((oc + 1) & 1);
+    }
+    // ---- dx = mask(x) * acc: P consecutive positions per (lane, input channel); 16-byte accesses when the rows are
+    // 16-byte aligned (L_in a multiple of 4: a lane's first position is a multiple of P)
+    if (clip < a.B) {
+      const size_t rowb = ((size_t)clip * c_in + (size_t)g * CG) * a.L_in;
+      const bool vec = (a.L_in & 3) == 0 && ((((size_t)gdx) | ((size_t)gmask) | ((size_t)gres)) & 15) == 0;
+#pragma unroll
+      for (int c = 0; c < CG / 2; ++c) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const size_t rb = rowb + (size_t)(2 * c + h) * a.L_in;
+          if (vec) {
+#pragma unroll
+            for (int p = 0; p < P; p += 4) {
+              if (i0 + p < a.L_in) {                  // whole quads: L_in is a multiple of 4
+                f32x4 v;
+                v.x = h ? acc[c][p].y : acc[c][p].x;
+                v.y = h ? acc[c][p + 1].y : acc[c][p + 1].x;
+                v.z = h ? acc[c][p + 2].y : acc[c][p + 2].x;
+                v.w = h ? acc[c][p + 3].y : acc[c][p + 3].x;
+                if (gmask) {
+                  const f32x4 m = *reinterpret_cast<const f32x4*>(gmask + rb + i0 + p);
+                  v.x *= m.x > 0.f ? 1.f : a.slope; v.y *= m.y > 0.f ? 1.f : a.slope;
+                  v.z *= m.z > 0.f ? 1.f : a.slope; v.w *= m.w > 0.f ? 1.f : a.slope;
+                }
+                if (gres) {
+                  const f32x4 r = *reinterpret_cast<const f32x4*>(gres + rb + i0 + p);
+                  v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+                }
+                *reinterpret_cast<f32x4*>(gdx + rb + i0 + p) = v;
+              }
+            }
+          } else {
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+              if (i0 + p < a.L_in) {
+                float v = h ? acc[c][p].y : acc[c][p].x;
+                if (gmask) v *= gmask[rb + i0 + p] > 0.f ? 1.f : a.slope;
+                if (gres) v += gres[rb + i0 + p];
+                gdx[rb + i0 + p] = v;
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int MG, int CG, int S, int P, int LPC>
+int launch_bwd_lpc(const RtgGconvDesc* d, const float* dy, const float* w, const float* mask, const float* res, float* dx,
+                   const GcArgs& a0,
+                   hipStream_t s) {
+  GcArgs a = a0;
+  a.tiles = rtg_ceil_div(d->L_in, LPC * P);
+  a.csets = rtg_ceil_div(d->B, 64 / LPC);
+  const long long items = (long long)d->groups * a.csets * a.tiles;
+  if (items > (1ll << 30)) return RTG_ERANGE;
+  a.n_items = (int)items;
+  int blocks = rtg_ceil_div(items, 4);
+  if (blocks > 2048) blocks = 2048;
+  RTG_KLAUNCH((gconv_bwd_kernel<MG, CG, S, P, LPC>), dim3(blocks), dim3(RTG_THREADS), 0, s, dy, w, mask, res, dx, a);
+  return rtg_launch_status();
+}
+
+template <int MG, int CG, int S, int P>
+int launch_bwd(const RtgGconvDesc* d, const float* dy, const float* w, const float* mask, const float* res, float* dx,
+               const GcArgs& a,
+               hipStream_t s) {
+  const int need = rtg_ceil_div(d->L_in, P);
+  if (need > 32) return launch_bwd_lpc<MG, CG, S, P, 64>(d, dy, w, mask, res, dx, a, s);
+  if (need > 16) return launch_bwd_lpc<MG, CG, S, P, 32>(d, dy, w, mask, res, dx, a, s);
+  if (need > 8) return launch_bwd_lpc<MG, CG, S, P, 16>(d, dy, w, mask, res, dx, a, s);
+  return launch_bwd_lpc<MG, CG, S, P, 8>(d, dy, w, mask, res, dx, a, s);
+}
+
 // instance serving the problem: 1 = (16, 8, s2), 2 = (16, 4, s4), 3 = (8, 8, s4); 0 = none
 int gconv_kind(const RtgGconvDesc* d) {
-  if (!d || d->K != GK || d->B < 1 || d->groups < 1 || d->L_in < 1 || d->L_out < 1 || d->pad < 0) return 0;
+  if (!d || d->K != GK || d->B < 1 || d->groups < 1 || d->L_in < 1 || d->L_out < 1 || d->pad != GPAD) return 0;
   if ((long long)d->B * d->groups * (d->Cg > d->Mg ? d->Cg : d->Mg) * (d->L_in > d->L_out ? d->L_in : d->L_out) * 4 >=
       (1ll << 31))
     return 0;
@@ -277,6 +498,30 @@ extern "C" int rtg_gconv_prepare(const RtgGconvDesc* d, const float* v, const fl
   RTG_KLAUNCH(gconv_prep_kernel, dim3(rtg_ceil_div(total, RTG_THREADS)), dim3(RTG_THREADS), 0, (hipStream_t)stream, v, scale, w,
               d->Mg, d->Cg * d->K, total);
   return rtg_launch_status();
+}
+
+extern "C" int rtg_gconv_prepare_bwd(const RtgGconvDesc* d, const float* v, const float* scale, float* w, void* stream) {
+  if (!d || !v || !scale || !w) return RTG_ENULL;
+  if (!gconv_kind(d)) return RTG_EINVAL;
+  const int total = d->groups * d->Mg * d->Cg * d->K;
+  RTG_KLAUNCH(gconv_prep_bwd_kernel, dim3(rtg_ceil_div(total, RTG_THREADS)), dim3(RTG_THREADS), 0, (hipStream_t)stream, v, scale,
+              w, d->Cg, d->K, total);
+  return rtg_launch_status();
+}
+
+extern "C" int rtg_gconv_backward_data(const RtgGconvDesc* d, const float* dy, const float* w, const float* mask,
+                                       const float* res, float* dx, void* stream) {
+  if (!d || !dy || !w || !dx) return RTG_ENULL;
+  const int kind = gconv_kind(d);
+  if (!kind) return RTG_EINVAL;
+  GcArgs a;
+  a.B = d->B; a.groups = d->groups; a.L_in = d->L_in; a.L_out = d->L_out; a.pad = d->pad;
+  a.slope = d->pre_slope;
+  a.tiles = 0; a.csets = 0; a.n_items = 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (kind == 1) return launch_bwd<16, 8, 2, 8>(d, dy, w, mask, res, dx, a, s);
+  if (kind == 2) return launch_bwd<16, 4, 4, 16>(d, dy, w, mask, res, dx, a, s);
+  return launch_bwd<8, 8, 4, 8>(d, dy, w, mask, res, dx, a, s);
 }
 
 extern "C" int rtg_gconv_forward(const RtgGconvDesc* d, const float* x, const float* w, const float* bias, float* out,

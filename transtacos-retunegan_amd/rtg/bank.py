@@ -266,14 +266,17 @@ class WeightBank:
         check(lib.rtg_axpby(_p(src), None, C.c_void_p(self.gflat.data_ptr() + 4 * self.n_params), 1, 1.0, 0.0, 0,
                             _stream()), 'set_flag')
 
-    def gconv_weights(self, ly, gd, tok_id):
-        """the layer's effective weights in the [group][ci][tap][oc] order of rtg_gconv.hip, refreshed once per forward
-        pass (token) from the raw weight-norm parameters and the scales the pass's prepare() wrote"""
-        ent = self._gconv.get(ly.lid)
+    def gconv_weights(self, ly, gd, tok_id, bwd=False):
+        """the layer's effective weights in the [group][ci][tap][oc] order of rtg_gconv.hip ([group][oc][tap][ci] for the
+        backward-data kernel), refreshed once per forward pass (token) from the raw weight-norm parameters and the
+        scales the pass's prepare() wrote"""
+        key = (ly.lid, bwd)
+        ent = self._gconv.get(key)
         if ent is None:
-            ent = self._gconv[ly.lid] = [torch.empty(lib.rtg_gconv_workspace(C.byref(gd)), device=self.device), -1]
+            ent = self._gconv[key] = [torch.empty(lib.rtg_gconv_workspace(C.byref(gd)), device=self.device), -1]
         if ent[1] != tok_id:
-            check(lib.rtg_gconv_prepare(C.byref(gd), C.c_void_p(self.flat.data_ptr() + 4 * ly.v_off),
+            prep = lib.rtg_gconv_prepare_bwd if bwd else lib.rtg_gconv_prepare
+            check(prep(C.byref(gd), C.c_void_p(self.flat.data_ptr() + 4 * ly.v_off),
                                         C.c_void_p(self.scales.data_ptr() + 4 * ly.scale_off), _p(ent[0]), _stream()),
                   'gconv_prepare')
             ent[1] = tok_id

@@ -108,6 +108,8 @@ PROTOTYPES = {
     'rtg_gconv_workspace': (C.c_longlong, [C.POINTER(GconvDesc)]),
     'rtg_gconv_prepare': (_I, [C.POINTER(GconvDesc), _P, _P, _P, _P]),
     'rtg_gconv_forward': (_I, [C.POINTER(GconvDesc), _P, _P, _P, _P, _P]),
+    'rtg_gconv_prepare_bwd': (_I, [C.POINTER(GconvDesc), _P, _P, _P, _P]),
+    'rtg_gconv_backward_data': (_I, [C.POINTER(GconvDesc), _P, _P, _P, _P, _P, _P]),
     'rtg_wgrad_splits': (_I, [C.POINTER(WgradDesc)]),
     'rtg_wgrad_shape_candidates': (_I, [C.POINTER(WgradDesc), C.POINTER(C.c_int), _I]),
     'rtg_weightnorm_scales': (_I, [_P, _I, _I, _P, _P, _P]),

@@ -260,6 +260,24 @@ def _gconv_forward(ly, bank, tok_id, d, args, x_ptr, B, L_in, out, pre_slope, fl
     return True
 
 
+def _gconv_dgrad(ly, bank, tok_id, d, args, dy_ptr, mask_ptr, res_ptr, B, L_in, L_out, dx, pre_slope, flop, label):
+    """backward-data of the same layers: dx = res + lrelu'(x) * conv_transpose(dy); d / args: the rtg_conv1d launch of it"""
+    if not (GCONV and ly.kind == 'conv' and ly.groups > 1 and ly.k == 41 and not ly.bwd_bf):
+        return False
+    gd = L.GconvDesc(B, ly.groups, ly.cin // ly.groups, ly.cout // ly.groups, ly.k, ly.stride, ly.pad, L_in, L_out, pre_slope)
+    if lib.rtg_gconv_ok(C.byref(gd)) != 1:
+        return False
+    d.tile_cfg = tune.conv_cfg(d, lambda: lib.rtg_conv1d(C.byref(d), *args))
+    gargs = (dy_ptr, _p(bank.gconv_weights(ly, gd, tok_id, bwd=True)), mask_ptr if pre_slope != 1.0 else None, res_ptr, _p(dx),
+             _stream())
+    if tune.alt_choice(b'gconv_bwd' + bytes(gd), [lambda: lib.rtg_conv1d(C.byref(d), *args),
+                                                 lambda: lib.rtg_gconv_backward_data(C.byref(gd), *gargs)]) != 1:
+        return False
+    check(_timed('conv1d', 7201, flop, lambda: lib.rtg_gconv_backward_data(C.byref(gd), *gargs), label,
+                 _conv_bytes(d, args) if PROFILE is not None else 0), f'gconv {label}')
+    return True
+
+
 class ConvFn(torch.autograd.Function):
     """out = act(out_scale * (conv(pre(xcat)) + bias + res)), conv being the layer's Conv1d or ConvTranspose1d."""
 
@@ -367,8 +385,11 @@ class ConvFn(torch.autograd.Function):
                           mask_slope=pre_slope, out_scale=out_scale, tile_m=ly.bwd_tm, out_split=split,
                           tap_major=ly.bwd_tap, bf16=ly.bwd_bf)
             lc = L_out if ly.kind == 'conv' else L_in
-            _run_conv(d, (_p(dy), None, _p(out), bank.bwd_ptr(ly), None, _p(mask), _p(resg), _p(dx1), _p(dx2), st),
-                      _conv_flop(ly, B, lc), f'dgrad {ly.name} B{B} L{L_in}', f'conv1d bwd-data {ly.name}')
+            dargs = (_p(dy), None, _p(out), bank.bwd_ptr(ly), None, _p(mask), _p(resg), _p(dx1), _p(dx2), st)
+            plain = C2 == 0 and gy_mode == L.PRE_NONE and out_scale == 1.0 and dx2 is None
+            if not (plain and _gconv_dgrad(ly, bank, ctx.tok_id, d, dargs, _p(dy), _p(x1), _p(resg), B, L_in, L_out, dx1, pre_slope,
+                                           _conv_flop(ly, B, lc), f'dgrad {ly.name} B{B} L{L_in}')):
+                _run_conv(d, dargs, _conv_flop(ly, B, lc), f'dgrad {ly.name} B{B} L{L_in}', f'conv1d bwd-data {ly.name}')
             if not need_x1:
                 dx1 = None
 
@@ -701,7 +722,7 @@ class PairConvFn(torch.autograd.Function):
                               f'fwd {ly.name} B{2 * B} L{L_in}'):
             _run_conv(d, args, _conv_flop(ly, 2 * B, L_out), f'fwd {ly.name} B{2 * B} L{L_in}', f'conv1d fwd {ly.name}')
         o_c, o_g = out[:B], out[B:]
-        ctx.ly, ctx.bank, ctx.pre_slope = ly, bank, pre_slope
+        ctx.ly, ctx.bank, ctx.pre_slope, ctx.tok_id = ly, bank, pre_slope, token._rtg_id
         ctx.save_for_backward(x_g)
         ctx.mark_non_differentiable(o_c)
         ctx.set_materialize_grads(False)
@@ -728,9 +749,11 @@ class PairConvFn(torch.autograd.Function):
         dx = torch.empty_like(x_g)
         d = _dgrad_desc(ly, B, L_in, L_out, pre_slope)
         res = _c(d_tap) if d_tap is not None else None            # dx = lrelu'(x) * convT(d_g) + d_tap
-        _run_conv(d, (_p(d_g), None, None, bank.bwd_ptr(ly), None, _p(x_g) if pre_slope != 1.0 else None, _p(res), _p(dx),
-                      None, _stream()),
-                  _conv_flop(ly, B, L_out), f'dgrad {ly.name} B{B} L{L_in}', f'conv1d bwd-data {ly.name}')
+        dargs = (_p(d_g), None, None, bank.bwd_ptr(ly), None, _p(x_g) if pre_slope != 1.0 else None, _p(res), _p(dx), None,
+                 _stream())
+        if not _gconv_dgrad(ly, bank, ctx.tok_id, d, dargs, _p(d_g), _p(x_g), _p(res), B, L_in, L_out, dx, pre_slope,
+                            _conv_flop(ly, B, L_out), f'dgrad {ly.name} B{B} L{L_in}'):
+            _run_conv(d, dargs, _conv_flop(ly, B, L_out), f'dgrad {ly.name} B{B} L{L_in}', f'conv1d bwd-data {ly.name}')
         return None, None, None, None, None, dx
 
 
