@@ -403,4 +403,10 @@ def test_full_size_generator_side_gradient_is_per_clip(nets):
     b0 = 9
     part = grad_of(y[b0:b0 + 2].contiguous(), yh[b0:b0 + 2].contiguous())
     scale = full.abs().max().item()
-    np.testing.assert_allclose(part.cpu().numpy(), full[b0:b0 + 2].cpu().numpy(), atol=2e-4 * scale, rtol=1e-3)
+    # the batch of 32 and the batch of 2 are different problems for the tuner (matrix-core or vector-ALU kernel, block
+    # shape: other summation orders), so a feature-map element within rounding of 0 can take the other leaky-relu branch
+    # in one of them: relative L2 over the wave, and a bound on the few elements such a flip moves
+    a, b = part.cpu().double(), full[b0:b0 + 2].cpu().double()
+    assert ((a - b).norm() / b.norm()).item() < 2e-4
+    assert (a - b).abs().max().item() < 3e-3 * scale
+    assert ((a - b).abs() > 2e-4 * scale).double().mean().item() < 5e-3

@@ -233,3 +233,30 @@ def test_grouped_wgrad_is_bit_identical_to_the_members_own_launches(members, div
     # refused: a member on a kernel of its own (shape 8), and a member whose rows use the 16-row tile
     darr[0].shape_cfg = 8
     assert lib.rtg_conv1d_wgrad_group(n, darr, parr, None) != 0
+
+
+GCONV_CASES = [
+    # the thin-group k41 layers of DiscriminatorS (discrminator.py:39-43), three scales, ragged batches / lengths
+    (3, 32, 64, 8192, 41, 2, 1, 20, 4),
+    (2, 64, 128, 4096, 41, 2, 1, 20, 8),
+    (2, 128, 512, 2048, 41, 4, 1, 20, 32),
+    (3, 512, 512, 512, 41, 4, 1, 20, 64),
+    (5, 512, 512, 128, 41, 4, 1, 20, 64),
+    (2, 128, 512, 1001, 41, 4, 1, 20, 32),    # ragged: the last position block of a clip is partial
+    (1, 64, 128, 37, 41, 2, 1, 20, 8),        # shorter than the kernel
+]
+
+
+@pytest.mark.parametrize('case', GCONV_CASES)
+def test_gconv_wgrad_on_the_vector_alus(case):
+    """rtg_gconv.hip backward-weight (shape code 9): listed as a candidate for exactly these layers; weight, bias and
+    weight-norm gradients through the usual split partials against torch autograd."""
+    from rtg.lib import lib, WgradDesc
+    B, Cin, Cout, L, K, s, d, p, g = case
+    Lo = (L + 2 * p - d * (K - 1) - 1) // s + 1
+    probe = WgradDesc(B=B, C1=Cin, C2=0, L_in=L, groups=g, Cg=Cin // g, Mg=Cout // g, K=K, stride=s, dil=d, pad=p, Q=Lo,
+                      dy_L=Lo, pre_mode=1, pre_slope=0.15, gy_mode=0, gy_slope=1.0, gy_scale=1.0, splits=1, part_stride=0)
+    cands = (C.c_int * 12)()
+    n = lib.rtg_wgrad_shape_candidates(C.byref(probe), cands, 12)
+    assert 9 in list(cands[:n])
+    _check_case(case, shape_cfg=9, act='none')

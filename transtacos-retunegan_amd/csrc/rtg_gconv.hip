@@ -469,6 +469,188 @@ int launch_bwd(const RtgGconvDesc* d, const float* dy, const float* w, const flo
   return launch_bwd_lpc<MG, CG, S, P, 8>(d, dy, w, mask, res, dx, a, s);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// backward-weight: dW[oc][ci][t] = sum over (clip, q) of dy[oc][q] * act(x[ci][q*S + t - PAD]), bias: sum of dy.
+// Here the OUTPUTS are spread over the lanes: a lane owns COLS of a group's CG*41 + 1 (input channel, tap) columns (the
+// last one is the bias: x = 1) for 8 output channels, and walks positions; dy is uniform over the lanes: SGPR pairs of
+// two consecutive positions (one s_buffer_load_dwordx4 per output channel and 4 positions, range-checked: the row tail
+// reads as 0), x pairs of the same two positions come from the wave's staged LDS rows (two reads S apart per column).
+// One packed FMA adds both positions into an (even, odd) accumulator pair, summed at the end.  No cross-lane reduction;
+// a wave handles one (group, output-channel half, split) and writes one split partial in the bank's layout
+// ([split][rows][CG*41] + [rows] bias), reduced in fixed order by rtg_weightnorm_backward like every other partial.
+// ---------------------------------------------------------------------------------------------------------------
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+struct GwArgs {
+  int B, groups, L_in, L_out;
+  int W, bpc, n_blocks, per;                // splits, position blocks per clip, blocks in all, blocks per split
+  long long part_stride;
+  float slope;
+};
+
+__device__ __forceinline__ void sbload4(f32x4& w, u32x4 rsrc, unsigned off) {
+  asm volatile("s_buffer_load_dwordx4 %0, %1, %2" : "=&s"(w) : "s"(rsrc), "s"(off));
+}
+__device__ __forceinline__ void swait4(f32x4& w) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(w)); }
+// acc.{lo,hi} += dy.{lo,hi} * x.{lo,hi}
+__device__ __forceinline__ void pkfma2(f32x2& acc, f32x2 w, f32x2 x) {
+  asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc) : "s"(w), "v"(x));
+}
+
+template <int MG, int CG, int S>
+__global__ __launch_bounds__(RTG_THREADS) void gconv_wgrad_kernel(const float* __restrict__ gx, const float* __restrict__ gdy,
+                                                                  float* __restrict__ gpart, const GwArgs a) {
+  constexpr int OCW = 8, HALVES = MG / OCW;
+  constexpr int N = CG * GK, COLS = (N + 1 + 63) / 64;
+  constexpr int PB = 32;                                    // positions per staged block
+  constexpr int ROWW = (((PB - 1) * S + GK) + 3) & ~3;      // staged samples per input channel
+  constexpr int NLD = (CG * ROWW + 63) / 64;
+  constexpr int ONES = CG * ROWW, ZEROS = ONES + ROWW;
+  __shared__ __attribute__((aligned(16))) float xs[4][ZEROS + ROWW];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wi = blockIdx.x * 4 + wave;
+  if (wi >= a.groups * HALVES * a.W) return;                // (no block barriers below: every wave is on its own)
+  const int split = wi % a.W;
+  const int gh = wi / a.W;
+  const int half = gh % HALVES, g = gh / HALVES;
+  const int c_in = a.groups * CG, c_out = a.groups * MG;
+  float* xw = xs[wave];
+  for (int k = lane; k < ROWW; k += 64) { xw[ONES + k] = 1.f; xw[ZEROS + k] = 0.f; }
+  int colbase[COLS];
+#pragma unroll
+  for (int j = 0; j < COLS; ++j) {
+    const int n = lane + 64 * j;
+    const int ci = n / GK, t = n - ci * GK;
+    colbase[j] = n < N ? ci * ROWW + t : (n == N ? ONES : ZEROS);
+  }
+  f32x2 acc[OCW][COLS];
+#pragma unroll
+  for (int o = 0; o < OCW; ++o)
+#pragma unroll
+    for (int j = 0; j < COLS; ++j) { acc[o][j].x = 0.f; acc[o][j].y = 0.f; }
+  const rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)gx, 0, a.B * c_in * a.L_in * 4, 0x00020000);
+  const bool act = a.slope != 1.f;
+  const int blk0 = split * a.per;
+  int blk1 = blk0 + a.per;
+  if (blk1 > a.n_blocks) blk1 = a.n_blocks;
+  float st[NLD];
+  auto fetch = [&](int blk) __attribute__((always_inline)) {
+    const int b = blk / a.bpc, q0 = (blk - b * a.bpc) * PB;
+    const int e0 = q0 * S - GPAD;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int e = lane + 64 * i;
+      const int ci = e / ROWW, k = e - ci * ROWW;
+      const int idx = e0 + k;
+      const bool ok = e < CG * ROWW && idx >= 0 && idx < a.L_in;
+      st[i] = gload(rx, ok ? (unsigned)((b * c_in + g * CG + ci) * a.L_in + idx) * 4u : 0x80000000u);
+    }
+  };
+  auto publish = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int e = lane + 64 * i;
+      float v = st[i];
+      if (act) v = v > 0.f ? v : v * a.slope;
+      if (e < CG * ROWW) xw[e] = v;
+    }
+  };
+  if (blk0 < blk1) fetch(blk0);
+#pragma unroll 1
+  for (int blk = blk0; blk < blk1; ++blk) {
+    publish();
+    if (blk + 1 < blk1) fetch(blk + 1);               // in flight during this block's FMAs
+    const int b = blk / a.bpc, q0 = (blk - b * a.bpc) * PB;
+    // dy rows of this wave's 8 output channels: one range-checked descriptor per row (built on the scalar unit)
+    const unsigned long long row0 = (unsigned long long)gdy +
+                                    ((unsigned long long)(b * c_out + g * MG + half * OCW) * a.L_out) * 4ull;
+    auto rsrc_of = [&](int o) __attribute__((always_inline)) {
+      const unsigned long long p = row0 + (unsigned long long)o * a.L_out * 4ull;
+      u32x4 r;
+      r.x = (unsigned)p; r.y = (unsigned)(p >> 32) & 0xffffu; r.z = (unsigned)a.L_out * 4u; r.w = 0x00020000u;
+      return r;
+    };
+    // sub-blocks of 4 positions: the dy of sub-block sb + 1 is requested right after the wait for sub-block sb and has
+    // its 96 packed FMAs to land.  (Requesting the x pairs one sub-block ahead as well costs 24 registers and a wave per
+    // SIMD: slower, 0.34 -> 0.40 ms on the largest layer.)
+    f32x4 dq[2][OCW];
+#pragma unroll
+    for (int o = 0; o < OCW; ++o) sbload4(dq[0][o], rsrc_of(o), (unsigned)q0 * 4u);
+#pragma unroll
+    for (int sb = 0; sb < PB / 4; ++sb) {
+      // x pairs of the sub-block's two position pairs, for the lane's columns
+      f32x2 xv[COLS][2];
+#pragma unroll
+      for (int j = 0; j < COLS; ++j)
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+          const float* xp = xw + colbase[j] + (sb * 4 + pp * 2) * S;
+          xv[j][pp].x = xp[0];
+          xv[j][pp].y = xp[S];
+        }
+#pragma unroll
+      for (int o = 0; o < OCW; ++o) swait4(dq[sb % 2][o]);
+      if (sb + 1 < PB / 4) {
+#pragma unroll
+        for (int o = 0; o < OCW; ++o) sbload4(dq[(sb + 1) % 2][o], rsrc_of(o), (unsigned)(q0 + (sb + 1) * 4) * 4u);
+      }
+#pragma unroll
+      for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+        for (int o = 0; o < OCW; ++o) {
+          const f32x4 d4 = dq[sb % 2][o];
+          f32x2 d2;
+          d2.x = pp ? d4.z : d4.x; d2.y = pp ? d4.w : d4.y;
+#pragma unroll
+          for (int j = 0; j < COLS; ++j) pkfma2(acc[o][j], d2, xv[j][pp]);
+        }
+    }
+  }
+  // ---- this wave's split partial
+  float* wpart = gpart + (size_t)split * a.part_stride;
+  float* bpart = wpart + (size_t)c_out * N;
+#pragma unroll
+  for (int o = 0; o < OCW; ++o) {
+    const int row = g * MG + half * OCW + o;
+#pragma unroll
+    for (int j = 0; j < COLS; ++j) {
+      const int n = lane + 64 * j;
+      const float v = acc[o][j].x + acc[o][j].y;
+      if (n < N) wpart[(size_t)row * N + n] = v;
+      else if (n == N) bpart[row] = v;
+    }
+  }
+}
+
+int gconv_wgrad_kind(const RtgWgradDesc* d) {
+  if (!d || d->K != GK || d->pad != GPAD || d->dil != 1 || d->C2 != 0 || d->groups < 2 || d->bf16) return 0;
+  if (d->h_k > 1 || d->h_n > 1 || d->gy_mode != RTG_PRE_NONE) return 0;
+  if (d->pre_mode != RTG_PRE_NONE && d->pre_mode != RTG_PRE_LRELU) return 0;
+  if (d->C1 != d->groups * d->Cg || d->dy_L != d->Q) return 0;
+  if (d->Q != (d->L_in + 2 * GPAD - (GK - 1) - 1) / d->stride + 1) return 0;
+  if ((long long)d->B * d->groups * (d->Cg > d->Mg ? d->Cg : d->Mg) * (d->L_in > d->Q ? d->L_in : d->Q) * 4 >= (1ll << 31))
+    return 0;
+  if (d->Mg == 16 && d->Cg == 8 && d->stride == 2) return 1;
+  if (d->Mg == 16 && d->Cg == 4 && d->stride == 4) return 2;
+  if (d->Mg == 8 && d->Cg == 8 && d->stride == 4) return 3;
+  return 0;
+}
+
+template <int MG, int CG, int S>
+int launch_wgrad(const RtgWgradDesc* d, const float* x, const float* dy, float* part, hipStream_t s) {
+  GwArgs a;
+  a.B = d->B; a.groups = d->groups; a.L_in = d->L_in; a.L_out = d->Q;
+  a.W = d->splits;
+  a.bpc = rtg_ceil_div(d->Q, 32);
+  a.n_blocks = d->B * a.bpc;
+  a.per = rtg_ceil_div(a.n_blocks, a.W);
+  a.part_stride = d->part_stride;
+  a.slope = d->pre_mode == RTG_PRE_LRELU ? d->pre_slope : 1.f;
+  const int waves = d->groups * (MG / 8) * a.W;
+  RTG_KLAUNCH((gconv_wgrad_kernel<MG, CG, S>), dim3(rtg_ceil_div(waves, 4)), dim3(RTG_THREADS), 0, s, x, dy, part, a);
+  return rtg_launch_status();
+}
+
 // instance serving the problem: 1 = (16, 8, s2), 2 = (16, 4, s4), 3 = (8, 8, s4); 0 = none
 int gconv_kind(const RtgGconvDesc* d) {
   if (!d || d->K != GK || d->B < 1 || d->groups < 1 || d->L_in < 1 || d->L_out < 1 || d->pad != GPAD) return 0;
@@ -537,4 +719,33 @@ extern "C" int rtg_gconv_forward(const RtgGconvDesc* d, const float* x, const fl
   if (kind == 1) return launch_fwd<16, 8, 2, 4>(d, x, w, bias, out, a, s);
   if (kind == 2) return launch_fwd<16, 4, 4, 4>(d, x, w, bias, out, a, s);
   return launch_fwd<8, 8, 4, 4>(d, x, w, bias, out, a, s);
+}
+
+// ---- hooks of rtg_wgrad.hip (shape code 9 of RtgWgradDesc.shape_cfg)
+int rtg_gconv_wgrad_ok(const RtgWgradDesc* d) {
+  const char* e = getenv("RTG_GCONV");                   // A/B knob, as in rtg/ops.py: 0 = matrix cores only
+  if (e && e[0] == '0') return 0;
+  return gconv_wgrad_kind(d) > 0 ? 1 : 0;
+}
+
+int rtg_gconv_wgrad_splits(const RtgWgradDesc* d) {
+  const int kind = gconv_wgrad_kind(d);
+  if (!kind) return RTG_EINVAL;
+  // a wave per (group, 8 output channels, split): about 3000 waves in all (three per SIMD), at least 8 position blocks each
+  const int gh = d->groups * (d->Mg / 8);
+  const int n_blocks = d->B * rtg_ceil_div(d->Q, 32);
+  int w = rtg_ceil_div(3072, gh);
+  const int w_max = n_blocks / 8 > 0 ? n_blocks / 8 : 1;
+  if (w > w_max) w = w_max;
+  if (w > 512) w = 512;
+  return w < 1 ? 1 : w;
+}
+
+int rtg_gconv_wgrad_launch(const RtgWgradDesc* d, const float* x, const float* dy, float* part, hipStream_t s) {
+  const int kind = gconv_wgrad_kind(d);
+  if (!kind) return RTG_EINVAL;
+  if (d->splits != rtg_gconv_wgrad_splits(d)) return RTG_EINVAL;
+  if (kind == 1) return launch_wgrad<16, 8, 2>(d, x, dy, part, s);
+  if (kind == 2) return launch_wgrad<16, 4, 4>(d, x, dy, part, s);
+  return launch_wgrad<8, 8, 4>(d, x, dy, part, s);
 }
