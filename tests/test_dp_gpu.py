@@ -52,7 +52,7 @@ def _noise(batch):
     return [torch.rand(batch, *s, generator=g) for s in shapes]
 
 
-def _worker(rank, world, port, q, full=False):
+def _worker(rank, world, port, q, full=False, graphed=False):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     _setup()
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -62,7 +62,10 @@ def _worker(rank, world, port, q, full=False):
     x, y_tmpl, y = O.golden_inputs(batch=2)
     sl = slice(rank, rank + 1)
     noise = [n[sl].cuda() for n in _noise(2)]
-    dl, gl = tr.train_step(x[sl].cuda(), y_tmpl[sl].cuda(), y[sl].cuda(), noise_list=noise)
+    if graphed:
+        dl, gl = tr.train_step_graphed(x[sl].cuda(), y_tmpl[sl].cuda(), y[sl].cuda())
+    else:
+        dl, gl = tr.train_step(x[sl].cuda(), y_tmpl[sl].cuda(), y[sl].cuda(), noise_list=noise)
     torch.cuda.synchronize()
     q.put((rank, _params(tr).numpy(), gl['gen_all'].item()))
     dist.barrier()
@@ -107,3 +110,42 @@ def test_two_ranks_match_single_process_step(full):
     assert frac_bad < (5e-2 if full else 2e-3), frac_bad
     # mean of per-rank generator losses = single-process loss on the global batch
     np.testing.assert_allclose(0.5 * (got[0][1] + got[1][1]), gl['gen_all'].item(), rtol=1e-2 if full else 2e-3)
+
+
+def test_two_ranks_graphed_step():
+    """The step replayed from HIP graphs under data parallelism (what `RTG_GRAPH=1 bench.py --gpus N` runs): the graph
+    segments end where gradients are exchanged, the all-reduces run eagerly between them.  train_step_graphed tunes with
+    two eager steps, captures and replays once: three updates.  Both ranks end with identical parameters, and these
+    follow the single-process graphed run on the 2-clip batch (noise.w = 0: the device-drawn noise does not enter the
+    forward)."""
+    _setup()
+    tr, O = _make_trainer(False)
+    x, y_tmpl, y = O.golden_inputs(batch=2)
+    before = _params(tr).clone()
+    dl, gl = tr.train_step_graphed(x.cuda(), y_tmpl.cuda(), y.cuda())
+    torch.cuda.synchronize()
+    ref = _params(tr).numpy()
+    ref_loss = gl['gen_all'].item()
+    del tr
+    torch.cuda.empty_cache()
+
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, False, True)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(2):
+        r, params, loss = q.get(timeout=600)
+        got[r] = (params, loss)
+    for p in procs:
+        p.join(timeout=120)
+    assert all(p.exitcode == 0 for p in procs)
+    np.testing.assert_array_equal(got[0][0], got[1][0])
+    assert np.isfinite(got[0][0]).all()
+    move_ref, move_dp = ref - before.numpy(), got[0][0] - before.numpy()
+    assert np.abs(move_ref).max() > 1e-5
+    frac_bad = np.mean(np.abs(move_dp - move_ref) > 0.2 * 3 * 2e-4)          # three lr-sized updates
+    assert frac_bad < 2e-2, frac_bad
+    np.testing.assert_allclose(0.5 * (got[0][1] + got[1][1]), ref_loss, rtol=2e-2)

@@ -297,10 +297,12 @@ class Trainer:
         self.optim_d.step(use_bank_flag=True)
         return losses
 
-    def _d_reduce(self):
+    def _d_reduce(self, replay=False):
+        """replay: called between replayed graph segments — the flush hooks that issue the all-reduces in the eager step
+        do not run there (no Python runs inside a replay), so every bank is reduced here"""
         if self.dp.enabled:
             for d in self.discs:
-                if getattr(d.bank(), 'on_flush', None) is None:
+                if replay or getattr(d.bank(), 'on_flush', None) is None:
                     d.bank().sync_grads()
                     self.dp.reduce_async(d.bank().gflat)
             self.dp.wait()
@@ -436,7 +438,7 @@ class Trainer:
             self.optim_g.step(use_bank_flag=True)
 
         def after_d():
-            self._d_reduce()
+            self._d_reduce(replay=True)
 
         def after_g():
             self._g_reduce()
