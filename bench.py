@@ -251,11 +251,16 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    if os.environ.get('RTG_BENCH_REHEARSE') == '1':      # dev aid: all ranks on cuda:0, gradients over gloo (a one-GPU box)
+        local = 0
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         torch.cuda.set_device(local)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        if os.environ.get('RTG_BENCH_REHEARSE') == '1':
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the hot path has no CPU fallback')
     device = torch.device('cuda', local)
@@ -281,11 +286,31 @@ def main():
     # set-up, outside warm-up and timing: the first train step of a Trainer also times the candidate block shapes of
     # every conv / weight-gradient launch and keeps the fastest per problem (rtg/tune.py) — part of building the step,
     # like compiling a kernel; with it here --warmup 0 still times tuned steps only
-    # RTG_GRAPH=1: the step replayed from HIP graphs (Trainer.train_step_graphed) — same kernels, issued by the graph
-    # executor; for hosts whose cores cannot feed 8 ranks x ~900 launches per step (tools/scale.sh)
-    step = tr.train_step_graphed if os.environ.get('RTG_GRAPH') == '1' else tr.train_step
+    # The timed step is replayed from HIP graphs (Trainer.train_step_graphed): the same kernels in the same order, issued by
+    # the graph executor instead of ~770 Python-side launches per step (1.4 % faster on one GPU; with 8 ranks per host the
+    # launches of all ranks compete for the host's cores).  The graphs are cut where data parallelism exchanges
+    # gradients; the all-reduces run between the segments (tests/test_dp_gpu.py::test_two_ranks_graphed_step).
+    # RTG_GRAPH=0: the eager step.  Capture happens here, outside warm-up and timing; if it fails the eager step is timed
+    # and the record says so.
+    mode = 'hip-graph replay'
     tr.train_step(*next_batch())
     torch.cuda.synchronize()
+    step = tr.train_step
+    if os.environ.get('RTG_GRAPH', '1') != '0':
+        try:
+            tr.train_step_graphed(*next_batch())
+            torch.cuda.synchronize()
+            step = tr.train_step_graphed
+        except Exception as e:  # noqa: BLE001
+            mode = f'eager (graph capture failed: {type(e).__name__}: {e})'[:200]
+            tr._graphs = None
+    else:
+        mode = 'eager'
+    if world > 1:           # every rank must time the same kind of step
+        flag = torch.tensor([1.0 if step == tr.train_step_graphed else 0.0], device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if flag.item() == 0.0 and step == tr.train_step_graphed:
+            step, mode, tr._graphs = tr.train_step, 'eager (graph capture failed on another rank)', None
     for _ in range(a.warmup):
         step(*next_batch())
     torch.cuda.synchronize()
@@ -329,7 +354,7 @@ def main():
             'dtype': 'f32' if dtype == 'fp32' else 'bf16 operands, f32 accumulate', 'data': 'synthetic' if feeder is None else 'synthetic, fed from pinned host memory every step',
             'config': {'workload': f'{a.workload}: {desc}', 'per_gpu_batch': batch, 'clip_samples': T,
                        'global_batch': world * batch, 'd_train_times': d_times,
-                       'parallelism': f'dp{world}' if world > 1 else 'single'},
+                       'parallelism': f'dp{world}' if world > 1 else 'single', 'launch': mode},
             'roofline': roof, 'cpu_baseline': cpu,
             'final_losses': {'gen_all': round(loss_g, 4), 'disc_all': round(loss_d, 4)},
         }
