@@ -169,26 +169,36 @@ def _pmc_for(prefix):
 
 
 def roofline(trainer, batch, bf16=False):
-    """Live per-kernel timing of ONE extra step: every conv launch bracketed by HIP events on its launch stream."""
+    """Live per-kernel timing of extra (eager) steps: every conv launch bracketed by HIP events on its launch stream."""
     from rtg import ops
-    ops.PROFILE = []
+    # an eager step first (the timed steps were graph replays: allocator blocks and caches of the eager path are cold), then
+    # three instrumented steps; a launch's duration is the median of its three (the launch order is the same every step)
     trainer.train_step(*batch)
-    torch.cuda.synchronize()
-    rec, ops.PROFILE = ops.PROFILE, None
+    runs = []
+    for _ in range(3):
+        ops.PROFILE = []
+        trainer.train_step(*batch)
+        torch.cuda.synchronize()
+        rec, ops.PROFILE = ops.PROFILE, None
+        runs.append([(k, v, f, e0.elapsed_time(e1), lab, nb) for k, v, f, e0, e1, lab, nb in rec])
+    if not all(len(r) == len(runs[0]) and all(a[:2] == b[:2] for a, b in zip(r, runs[0])) for r in runs):
+        runs = runs[:1]                              # (a step that met a new problem shape: keep the first as it is)
+    rec = [(r0[0], r0[1], r0[2], sorted(r[i][3] for r in runs)[len(runs) // 2], r0[4], r0[5])
+           for i, r0 in enumerate(runs[0])]
     agg = {}
     bw = {}
-    for kernel, variant, flop, e0, e1, _label, nbytes in rec:
+    for kernel, variant, flop, ms, _label, nbytes in rec:
         # bandwidth kernels: the weight-norm / optimizer / STFT launches (ops.timed_bw) and the 1-channel conv shapes
         name = kernel[3:] if kernel.startswith('bw:') else ({1: 'thin_cin1', 2: 'thin_cout1'}.get(variant) if kernel == 'conv1d' else None)
         if name:
             e = bw.setdefault(name, [0, 0.0, 0.0])
-            e[0] += 1; e[1] += e0.elapsed_time(e1) * 1e-3; e[2] += nbytes
+            e[0] += 1; e[1] += ms * 1e-3; e[2] += nbytes
         if kernel.startswith('bw:'):
             continue
         k = (kernel, variant)
         a = agg.setdefault(k, [0, 0.0, 0.0, 0.0])
         a[0] += 1
-        a[1] += e0.elapsed_time(e1) * 1e-3
+        a[1] += ms * 1e-3
         a[2] += flop
         a[3] += nbytes
     # the dominant MATRIX kernel (the bandwidth kernels of the 1-channel layers, variants < 100, are reported in by_kernel)
@@ -216,8 +226,8 @@ def roofline(trainer, batch, bf16=False):
         out['pmc_stale'] = pmc['stale']      # True: the committed PMC pass was taken on other kernel sources than this build
     # the UNet-G conv stack alone (north-star target: >= 30 % of the fp32 matrix peak)
     conv_rec = [r for r in rec if not r[0].startswith('bw:')]
-    g_flop = sum(f for k_, v_, f, e0, e1, lb, _nb in conv_rec if not lb.split()[1].startswith('discriminators'))
-    g_s = sum(e0.elapsed_time(e1) * 1e-3 for k_, v_, f, e0, e1, lb, _nb in conv_rec if not lb.split()[1].startswith('discriminators'))
+    g_flop = sum(f for k_, v_, f, ms_, lb, _nb in conv_rec if not lb.split()[1].startswith('discriminators'))
+    g_s = sum(ms_ * 1e-3 for k_, v_, f, ms_, lb, _nb in conv_rec if not lb.split()[1].startswith('discriminators'))
     if g_s > 0:
         out['unet_g_conv_stack'] = {'tflops': round(g_flop / g_s / 1e12, 3),
                                     'frac': None if bf16 else round(g_flop / g_s / 1e12 / PEAK_FP32_MATRIX_TFLOPS, 4),

@@ -40,8 +40,8 @@ for sub, L0 in ((0, 8192), (1, 4096), (2, 2048)):
             gd = GconvDesc(B, ly.groups, ly.cin // ly.groups, ly.cout // ly.groups, ly.k, ly.stride, ly.pad, L, Lo, 0.15)
             gargs = (ops._p(x), ops._p(bank.gconv_weights(ly, gd, tok._rtg_id)), bank.bias_ptr(ly), ops._p(out), None)
             tune.REPS = 20
-            t0 = tune._time(lambda: lib.rtg_conv1d(C.byref(d), *args)) / 20
-            t1 = tune._time(lambda: lib.rtg_gconv_forward(C.byref(gd), *gargs)) / 20
+            t0 = tune._time(lambda: lib.rtg_conv1d(C.byref(d), *args))
+            t1 = tune._time(lambda: lib.rtg_gconv_forward(C.byref(gd), *gargs))
             tune.REPS = 3
             fl = 2.0 * B * Lo * ly.cout * (ly.cin // ly.groups) * ly.k
             print(f'd{sub}.convs.{li} Cg{ly.cin // ly.groups} Mg{ly.cout // ly.groups} s{ly.stride} L{L}: mfma {t0 * 1e3:7.1f} us '
@@ -58,8 +58,8 @@ for sub, L0 in ((0, 8192), (1, 4096), (2, 2048)):
             lib.rtg_gconv_prepare_bwd(C.byref(gd), bank_v(ly), bank_s(ly), ops._p(wb), None)
             bargs = (ops._p(dy), ops._p(wb), ops._p(x), None, ops._p(dx), None)
             tune.REPS = 20
-            t0 = tune._time(lambda: lib.rtg_conv1d(C.byref(dd), *dargs)) / 20
-            t1 = tune._time(lambda: lib.rtg_gconv_backward_data(C.byref(gd), *bargs)) / 20
+            t0 = tune._time(lambda: lib.rtg_conv1d(C.byref(dd), *dargs))
+            t1 = tune._time(lambda: lib.rtg_gconv_backward_data(C.byref(gd), *bargs))
             tune.REPS = 3
             print(f'   dgrad: mfma {t0 * 1e3:7.1f} us {fl / t0 / 1e9:6.1f} TF/s (cfg {dd.tile_cfg})   valu {t1 * 1e3:7.1f} us '
                   f'{fl / t1 / 1e9:6.1f} TF/s')

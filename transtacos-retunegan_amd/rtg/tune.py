@@ -25,6 +25,9 @@ _conv, _wgrad, _group, _wgroup, _alt = {}, {}, {}, {}, {}
 
 
 def _time(launch):
+    """average duration of `launch` (ms); None if it fails.  Short launches are repeated more often: three repetitions of
+    a 15 us kernel measure the event bracket as much as the kernel, and a wrong pick among candidates 2-3 % apart costs
+    the small layers of UNet-G more than the extra repetitions cost the tuning step."""
     st = launch()                                   # warm-up: code object load, caches
     if st:
         return None
@@ -34,7 +37,16 @@ def _time(launch):
         launch()
     e1.record()
     e1.synchronize()
-    return e0.elapsed_time(e1)
+    t = e0.elapsed_time(e1) / REPS
+    if t < 0.1:                                     # < 100 us per launch: measure again over ~1 ms
+        n = min(40, max(REPS, int(1.0 / max(t, 0.005))))
+        e0.record()
+        for _ in range(n):
+            launch()
+        e1.record()
+        e1.synchronize()
+        t = e0.elapsed_time(e1) / n
+    return t
 
 
 def _miss():

@@ -378,9 +378,8 @@ class Trainer:
     def train_step_graphed(self, x, y_tmpl, y):
         """train_step() captured once into HIP graphs and replayed: the ~900 kernel launches of a step (and the forks /
         joins of the sub-network streams) are issued by the graph executor instead of the Python autograd machinery.
-        Measured on MI355X at batch 32 it is NOT faster than the eager step (41.6 vs 41.7 ms: the step is bound by the
-        GPU-side cost of its many short kernels, not by the host), so bench.py and the default trainer stay eager; the
-        path is kept for hosts with slow cores.  ROCm 7.2 notes: a fork inside a forked stream crashes
+        Measured on MI355X at batch 32: 31.9 vs 32.4 ms eager (round 1, with slower kernels: 41.6 vs 41.7); bench.py
+        times this path, the default trainer API stays eager.  ROCm 7.2 notes: a fork inside a forked stream crashes
         hipStreamEndCapture (hence the flat fork of run_stacks), and a capturing stream must not wait on a stream of
         an earlier capture (WeightBank.sync_grads re-homes the flush stream).  The step is cut where data parallelism exchanges
         gradients — [G forward, D backward] | [D update, D backward] ... | [D update, G backward] | [G update] — and the
