@@ -3,8 +3,8 @@
 #     tools/scale.sh [workload=config4] [steps=20] [warmup=5]
 # prints audio-s/s per N and the efficiency against N x the 1-GPU value.  Needs as many visible GPUs as the largest N
 # (the build's gpurun boxes expose one: the driver runs this sweep on an 8-GPU node at round end).
-# RTG_GRAPH=1 replays the step from HIP graphs (train.Trainer.train_step_graphed): for hosts whose cores cannot issue
-# the ~900 launches of a step for 8 ranks at once.
+# bench.py replays the step from HIP graphs (train.Trainer.train_step_graphed) at every N; RTG_GRAPH=0 times the eager
+# step (8 ranks then issue ~770 Python-side launches per step each).
 set -e
 WL=${1:-config4}; STEPS=${2:-20}; WARM=${3:-5}
 cd "$(dirname "$0")/.."
