@@ -401,6 +401,77 @@ __global__ __launch_bounds__(kShortThreads) void cout1_short_kernel(const ThinAr
   }
 }
 
+// ---- one output channel, k3 "same" (conv_post of every discriminator: 512 -> 1, rows of 10..128 positions).  The clips
+// are 20-260 KB each and there are 64-704 of them: a block per clip (cout1_short) leaves the chip latency bound (27-47 us
+// for 14-40 MB).  Here the 64 lanes of a wave are 64 (clip, position) columns — several whole clips side by side when
+// the rows are short, a 64-position block of a clip when they are long — and the 8 waves of a block split the input
+// channels: a wave requests its C / 8 channels' three samples per column (16 channels = 48 loads in flight, the
+// neighbours come from the same cache lines), the 8 partial sums of a column meet in LDS and are added in fixed order.
+constexpr int kK3Waves = 8;
+__global__ __launch_bounds__(64 * kK3Waves) void cout1_k3_kernel(const ThinArgs a, int cpb, int bpc) {
+  // cpb: clips per block (rows of <= 64 positions), bpc: position blocks per clip (longer rows; then cpb == 1)
+  __shared__ float wl[3 * 1024];                      // [C][3] (C <= 1024)
+  __shared__ float part[kK3Waves][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int e = tid; e < a.C * 3; e += 64 * kK3Waves) {
+    const int c = e / 3, j = e - c * 3;
+    wl[e] = a.wp[packed_index(0, c, j, a.C, 3, a.tile_m, a.tap_major)];
+  }
+  int clip, pos;
+  bool col_ok;
+  if (bpc == 1) {
+    const int sub = lane / a.L_in;                    // (L_in == Q: "same" conv)
+    clip = blockIdx.x * cpb + sub;
+    pos = lane - sub * a.L_in;
+    col_ok = sub < cpb && clip < a.B;
+  } else {
+    clip = blockIdx.x / bpc;
+    pos = (blockIdx.x - clip * bpc) * 64 + lane;
+    col_ok = pos < a.L_in;
+  }
+  const rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.B * a.C * a.L_in * 4, 0x00020000);
+  const int cps = a.C / kK3Waves;                     // channels per wave
+  const int c0 = wave * cps;
+  unsigned off[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int p = pos + j - 1;
+    off[j] = (col_ok && p >= 0 && p < a.L_in) ? (unsigned)((clip * a.C + c0) * a.L_in + p) * 4u : 0x80000000u;
+  }
+  __syncthreads();
+  float acc = 0.f;
+  const unsigned rowb = (unsigned)a.L_in * 4u;
+  for (int cb = 0; cb < cps; cb += 16) {
+    float v[16][3];
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        v[i][j] = (cb + i < cps) ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, off[j] + (unsigned)(cb + i) * rowb, 0, 0))
+                                 : 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      if (cb + i < cps) {
+        const float* w = wl + (c0 + cb + i) * 3;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc = fmaf(w[j], thin_pre(v[i][j], a), acc);
+      }
+    }
+  }
+  part[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && col_ok) {
+    float s_ = part[0][lane];
+#pragma unroll
+    for (int k = 1; k < kK3Waves; ++k) s_ += part[k][lane];                          // fixed order
+    if (a.bias) s_ += a.bias[0];
+    const size_t o = (size_t)clip * a.out_L + pos;
+    if (a.mask) s_ *= (a.mask[o] > 0.f ? 1.f : a.mask_slope);
+    if (a.res) s_ += a.res[o];
+    a.out[o] = thin_act(s_ * a.out_scale, a.act, a.act_slope);
+  }
+}
+
 // stage the input window [g0, g0 + W) of clip b (one channel) into xs, pre-activation and aux factors applied
 __device__ __forceinline__ void cin1_stage(const ThinArgs& a, int b, int g0, int W, float* xs) {
   const float* xr = a.x + (size_t)b * a.L_in;
@@ -699,6 +770,17 @@ int rtg_thin_launch(int kind, const RtgConv1dDesc* d, const float* x, const floa
         RTG_KLAUNCH(cin1_flat_kernel, dim3((unsigned)bx), dim3(RTG_THREADS), lds, s, a, g);
         return rtg_launch_status();
       }
+    }
+  }
+  if (kind == 2 && !legacy && !a.aux && d->K == 3 && d->stride == 1 && d->dil == 1 && d->pad == 1 && d->Q == d->L_in &&
+      d->Q == d->out_L && d->Cg % (8 * 16) == 0 && d->Cg <= 1024 && (long long)d->B * d->Cg * d->L_in * 4 < (1ll << 31) &&
+      !getenv("RTG_THIN_NOK3")) {
+    const int cpb = d->L_in <= 64 ? 64 / d->L_in : 1;
+    const int bpc = d->L_in <= 64 ? 1 : rtg_ceil_div(d->L_in, 64);
+    const long long bx = bpc == 1 ? rtg_ceil_div(d->B, cpb) : (long long)d->B * bpc;
+    if (bx <= 0x7fffffffLL) {
+      RTG_KLAUNCH(cout1_k3_kernel, dim3((unsigned)bx), dim3(64 * kK3Waves), 0, s, a, cpb, bpc);
+      return rtg_launch_status();
     }
   }
   if (kind == 2 && !legacy && !a.aux) {
