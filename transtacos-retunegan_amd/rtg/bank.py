@@ -77,6 +77,11 @@ class ConvLayer:
             self.bwd_op = (L.PACK_FWD, 1, self.cin, self.cout, self.k, 1)
         self.fwd_tm = 32 if self.fwd_op[2] >= 32 else 16
         self.bwd_tm = 32 if self.bwd_op[2] >= 32 else 16
+        if os.environ.get('RTG_TM16_ODD', '1') == '1' and self.bwd_op[2] >= 32 and self.bwd_op[2] % 32 == 16 and \
+                self.bwd_op[2] < 256 and self.groups == 1 and self.kind == 'conv' and self.stride == 1:
+            # 48 or 208 rows: 16-row tiles cover them exactly, 32-row tiles pad 25 % / 7 % (backward-data of the UNet-G
+            # merge / fuse convs, whose row count is the concatenated input's channel count)
+            self.bwd_tm = 16
         # tap-major K order where it needs fewer MFMAs (few input channels per group); 1-D operators only
         one_d = self.kind != 'conv2d'
         self.fwd_tap = int(one_d and lib.rtg_tapmajor_pays(self.fwd_op[3], self.fwd_op[4], self.fwd_tm) == 1)
