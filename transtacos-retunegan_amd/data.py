@@ -228,8 +228,17 @@ class PinnedFeeder:
         return dev
 
     def close(self):
+        """stop the producer and WAIT for it: a daemon thread still inside torch when the interpreter finalises aborts
+        the process ("terminate called without an active exception", exit code 134)"""
         self._stop = True
         self.free.put(None)
+        if self._started:
+            while self._thread.is_alive():
+                try:
+                    self.ready.get(timeout=0.05)           # a producer blocked on a full queue can finish its put
+                except queue.Empty:
+                    pass
+            self._thread.join()
         try:
             while True:
                 self.ready.get_nowait()
