@@ -189,7 +189,7 @@ def roofline(trainer, batch, bf16=False):
     bw = {}
     for kernel, variant, flop, ms, _label, nbytes in rec:
         # bandwidth kernels: the weight-norm / optimizer / STFT launches (ops.timed_bw) and the 1-channel conv shapes
-        name = kernel[3:] if kernel.startswith('bw:') else ({1: 'thin_cin1', 2: 'thin_cout1'}.get(variant) if kernel == 'conv1d' else None)
+        name = kernel[3:] if kernel.startswith('bw:') else ({1: 'thin_cin1', 2: 'thin_cout1', 3: 'thin_cout1'}.get(variant) if kernel == 'conv1d' else None)
         if name:
             e = bw.setdefault(name, [0, 0.0, 0.0])
             e[0] += 1; e[1] += ms * 1e-3; e[2] += nbytes

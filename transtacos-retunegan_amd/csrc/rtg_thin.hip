@@ -472,6 +472,70 @@ __global__ __launch_bounds__(64 * kK3Waves) void cout1_k3_kernel(const ThinArgs 
   }
 }
 
+// ---- one output channel, 3 x 3 "same" in two dimensions (conv_post of the STFT discriminators, discrminator.py:262:
+// Conv2d(512, 1, (3, 3), padding (1, 1)) on maps of 29 x 5 .. 8 x 18).  On the matrix-core path one of 16 tile rows is
+// used and a launch takes 220 us (0.2-0.4 TFLOP/s, 2.6 ms of a full-stack step).  Same scheme as cout1_k3_kernel: a lane
+// is one (item, row, column) output, the 8 waves of a block split the input channels (8 channels = 72 loads in flight
+// per lane, neighbours from the same cache lines), fixed-order LDS reduction.
+__global__ __launch_bounds__(64 * kK3Waves) void cout1_k3x3_kernel(const ThinArgs a, int C, int H, int items) {
+  __shared__ float wl[9 * 512];                       // [C][kh][kw] (C <= 512)
+  __shared__ float part[kK3Waves][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int W = a.L_in;
+  for (int e = tid; e < C * 9; e += 64 * kK3Waves) {
+    const int c = e / 9, r = e - c * 9;
+    // the 1-D operator's channels are (c, kernel row) pairs, its taps the kernel columns
+    wl[e] = a.wp[packed_index(0, c * 3 + r / 3, r % 3, C * 3, 3, a.tile_m, a.tap_major)];
+  }
+  const int col = blockIdx.x * 64 + lane;
+  const int hw = H * W;
+  const int item = col / hw;
+  const int rem = col - item * hw;
+  const int h = rem / W, w = rem - h * W;
+  const bool col_ok = item < items;
+  const rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, items * C * hw * 4, 0x00020000);
+  const int cps = C / kK3Waves;
+  const int c0 = wave * cps;
+  unsigned off[9];
+#pragma unroll
+  for (int r = 0; r < 9; ++r) {
+    const int hh = h + r / 3 - 1, ww = w + r % 3 - 1;
+    off[r] = (col_ok && hh >= 0 && hh < H && ww >= 0 && ww < W) ? (unsigned)(((item * C + c0) * H + hh) * W + ww) * 4u
+                                                                 : 0x80000000u;
+  }
+  __syncthreads();
+  float acc = 0.f;
+  const unsigned planeb = (unsigned)hw * 4u;
+  for (int cb = 0; cb < cps; cb += 8) {
+    float v[8][9];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int r = 0; r < 9; ++r)
+        v[i][r] = (cb + i < cps) ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, off[r] + (unsigned)(cb + i) * planeb, 0, 0))
+                                 : 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (cb + i < cps) {
+        const float* wq = wl + (c0 + cb + i) * 9;
+#pragma unroll
+        for (int r = 0; r < 9; ++r) acc = fmaf(wq[r], thin_pre(v[i][r], a), acc);
+      }
+    }
+  }
+  part[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && col_ok) {
+    float s_ = part[0][lane];
+#pragma unroll
+    for (int k = 1; k < kK3Waves; ++k) s_ += part[k][lane];                          // fixed order
+    if (a.bias) s_ += a.bias[0];
+    if (a.mask) s_ *= (a.mask[col] > 0.f ? 1.f : a.mask_slope);
+    if (a.res) s_ += a.res[col];
+    a.out[col] = thin_act(s_ * a.out_scale, a.act, a.act_slope);
+  }
+}
+
 // stage the input window [g0, g0 + W) of clip b (one channel) into xs, pre-activation and aux factors applied
 __device__ __forceinline__ void cin1_stage(const ThinArgs& a, int b, int g0, int W, float* xs) {
   const float* xr = a.x + (size_t)b * a.L_in;
@@ -643,7 +707,16 @@ __global__ __launch_bounds__(RTG_THREADS) void cin1_flat_kernel(const ThinArgs a
 // 0: not a thin shape (use the MFMA kernel), 1: one input channel, 2: one output channel
 int rtg_thin_kind(const RtgConv1dDesc* d) {
   if (d->groups != 1 || d->C2 != 0 || d->shuf_S != 1 || d->out_split != 0 || d->accumulate) return 0;
-  if (d->h_k > 1 || d->h_n > 1) return 0;
+  if (d->h_k > 1 || d->h_n > 1) {
+    // kind 3: one output channel, 3 x 3, stride 1, "same" padding, forward addressing (cout1_k3x3_kernel)
+    if (d->Mg == 1 && d->h_mode == 0 && d->h_k == 3 && d->K == 3 && d->stride == 1 && d->h_stride == 1 && d->dil == 1 &&
+        d->pad == 1 && d->h_pad == 1 && d->h_n == d->h_in && d->Q == d->L_in && d->out_L == d->Q && d->h_n > 0 &&
+        d->B % d->h_n == 0 && d->Cg % 3 == 0 && (d->Cg / 3) % (8 * 8) == 0 && d->Cg / 3 <= 512 && !d->bf16 &&
+        d->pre_mode < RTG_PRE_MUL_DLRELU && (long long)d->B * d->Cg / 3 * d->L_in * 4 < (1ll << 31) &&
+        !getenv("RTG_THIN_NOK3"))
+      return 3;
+    return 0;
+  }
   if (d->Cg == 1 && d->K <= kMaxTaps) return 1;
   if (d->Mg == 1 && (long long)d->Cg * d->K <= 12288 && (long long)d->B * d->Cg * d->L_in * 4 < (1ll << 31)) return 2;
   return 0;
@@ -726,6 +799,12 @@ int rtg_thin_launch(int kind, const RtgConv1dDesc* d, const float* x, const floa
   a.n_pos = (long long)d->B * d->Q;
   const bool legacy = getenv("RTG_THIN_LEGACY") != nullptr;       // A/B knob: the round-1 kernels
   TileGeo g = {};
+  if (kind == 3) {
+    const int items = d->B / d->h_n, C = d->Cg / 3;
+    const long long cols = (long long)items * d->h_in * d->L_in;
+    RTG_KLAUNCH(cout1_k3x3_kernel, dim3((unsigned)rtg_ceil_div(cols, 64)), dim3(64 * kK3Waves), 0, s, a, C, d->h_in, items);
+    return rtg_launch_status();
+  }
   if (kind == 1 && !legacy && d->Q == d->out_L) {
     const long long wq = (long long)(d->Q - 1) * d->stride + (long long)(d->K - 1) * d->dil + 1;
     const bool vec_io = d->out_L % 4 == 0 && aligned16(out) && (!mask || aligned16(mask)) && (!res || aligned16(res));
