@@ -16,6 +16,8 @@ CASES = [
     (3, 256, 512, 22, 9, (5, 3), (3, 2), (2, 1)),
     (2, 512, 512, 8, 5, (3, 3), (1, 1), (1, 1)),
     (2, 512, 1, 8, 18, (3, 3), (1, 1), (1, 1)),
+    (3, 512, 1, 29, 5, (3, 3), (1, 1), (1, 1)),      # conv_post on the other map shapes (cout1_k3x3_kernel: 435 columns,
+    (5, 512, 1, 15, 9, (3, 3), (1, 1), (1, 1)),      # 675 columns: partial last block)
 ]
 
 
