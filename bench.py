@@ -307,20 +307,26 @@ def main():
     torch.cuda.synchronize()
     step = tr.train_step
     if os.environ.get('RTG_GRAPH', '1') != '0':
+        # capture WITHOUT replaying, then agree on the outcome, then replay: a rank whose capture failed must not head for
+        # the eager step's collectives while the others are inside a replay's (different buffers and sizes: RCCL would hang)
+        ok = 1.0
         try:
+            tr.prepare_graphs(*next_batch())
+        except Exception as e:  # noqa: BLE001
+            ok = 0.0
+            mode = f'eager (graph capture failed: {type(e).__name__}: {e})'[:200]
+            tr._graphs = None
+        if world > 1:
+            flag = torch.tensor([ok], device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if flag.item() == 0.0 and ok:
+                ok, mode, tr._graphs = 0.0, 'eager (graph capture failed on another rank)', None
+        if ok:
             tr.train_step_graphed(*next_batch())
             torch.cuda.synchronize()
             step = tr.train_step_graphed
-        except Exception as e:  # noqa: BLE001
-            mode = f'eager (graph capture failed: {type(e).__name__}: {e})'[:200]
-            tr._graphs = None
     else:
         mode = 'eager'
-    if world > 1:           # every rank must time the same kind of step
-        flag = torch.tensor([1.0 if step == tr.train_step_graphed else 0.0], device=device)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if flag.item() == 0.0 and step == tr.train_step_graphed:
-            step, mode, tr._graphs = tr.train_step, 'eager (graph capture failed on another rank)', None
     for _ in range(a.warmup):
         step(*next_batch())
     torch.cuda.synchronize()
@@ -335,7 +341,20 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    per_rank = None
     if world > 1:
+        # every rank's own time and a digest of its tuner's picks (ranks tune independently: different picks are harmless
+        # for the result, the gradients are summed, but they show as different per-rank step times)
+        import hashlib
+        from rtg import tune
+        picks = repr(sorted((k.hex(), v) for d_ in (tune._conv, tune._wgrad, tune._group, tune._wgroup, tune._alt)
+                            for k, v in d_.items())).encode()
+        mine = torch.tensor([elapsed / a.steps * 1e3, float(int(hashlib.sha256(picks).hexdigest()[:6], 16))],
+                            device=device, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = {'ms_per_step': [round(t[0].item(), 3) for t in allr],
+                    'tuner_picks_digest': [f'{int(t[1].item()):06x}' for t in allr]}
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
@@ -346,7 +365,9 @@ def main():
     data = next_batch()
     if feeder is not None:
         feeder.close()
-    if not a.no_roofline and rank == 0:
+    if not a.no_roofline:
+        # every rank runs the instrumented steps (they are train steps: under data parallelism their gradient all-reduces
+        # need all ranks), rank 0 reports its own launches
         roof = roofline(tr, data, bf16=dtype == 'bf16')
     if world > 1:
         dist.barrier()
@@ -364,7 +385,8 @@ def main():
             'dtype': 'f32' if dtype == 'fp32' else 'bf16 operands, f32 accumulate', 'data': 'synthetic' if feeder is None else 'synthetic, fed from pinned host memory every step',
             'config': {'workload': f'{a.workload}: {desc}', 'per_gpu_batch': batch, 'clip_samples': T,
                        'global_batch': world * batch, 'd_train_times': d_times,
-                       'parallelism': f'dp{world}' if world > 1 else 'single', 'launch': mode},
+                       'parallelism': f'dp{world}' if world > 1 else 'single', 'launch': mode,
+                       **({'per_rank': per_rank} if per_rank else {})},
             'roofline': roof, 'cpu_baseline': cpu,
             'final_losses': {'gen_all': round(loss_g, 4), 'disc_all': round(loss_d, 4)},
         }

@@ -149,3 +149,79 @@ def test_two_ranks_graphed_step():
     frac_bad = np.mean(np.abs(move_dp - move_ref) > 0.2 * 3 * 2e-4)          # three lr-sized updates
     assert frac_bad < 2e-2, frac_bad
     np.testing.assert_allclose(0.5 * (got[0][1] + got[1][1]), ref_loss, rtol=2e-2)
+
+
+def _rccl_worker(port, q):
+    """ONE rank on the real RCCL backend with data parallelism forced on (RTG_DP_FORCE): the flush hooks, the priority
+    communication stream, ncclAllReduce on the flat gradient banks, the flag slot, and — graphed — the per-discriminator
+    segment / collective interleave all run on the hardware, as they will on the driver's 8-GPU node."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0', RTG_DP_FORCE='1',
+                      RTG_TUNE='0')
+    _setup()
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    out = {}
+    for full in (False, True):
+        tr, O = _make_trainer(full)
+        assert tr.dp.enabled and tr.dp.world == 1
+        assert all(d.bank().on_flush is not None for d in tr.discs)
+        x, y_tmpl, y = (t.cuda() for t in O.golden_inputs(batch=2))
+        noise = [n.cuda() for n in _noise(2)]
+        tr.train_step(x, y_tmpl, y, noise_list=noise)                     # eager: all-reduces from the flush hooks
+        torch.cuda.synchronize()
+        assert tr.dp.comm_stream is not None                              # the RCCL path ran
+        out[f'eager{int(full)}'] = _params(tr).numpy()
+        dl, gl = tr.train_step_graphed(x, y_tmpl, y)                      # 2 eager tuning steps, capture, one replay
+        dl, gl = tr.train_step_graphed(x, y_tmpl, y)                      # ... and a second replay of the same graphs
+        torch.cuda.synchronize()
+        n_seg = len(tr._graphs)
+        # D backward cut per discriminator: first | (n_disc - 1) tails, per D update, + the G-update and final segments
+        assert n_seg == (1 + (len(tr.discs) - 1)) * tr.d_train_times + 2, n_seg
+        out[f'graph{int(full)}'] = _params(tr).numpy()
+        out[f'loss{int(full)}'] = (dl['disc_all'].item(), gl['gen_all'].item())
+        del tr
+        torch.cuda.empty_cache()
+    q.put(out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_single_rank_rccl_forced_dp_equals_plain_step(monkeypatch):
+    """RCCL itself, on the one GPU of the box: a forced-DP trainer over a 1-rank 'nccl' group must reproduce the plain
+    trainer bit for bit (an all-reduce over one rank is the identity, grad_scale = 1) — eager and replayed from graphs,
+    G + MSD + MPD and the full stack with MTD and d_train_times = 2.  The tuner is off in both processes (the library's
+    heuristic block shapes: the weight-gradient split counts, hence the summation orders, are then the same)."""
+    _setup()
+    from rtg import tune
+    monkeypatch.setattr(tune, 'ENABLED', False)
+    ref = {}
+    for full in (False, True):
+        tr, O = _make_trainer(full)
+        assert not tr.dp.enabled
+        x, y_tmpl, y = (t.cuda() for t in O.golden_inputs(batch=2))
+        noise = [n.cuda() for n in _noise(2)]
+        tr.train_step(x, y_tmpl, y, noise_list=noise)
+        torch.cuda.synchronize()
+        ref[f'eager{int(full)}'] = _params(tr).numpy()
+        dl, gl = tr.train_step_graphed(x, y_tmpl, y)
+        dl, gl = tr.train_step_graphed(x, y_tmpl, y)
+        torch.cuda.synchronize()
+        ref[f'graph{int(full)}'] = _params(tr).numpy()
+        ref[f'loss{int(full)}'] = (dl['disc_all'].item(), gl['gen_all'].item())
+        del tr
+        torch.cuda.empty_cache()
+
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p.start()
+    got = q.get(timeout=900)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    for full in (0, 1):
+        np.testing.assert_array_equal(got[f'eager{full}'], ref[f'eager{full}'])
+        # graphed: the forced-DP run cuts the D backward per discriminator (three backward calls instead of one over the
+        # summed loss): the same kernels on the same operands, the same bits
+        np.testing.assert_array_equal(got[f'graph{full}'], ref[f'graph{full}'])
+        assert np.isfinite(got[f'graph{full}']).all()
+        np.testing.assert_allclose(got[f'loss{full}'], ref[f'loss{full}'], rtol=1e-6)

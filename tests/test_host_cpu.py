@@ -147,6 +147,22 @@ def test_exponential_lr_matches_torch_fresh_and_resumed():
     assert opt2.initial_lr == hp.learning_rate_d
 
 
+def test_exponential_lr_legacy_resume(monkeypatch):
+    """hparam.legacy_resume_lr: torch 1.8's constructor sent the loaded lr through get_lr() once more on resume (one extra
+    factor of gamma per resume); a fresh run is unaffected."""
+    import train
+    import hparam as hp
+    monkeypatch.setattr(hp, 'legacy_resume_lr', True, raising=False)
+    opt = train.AdamW([], hp.learning_rate_d, betas=[hp.adam_b1, hp.adam_b2])
+    sch = train.ExponentialLR(opt, gamma=hp.lr_decay)
+    assert sch.get_last_lr() == [hp.learning_rate_d]
+    lr3 = hp.learning_rate_d * hp.lr_decay ** 3
+    opt2 = train.AdamW([], hp.learning_rate_d, betas=[hp.adam_b1, hp.adam_b2])
+    opt2.load_state_dict({'state': {}, 'param_groups': [{'lr': lr3, 'initial_lr': hp.learning_rate_d}]})
+    sch2 = train.ExponentialLR(opt2, gamma=hp.lr_decay, last_epoch=3)
+    assert sch2.last_epoch == 4 and sch2.get_last_lr()[0] == pytest.approx(lr3 * hp.lr_decay, rel=1e-15)
+
+
 def test_loss_switches_refuse_cpu():
     from models import envelope_loss, strip_mirror_loss
     from rtg.lib import RtgError

@@ -21,6 +21,8 @@ for N in 1 2 4 8; do
   fi
   val=$(echo "$out" | python3 -c 'import sys, json; d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d["value"], d["ms_per_step"])')
   v=${val% *}; ms=${val#* }
+  # per-rank step times and tuner-pick digests (ranks tune their block shapes independently)
+  echo "$out" | python3 -c 'import sys, json; d = json.loads(sys.stdin.read().strip().splitlines()[-1]); pr = d["config"].get("per_rank"); print("      per rank ms/step", pr["ms_per_step"], "tuner picks", pr["tuner_picks_digest"]) if pr else None'
   [ -z "$base" ] && base=$v
   eff=$(python3 -c "print(round($v / ($N * $base), 3))")
   echo "N=$N  $v audio-s/s  $ms ms/step  efficiency $eff"

@@ -18,6 +18,10 @@ LIB = os.path.join(HERE, 'librtg.so')
 STAMP = os.path.join(HERE, 'csrc', '.build_stamp')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-comment', '-Wno-unused-result'] + os.environ.get('RTG_EXTRA_FLAGS', '').split()
 JOBS = max(1, min(8, os.cpu_count() or 1))
+# ablation / diagnostic hooks of the kernel headers (-DRTG_EXP_*, -DRTG_STAMPS) change what the kernels compute or write:
+# they belong to the side libraries of tools/dev_build.sh (librtg_dev*.so, loaded through RTG_DEV_LIB), never to librtg.so
+if any(f.startswith(('-DRTG_EXP_', '-DRTG_STAMPS')) for f in FLAGS):
+    raise SystemExit('build.py: RTG_EXTRA_FLAGS carries an ablation / diagnostic define; build those with tools/dev_build.sh')
 
 
 def _headers_digest():

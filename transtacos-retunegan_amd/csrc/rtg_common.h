@@ -25,6 +25,13 @@ static inline int rtg_launch_status() {
   return e == hipSuccess ? RTG_OK : -(1000 + (int)e);
 }
 
+// A/B and tuning knobs of the host launch path are read from the environment ONCE per process (a conv launch must not
+// scan the environment; changing a knob mid-process would also silently invalidate the choices cached in rtg/tune.py).
+#include <stdlib.h>
+#define RTG_ENV_SET(name) ([]() -> bool { static const bool v = getenv(name) != nullptr; return v; }())
+#define RTG_ENV_INT(name, dflt) \
+  ([]() -> int { static const int v = []() -> int { const char* e = getenv(name); return e ? atoi(e) : (dflt); }(); return v; }())
+
 static inline int rtg_ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 __device__ __forceinline__ float rtg_lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }

@@ -345,8 +345,8 @@ static int conv_plan(const RtgConv1dDesc* d, const float* x1, const float* x2, c
   a.tab_off = 2 * RTG_CK * a.ROW;
   size_t lds_bytes = (size_t)(2 * RTG_CK * a.ROW + (a.tapmajor ? a.K * RTG_CK : 0)) * sizeof(float);
 #ifdef RTG_STAMPS
-  if (const char* e = getenv("RTG_DEV_OCC")) {            // diagnostic builds: cap the resident blocks per CU through LDS
-    const int cap = atoi(e);
+  if (RTG_ENV_SET("RTG_DEV_OCC")) {            // diagnostic builds: cap the resident blocks per CU through LDS
+    const int cap = RTG_ENV_INT("RTG_DEV_OCC", 0);
     if (cap > 0 && lds_bytes < (size_t)(160 * 1024 / cap - 1024)) lds_bytes = 160 * 1024 / cap - 1024;
   }
 #endif

@@ -579,4 +579,11 @@ extern "C" int rtg_adamw(float* params, const float* grads, float* exp_avg, floa
 }
 
 extern "C" int rtg_abi_version(void) { return RTG_ABI_VERSION; }
-extern "C" const char* rtg_build_info(void) { return "librtg gfx950 fp32-mfma " __DATE__ " " __TIME__; }
+// (a library compiled with an ablation / diagnostic define says so: rtg/lib.py refuses it as the product library)
+#if defined(RTG_EXP_NOMFMA_BF) || defined(RTG_EXP_EMPTY) || defined(RTG_EXP_SKIPLOOP) || defined(RTG_EXP_NOGENERAL) || \
+    defined(RTG_STAMPS)
+#define RTG_BUILD_KIND " ABLATION"
+#else
+#define RTG_BUILD_KIND ""
+#endif
+extern "C" const char* rtg_build_info(void) { return "librtg gfx950 fp32-mfma" RTG_BUILD_KIND " " __DATE__ " " __TIME__; }

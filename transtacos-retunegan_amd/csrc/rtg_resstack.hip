@@ -226,7 +226,7 @@ extern "C" int rtg_resstack_ok(const RtgResStackDesc* d) {
   // / backward, against six launches of the general kernel): (128, 32) 73 / 115 vs 150 / 170 — served; (64, 256) 79 / 113 vs
   // 102 / 120 and (32, 2048) 93 / 130 vs 96 / 114 (stand-alone) — no gain: a block per clip (tile) leaves most of the chip
   // idle or, tiled, moves 58-108 MB through 4-byte epilogue accesses.  Both are built and tested but not served.
-  const int served = getenv("RTG_RESSTACK_KINDS") ? atoi(getenv("RTG_RESSTACK_KINDS")) : 1;
+  const int served = RTG_ENV_INT("RTG_RESSTACK_KINDS", 1);
   return (kind > 0 && (served & (1 << (kind - 1)))) ? 1 : 0;
 }
 

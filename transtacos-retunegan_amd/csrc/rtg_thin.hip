@@ -713,7 +713,7 @@ int rtg_thin_kind(const RtgConv1dDesc* d) {
         d->pad == 1 && d->h_pad == 1 && d->h_n == d->h_in && d->Q == d->L_in && d->out_L == d->Q && d->h_n > 0 &&
         d->B % d->h_n == 0 && d->Cg % 3 == 0 && (d->Cg / 3) % (8 * 8) == 0 && d->Cg / 3 <= 512 && !d->bf16 &&
         d->pre_mode < RTG_PRE_MUL_DLRELU && (long long)d->B * d->Cg / 3 * d->L_in * 4 < (1ll << 31) &&
-        !getenv("RTG_THIN_NOK3"))
+        !RTG_ENV_SET("RTG_THIN_NOK3"))
       return 3;
     return 0;
   }
@@ -797,7 +797,7 @@ int rtg_thin_launch(int kind, const RtgConv1dDesc* d, const float* x, const floa
   a.mask_slope = d->mask_slope; a.out_scale = d->out_scale; a.act = d->act; a.act_slope = d->act_slope;
   a.tile_m = d->tile_m; a.tap_major = d->tap_major ? 1 : 0;
   a.n_pos = (long long)d->B * d->Q;
-  const bool legacy = getenv("RTG_THIN_LEGACY") != nullptr;       // A/B knob: the round-1 kernels
+  const bool legacy = RTG_ENV_SET("RTG_THIN_LEGACY");       // A/B knob: the round-1 kernels
   TileGeo g = {};
   if (kind == 3) {
     const int items = d->B / d->h_n, C = d->Cg / 3;
@@ -853,7 +853,7 @@ int rtg_thin_launch(int kind, const RtgConv1dDesc* d, const float* x, const floa
   }
   if (kind == 2 && !legacy && !a.aux && d->K == 3 && d->stride == 1 && d->dil == 1 && d->pad == 1 && d->Q == d->L_in &&
       d->Q == d->out_L && d->Cg % (8 * 16) == 0 && d->Cg <= 1024 && (long long)d->B * d->Cg * d->L_in * 4 < (1ll << 31) &&
-      !getenv("RTG_THIN_NOK3")) {
+      !RTG_ENV_SET("RTG_THIN_NOK3")) {
     const int cpb = d->L_in <= 64 ? 64 / d->L_in : 1;
     const int bpc = d->L_in <= 64 ? 1 : rtg_ceil_div(d->L_in, 64);
     const long long bx = bpc == 1 ? rtg_ceil_div(d->B, cpb) : (long long)d->B * bpc;

@@ -107,7 +107,7 @@ int geometry(const RtgWgradDesc* d, WgGeom* o) {
   if ((long long)d->B * Lseg * d->stride + RTG_PW_MAX >= (1ll << 24)) return RTG_ERANGE;   // float-reciprocal division
   const int per_clip = rtg_ceil_div(d->Q, TT);
   o->cont = ((double)d->Q / Lseg > 1.08 * (double)d->Q / ((double)per_clip * TT) && d->B >= 2) ? 1 : 0;
-  if (const char* f = getenv("RTG_DEV_WGRAD_CONT")) o->cont = (f[0] == '1' && d->B >= 2) ? 1 : 0;   // tuning aid
+  if (RTG_ENV_SET("RTG_DEV_WGRAD_CONT")) o->cont = (RTG_ENV_INT("RTG_DEV_WGRAD_CONT", 0) == 1 && d->B >= 2) ? 1 : 0;   // tuning aid
   if (o->cont) {
     o->n_ttiles = 1;
     o->n_tiles_total = rtg_ceil_div((long long)d->B * Lseg, TT);
@@ -159,7 +159,7 @@ extern "C" int rtg_wgrad_splits(const RtgWgradDesc* d) {
   if (st) return st;
   const long long base = (long long)d->groups * g.m_blocks * g.n_cchunk;
   const long long total = g.n_tiles_total;
-  if (const char* f = getenv("RTG_DEV_SPLIT_OLD")) {   // tuning aid: the former "aim at 640 blocks" rule
+  if (RTG_ENV_SET("RTG_DEV_SPLIT_OLD")) {   // tuning aid: the former "aim at 640 blocks" rule
     long long s = (640 + base - 1) / base;
     if (s > total) s = total;
     if (s > 512) s = 512;

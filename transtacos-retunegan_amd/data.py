@@ -179,8 +179,17 @@ class PinnedFeeder:
         self.free, self.ready = queue.Queue(), queue.Queue(maxsize=depth)
         self.slots = None
         self._stop = False
-        self._thread = threading.Thread(target=self._produce, daemon=True)
+        self._thread = threading.Thread(target=self._produce_guarded, daemon=True)
         self._started = False
+        self._held = None
+        self._error = None
+
+    def _produce_guarded(self):
+        try:
+            self._produce()
+        except BaseException as e:  # noqa: BLE001  a failing producer must not leave next() blocked forever
+            self._error = e
+            self.ready.put(None)
 
     def _alloc(self, batch):
         self.slots = []
@@ -214,14 +223,19 @@ class PinnedFeeder:
             step += 1
 
     def next(self):
+        if self._stop:
+            raise RuntimeError('PinnedFeeder.next() after close()')
         if not self._started:
             self._started = True
             self._thread.start()
-        if getattr(self, '_held', None) is not None:           # release the slot handed out last time
+        if self._held is not None:                             # release the slot handed out last time
             host, dev, copied, consumed = self.slots[self._held]
             consumed.record(torch.cuda.current_stream(self.device))
             self.free.put(self._held)
+            self._held = None
         i = self.ready.get()
+        if i is None:
+            raise RuntimeError(f'PinnedFeeder: the producer thread failed: {self._error!r}') from self._error
         self._held = i
         host, dev, copied, consumed = self.slots[i]
         torch.cuda.current_stream(self.device).wait_event(copied)
@@ -230,6 +244,8 @@ class PinnedFeeder:
     def close(self):
         """stop the producer and WAIT for it: a daemon thread still inside torch when the interpreter finalises aborts
         the process ("terminate called without an active exception", exit code 134)"""
+        if self._stop and not self._thread.is_alive():         # second close(): nothing left to stop
+            return
         self._stop = True
         self.free.put(None)
         if self._started:

@@ -94,3 +94,6 @@ valid_limit = batch_size * 4
 # cores (BASELINE configs[1]); 'bf16' = operands rounded to bf16 on the bf16 matrix cores, fp32 accumulation, fp32 tensors,
 # fp32 losses and optimizer (BASELINE configs[2]); read when a model's weight bank is built.
 compute_dtype = 'fp32'
+# resume schedule: False = the installed torch's ExponentialLR (2.x: the constructor leaves the loaded lr untouched);
+# True = torch 1.8's (the reference's README.md:15): one more factor of lr_decay per resume.  See train.ExponentialLR.
+legacy_resume_lr = False

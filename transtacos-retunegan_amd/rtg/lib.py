@@ -167,6 +167,9 @@ class _Lib:
             if hasattr(dll, 'rtg_abi_version') and dll.rtg_abi_version() != ABI_VERSION:
                 raise RtgError(f'{LIB_PATH} has ABI version {dll.rtg_abi_version()}, these bindings are for '
                                f'{ABI_VERSION}: stale build — run `python transtacos-retunegan_amd/build.py`')
+            if not os.environ.get('RTG_DEV_LIB') and hasattr(dll, 'rtg_build_info') and b'ABLATION' in dll.rtg_build_info():
+                raise RtgError(f'{LIB_PATH} was compiled with an ablation / diagnostic define (its results are wrong by '
+                               'design): rebuild with `python transtacos-retunegan_amd/build.py --force`')
             self._dll = dll
         return self._dll
 

@@ -849,6 +849,20 @@ def group_conv(token, lys, xs, pre_slope=1.0, res_self=False):
 MRF_GROUP = int(_os.environ.get('RTG_MRF_GROUP', '1'))
 
 
+_GROUP_OK = {}
+
+
+def _common_group_code(descs):
+    """True when the members of a grouped launch share at least one general block shape (what tune.group_cfg picks from)"""
+    lists = []
+    for d in descs:
+        d.tile_cfg = 0
+        cands = (C.c_int * 32)()
+        k = lib.rtg_conv1d_tile_candidates(C.byref(d), cands, 32)
+        lists.append({c for c in cands[:max(k, 0)] if 0 < c < 7000})
+    return bool(set.intersection(*lists)) if lists else False
+
+
 def mrf_group_ok(lys, x):
     if MRF_GROUP == 0 or len(lys) < 2 or len(lys) > L.MAX_GROUP:
         return False
@@ -856,7 +870,18 @@ def mrf_group_ok(lys, x):
     if any(ly.kind != 'conv' or ly.stride != 1 or ly.groups != 1 or ly.cin != c or ly.cout != c or
            2 * ly.pad != ly.dil * (ly.k - 1) for ly in lys):
         return False
-    return c >= 64 or MRF_GROUP == 2
+    if not (c >= 64 or MRF_GROUP == 2):
+        return False
+    # the k3 / k5 / k7 members must also share a block shape, forward and backward-data, at THIS batch and length
+    # (GroupConvFn raises otherwise): any other segment length or batch falls back to the forked branches
+    B, _, L_in = x.shape
+    key = (tuple(ly.lid for ly in lys), id(lys[0]), B, L_in)
+    ok = _GROUP_OK.get(key)
+    if ok is None:
+        ok = _common_group_code([_fwd_desc(ly, B, c, L_in, 0.15)[0] for ly in lys]) and \
+            _common_group_code([_dgrad_desc(ly, B, L_in, L_in, 0.15) for ly in lys])
+        _GROUP_OK[key] = ok
+    return ok
 
 
 # ---------------------------------------------------------------------------------------------------------------

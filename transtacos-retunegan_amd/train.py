@@ -152,8 +152,10 @@ class ExponentialLR:
     semantics of the torch this package runs on (2.x; tests/test_host_cpu.py compares with torch's own class): the
     constructor counts one step without touching the learning rate — a fresh run (last_epoch=-1) ends at last_epoch 0
     with lr = initial_lr, a resumed run (last_epoch=e, lr loaded from the checkpoint's param_groups) at e+1 with the
-    loaded lr — and every step() multiplies the CURRENT lr by gamma (the chainable form).  (torch 1.8, which the
-    reference pins, multiplied once more inside the constructor on resume.)"""
+    loaded lr — and every step() multiplies the CURRENT lr by gamma (the chainable form).
+    Deviation: torch 1.8.0, the version the reference's README.md:15 names, multiplied the loaded lr by
+    gamma once more inside the constructor on resume; `hparam.legacy_resume_lr = True` reproduces that, so a run resumed
+    here follows the schedule of a reference run resumed under its era's torch."""
 
     def __init__(self, optimizer, gamma, last_epoch=-1):
         self.optimizer, self.gamma = optimizer, gamma
@@ -164,6 +166,8 @@ class ExponentialLR:
             raise KeyError("param 'initial_lr' is not specified in param_groups[0] when resuming an optimizer")
         self.base_lrs = [group['initial_lr']]
         self.last_epoch = last_epoch + 1          # the constructor's initial step
+        if last_epoch != -1 and getattr(hp, 'legacy_resume_lr', False):
+            group['lr'] = group['lr'] * gamma     # torch 1.x: that initial step went through get_lr()
 
     def step(self):
         self.last_epoch += 1
@@ -181,7 +185,10 @@ class DataParallel:
     summed with all_reduce on each model's flat gradient buffer and averaged inside the AdamW kernel (grad_scale)."""
 
     def __init__(self, models, process_group=None):
-        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1
+        # RTG_DP_FORCE=1: keep the whole data-parallel machinery (flush hooks, communication stream, collectives between
+        # graph segments) on in a group of ONE rank — how tests/test_dp_gpu.py runs RCCL itself on a one-GPU box
+        self.enabled = dist.is_available() and dist.is_initialized() and (
+            dist.get_world_size(process_group) > 1 or os.environ.get('RTG_DP_FORCE') == '1')
         self.group = process_group
         self.world = dist.get_world_size(process_group) if self.enabled else 1
         self.models = [m for m in models if m is not None]
@@ -268,8 +275,8 @@ class Trainer:
             for p in d.parameters():
                 p.requires_grad_(not flag)
 
-    def d_step(self, y, y_g_hat_detach, apply=True):
-        """train.py:133-160.  apply=False stops after the backward (graph segments: reduce + update come later)."""
+    def _d_forward(self, y, y_g_hat_detach):
+        """train.py:133-157 up to the backward: -> (losses, [(discriminator, its loss term)])"""
         self.optim_d.zero_grad()
         S = S_g = None
         if self.mtd is not None:
@@ -287,7 +294,12 @@ class Trainer:
         losses['disc_all'] = total
         for d in self.discs:                 # before the backward: the flush hooks all-reduce the buffers, flag included
             d.bank().set_flag(total)
-        total.backward()
+        return losses, [(job[0], losses[tag]) for tag, job in jobs]
+
+    def d_step(self, y, y_g_hat_detach, apply=True):
+        """train.py:133-160.  apply=False stops after the backward (graph segments: reduce + update come later)."""
+        losses, _parts = self._d_forward(y, y_g_hat_detach)
+        losses['disc_all'].backward()
         losses = _detached(losses)           # nobody differentiates them again: let the autograd graph go now
         if not apply:
             for d in self.discs:             # join the streams the gradient flushes ran on (a graph segment ends here)
@@ -375,6 +387,16 @@ class Trainer:
         return dl, gl
 
     # -- the same step replayed from HIP graphs
+    def prepare_graphs(self, x, y_tmpl, y):
+        """tune (eagerly, two steps) and capture the step's HIP graphs WITHOUT replaying them: under data parallelism every
+        rank must know that every rank captured before the first replay — a rank whose capture failed would otherwise
+        enter other collectives than the ranks already replaying (bench.py agrees on the outcome in between)."""
+        if self._graphs is None:
+            if not self._tuned or tune.MISSED:                  # block shapes are timed eagerly, never under capture
+                for _ in range(2):
+                    self.train_step(x, y_tmpl, y)
+            self._capture(x, y_tmpl, y)
+
     def train_step_graphed(self, x, y_tmpl, y):
         """train_step() captured once into HIP graphs and replayed: the ~900 kernel launches of a step (and the forks /
         joins of the sub-network streams) are issued by the graph executor instead of the Python autograd machinery.
@@ -386,11 +408,7 @@ class Trainer:
         all-reduces run eagerly between the segments, so one code path serves 1 and N GPUs.  Inputs are copied into
         static buffers; the returned loss dicts hold static device scalars overwritten by every replay.  The learning
         rate is a launch argument: end_epoch() drops the graphs and the next step captures them again."""
-        if self._graphs is None:
-            if not self._tuned or tune.MISSED:                  # block shapes are timed eagerly, never under capture
-                for _ in range(2):
-                    self.train_step(x, y_tmpl, y)
-            self._capture(x, y_tmpl, y)
+        self.prepare_graphs(x, y_tmpl, y)
         sx, sy_tmpl, sy = self._static_in
         for dst, src in ((sx, x), (sy_tmpl, y_tmpl), (sy, y)):
             if dst.data_ptr() != src.data_ptr():
@@ -417,17 +435,50 @@ class Trainer:
         state = {}
         n_d = self.d_train_times
 
+        # Under data parallelism the D backward is cut per discriminator, largest gradient buffer first (MTD, MPD, MSD:
+        # the stacks share no parameter and their loss terms are summed, so three backward calls give the bits of one): the
+        # all-reduce of a stack's flat gradient buffer is issued right after ITS segment and runs on the communication
+        # stream while the next stack's backward segment replays — the overlap the eager step gets from the flush hooks
+        # (BASELINE configs[3]).  One rank: one segment per D update, nothing to overlap.
+        dp = self.dp.enabled
+        order = sorted(self.discs, key=lambda d: -d.bank().n_params)
+
+        def d_forward_and_first():
+            losses, parts = self._d_forward(sy, state['y_hat'].detach())
+            state['dl'] = _detached(losses)
+            state['parts'] = {id(d): t for d, t in parts}
+            d_backward(order[0])()
+
+        def d_backward(d):
+            def run():
+                state['parts'].pop(id(d)).backward()
+                d.bank().sync_grads()
+            return run
+
+        def reduce_of(d, last):
+            def run():
+                self.dp.reduce_async(d.bank().gflat)
+                if last:
+                    self.dp.wait()
+            return run
+
         def seg_first():
             state['cache'] = stft_cache()
             state['cache'].__enter__()
             state['y_hat'] = self.generator(sx, sy_tmpl)
-            state['dl'] = self.d_step(sy, state['y_hat'].detach(), apply=False)
+            if dp:
+                d_forward_and_first()
+            else:
+                state['dl'] = self.d_step(sy, state['y_hat'].detach(), apply=False)
 
         def seg_d(i):
             def run():
                 self.optim_d.step(use_bank_flag=True)
                 if i < n_d:
-                    state['dl'] = self.d_step(sy, state['y_hat'].detach(), apply=False)
+                    if dp:
+                        d_forward_and_first()
+                    else:
+                        state['dl'] = self.d_step(sy, state['y_hat'].detach(), apply=False)
                 else:
                     state['gl'] = self.g_step(sy, state['y_hat'], apply=False)
                     state['cache'].__exit__(None, None, None)
@@ -436,16 +487,22 @@ class Trainer:
         def seg_last():
             self.optim_g.step(use_bank_flag=True)
 
-        def after_d():
-            self._d_reduce(replay=True)
-
         def after_g():
             self._g_reduce()
 
-        segs = [(seg_first, after_d)]
+        def d_tail():
+            """the segments that finish a D update whose forward + first backward sit in the previous segment"""
+            if not dp:
+                return []
+            return [(d_backward(d), reduce_of(d, j == len(order) - 1)) for j, d in enumerate(order) if j > 0]
+
+        first_after = reduce_of(order[0], len(order) == 1) if dp else None
+        segs = [(seg_first, first_after)] + d_tail()
         for i in range(1, n_d + 1):
             last_d = i == n_d
-            segs.append((seg_d(i), after_g if last_d else after_d))
+            segs.append((seg_d(i), after_g if last_d else first_after))
+            if not last_d:
+                segs += d_tail()
         segs.append((seg_last, None))
         graphs = []
         try:

@@ -2,7 +2,6 @@
 Plotting helpers are not part of the hot path and are left out."""
 import glob
 import os
-from time import time
 
 import torch
 
@@ -27,15 +26,6 @@ def get_same_padding(kernel_size, dilation=1):
     return dilation * (kernel_size // 2)
 
 
-def truncate_align(x, y):
-    d = x.shape[-1] - y.shape[-1]
-    if d > 0:
-        x = x[:, :, d // 2: -(d - d // 2)]
-    elif d < 0:
-        y = y[:, :, (-d) // 2: -((-d) - (-d) // 2)]
-    return x, y
-
-
 def get_param_cnt(model):
     return sum(p.numel() for p in model.parameters())
 
@@ -57,12 +47,3 @@ def save_checkpoint(fp, obj):
 def scan_checkpoint(dp, prefix):
     cp_list = glob.glob(os.path.join(dp, prefix + '*'))
     return len(cp_list) and sorted(cp_list)[-1] or None
-
-
-def timer(fn):
-    def wrapper(*args, **kwargs):
-        start = time()
-        r = fn(*args, **kwargs)
-        print(f'[Timer]: {fn.__name__} took {time() - start:.2f}')
-        return r
-    return wrapper
