@@ -204,7 +204,11 @@ def roofline(trainer, batch, bf16=False):
     # the dominant MATRIX kernel (the bandwidth kernels of the 1-channel layers, variants < 100, are reported in by_kernel)
     (kernel, variant), (n, secs, flop, nbytes) = max(((k, v) for k, v in agg.items() if not (k[0] == 'conv1d' and k[1] < 100)),
                                              key=lambda kv: kv[1][1])
-    if kernel == 'conv1d':
+    DSHAPES = {1: (2, 4), 2: (1, 8), 3: (1, 4), 4: (2, 8)}      # rtg_dconv.hip: code digit -> (16-row tiles per wave, waves)
+    if kernel == 'conv1d' and variant > 8000:
+        rw, wb = DSHAPES[(variant - 8000) // 100]
+        name = f'dconv_kernel<{rw},{wb},{variant % 100}>'
+    elif kernel == 'conv1d':
         name = f'conv1d_mfma_group_kernel<{variant // 100},{variant // 10 % 10},{variant % 10}>'
     else:
         name = f'wgrad_kernel<{variant}>'
@@ -216,8 +220,11 @@ def roofline(trainer, batch, bf16=False):
            'algorithmic_bytes_per_launch': round(nbytes / n) if nbytes else None}
     # HBM traffic and matrix-pipe occupancy of that kernel from the committed PMC passes (rocprofv3 --pmc cannot run inside
     # this process): profiles/*_pmc.json, written by tools/pmc_pass.sh + tools/pmc_summary.py from this same command
-    pmc = _pmc_for(f'conv1d_mfma_group_kernel<{variant // 100}, {variant // 10 % 10}, {variant % 10},' if kernel == 'conv1d'
-                   else f'wgrad_kernel<{variant},')
+    if kernel == 'conv1d' and variant > 8000:
+        pmc = _pmc_for(f'dconv_kernel<{rw}, {wb}, {variant % 100},')
+    else:
+        pmc = _pmc_for(f'conv1d_mfma_group_kernel<{variant // 100}, {variant // 10 % 10}, {variant % 10},' if kernel == 'conv1d'
+                       else f'wgrad_kernel<{variant},')
     if pmc and not bf16:                     # the committed PMC passes are of the fp32 instances
         out['traffic'] = pmc['traffic']
         out['traffic_unit'] = 'bytes/launch (HBM read + write, PMC FETCH_SIZE x2 + WRITE_SIZE)'

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define RTG_ABI_VERSION 5
+#define RTG_ABI_VERSION 6
 
 #define RTG_OK 0
 #define RTG_EINVAL (-1)   /* inconsistent descriptor               */
@@ -88,6 +88,10 @@ typedef struct RtgConv1dDesc {
                                   rtg_weights_pack with RtgPackJob.bf16) and multiplied on the bf16 matrix cores
                                   (v_mfma_f32_32x32x8_bf16_1k / 16x16x16), fp32 accumulate, fp32 tensors in HBM
                                   (BASELINE configs[2]).  Not with tap_major.                                  */
+  int wp16;                    /* 1 (ABI 6): `wp` carries a second image of the layer's weights right behind the standard
+                                  one (at wp + rtg_packed_size(groups, Mg, Cg, K, tile_m) floats): the 16-byte-fragment
+                                  image RtgPackJob.frag16 writes (rtg_packed_size_frag16 floats).  The dense-layer kernel
+                                  of rtg_dconv.hip (block-shape codes 8xxx) is only listed / accepted with it          */
 } RtgConv1dDesc;
 
 int rtg_conv1d(const RtgConv1dDesc* d, const float* x1, const float* x2, const float* aux, const float* wp,
@@ -114,6 +118,8 @@ int rtg_conv1d_tile_candidates(const RtgConv1dDesc* d, int* cfgs, int max);
 
 /* number of floats of the packed weight buffer for a layer with the given logical shape */
 long long rtg_packed_size(int groups, int Mg, int Cg, int K, int tile_m);
+/* ... of the 16-byte-fragment image (RtgPackJob.frag16; groups == 1): ceil(Mg/16) x ceil(Cg/16) x K x 256 */
+long long rtg_packed_size_frag16(int Mg, int Cg, int K);
 /* the same for the tap-major order, and whether that order needs fewer MFMAs than the channel-major one (1 / 0) */
 long long rtg_packed_size_bf16(int groups, int Mg, int Cg, int K, int tile_m);   /* floats (2 bf16 each) */
 long long rtg_packed_size_tapmajor(int groups, int Mg, int Cg, int K, int tile_m);
@@ -223,6 +229,9 @@ typedef struct RtgPackJob {      /* one per packed layout of a layer            
   int bf16;                      /* 1: bf16 fragments [g][m-tile][chunk][tap][mfma][lane][4] (dst_size in floats =
                                     rtg_packed_size_bf16); lane (kk, m) holds channels 8*mfma + 4*kk .. +3 of the chunk
                                     (tile_m 32, two MFMAs per chunk) or 4*kk .. +3 (tile_m 16, one MFMA)             */
+  int frag16;                    /* 1 (ABI 6; fp32, channel-major, groups == 1): the 16-byte-fragment image
+                                    [16-row tile][chunk][tap][kgrp 4][m 16][kq 4] with channel = 4*kq + kgrp of the chunk
+                                    (dst_size = rtg_packed_size_frag16): what rtg_dconv.hip (codes 8xxx) reads           */
 } RtgPackJob;
 
 typedef struct RtgWnBwdJob {     /* one per weight-normed tensor                                               */

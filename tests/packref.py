@@ -81,3 +81,15 @@ def logical_convT_poly(w, s):
 def logical_convT_dgrad(w):
     """ConvTranspose1d backward-data = strided conv of dy: rows = ci, reduce over co."""
     return w[None].copy()
+
+
+def pack_frag16(W):
+    """W: [1, Mg, Cg, K] logical operator -> the 16-byte-fragment image of rtg_dconv.hip (RtgPackJob.frag16):
+    [16-row tile][chunk][tap][kgrp 4][m 16][kq 4] with channel = 16 * chunk + 4 * kq + kgrp, zero padded."""
+    G, Mg, Cg, K = W.shape
+    assert G == 1
+    n_mt, n_cc = -(-Mg // 16), -(-Cg // CK)
+    P = np.zeros((n_mt * 16, n_cc * CK, K), dtype=np.float32)
+    P[:Mg, :Cg] = W[0]
+    P = P.reshape(n_mt, 16, n_cc, 4, 4, K)                       # mt, m, cc, kq, kgrp, tap
+    return np.ascontiguousarray(P.transpose(0, 2, 5, 4, 1, 3)).reshape(-1)

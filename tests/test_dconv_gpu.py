@@ -1,0 +1,189 @@
+"""rtg_dconv.hip — the dense-layer conv kernel (block-shape codes 8xxx of rtg_conv1d): every code the library lists for a
+problem must reproduce the general kernel BIT FOR BIT (same accumulation order, same epilogue arithmetic) and agree with
+an fp64 torch convolution; the 16-byte-fragment weight image of rtg_weights_pack must equal the host statement of it.
+Shapes: the DiscriminatorP / DiscriminatorS layers the kernel was written for (discrminator.py:44,155-163) at reduced
+batch, plus ragged rows / columns / clips."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import packref
+
+pytestmark = pytest.mark.gpu
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _both_images(W, tile_m=32):
+    """standard image followed by the 16-byte-fragment image (what a bank layer with wp16 holds)"""
+    return np.concatenate([packref.pack_logical(W, tile_m), packref.pack_frag16(W)])
+
+
+def _run(desc_kw, x, wp, bias=None, mask=None, res=None, out_shape=None, cfg=0, out_init=None):
+    from rtg.lib import lib, Conv1dDesc
+    d = Conv1dDesc(**desc_kw)
+    d.tile_cfg = cfg
+    out = torch.full(out_shape, float('nan'), device='cuda') if out_init is None else out_init.clone()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rc = lib.rtg_conv1d(C.byref(d), _ptr(x), None, None, _ptr(wp), _ptr(bias), _ptr(mask), _ptr(res), _ptr(out), None, st)
+    torch.cuda.synchronize()
+    return rc, out
+
+
+def _codes(desc_kw):
+    from rtg.lib import lib, Conv1dDesc
+    d = Conv1dDesc(**desc_kw)
+    cands = (C.c_int * 48)()
+    n = lib.rtg_conv1d_tile_candidates(C.byref(d), cands, 48)
+    return [c for c in cands[:n] if c > 8000]
+
+
+def _desc(B, Cin, L_in, Mg, K, stride, pad, Q, out_C, out_L, **kw):
+    d = dict(B=B, C1=Cin, C2=0, L_in=L_in, groups=1, Cg=Cin, Mg=Mg, K=K, stride=stride, dil=1, pad=pad, Q=Q, out_C=out_C,
+             out_L=out_L, shuf_S=1, shuf_P=0, pre_mode=0, pre_slope=1.0, mask_slope=1.0, out_scale=1.0, act=0,
+             act_slope=1.0, accumulate=0, tile_m=32, out_split=0, wp16=1)
+    d.update(kw)
+    return d
+
+
+FWD = [
+    # B, C_in, C_out, L, stride      (k = 5, pad = 2)
+    (24, 512, 512, 10, 1),       # DiscriminatorP convs.4, period 11: rows of 10
+    (7, 512, 512, 34, 1),        # period 3: rows of 34, a ragged clip count
+    (5, 512, 512, 128, 1),       # DiscriminatorS convs.5: one clip per 128-column tile
+    (3, 512, 512, 64, 1),
+    (9, 256, 512, 102, 3),       # DiscriminatorP convs.3 (stride 3)
+    (13, 256, 512, 28, 3),
+    (6, 128, 256, 304, 3),       # convs.2
+    (4, 128, 144, 83, 3),        # rows not a multiple of 128 / 64: clamped row tiles
+]
+
+
+@pytest.mark.parametrize('case', FWD)
+def test_forward_codes_bit_identical_to_the_general_kernel(case):
+    B, Cin, Cout, L, s = case
+    K, p = 5, 2
+    gen = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    x = torch.randn(B, Cin, L, generator=gen)
+    w = torch.randn(Cout, Cin, K, generator=gen) / np.sqrt(Cin * K)
+    bias = torch.randn(Cout, generator=gen)
+    ref = F.conv1d(F.leaky_relu(x, 0.15).double(), w.double(), bias.double(), s, p).float()
+    Lo = ref.shape[-1]
+    wp = torch.from_numpy(_both_images(packref.logical_fwd(w.numpy(), 1))).cuda()
+    kw = _desc(B, Cin, L, Cout, K, s, p, Lo, Cout, Lo, pre_mode=1, pre_slope=0.15)
+    xd, bd = x.cuda(), bias.cuda()
+    rc, base = _run(kw, xd, wp, bias=bd, out_shape=(B, Cout, Lo))
+    assert rc == 0
+    np.testing.assert_allclose(base.cpu().numpy(), ref.numpy(), rtol=1e-4, atol=2e-5)
+    codes = _codes(kw)
+    assert codes, 'no dense-layer code listed'
+    for c in codes:
+        rc, out = _run(kw, xd, wp, bias=bd, out_shape=(B, Cout, Lo), cfg=c)
+        assert rc == 0, c
+        assert torch.equal(out, base), (c, (out - base).abs().max().item())
+
+
+def test_without_the_fragment_image_no_dense_code_is_listed_or_accepted():
+    kw = _desc(8, 512, 34, 512, 5, 1, 2, 34, 512, 34, wp16=0)
+    assert _codes(kw) == []
+    x = torch.zeros(8, 512, 34, device='cuda')
+    wp = torch.zeros(512 * 512 * 5, device='cuda')
+    rc, _ = _run(kw, x, wp, out_shape=(8, 512, 34), cfg=8107)
+    assert rc == -1
+
+
+@pytest.mark.parametrize('case', [(10, 512, 512, 21), (3, 512, 512, 128), (5, 256, 384, 15)])
+def test_dgrad_stride1_codes(case):
+    """backward-data of a stride-1 k5 layer: the same operator on flipped / transposed weights, leaky-relu-derivative mask
+    and a residual gradient (PairConvFn's tap) in the epilogue, out_scale and accumulate too"""
+    B, Cin, Cout, L = case
+    K, p = 5, 2
+    gen = torch.Generator().manual_seed(17)
+    x = torch.randn(B, Cin, L, generator=gen, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(Cout, Cin, K, generator=gen) / np.sqrt(Cin * K)
+    y = F.conv1d(F.leaky_relu(x, 0.15), w.double(), None, 1, p)
+    dy = torch.randn(y.shape, generator=gen)
+    tap = torch.randn(B, Cin, L, generator=gen)
+    y.backward(dy.double())
+    ref = (x.grad.float() + tap)
+    wp = torch.from_numpy(_both_images(packref.logical_dgrad_s1(w.numpy(), 1))).cuda()
+    kw = _desc(B, Cout, L, Cin, K, 1, (K - 1) - p, L, Cin, L, mask_slope=0.15)
+    xm, dyd, tapd = x.detach().float().cuda(), dy.cuda(), tap.cuda()
+    rc, base = _run(kw, dyd, wp, mask=xm, res=tapd, out_shape=(B, Cin, L))
+    assert rc == 0
+    np.testing.assert_allclose(base.cpu().numpy(), ref.numpy(), rtol=1e-4, atol=3e-5)
+    init = torch.randn(B, Cin, L, device='cuda')
+    kw2 = dict(kw, accumulate=1, out_scale=0.5)
+    rc, base2 = _run(kw2, dyd, wp, mask=xm, res=tapd, out_shape=(B, Cin, L), out_init=init)
+    codes = _codes(kw)
+    assert codes
+    for c in codes:
+        rc, out = _run(kw, dyd, wp, mask=xm, res=tapd, out_shape=(B, Cin, L), cfg=c)
+        assert rc == 0 and torch.equal(out, base), c
+        rc, out = _run(kw2, dyd, wp, mask=xm, res=tapd, out_shape=(B, Cin, L), cfg=c, out_init=init)
+        assert rc == 0 and torch.equal(out, base2), c
+
+
+@pytest.mark.parametrize('case', [(9, 256, 512, 102), (13, 256, 512, 28), (6, 128, 256, 304), (5, 128, 256, 83)])
+def test_dgrad_polyphase_codes(case):
+    """backward-data of the stride-3 k5 layers: 2-tap stride-1 operator over dy with (channel, phase) rows and the
+    interleaving store"""
+    B, Cin, Cout, L = case
+    K, s, p = 5, 3, 2
+    gen = torch.Generator().manual_seed(19)
+    x = torch.randn(B, Cin, L, generator=gen, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(Cout, Cin, K, generator=gen) / np.sqrt(Cin * K)
+    y = F.conv1d(F.leaky_relu(x, 0.15), w.double(), None, s, p)
+    Lo = y.shape[-1]
+    dy = torch.randn(y.shape, generator=gen)
+    y.backward(dy.double())
+    ref = x.grad.float()
+    W = packref.logical_dgrad_poly(w.numpy(), 1, s)
+    nt = W.shape[-1]
+    wp = torch.from_numpy(_both_images(W)).cuda()
+    nq = (L - 1 + p) // s + 1
+    kw = _desc(B, Cout, Lo, Cin * s, nt, 1, nt - 1, nq, Cin, L, shuf_S=s, shuf_P=p, mask_slope=0.15)
+    xm, dyd = x.detach().float().cuda(), dy.cuda()
+    rc, base = _run(kw, dyd, wp, mask=xm, out_shape=(B, Cin, L))
+    assert rc == 0
+    np.testing.assert_allclose(base.cpu().numpy(), ref.numpy(), rtol=1e-4, atol=3e-5)
+    codes = _codes(kw)
+    assert codes
+    for c in codes:
+        rc, out = _run(kw, dyd, wp, mask=xm, out_shape=(B, Cin, L), cfg=c)
+        assert rc == 0 and torch.equal(out, base), c
+
+
+def test_pack_kernel_writes_the_fragment_image():
+    """rtg_weights_pack with RtgPackJob.frag16 against tests/packref.pack_frag16, forward and both backward-data operators"""
+    from rtg import lib as L
+    from rtg.lib import lib
+    gen = torch.Generator().manual_seed(23)
+    Cout, Cin, K = 144, 128, 5
+    v = torch.randn(Cout, Cin, K, generator=gen)
+    g = torch.rand(Cout, generator=gen) + 0.5
+    w_eff = (v * (g / v.flatten(1).norm(dim=1)).view(-1, 1, 1)).numpy()
+    params = torch.cat([g, v.flatten()]).cuda()
+    scales = torch.empty(2 * Cout, device='cuda')
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    norm = (L.NormJob * 1)(L.NormJob(0, Cout, 0, Cout, Cin * K))
+    norm_d = torch.frombuffer(bytearray(bytes(memoryview(norm).cast('B'))), dtype=torch.uint8).cuda()
+    assert lib.rtg_weightnorm_scales(_ptr(norm_d), 1, Cout, _ptr(params), _ptr(scales), st) == 0
+    for mode, W in ((L.PACK_FWD, packref.logical_fwd(w_eff, 1)), (L.PACK_DGRAD_S1, packref.logical_dgrad_s1(w_eff, 1)),
+                    (L.PACK_DGRAD_POLY, packref.logical_dgrad_poly(w_eff, 1, 3))):
+        _, Mg, Cg, Kp = W.shape
+        size = lib.rtg_packed_size_frag16(Mg, Cg, Kp)
+        ref = packref.pack_frag16(W)
+        assert size == ref.size
+        job = (L.PackJob * 1)(L.PackJob(Cout, 0, 0, size, mode, 1, Mg, Cg, Kp, K, Cin, 3 if mode == L.PACK_DGRAD_POLY else 1,
+                                       16, 1, 0, 0, 1))
+        job_d = torch.frombuffer(bytearray(bytes(memoryview(job).cast('B'))), dtype=torch.uint8).cuda()
+        packed = torch.full((size,), float('nan'), device='cuda')
+        assert lib.rtg_weights_pack(_ptr(job_d), 1, size, _ptr(params), _ptr(scales), _ptr(packed), st) == 0
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(packed.cpu().numpy(), ref, rtol=1e-6, atol=1e-7)

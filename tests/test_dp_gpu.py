@@ -194,6 +194,8 @@ def test_single_rank_rccl_forced_dp_equals_plain_step(monkeypatch):
     _setup()
     from rtg import tune
     monkeypatch.setattr(tune, 'ENABLED', False)
+    for name in ('_conv', '_wgrad', '_group', '_wgroup', '_alt'):      # choices cached by earlier tests of this process
+        monkeypatch.setattr(tune, name, {})
     ref = {}
     for full in (False, True):
         tr, O = _make_trainer(full)

@@ -1,0 +1,108 @@
+#!/usr/bin/env python3
+"""Dev tool: the dense-layer kernel (rtg_dconv.hip, codes 8xxx) against the general kernel's candidates on the layer
+shapes it serves, at the train step's batch.  usage: bench_dconv.py [fwd|dgrad|poly ...]"""
+import ctypes as C
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(REPO, 'transtacos-retunegan_amd'))
+sys.path.insert(0, os.path.join(REPO, 'tests'))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import packref  # noqa: E402
+from rtg.lib import lib, Conv1dDesc  # noqa: E402
+
+
+def P(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def timeit(f, iters=20):
+    for _ in range(3):
+        f()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        f()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def bench(kind, B, Cin, Cout, L, s):
+    K, p = 5, 2
+    w = (np.random.RandomState(1).randn(Cout, Cin, K) / np.sqrt(Cin * K)).astype(np.float32)
+    Lo = (L + 2 * p - K) // s + 1
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    base = dict(C2=0, groups=1, dil=1, pre_slope=1.0, mask_slope=1.0, out_scale=1.0, act=0, act_slope=1.0, accumulate=0,
+                tile_m=32, out_split=0, wp16=1, shuf_S=1, shuf_P=0, pre_mode=0)
+    if kind == 'fwd':
+        W = packref.logical_fwd(w, 1)
+        x = torch.randn(B, Cin, L, device='cuda')
+        out = torch.empty(B, Cout, Lo, device='cuda')
+        d = Conv1dDesc(**dict(base, B=B, C1=Cin, L_in=L, Cg=Cin, Mg=Cout, K=K, stride=s, pad=p, Q=Lo, out_C=Cout, out_L=Lo,
+                              pre_mode=1, pre_slope=0.15))
+        mask = None
+    elif kind == 'dgrad':
+        W = packref.logical_dgrad_s1(w, 1)
+        x = torch.randn(B, Cout, Lo, device='cuda')
+        out = torch.empty(B, Cin, L, device='cuda')
+        mask = torch.randn(B, Cin, L, device='cuda')
+        d = Conv1dDesc(**dict(base, B=B, C1=Cout, L_in=Lo, Cg=Cout, Mg=Cin, K=K, stride=1, pad=K - 1 - p, Q=L, out_C=Cin,
+                              out_L=L, mask_slope=0.15))
+    else:
+        W = packref.logical_dgrad_poly(w, 1, s)
+        nt = W.shape[-1]
+        x = torch.randn(B, Cout, Lo, device='cuda')
+        out = torch.empty(B, Cin, L, device='cuda')
+        mask = torch.randn(B, Cin, L, device='cuda')
+        d = Conv1dDesc(**dict(base, B=B, C1=Cout, L_in=Lo, Cg=Cout, Mg=Cin * s, K=nt, stride=1, pad=nt - 1,
+                              Q=(L - 1 + p) // s + 1, out_C=Cin, out_L=L, shuf_S=s, shuf_P=p, mask_slope=0.15))
+    wp = torch.from_numpy(np.concatenate([packref.pack_logical(W, 32), packref.pack_frag16(W)])).cuda()
+    flop = 2.0 * B * Lo * Cout * Cin * K
+    cands = (C.c_int * 48)()
+    n = lib.rtg_conv1d_tile_candidates(C.byref(d), cands, 48)
+    res = []
+    ref = None
+    for c in list(cands[:n]):
+        d.tile_cfg = c
+        rc = lib.rtg_conv1d(C.byref(d), P(x), None, None, P(wp), None, P(mask), None, P(out), None, st)
+        if rc:
+            res.append((c, None, rc))
+            continue
+        torch.cuda.synchronize()
+        if ref is None:
+            ref = out.clone()
+        same = torch.equal(out, ref)
+        ms = timeit(lambda: lib.rtg_conv1d(C.byref(d), P(x), None, None, P(wp), None, P(mask), None, P(out), None, st))
+        res.append((c, ms, same))
+    gen = [r for r in res if r[0] < 8000 and r[1]]
+    dc = [r for r in res if r[0] > 8000 and r[1]]
+    bg = min(gen, key=lambda r: r[1])
+    bd = min(dc, key=lambda r: r[1]) if dc else None
+    line = f'{kind:5s} B{B:4d} {Cin}->{Cout} L{L:4d} s{s}: general best {bg[0]} {bg[1] * 1e3:7.1f} us {flop / bg[1] / 1e9:6.1f} TF/s'
+    if bd:
+        line += f' | dconv best {bd[0]} {bd[1] * 1e3:7.1f} us {flop / bd[1] / 1e9:6.1f} TF/s  x{bg[1] / bd[1]:.2f}'
+    bad = [r[0] for r in res if r[2] is not True]
+    print(line + (f'  MISMATCH/ERR {bad}' if bad else ''), flush=True)
+    if os.environ.get('BD_ALL'):
+        for c, ms, same in res:
+            if c > 8000 and ms:
+                print(f'      {c}: {ms * 1e3:7.1f} us {flop / ms / 1e9:6.1f} TF/s')
+
+
+SHAPES = [
+    ('fwd', 704, 512, 512, 10, 1), ('fwd', 448, 512, 512, 15, 1), ('fwd', 320, 512, 512, 21, 1), ('fwd', 192, 512, 512, 34, 1),
+    ('fwd', 64, 512, 512, 128, 1), ('fwd', 64, 512, 512, 64, 1), ('fwd', 64, 512, 512, 32, 1),
+    ('dgrad', 704, 512, 512, 10, 1), ('dgrad', 192, 512, 512, 34, 1), ('dgrad', 352, 512, 512, 10, 1), ('dgrad', 64, 512, 512, 128, 1),
+    ('fwd', 704, 256, 512, 28, 3), ('fwd', 192, 256, 512, 102, 3), ('fwd', 704, 128, 256, 83, 3), ('fwd', 192, 128, 256, 304, 3),
+    ('poly', 704, 256, 512, 28, 3), ('poly', 192, 256, 512, 102, 3), ('poly', 704, 128, 256, 83, 3), ('poly', 192, 128, 256, 304, 3),
+]
+
+if __name__ == '__main__':
+    kinds = sys.argv[1:]
+    for sh in SHAPES:
+        if not kinds or sh[0] in kinds:
+            bench(*sh)

@@ -168,8 +168,23 @@ int rtg_resconv_launch(const RtgConv1dDesc* d, int nt, const float* x, const flo
                        const float* mask, const float* res, float* out, hipStream_t s);
 #define RTG_RESCONV_CODE 7000
 
+// rtg_dconv.hip: the dense-layer kernel (16-byte operand fragments, 16-column tiles) for the 128..512-channel layers of
+// the discriminators (block-shape codes 8000 + 100 * shape + 16-column tiles per block; needs RtgConv1dDesc.wp16)
+int rtg_dconv_candidates(const RtgConv1dDesc* d, int* codes, int max);
+int rtg_dconv_launch(const RtgConv1dDesc* d, int code, const float* x, const float* wp, const float* bias,
+                     const float* mask, const float* res, float* out, hipStream_t s);
+#define RTG_DCONV_CODE 8000
+static bool dconv_code_ok(const RtgConv1dDesc* d) {
+  int codes[16];
+  const int n = rtg_dconv_candidates(d, codes, 16);
+  for (int i = 0; i < n; ++i)
+    if (codes[i] == d->tile_cfg) return true;
+  return false;
+}
+
 extern "C" int rtg_conv1d_variant(const RtgConv1dDesc* d) {
   if (!d) return RTG_ENULL;
+  if (d->tile_cfg > RTG_DCONV_CODE) return dconv_code_ok(d) ? d->tile_cfg : RTG_EINVAL;
   if (d->tile_cfg > RTG_RESCONV_CODE && d->tile_cfg <= RTG_RESCONV_CODE + 2)
     return (rtg_resconv_variants(d) & (1 << (d->tile_cfg - RTG_RESCONV_CODE - 1))) ? d->tile_cfg : RTG_EINVAL;
   if ((d->tile_m != 32 && d->tile_m != 16) || d->Mg < 1 || d->Q < 1 || d->B < 1 || d->groups < 1 || d->stride < 1 ||
@@ -208,6 +223,8 @@ extern "C" int rtg_conv1d_tile_candidates(const RtgConv1dDesc* d, int* cfgs, int
   const int rv = rtg_resconv_variants(d);
   for (int nt = 2; nt >= 1; --nt)
     if ((rv & (1 << (nt - 1))) && cnt < max) cfgs[cnt++] = RTG_RESCONV_CODE + nt;
+  // the dense-layer kernel's best-scored shapes (all of them would double the tuning step's work on these layers)
+  if (cnt < max) cnt += rtg_dconv_candidates(d, cfgs + cnt, max - cnt < 8 ? max - cnt : 8);
   return cnt;
 }
 
@@ -366,6 +383,8 @@ extern "C" int rtg_conv1d(const RtgConv1dDesc* d, const float* x1, const float* 
       return rtg_thin_launch(thin, d, x1, aux, wp, bias, mask, res, out, (hipStream_t)stream);
     }
   }
+  if (d->tile_cfg > RTG_DCONV_CODE)
+    return rtg_dconv_launch(d, d->tile_cfg, x1, wp, bias, mask, res, out, (hipStream_t)stream);
   if (d->tile_cfg > RTG_RESCONV_CODE && d->tile_cfg <= RTG_RESCONV_CODE + 2)
     return rtg_resconv_launch(d, d->tile_cfg - RTG_RESCONV_CODE, x1, wp, bias, mask, res, out, (hipStream_t)stream);
   ConvPlan pl;

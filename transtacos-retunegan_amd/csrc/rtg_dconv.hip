@@ -1,0 +1,434 @@
+// rtg_dconv.hip — the dense-layer implicit-GEMM Conv1d kernel ("conv kernel v2", round 3): the 128..512-channel, dilation-1
+// layers at the top of the discriminators, where 75 % of their multiply-accumulates sit
+//   DiscriminatorP convs.2 / .3 / .4  (128 -> 256 -> 512 -> 512, (5,1) kernels, stride 3 / 3 / 1)   discrminator.py:155-163
+//   DiscriminatorS convs.5            (512 -> 512, k5, stride 1)                                     discrminator.py:44
+// forward, backward-data of the stride-1 layers (same operator on RTG_PACK_DGRAD_S1 weights) and the polyphase
+// backward-data of the stride-3 layers (a stride-1 operator with ceil(5/3) = 2 taps and a "shuffle" store).
+//
+// What the general kernel (rtg_conv1d_kernel.h) spends besides matrix instructions on these layers, and what is done here:
+//   operand fetches  one 4-byte LDS read and one 4-byte weight load per v_mfma_f32_32x32x2_f32 -> ONE 16-byte fetch per
+//                    FOUR matrix instructions for both operands: the 16 channels of a chunk are the four k-steps of
+//                    v_mfma_f32_16x16x4_f32 (lane (kgrp, n) holds channel 4 * kq + kgrp of k-step kq), the staged patch is
+//                    position-major with those four values of a lane adjacent ([position][kgrp][kq], 80-byte rows: bank
+//                    conflict free for stride 1 and 3 without a swizzle), the weights come packed the same way
+//                    (RtgPackJob.frag16) and are read straight from L2, one coalesced 1-KB load per 16 rows and (chunk, tap);
+//   column waste     32-column tile granularity and whole-clip patches -> 16-column granularity (the tile width is chosen
+//                    so that the grid is one full round of the chip: 512 x 7040 outputs are 252 tiles of 128 x 112) and a
+//                    staged window of exactly the positions the tile's columns read, whatever clips it straddles;
+//   geometry         run-time taps / stride / dilation / 2-D / grouping -> compile-time taps and stride, tap offsets are
+//                    immediates of the LDS reads;
+//   weight re-reads  waves are stacked along the output rows only, so no two waves of a block load the same weights;
+//   barriers         one per 16-channel chunk, placed one tap before the chunk ends: the next chunk's patch is published
+//                    while the last tap still multiplies, and the fragment prefetch never waits at a chunk boundary.
+// The accumulation order of every output element — chunk, tap, channel ascending, one fused multiply-add each — is the
+// general kernel's (v_mfma_f32_16x16x4_f32 chains k = 0..3 exactly like two v_mfma_f32_32x32x2_f32), and so is the
+// epilogue arithmetic: results are bit-identical to every other block shape (tests/test_dconv_gpu.py).
+// Exposed through rtg_conv1d as block-shape codes 8000 + 100 * shape + NT (RtgConv1dDesc.tile_cfg) when the descriptor
+// says the 16-byte-fragment weight image is there (RtgConv1dDesc.wp16); the tuner times them like any other shape.
+#include "rtg_common.h"
+
+namespace {
+
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+#define DC_OOB 0x80000000u
+constexpr int kRowF = 20;                 // floats per staged position: 16 channels + 4 of padding (80 bytes)
+
+struct DArgs {
+  const float *x, *wp, *bias, *mask, *res;
+  float* out;
+  int B, C, L_in, Mg, n_cc, Q, pad, out_C, out_L, shuf_S, shuf_P;
+  int pre, act, accumulate;
+  float pre_slope, mask_slope, out_scale, act_slope;
+  int seg_pw;                 // virtual positions per clip: (Q - 1) * S + K
+  int n_cols;                 // B * Q
+  int n_mb, total, per_xcd;   // row blocks, work items, work items per XCD
+  int PW;                     // staged positions per buffer
+  int x_bytes, out_bytes;
+};
+
+__device__ __forceinline__ float dc_load(rsrc_t r, unsigned off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+}
+
+constexpr int kMinQ = 8;                  // shortest row served (bounds the clip boundaries a column tile can straddle)
+
+// positions a column tile of `cols` columns reads: the span of its columns' virtual positions plus the taps; every clip
+// boundary inside the tile adds the gap between two clips' segments (seg_pw - Q * S = K - S)
+constexpr int window_positions(int cols, int Q, int S, int K) {
+  const int crossings = Q >= cols ? 1 : (cols - 2) / Q + 1;          // most clip boundaries between the first and last column
+  return (cols - 1) * S + K + crossings * (K - S);
+}
+
+// RW16: 16-row tiles per wave; WB: waves per block (stacked along the rows); NT16: 16-column tiles per block (= per wave);
+// S: stride of the B-operand walk (1 or 3); K: taps
+template <int RW16, int WB, int NT16, int S, int K>
+__global__ __launch_bounds__(WB * 64, 2) void dconv_kernel(const DArgs a) {
+  constexpr int BN = NT16 * 16;
+  // positions staged per lane: enough for the widest window of the shape (rows of kMinQ positions); iterations past the
+  // actual window load nothing (out-of-range offsets) and write nothing
+  constexpr int MAXIT = (window_positions(BN, kMinQ, S, K) + 64 * (WB / 4) - 1) / (64 * (WB / 4));
+  constexpr int SPI = 64 * (WB / 4);                 // positions staged per iteration by the WB / 4 waves of a channel group
+  constexpr int TW = K >= 3 ? K - 2 : 0;             // tap after which the next chunk's patch is written and published
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // block -> work item: blocks b and b + 8 share an XCD, each XCD walks a contiguous range of items, the row blocks of
+  // one column tile next to each other (they read the same input window: L2 hits)
+  const int item = (int)(blockIdx.x & 7u) * a.per_xcd + (int)(blockIdx.x >> 3);
+  if (item >= a.total) return;
+  const int mb = item % a.n_mb, nt = item / a.n_mb;
+  const int n0 = nt * BN;
+  const int clip0 = n0 / a.Q, q0 = n0 - clip0 * a.Q;
+  const int g0 = q0 * S;                             // virtual position (within clip0's segment) of LDS position 0
+  const int bufF = a.PW * kRowF;                     // floats per LDS buffer
+
+  // ---- staging geometry: LDS position o <-> (clip, input position); a wave stages channels kgrp, kgrp + 4, + 8, + 12 of
+  // the chunk (one 16-byte LDS row segment per position)
+  const int skgrp = wave & 3;
+  unsigned soff[MAXIT];                              // byte offset of (clip, channel 0, position) in x, or out of range
+#pragma unroll
+  for (int it = 0; it < MAXIT; ++it) {
+    const int o = (wave >> 2) * 64 + lane + SPI * it;
+    const int G = g0 + o;
+    const int seg = G / a.seg_pw, w = G - seg * a.seg_pw;
+    const int clip = clip0 + seg, pos = w - a.pad;
+    const bool ok = o < a.PW && clip < a.B && pos >= 0 && pos < a.L_in;
+    soff[it] = ok ? ((unsigned)clip * (unsigned)a.C * (unsigned)a.L_in + (unsigned)pos) * 4u : DC_OOB;
+  }
+  const rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+  const unsigned chb = (unsigned)a.L_in * 4u;        // bytes per channel row
+  float st[4][MAXIT];
+  // (unconditional: past the last chunk the loads go out of range and return zeros that nobody writes — a branch around
+  // them would make the compiler's vmcnt bookkeeping pessimistic for every weight fetch after the join)
+  auto stage_issue = [&](int cc) __attribute__((always_inline)) {
+    const unsigned past = cc < a.n_cc ? 0u : DC_OOB;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const unsigned coff = (unsigned)(cc * RTG_CK + skgrp + 4 * i) * chb | past;
+#pragma unroll
+      for (int it = 0; it < MAXIT; ++it) st[i][it] = dc_load(rx, (soff[it] + coff) | (soff[it] & DC_OOB));
+    }
+  };
+  const float wslope = a.pre ? a.pre_slope : 1.f;
+  auto stage_write = [&](float* buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+      const int o = (wave >> 2) * 64 + lane + SPI * it;
+      if (o < a.PW) {
+        f32x4 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float t = st[i][it];
+          asm volatile("" : "+v"(t));                // keep the consumption (and its wait) here, below the multiplications
+          v[i] = t > 0.f ? t : t * wslope;
+        }
+        *reinterpret_cast<f32x4*>(buf + o * kRowF + skgrp * 4) = v;
+      }
+    }
+  };
+
+  // ---- operand addressing
+  const int n16 = lane & 15, kgrp = lane >> 4;
+  int bcol[NT16];                                    // float offset of this lane's fragment of column tile j at tap 0
+#pragma unroll
+  for (int j = 0; j < NT16; ++j) {
+    int n = n0 + j * 16 + n16;
+    if (n > a.n_cols - 1) n = a.n_cols - 1;          // junk column: a valid position, dropped in the epilogue
+    const int clip = n / a.Q, q = n - clip * a.Q;
+    bcol[j] = ((clip - clip0) * a.seg_pw + q * S - g0) * kRowF + kgrp * 4;
+  }
+  const int n_mt16 = (a.Mg + 15) >> 4;
+  const f32x4* aptr[RW16];
+#pragma unroll
+  for (int i = 0; i < RW16; ++i) {
+    int mt = (mb * WB + wave) * RW16 + i;
+    if (mt > n_mt16 - 1) mt = n_mt16 - 1;            // clamped duplicate tile, dropped in the epilogue
+    aptr[i] = reinterpret_cast<const f32x4*>(a.wp) + (size_t)mt * a.n_cc * K * 64 + lane;
+  }
+  const int n_steps = a.n_cc * K;
+
+  f32x4 acc[RW16][NT16];
+#pragma unroll
+  for (int i = 0; i < RW16; ++i)
+#pragma unroll
+    for (int j = 0; j < NT16; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  struct Frag {
+    f32x4 a[RW16], b[NT16];
+  };
+  // the fragments of (chunk, tap) step s: RW16 coalesced 1-KB weight loads from L2, NT16 16-byte LDS reads
+  auto fetch = [&](Frag& f, int s, const float* bsrc) __attribute__((always_inline)) {
+    const int sc = s < n_steps ? s : n_steps - 1;    // (past the end: re-read the last step, never used)
+#pragma unroll
+    for (int i = 0; i < RW16; ++i) f.a[i] = aptr[i][(size_t)sc * 64];
+#pragma unroll
+    for (int j = 0; j < NT16; ++j) f.b[j] = *reinterpret_cast<const f32x4*>(bsrc + bcol[j]);
+  };
+  auto mma = [&](const Frag& f) __attribute__((always_inline)) {
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq)
+#pragma unroll
+      for (int i = 0; i < RW16; ++i)
+#pragma unroll
+        for (int j = 0; j < NT16; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[i][kq], f.b[j][kq], acc[i][j], 0, 0, 0);
+  };
+
+  // ---- prologue: chunk 0 staged and published, chunk 1 requested, fragments of step 0 fetched
+  stage_issue(0);
+  stage_write(lds);
+  __syncthreads();
+  stage_issue(1);
+  Frag f0, f1;
+  fetch(f0, 0, lds);
+
+  // one chunk: K taps; `cur` holds the fragments of tap 0 on entry, and of the next chunk's tap 0 on exit (in `cur` again
+  // when K is even, in `oth` when K is odd: the caller alternates)
+  auto chunk = [&](int cc, Frag& cur, Frag& oth) __attribute__((always_inline)) {
+    const float* bufc = lds + (cc & 1) * bufF;
+    float* bufn = lds + ((cc + 1) & 1) * bufF;
+#pragma unroll
+    for (int t = 0; t < K; ++t) {
+      Frag& fc = (t & 1) ? oth : cur;
+      Frag& fn = (t & 1) ? cur : oth;
+      // request the next step's fragments, THEN (last tap) the patch of the chunk after the next: the wait for the
+      // fragments one step later does not include the patch loads (vmcnt retires in order)
+      fetch(fn, cc * K + t + 1, t + 1 < K ? bufc + (t + 1) * kRowF : bufn);
+      if (t == K - 1) stage_issue(cc + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(fc);
+      __builtin_amdgcn_sched_barrier(0);
+      if (t == TW) {
+        // publish the next chunk's patch: its buffer was last read by fragment fetches that completed before the
+        // previous chunk's barrier; the reads of this chunk's last tap (just requested) are waited for here too
+        if (cc + 1 < a.n_cc) stage_write(bufn);
+        // (one asm statement: nothing can be scheduled between the wait and the barrier, no memory access across it)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+  int cc = 0;
+  if constexpr (K & 1) {
+    for (; cc + 1 < a.n_cc; cc += 2) {
+      chunk(cc, f0, f1);
+      chunk(cc + 1, f1, f0);
+    }
+    if (cc < a.n_cc) chunk(cc, f0, f1);
+  } else {
+    for (; cc < a.n_cc; ++cc) chunk(cc, f0, f1);
+  }
+
+  // ---- epilogue: out = act(((acc + bias) * dmask + res) * out_scale) (+ out), the arithmetic and rounding of the general
+  // kernel; 32-bit element offsets through buffer descriptors, invalid rows / columns go to an out-of-range offset the
+  // hardware drops.  Row m' of the GEMM is output channel m' / S_out at phase m' % S_out (polyphase backward-data).
+  const rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, a.out_bytes, 0x00020000);
+  const rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(a.bias ? a.bias : a.out), 0, a.bias ? a.out_C * 4 : 0, 0x00020000);
+  const rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc((void*)(a.mask ? a.mask : a.out), 0, a.mask ? a.out_bytes : 0, 0x00020000);
+  const rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)(a.res ? a.res : a.out), 0, a.res ? a.out_bytes : 0, 0x00020000);
+  const float mslope = a.mask ? a.mask_slope : 1.f;
+  const int So = a.shuf_S;
+  const float invS = 1.0f / (float)So;
+#pragma unroll
+  for (int i = 0; i < RW16; ++i) {
+    const int mt = (mb * WB + wave) * RW16 + i;
+    if (mt >= n_mt16) continue;
+    float bv[4];
+    unsigned rowoff[4];
+    int rowph[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = mt * 16 + kgrp * 4 + r;
+      int ch = m, ph = 0;
+      if (So != 1) {                                  // m / S through the float reciprocal (m < 2^24), one correction step
+        ch = (int)((float)m * invS);
+        ph = m - ch * So;
+        if (ph < 0) { --ch; ph += So; }
+        else if (ph >= So) { ++ch; ph -= So; }
+        ph -= a.shuf_P;
+      }
+      const bool rok = m < a.Mg;
+      rowoff[r] = (unsigned)(ch * a.out_L + ph) * 4u;
+      rowph[r] = rok ? ph : -(1 << 28);
+      bv[r] = dc_load(rb, rok ? (unsigned)ch * 4u : DC_OOB);
+    }
+#pragma unroll
+    for (int j = 0; j < NT16; ++j) {
+      const int n = n0 + j * 16 + n16;
+      const int clip = n / a.Q, q = n - clip * a.Q;
+      const int qs = n < a.n_cols ? q * So : -(1 << 28);
+      const unsigned col = ((unsigned)(clip * a.out_C) * (unsigned)a.out_L + (unsigned)(q * So)) * 4u;
+      unsigned off[4];
+      float mv[4], rv[4], av[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) off[r] = ((unsigned)(qs + rowph[r]) < (unsigned)a.out_L) ? col + rowoff[r] : DC_OOB;
+      if (a.mask) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mv[r] = dc_load(rm, off[r]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mv[r] = 1.f;
+      }
+      if (a.res) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rv[r] = dc_load(rr, off[r]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rv[r] = 0.f;
+      }
+      if (a.accumulate) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) av[r] = dc_load(ro, off[r]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) av[r] = 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = acc[i][j][r] + bv[r];
+        v = __builtin_fmaf(v, mv[r] > 0.f ? 1.f : mslope, rv[r]) * a.out_scale;
+        if (a.act == RTG_ACT_LRELU) v = rtg_lrelu(v, a.act_slope);
+        else if (a.act == RTG_ACT_TANH) v = tanhf(v);
+        v += av[r];
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ro, off[r], 0, 0);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- host
+struct DShape {
+  int rw16, wb;
+};
+constexpr DShape kShapes[] = {{2, 4}, {1, 8}, {1, 4}, {2, 8}};       // code digit 1..4: rows per block 128, 128, 64, 256
+constexpr int kNT[] = {4, 6, 7, 8};
+
+bool dconv_eligible(const RtgConv1dDesc* d) {
+  if (!d->wp16 || d->groups != 1 || d->C2 != 0 || d->out_split != 0 || d->h_k > 1 || d->h_n > 1 || d->tap_major || d->bf16)
+    return false;
+  if (d->dil != 1 || (d->stride != 1 && d->stride != 3)) return false;
+  if (!((d->K == 5) || (d->K == 2 && d->stride == 1))) return false;
+  if (d->Cg != d->C1 || d->Cg % RTG_CK != 0 || d->Cg < 64 || d->Mg < 64 || d->Q < kMinQ) return false;
+  if (d->pre_mode != RTG_PRE_NONE && d->pre_mode != RTG_PRE_LRELU) return false;
+  if ((long long)d->groups * d->Mg != (long long)d->out_C * d->shuf_S) return false;
+  if ((long long)d->B * d->C1 * d->L_in * 4 >= (1ll << 31) || (long long)d->B * d->out_C * d->out_L * 4 >= (1ll << 31)) return false;
+  if ((long long)d->B * d->Q >= (1ll << 30)) return false;
+  return true;
+}
+
+template <int RW16, int WB, int NT16, int S, int K>
+int launch(const DArgs& a, unsigned blocks, size_t lds_bytes, hipStream_t s) {
+  auto k = dconv_kernel<RW16, WB, NT16, S, K>;
+  if (lds_bytes > 64 * 1024) {
+    static bool attr_set = false;                      // (> 64 KB of dynamic LDS needs the opt-in once per kernel)
+    if (!attr_set) {
+      if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        return RTG_ERANGE;
+      attr_set = true;
+    }
+  }
+  RTG_KLAUNCH(k, dim3(blocks), dim3(WB * 64), lds_bytes, s, a);
+  return rtg_launch_status();
+}
+
+template <int RW16, int WB, int NT16>
+int launch_sk(const DArgs& a, int S, int K, unsigned blocks, size_t lds_bytes, hipStream_t s) {
+  if (S == 1 && K == 5) return launch<RW16, WB, NT16, 1, 5>(a, blocks, lds_bytes, s);
+  if (S == 3 && K == 5) return launch<RW16, WB, NT16, 3, 5>(a, blocks, lds_bytes, s);
+  if (S == 1 && K == 2) return launch<RW16, WB, NT16, 1, 2>(a, blocks, lds_bytes, s);
+  return RTG_EINVAL;
+}
+
+}  // namespace
+
+#define RTG_DCONV_CODE 8000
+
+// the block-shape codes (8000 + 100 * shape + NT16) that serve the descriptor, best guess first; returns the count
+int rtg_dconv_candidates(const RtgConv1dDesc* d, int* codes, int max) {
+  if (!dconv_eligible(d)) return 0;
+  const long long n_cols = (long long)d->B * d->Q;
+  const int n_mt16 = rtg_ceil_div(d->Mg, 16);
+  struct Cand {
+    int code;
+    double score;
+  } c[16];
+  int n = 0;
+  for (int si = 0; si < 4; ++si) {
+    const int mb16 = kShapes[si].rw16 * kShapes[si].wb;
+    if (si == 3 && n_mt16 % mb16 != 0) continue;                     // 256-row blocks only where they divide the rows
+    const int n_mb = rtg_ceil_div(n_mt16, mb16);
+    for (int ni = 0; ni < 4; ++ni) {
+      const int BN = kNT[ni] * 16;
+      const int pw = window_positions((int)(n_cols < BN ? n_cols : BN), d->Q, d->stride, d->K);
+      if (2ll * pw * kRowF * 4 > 150 * 1024) continue;
+      const long long blocks = (long long)n_mb * ((n_cols + BN - 1) / BN);
+      // rounds of the chip at one block per CU (two for the 4-wave shapes): the tail round's idle CUs are the loss
+      const double slots = 256.0 * (kShapes[si].wb == 4 ? 2 : 1);
+      const double rounds = (double)blocks / slots;
+      const double eff = rounds / (double)(long long)(rounds + 0.999999);
+      const double rows_eff = (double)n_mt16 / (double)(n_mb * mb16);
+      const double cols_eff = (double)n_cols / (double)(((n_cols + BN - 1) / BN) * BN);
+      c[n].code = RTG_DCONV_CODE + 100 * (si + 1) + kNT[ni];
+      c[n].score = eff * rows_eff * cols_eff * (kShapes[si].rw16 == 2 ? 1.0 : 0.95);
+      ++n;
+    }
+  }
+  int cnt = 0;
+  for (int k = 0; k < n && cnt < max; ++k) {
+    int bi = 0;
+    for (int i = 1; i < n; ++i)
+      if (c[i].score > c[bi].score) bi = i;
+    if (c[bi].score < 0) break;
+    codes[cnt++] = c[bi].code;
+    c[bi].score = -1.0;
+  }
+  return cnt;
+}
+
+int rtg_dconv_launch(const RtgConv1dDesc* d, int code, const float* x, const float* wp, const float* bias,
+                     const float* mask, const float* res, float* out, hipStream_t s) {
+  if (!dconv_eligible(d)) return RTG_EINVAL;
+  if (!x || !wp || !out) return RTG_ENULL;
+  if ((reinterpret_cast<uintptr_t>(wp) & 15) != 0) return RTG_EINVAL;
+  const int si = (code - RTG_DCONV_CODE) / 100 - 1, nt16 = (code - RTG_DCONV_CODE) % 100;
+  if (si < 0 || si > 3) return RTG_EINVAL;
+  const int rw16 = kShapes[si].rw16, wb = kShapes[si].wb, BN = nt16 * 16;
+  DArgs a;
+  // the 16-byte-fragment image follows the standard image of the layer (RtgConv1dDesc.wp16)
+  const long long std_size = rtg_packed_size(1, d->Mg, d->Cg, d->K, d->tile_m);
+  if (std_size < 0 || (std_size & 3) != 0) return RTG_EINVAL;
+  a.x = x; a.wp = wp + std_size; a.bias = bias; a.mask = mask; a.res = res; a.out = out;
+  a.B = d->B; a.C = d->C1; a.L_in = d->L_in; a.Mg = d->Mg; a.n_cc = d->Cg / RTG_CK; a.Q = d->Q; a.pad = d->pad;
+  a.out_C = d->out_C; a.out_L = d->out_L; a.shuf_S = d->shuf_S; a.shuf_P = d->shuf_P;
+  a.pre = d->pre_mode == RTG_PRE_LRELU ? 1 : 0; a.act = d->act; a.accumulate = d->accumulate;
+  a.pre_slope = d->pre_slope; a.mask_slope = d->mask_slope; a.out_scale = d->out_scale; a.act_slope = d->act_slope;
+  a.seg_pw = (d->Q - 1) * d->stride + d->K;
+  a.n_cols = d->B * d->Q;
+  const int n_mt16 = rtg_ceil_div(d->Mg, 16);
+  a.n_mb = rtg_ceil_div(n_mt16, rw16 * wb);
+  const long long total = (long long)a.n_mb * rtg_ceil_div(a.n_cols, BN);
+  if (total > (1ll << 28)) return RTG_ERANGE;
+  a.total = (int)total;
+  a.per_xcd = rtg_ceil_div(total, 8);
+  a.PW = window_positions(a.n_cols < BN ? a.n_cols : BN, d->Q, d->stride, d->K);
+  a.x_bytes = d->B * d->C1 * d->L_in * 4;
+  a.out_bytes = d->B * d->out_C * d->out_L * 4;
+  const size_t lds_bytes = (size_t)2 * a.PW * kRowF * sizeof(float);
+  if (lds_bytes > 150 * 1024) return RTG_ERANGE;
+  const unsigned blocks = (unsigned)(8 * a.per_xcd);
+#define RTG_DC(S_, N_)                                                                                                  \
+  if (si == S_ - 1 && nt16 == N_)                                                                                         \
+    return launch_sk<kShapes[S_ - 1].rw16, kShapes[S_ - 1].wb, N_>(a, d->stride, d->K, blocks, lds_bytes, s);
+  RTG_DC(1, 4) RTG_DC(1, 6) RTG_DC(1, 7) RTG_DC(1, 8)
+  RTG_DC(2, 4) RTG_DC(2, 6) RTG_DC(2, 7) RTG_DC(2, 8)
+  RTG_DC(3, 4) RTG_DC(3, 6) RTG_DC(3, 7) RTG_DC(3, 8)
+  RTG_DC(4, 4) RTG_DC(4, 6) RTG_DC(4, 7) RTG_DC(4, 8)
+#undef RTG_DC
+  return RTG_EINVAL;
+}
+
+extern "C" long long rtg_packed_size_frag16(int Mg, int Cg, int K) {
+  if (Mg < 1 || Cg < 1 || K < 1) return RTG_EINVAL;
+  return (long long)((Mg + 15) / 16) * ((Cg + RTG_CK - 1) / RTG_CK) * K * 256;
+}

@@ -100,6 +100,20 @@ __global__ __launch_bounds__(RTG_THREADS) void pack_kernel(const RtgPackJob* job
       packed[j.dst_off + e] = __builtin_bit_cast(float, bits);
       continue;
     }
+    if (j.frag16) {
+      // b128-fragment image of rtg_dconv.hip: [g][16-row tile][chunk][tap][kgrp 4][m 16][kq 4], channel = 4 * kq + kgrp —
+      // lane (kgrp, m) of a v_mfma_f32_16x16x4_f32 reads its A operands of the chunk's four k-steps with ONE 16-byte load
+      unsigned t2 = e;
+      const int kq = (int)(t2 % 4); t2 /= 4;
+      const int m2 = (int)(t2 % 16); t2 /= 16;
+      const int kgrp = (int)(t2 % 4); t2 /= 4;
+      const int tap2 = (int)(t2 % j.K); t2 /= j.K;
+      const int cc2 = (int)(t2 % n_cc); t2 /= n_cc;
+      const int n_mt16 = (j.Mg + 15) / 16;
+      const int mt2 = (int)(t2 % n_mt16); t2 /= n_mt16;
+      packed[j.dst_off + e] = pack_logical(j, params, scales, (int)t2, mt2 * 16 + m2, cc2 * RTG_CK + 4 * kq + kgrp, tap2);
+      continue;
+    }
     unsigned t = e;
     const int m = (int)(t % TM); t /= TM;
     const int kk = (int)(t % KK); t /= KK;

@@ -101,6 +101,21 @@ class ConvLayer:
 
         def ok(op, tap):
             return bool(want_bf and not tap and op[2] > 1 and op[3] > 1)
+        # the dense-layer kernel (rtg_dconv.hip, block-shape codes 8xxx) reads 16-byte operand fragments: layers it can serve
+        # (>= 128 channels on both sides, dilation 1, k5 at stride 1 / 3 forward, the k5 stride-1 or 2-tap polyphase
+        # backward-data operator) carry a second image of their weights behind the standard one (RtgPackJob.frag16,
+        # RtgConv1dDesc.wp16); the tuner then times both kernels per problem.  RTG_DCONV=0: never (A/B knob).
+        def dense(op, fwd):
+            mode, g, mg, cg, k, s = op
+            if os.environ.get('RTG_DCONV', '1') == '0' or want_bf or self.kind != 'conv' or self.dil != 1:
+                return 0
+            if g != 1 or cg % L.CK != 0 or cg < 128 or mg < 128:
+                return 0
+            if fwd:
+                return int(k == 5 and self.stride in (1, 3))
+            return int((mode == L.PACK_DGRAD_S1 and k == 5) or (mode == L.PACK_DGRAD_POLY and k == 2 and s == 3))
+        self.fwd16 = dense(self.fwd_op, True) if not self.fwd_tap else 0
+        self.bwd16 = dense(self.bwd_op, False) if not self.bwd_tap else 0
         self.fwd_bf = int(ok(self.fwd_op, self.fwd_tap))
         self.wgrad_bf = int(want_bf)          # the weight-gradient kernel has one K order: every layer
         self.bwd_bf = int(ok(self.bwd_op, self.bwd_tap))     # (the class-pure strided 2-D backward-data included)
@@ -116,7 +131,10 @@ class ConvLayer:
         bs = lib.rtg_packed_size_bf16 if self.bwd_bf else (lib.rtg_packed_size_tapmajor if self.bwd_tap else lib.rtg_packed_size)
         f = fs(self.fwd_op[1], self.fwd_op[2], self.fwd_op[3], self.fwd_op[4], self.fwd_tm)
         b = bs(self.bwd_op[1], self.bwd_op[2], self.bwd_op[3], self.bwd_op[4], self.bwd_tm)
-        return f, b
+        # (standard image, 16-byte-fragment image behind it) per operator
+        f16 = lib.rtg_packed_size_frag16(self.fwd_op[2], self.fwd_op[3], self.fwd_op[4]) if self.fwd16 else 0
+        b16 = lib.rtg_packed_size_frag16(self.bwd_op[2], self.bwd_op[3], self.bwd_op[4]) if self.bwd16 else 0
+        return (f, f16), (b, b16)
 
 
 class _BankPrep(torch.autograd.Function):
@@ -161,11 +179,11 @@ class WeightBank:
         self.scales = torch.empty(soff, device=self.device, dtype=torch.float32)
         poff = 0
         for ly in self.layers:
-            f, b = ly.packed_sizes()
-            ly.fwd_off, ly.fwd_size = poff, f
-            poff += f
-            ly.bwd_off, ly.bwd_size = poff, b
-            poff += b
+            (f, f16), (b, b16) = ly.packed_sizes()
+            ly.fwd_off, ly.fwd_size, ly.fwd16_size = poff, f, f16
+            poff += f + f16
+            ly.bwd_off, ly.bwd_size, ly.bwd16_size = poff, b, b16
+            poff += b + b16
         self.packed = torch.empty(poff, device=self.device, dtype=torch.float32)
         self._bind_params()
         self._build_tables()
@@ -235,8 +253,14 @@ class WeightBank:
                     (ly.fwd_op, ly.fwd_off, ly.fwd_size, ly.fwd_tm, ly.fwd_tap, ly.fwd_bf),
                     (ly.bwd_op, ly.bwd_off, ly.bwd_size, ly.bwd_tm, ly.bwd_tap, ly.bwd_bf)):
                 pack.append(L.PackJob(ly.v_off, ly.scale_off, off, size, mode, g, mg, cg, k, ly.k, ly.inner_c, s, tm,
-                                      ly.kh, tap, bf))
+                                      ly.kh, tap, bf, 0))
                 self.max_pack = max(self.max_pack, size)
+            for (mode, g, mg, cg, k, s), off, size in ((ly.fwd_op, ly.fwd_off + ly.fwd_size, ly.fwd16_size),
+                                                        (ly.bwd_op, ly.bwd_off + ly.bwd_size, ly.bwd16_size)):
+                if size:
+                    pack.append(L.PackJob(ly.v_off, ly.scale_off, off, size, mode, g, mg, cg, k, ly.k, ly.inner_c, s, 16,
+                                          ly.kh, 0, 0, 1))
+                    self.max_pack = max(self.max_pack, size)
         self.norm_table = _table(norm, self.device)
         self.pack_table = _table(pack, self.device)
         self.n_pack = len(pack)

@@ -19,7 +19,8 @@ class Conv1dDesc(C.Structure):
                                        'out_C', 'out_L', 'shuf_S', 'shuf_P', 'pre_mode')] + \
                [('pre_slope', C.c_float), ('mask_slope', C.c_float), ('out_scale', C.c_float), ('act', C.c_int),
                 ('act_slope', C.c_float), ('accumulate', C.c_int), ('tile_m', C.c_int), ('out_split', C.c_int)] + \
-               [(n, C.c_int) for n in ('h_in', 'h_k', 'h_stride', 'h_pad', 'h_n', 'h_mode', 'tap_major', 'tile_cfg', 'bf16')]
+               [(n, C.c_int) for n in ('h_in', 'h_k', 'h_stride', 'h_pad', 'h_n', 'h_mode', 'tap_major', 'tile_cfg', 'bf16',
+                                       'wp16')]
 
 
 class ConvPtrs(C.Structure):
@@ -55,7 +56,8 @@ class NormJob(C.Structure):
 class PackJob(C.Structure):
     _fields_ = [('v_off', C.c_longlong), ('scale_off', C.c_longlong), ('dst_off', C.c_longlong),
                 ('dst_size', C.c_longlong)] + \
-               [(n, C.c_int) for n in ('mode', 'groups', 'Mg', 'Cg', 'K', 'src_K', 'src_inner_c', 'S', 'tile_m', 'KH', 'tap_major', 'bf16')]
+               [(n, C.c_int) for n in ('mode', 'groups', 'Mg', 'Cg', 'K', 'src_K', 'src_inner_c', 'S', 'tile_m', 'KH', 'tap_major', 'bf16',
+                                       'frag16')]
 
 
 class WnBwdJob(C.Structure):
@@ -88,7 +90,7 @@ CK = 16
 LOSS_L1, LOSS_L1_L1LOG, LOSS_MSE_TARGET, LOSS_MSE_REL = 0, 1, 2, 3
 MAX_LOSS_JOBS = 48
 
-ABI_VERSION = 5            # RTG_ABI_VERSION of include/rtg.h these struct layouts / prototypes were written for
+ABI_VERSION = 6            # RTG_ABI_VERSION of include/rtg.h these struct layouts / prototypes were written for
 _P = C.c_void_p
 _I, _F, _D, _LL, _ULL = C.c_int, C.c_float, C.c_double, C.c_longlong, C.c_ulonglong
 
@@ -99,6 +101,7 @@ PROTOTYPES = {
     'rtg_conv1d_variant': (_I, [C.POINTER(Conv1dDesc)]),
     'rtg_conv1d_tile_candidates': (_I, [C.POINTER(Conv1dDesc), C.POINTER(C.c_int), _I]),
     'rtg_packed_size': (_LL, [_I, _I, _I, _I, _I]),
+    'rtg_packed_size_frag16': (_LL, [_I, _I, _I]),
     'rtg_packed_size_tapmajor': (_LL, [_I, _I, _I, _I, _I]),
     'rtg_packed_size_bf16': (_LL, [_I, _I, _I, _I, _I]),
     'rtg_tapmajor_pays': (_I, [_I, _I, _I]),

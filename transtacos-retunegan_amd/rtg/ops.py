@@ -297,7 +297,7 @@ class ConvFn(torch.autograd.Function):
             d = _desc(B=B, C1=C1, C2=C2, L_in=L_in, groups=g, Cg=cg, Mg=mg, K=k, stride=ly.stride, dil=ly.dil,
                       pad=ly.pad, Q=L_out, out_C=ly.cout, out_L=L_out, pre_mode=pre_mode, pre_slope=pre_slope,
                       out_scale=out_scale, act=act, act_slope=act_slope, tile_m=ly.fwd_tm, tap_major=ly.fwd_tap,
-                      bf16=ly.fwd_bf)
+                      bf16=ly.fwd_bf, wp16=ly.fwd16)
         else:
             nq = (L_out - 1 + ly.pad) // ly.stride + 1
             d = _desc(B=B, C1=C1, C2=C2, L_in=L_in, groups=1, Cg=cg, Mg=mg, K=k, stride=1, dil=1, pad=k - 1, Q=nq,
@@ -372,13 +372,13 @@ class ConvFn(torch.autograd.Function):
                 d = _desc(B=B, C1=ly.cout, L_in=L_out, groups=g, Cg=cg, Mg=mg, K=k, stride=1, dil=ly.dil,
                           pad=(ly.k - 1) * ly.dil - ly.pad, Q=L_in, out_C=ly.cin, out_L=L_in, pre_mode=gy_mode,
                           pre_slope=gy_slope, mask_slope=pre_slope, out_scale=out_scale, tile_m=ly.bwd_tm,
-                          out_split=split, tap_major=ly.bwd_tap, bf16=ly.bwd_bf)
+                          out_split=split, tap_major=ly.bwd_tap, bf16=ly.bwd_bf, wp16=ly.bwd16)
             elif ly.kind == 'conv':
                 nq = (L_in - 1 + ly.pad) // ly.stride + 1
                 d = _desc(B=B, C1=ly.cout, L_in=L_out, groups=g, Cg=cg, Mg=mg, K=k, stride=1, dil=1, pad=k - 1, Q=nq,
                           out_C=ly.cin, out_L=L_in, shuf_S=ly.stride, shuf_P=ly.pad, pre_mode=gy_mode,
                           pre_slope=gy_slope, mask_slope=pre_slope, out_scale=out_scale, tile_m=ly.bwd_tm,
-                          out_split=split, tap_major=ly.bwd_tap, bf16=ly.bwd_bf)
+                          out_split=split, tap_major=ly.bwd_tap, bf16=ly.bwd_bf, wp16=ly.bwd16)
             else:   # transposed conv: backward-data is the strided conv of dy
                 d = _desc(B=B, C1=ly.cout, L_in=L_out, groups=1, Cg=cg, Mg=mg, K=k, stride=ly.stride, dil=1,
                           pad=ly.pad, Q=L_in, out_C=ly.cin, out_L=L_in, pre_mode=gy_mode, pre_slope=gy_slope,
@@ -642,7 +642,7 @@ def _fwd_desc(ly, B, C1, L_in, pre_slope):
     pre_mode = L.PRE_LRELU if pre_slope != 1.0 else L.PRE_NONE
     return _desc(B=B, C1=C1, C2=0, L_in=L_in, groups=g, Cg=cg, Mg=mg, K=k, stride=ly.stride, dil=ly.dil, pad=ly.pad,
                  Q=L_out, out_C=ly.cout, out_L=L_out, pre_mode=pre_mode, pre_slope=pre_slope, tile_m=ly.fwd_tm,
-                 tap_major=ly.fwd_tap, bf16=ly.fwd_bf), L_out
+                 tap_major=ly.fwd_tap, bf16=ly.fwd_bf, wp16=ly.fwd16), L_out
 
 
 def _dgrad_desc(ly, B, L_in, L_out, pre_slope):
@@ -651,11 +651,11 @@ def _dgrad_desc(ly, B, L_in, L_out, pre_slope):
     if ly.stride == 1:
         return _desc(B=B, C1=ly.cout, L_in=L_out, groups=g, Cg=cg, Mg=mg, K=k, stride=1, dil=ly.dil,
                      pad=(ly.k - 1) * ly.dil - ly.pad, Q=L_in, out_C=ly.cin, out_L=L_in, mask_slope=pre_slope,
-                     tile_m=ly.bwd_tm, tap_major=ly.bwd_tap, bf16=ly.bwd_bf)
+                     tile_m=ly.bwd_tm, tap_major=ly.bwd_tap, bf16=ly.bwd_bf, wp16=ly.bwd16)
     nq = (L_in - 1 + ly.pad) // ly.stride + 1
     return _desc(B=B, C1=ly.cout, L_in=L_out, groups=g, Cg=cg, Mg=mg, K=k, stride=1, dil=1, pad=k - 1, Q=nq,
                  out_C=ly.cin, out_L=L_in, shuf_S=ly.stride, shuf_P=ly.pad, mask_slope=pre_slope, tile_m=ly.bwd_tm,
-                 tap_major=ly.bwd_tap, bf16=ly.bwd_bf)
+                 tap_major=ly.bwd_tap, bf16=ly.bwd_bf, wp16=ly.bwd16)
 
 
 def _launch_group(descs, ptr_rows, flops, label, what):

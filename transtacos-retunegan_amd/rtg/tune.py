@@ -64,8 +64,8 @@ def conv_cfg(d, launch):
         return cfg
     if not (ENABLED and ACTIVE):
         return _miss()
-    cands = (C.c_int * 32)()
-    n = lib.rtg_conv1d_tile_candidates(C.byref(d), cands, 32)
+    cands = (C.c_int * 48)()
+    n = lib.rtg_conv1d_tile_candidates(C.byref(d), cands, 48)
     best, best_t = 0, None
     for c in cands[:max(n, 0)]:
         d.tile_cfg = c
