@@ -195,7 +195,9 @@ def roofline(trainer, batch, bf16=False):
             e[0] += 1; e[1] += ms * 1e-3; e[2] += nbytes
         if kernel.startswith('bw:'):
             continue
-        k = (kernel, variant)
+        # one entry per kernel TEMPLATE: wgrad:<rows per MFMA> and conv1d:<instance> as before; the block shapes of the
+        # dense-layer kernel (codes 8xxx: rows per wave x waves x column tiles of one template) are one kernel, dconv
+        k = ('dconv', 16) if kernel == 'conv1d' and variant > 8000 else (kernel, variant)
         a = agg.setdefault(k, [0, 0.0, 0.0, 0.0])
         a[0] += 1
         a[1] += ms * 1e-3
@@ -204,10 +206,8 @@ def roofline(trainer, batch, bf16=False):
     # the dominant MATRIX kernel (the bandwidth kernels of the 1-channel layers, variants < 100, are reported in by_kernel)
     (kernel, variant), (n, secs, flop, nbytes) = max(((k, v) for k, v in agg.items() if not (k[0] == 'conv1d' and k[1] < 100)),
                                              key=lambda kv: kv[1][1])
-    DSHAPES = {1: (2, 4), 2: (1, 8), 3: (1, 4), 4: (2, 8)}      # rtg_dconv.hip: code digit -> (16-row tiles per wave, waves)
-    if kernel == 'conv1d' and variant > 8000:
-        rw, wb = DSHAPES[(variant - 8000) // 100]
-        name = f'dconv_kernel<{rw},{wb},{variant % 100}>'
+    if kernel == 'dconv':
+        name = 'dconv_kernel<rows per wave, waves, 16-column tiles, stride, taps> (rtg_dconv.hip, all block shapes)'
     elif kernel == 'conv1d':
         name = f'conv1d_mfma_group_kernel<{variant // 100},{variant // 10 % 10},{variant % 10}>'
     else:
@@ -220,8 +220,8 @@ def roofline(trainer, batch, bf16=False):
            'algorithmic_bytes_per_launch': round(nbytes / n) if nbytes else None}
     # HBM traffic and matrix-pipe occupancy of that kernel from the committed PMC passes (rocprofv3 --pmc cannot run inside
     # this process): profiles/*_pmc.json, written by tools/pmc_pass.sh + tools/pmc_summary.py from this same command
-    if kernel == 'conv1d' and variant > 8000:
-        pmc = _pmc_for(f'dconv_kernel<{rw}, {wb}, {variant % 100},')
+    if kernel == 'dconv':
+        pmc = _pmc_for('dconv_kernel<')
     else:
         pmc = _pmc_for(f'conv1d_mfma_group_kernel<{variant // 100}, {variant // 10 % 10}, {variant % 10},' if kernel == 'conv1d'
                        else f'wgrad_kernel<{variant},')

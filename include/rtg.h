@@ -288,8 +288,9 @@ int rtg_noise_lrelu_bwd(const float* x, const float* w, const float* u_in, const
                         float* dw_part, int n_blocks, long long n, float slope, unsigned long long seed,
                         const float* salt_dev, void* stream);
 
-/* out[c] += sum_{b,t} x[b,c,t]   (bias gradient of ConvTranspose1d layers; x is [B, C, L]) */
-int rtg_channel_sum(const float* x, float* out, int B, int C, int L, void* stream);
+/* out[c] += sum_{b,t} x[b,c,t]   (bias gradient of ConvTranspose1d layers; x is [B, C, L]); ws: 32 * C floats of scratch
+ * (two fixed-order stages: partial sums over every 32nd clip, then their sum) */
+int rtg_channel_sum(const float* x, float* out, int B, int C, int L, float* ws, void* stream);
 /* out[i] (+)= alpha * a[i] + beta * b[i]   (b may be NULL) */
 int rtg_axpby(const float* a, const float* b, float* out, long long n, float alpha, float beta, int accumulate,
               void* stream);
@@ -363,7 +364,8 @@ int rtg_adamw(float* params, const float* grads, float* exp_avg, float* exp_avg_
  *             backward-data weights (RTG_PACK_DGRAD_S1) of the layers in REVERSE order; masks: the forward tensors whose
  *             sign masks each step: r3, x2, r2, x1, r1, x0; gouts: g_r3, g_x2, g_r2, g_x1, g_r1, dx0 — the first five are
  *             the output cotangents the weight-gradient launches of the layers need.
- * rtg_resstack_ok: 1 when the shape is served.
+ * rtg_resstack_ok: the instance number (1: (C, L) = (128, 32), 2: (64, >= 64), 3: (32, >= 128)) that serves the shape, 0: none
+ * (only instance 1 measured faster than six launches; a caller chooses which it uses: rtg/ops.py RTG_RESSTACK_KINDS).
  * ------------------------------------------------------------------------------------------------------------ */
 typedef struct RtgResStackDesc {
   int B, C, L;

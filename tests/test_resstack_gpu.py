@@ -27,7 +27,7 @@ def _net(C):
 @pytest.mark.parametrize('C,L,B', [(128, 32, 5), (64, 256, 3), (64, 200, 2), (32, 2048, 2), (32, 500, 3)])
 def test_fused_residual_stack_matches_oracle_and_unfused(oracle, C, L, B, final, monkeypatch):
     from rtg import ops
-    monkeypatch.setenv('RTG_RESSTACK_KINDS', '7')        # the C = 32 instance is not served by default (not faster)
+    monkeypatch.setattr(ops, 'RESSTACK_KINDS', 7)        # the C = 64 / 32 instances are not used by default (not faster)
     torch.manual_seed(C + L)
     net = _net(C)
     ref = oracle.ResidualStack(C).double()
@@ -41,7 +41,7 @@ def test_fused_residual_stack_matches_oracle_and_unfused(oracle, C, L, B, final,
         # 'fused': one launch per direction; 'node': one autograd node, six launches per direction (residual gradient in
         # the backward-data epilogue, grouped weight gradients); 'legacy': one autograd node per conv
         ops.RESSTACK = mode != 'legacy'
-        monkeypatch.setenv('RTG_RESSTACK_KINDS', '7' if mode == 'fused' else '0')
+        ops.RESSTACK_KINDS = 7 if mode == 'fused' else 0
         try:
             net.zero_grad()
             xg = x.to(DEV).requires_grad_(True)
@@ -51,7 +51,7 @@ def test_fused_residual_stack_matches_oracle_and_unfused(oracle, C, L, B, final,
             return y.detach().cpu(), xg.grad.cpu(), {n: p.grad.detach().cpu().clone() for n, p in net.named_parameters()}
         finally:
             ops.RESSTACK = True
-            monkeypatch.setenv('RTG_RESSTACK_KINDS', '7')
+            ops.RESSTACK_KINDS = 7
 
     lys = [getattr(blk, n)._layer for blk in (net.stack.res_1, net.stack.res_2, net.stack.res_3) for n in ('1', '3')] \
         if net._bank is not None else None

@@ -35,7 +35,7 @@ def steady(rows):
 
 
 def short(n):
-    m = re.search(r'(conv1d_mfma_group_kernel<[^>]*>|conv1d_mfma_kernel<[^>]*>|wgrad_kernel<[^>]*>|[A-Za-z_0-9]+_kernel)', n)
+    m = re.search(r'(conv1d_mfma_group_kernel<[^>]*>|conv1d_mfma_kernel<[^>]*>|dconv_kernel<[^>]*>|dwgrad_kernel<[^>]*>|wgrad_kernel<[^>]*>|[A-Za-z_0-9]+_kernel)', n)
     return m.group(1) if m else n[:60]
 
 

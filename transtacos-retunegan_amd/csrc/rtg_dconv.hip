@@ -309,7 +309,7 @@ bool dconv_eligible(const RtgConv1dDesc* d) {
     return false;
   if (d->dil != 1 || (d->stride != 1 && d->stride != 3)) return false;
   if (!((d->K == 5) || (d->K == 2 && d->stride == 1))) return false;
-  if (d->Cg != d->C1 || d->Cg % RTG_CK != 0 || d->Cg < 64 || d->Mg < 64 || d->Q < kMinQ) return false;
+  if (d->Cg != d->C1 || d->Cg % RTG_CK != 0 || d->Cg < 32 || d->Mg < 64 || d->Q < kMinQ) return false;
   if (d->pre_mode != RTG_PRE_NONE && d->pre_mode != RTG_PRE_LRELU) return false;
   if ((long long)d->groups * d->Mg != (long long)d->out_C * d->shuf_S) return false;
   if ((long long)d->B * d->C1 * d->L_in * 4 >= (1ll << 31) || (long long)d->B * d->out_C * d->out_L * 4 >= (1ll << 31)) return false;

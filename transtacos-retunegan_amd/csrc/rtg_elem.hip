@@ -28,18 +28,41 @@ __device__ __forceinline__ unsigned long long mix_salt(unsigned long long seed, 
   return seed ^ (0xD1B54A32D192ED03ull * (unsigned long long)(__float_as_uint(*salt) + 1u));
 }
 
+// The element-wise kernels move 16 bytes per lane and access (Guideline 13 of the CDNA guide: a 4-byte-per-lane stream tops
+// out far below the HBM rate): VEC = 4 when every pointer is 16-byte aligned and n % 4 == 0 (all feature maps of the
+// path), else the scalar form.  Element i draws the same random number either way (the counter is the element index).
+template <int VEC>
 __global__ __launch_bounds__(RTG_THREADS) void noise_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                 const float* __restrict__ u_in, float* __restrict__ out,
                                                                 long long n, float slope, unsigned long long seed,
                                                                 const float* salt) {
   const float wv = *w;
   const unsigned long long sd = mix_salt(seed, salt);
-  for (long long i = (long long)blockIdx.x * RTG_THREADS + threadIdx.x; i < n; i += (long long)gridDim.x * RTG_THREADS) {
-    const float u = u_in ? u_in[i] : uniform01(sd, (unsigned long long)i);
-    out[i] = rtg_lrelu(x[i] + u * wv, slope);
+  const long long nv = n / VEC;
+  for (long long i = (long long)blockIdx.x * RTG_THREADS + threadIdx.x; i < nv; i += (long long)gridDim.x * RTG_THREADS) {
+    float xv[VEC], uv[VEC], ov[VEC];
+    if constexpr (VEC == 4) {
+      const f32x4 t = reinterpret_cast<const f32x4*>(x)[i];
+      xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
+      if (u_in) {
+        const f32x4 u4 = reinterpret_cast<const f32x4*>(u_in)[i];
+        uv[0] = u4.x; uv[1] = u4.y; uv[2] = u4.z; uv[3] = u4.w;
+      }
+    } else {
+      xv[0] = x[i];
+      if (u_in) uv[0] = u_in[i];
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const float u = u_in ? uv[e] : uniform01(sd, (unsigned long long)(i * VEC + e));
+      ov[e] = rtg_lrelu(xv[e] + u * wv, slope);
+    }
+    if constexpr (VEC == 4) reinterpret_cast<f32x4*>(out)[i] = f32x4{ov[0], ov[1], ov[2], ov[3]};
+    else out[i] = ov[0];
   }
 }
 
+template <int VEC>
 __global__ __launch_bounds__(RTG_THREADS) void noise_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                 const float* __restrict__ u_in,
                                                                 const float* __restrict__ dy, float* __restrict__ dx,
@@ -49,46 +72,103 @@ __global__ __launch_bounds__(RTG_THREADS) void noise_bwd_kernel(const float* __r
   const float wv = *w;
   const unsigned long long sd = mix_salt(seed, salt);
   float acc = 0.f;
-  for (long long i = (long long)blockIdx.x * RTG_THREADS + threadIdx.x; i < n; i += (long long)gridDim.x * RTG_THREADS) {
-    const float u = u_in ? u_in[i] : uniform01(sd, (unsigned long long)i);
-    const float pre = x[i] + u * wv;
-    const float g = dy[i] * (pre > 0.f ? 1.f : slope);
-    dx[i] = g;
-    acc += g * u;
+  const long long nv = n / VEC;
+  for (long long i = (long long)blockIdx.x * RTG_THREADS + threadIdx.x; i < nv; i += (long long)gridDim.x * RTG_THREADS) {
+    float xv[VEC], uv[VEC], gv[VEC], ov[VEC];
+    if constexpr (VEC == 4) {
+      const f32x4 t = reinterpret_cast<const f32x4*>(x)[i], g4 = reinterpret_cast<const f32x4*>(dy)[i];
+      xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
+      gv[0] = g4.x; gv[1] = g4.y; gv[2] = g4.z; gv[3] = g4.w;
+      if (u_in) {
+        const f32x4 u4 = reinterpret_cast<const f32x4*>(u_in)[i];
+        uv[0] = u4.x; uv[1] = u4.y; uv[2] = u4.z; uv[3] = u4.w;
+      }
+    } else {
+      xv[0] = x[i];
+      gv[0] = dy[i];
+      if (u_in) uv[0] = u_in[i];
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const float u = u_in ? uv[e] : uniform01(sd, (unsigned long long)(i * VEC + e));
+      const float pre = xv[e] + u * wv;
+      ov[e] = gv[e] * (pre > 0.f ? 1.f : slope);
+      acc += ov[e] * u;
+    }
+    if constexpr (VEC == 4) reinterpret_cast<f32x4*>(dx)[i] = f32x4{ov[0], ov[1], ov[2], ov[3]};
+    else dx[i] = ov[0];
   }
   acc = rtg_block_sum(acc, red);
   if (threadIdx.x == 0) dw_part[blockIdx.x] = acc;
 }
 
+template <int VEC>
 __global__ __launch_bounds__(RTG_THREADS) void axpby_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                             float* __restrict__ out, long long n, float alpha,
                                                             float beta, int accumulate) {
-  for (long long i = (long long)blockIdx.x * RTG_THREADS + threadIdx.x; i < n; i += (long long)gridDim.x * RTG_THREADS) {
-    float v = alpha * a[i];
-    if (b) v += beta * b[i];
-    if (accumulate) v += out[i];
-    out[i] = v;
+  const long long nv = n / VEC;
+  for (long long i = (long long)blockIdx.x * RTG_THREADS + threadIdx.x; i < nv; i += (long long)gridDim.x * RTG_THREADS) {
+    if constexpr (VEC == 4) {
+      f32x4 v = reinterpret_cast<const f32x4*>(a)[i] * alpha;
+      if (b) v += reinterpret_cast<const f32x4*>(b)[i] * beta;        // (separate multiply and add, like the scalar form)
+      if (accumulate) v += reinterpret_cast<const f32x4*>(out)[i];
+      reinterpret_cast<f32x4*>(out)[i] = v;
+    } else {
+      float v = alpha * a[i];
+      if (b) v += beta * b[i];
+      if (accumulate) v += out[i];
+      out[i] = v;
+    }
   }
 }
 
-__global__ __launch_bounds__(RTG_THREADS) void channel_sum_kernel(const float* __restrict__ x, float* __restrict__ out,
-                                                                 int B, int C, int L) {
+// sum over (clip, position) per channel of x [B, C, L], in two fixed-order stages: block (c, s) sums the clips
+// b = s, s + S, ... of channel c into ws[c * S + s] (one block per channel left the chip to 16-128 workgroups: 113 us for
+// 18 MB), then one wave per channel adds the S partials in ascending order to out[c].
+constexpr int CSUM_SLICES = 32;
+__global__ __launch_bounds__(RTG_THREADS) void channel_sum_stage1(const float* __restrict__ x, float* __restrict__ ws,
+                                                                  int B, int C, int L) {
   __shared__ float red[4];
-  const int c = blockIdx.x;
+  const int c = blockIdx.x, s = blockIdx.y;
   float acc = 0.f;
-  for (int b = 0; b < B; ++b) {
+  const bool vec = (L & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+  for (int b = s; b < B; b += CSUM_SLICES) {
     const float* xr = x + ((size_t)b * C + c) * L;
-    for (int i = threadIdx.x; i < L; i += RTG_THREADS) acc += xr[i];
+    if (vec) {
+      for (int i = threadIdx.x; i < (L >> 2); i += RTG_THREADS) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(xr)[i];
+        acc += (v.x + v.y) + (v.z + v.w);
+      }
+    } else {
+      for (int i = threadIdx.x; i < L; i += RTG_THREADS) acc += xr[i];
+    }
   }
   acc = rtg_block_sum(acc, red);
-  if (threadIdx.x == 0) out[c] += acc;
+  if (threadIdx.x == 0) ws[c * CSUM_SLICES + s] = acc;
+}
+__global__ __launch_bounds__(RTG_THREADS) void channel_sum_stage2(const float* __restrict__ ws, float* __restrict__ out, int C) {
+  const int c = blockIdx.x * RTG_THREADS + threadIdx.x;
+  if (c >= C) return;
+  float acc = 0.f;
+#pragma unroll
+  for (int s = 0; s < CSUM_SLICES; ++s) acc += ws[c * CSUM_SLICES + s];
+  out[c] += acc;
 }
 
+template <int VEC>
 __global__ __launch_bounds__(RTG_THREADS) void lrelu_bwd_kernel(const float* __restrict__ dy,
                                                                 const float* __restrict__ ref, float* __restrict__ dx,
                                                                 long long n, float slope) {
-  for (long long i = (long long)blockIdx.x * RTG_THREADS + threadIdx.x; i < n; i += (long long)gridDim.x * RTG_THREADS)
-    dx[i] = dy[i] * (ref[i] > 0.f ? 1.f : slope);
+  const long long nv = n / VEC;
+  for (long long i = (long long)blockIdx.x * RTG_THREADS + threadIdx.x; i < nv; i += (long long)gridDim.x * RTG_THREADS) {
+    if constexpr (VEC == 4) {
+      const f32x4 g = reinterpret_cast<const f32x4*>(dy)[i], r = reinterpret_cast<const f32x4*>(ref)[i];
+      reinterpret_cast<f32x4*>(dx)[i] = f32x4{g.x * (r.x > 0.f ? 1.f : slope), g.y * (r.y > 0.f ? 1.f : slope),
+                                              g.z * (r.z > 0.f ? 1.f : slope), g.w * (r.w > 0.f ? 1.f : slope)};
+    } else {
+      dx[i] = dy[i] * (ref[i] > 0.f ? 1.f : slope);
+    }
+  }
 }
 
 __global__ __launch_bounds__(RTG_THREADS) void avgpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ out,
@@ -331,6 +411,12 @@ __global__ void adamw_bump_kernel(float* step_state, const float* loss_flag) {
 
 #define RTG_REQ(c) \
   if (!(c)) return RTG_ENULL
+// 16-byte accesses: n a multiple of 4 and every (non-null) pointer 16-byte aligned
+static inline bool vec4_ok(long long n, const void* a, const void* b, const void* c = nullptr, const void* d = nullptr) {
+  const uintptr_t bits = reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c) |
+                         reinterpret_cast<uintptr_t>(d);
+  return (n & 3) == 0 && (bits & 15) == 0;
+}
 #define RTG_LAUNCH(k, g, b, sh, st, ...)                        \
   RTG_KLAUNCH(k, dim3(g), dim3(b), sh, (hipStream_t)st, __VA_ARGS__); \
   return rtg_launch_status()
@@ -339,7 +425,10 @@ extern "C" int rtg_noise_lrelu_fwd(const float* x, const float* w, const float* 
                                    float slope, unsigned long long seed, const float* salt_dev, void* stream) {
   RTG_REQ(x && w && out);
   if (n < 1) return RTG_EINVAL;
-  RTG_LAUNCH(noise_fwd_kernel, grid_for(n), RTG_THREADS, 0, stream, x, w, u_in, out, n, slope, seed, salt_dev);
+  if (vec4_ok(n, x, out, u_in)) {
+    RTG_LAUNCH(noise_fwd_kernel<4>, grid_for(n / 4, 2), RTG_THREADS, 0, stream, x, w, u_in, out, n, slope, seed, salt_dev);
+  }
+  RTG_LAUNCH(noise_fwd_kernel<1>, grid_for(n), RTG_THREADS, 0, stream, x, w, u_in, out, n, slope, seed, salt_dev);
 }
 
 extern "C" int rtg_noise_lrelu_bwd(const float* x, const float* w, const float* u_in, const float* dy, float* dx,
@@ -347,26 +436,38 @@ extern "C" int rtg_noise_lrelu_bwd(const float* x, const float* w, const float* 
                                    const float* salt_dev, void* stream) {
   RTG_REQ(x && w && dy && dx && dw_part);
   if (n < 1 || n_blocks < 1 || n_blocks > MAX_GRID) return RTG_EINVAL;
-  RTG_LAUNCH(noise_bwd_kernel, n_blocks, RTG_THREADS, 0, stream, x, w, u_in, dy, dx, dw_part, n, slope, seed, salt_dev);
+  if (vec4_ok(n, x, dy, dx, u_in)) {
+    RTG_LAUNCH(noise_bwd_kernel<4>, n_blocks, RTG_THREADS, 0, stream, x, w, u_in, dy, dx, dw_part, n, slope, seed, salt_dev);
+  }
+  RTG_LAUNCH(noise_bwd_kernel<1>, n_blocks, RTG_THREADS, 0, stream, x, w, u_in, dy, dx, dw_part, n, slope, seed, salt_dev);
 }
 
 extern "C" int rtg_axpby(const float* a, const float* b, float* out, long long n, float alpha, float beta,
                          int accumulate, void* stream) {
   RTG_REQ(a && out);
   if (n < 1) return RTG_EINVAL;
-  RTG_LAUNCH(axpby_kernel, grid_for(n), RTG_THREADS, 0, stream, a, b, out, n, alpha, beta, accumulate);
+  if (vec4_ok(n, a, out, b)) {
+    RTG_LAUNCH(axpby_kernel<4>, grid_for(n / 4, 2), RTG_THREADS, 0, stream, a, b, out, n, alpha, beta, accumulate);
+  }
+  RTG_LAUNCH(axpby_kernel<1>, grid_for(n), RTG_THREADS, 0, stream, a, b, out, n, alpha, beta, accumulate);
 }
 
-extern "C" int rtg_channel_sum(const float* x, float* out, int B, int C, int L, void* stream) {
-  RTG_REQ(x && out);
+extern "C" int rtg_channel_sum(const float* x, float* out, int B, int C, int L, float* ws, void* stream) {
+  RTG_REQ(x && out && ws);
   if (B < 1 || C < 1 || L < 1 || C > 65535) return RTG_EINVAL;
-  RTG_LAUNCH(channel_sum_kernel, C, RTG_THREADS, 0, stream, x, out, B, C, L);
+  RTG_KLAUNCH(channel_sum_stage1, dim3(C, CSUM_SLICES), dim3(RTG_THREADS), 0, (hipStream_t)stream, x, ws, B, C, L);
+  const int st = rtg_launch_status();
+  if (st != RTG_OK) return st;
+  RTG_LAUNCH(channel_sum_stage2, rtg_ceil_div(C, RTG_THREADS), RTG_THREADS, 0, stream, ws, out, C);
 }
 
 extern "C" int rtg_lrelu_bwd(const float* dy, const float* ref, float* dx, long long n, float slope, void* stream) {
   RTG_REQ(dy && ref && dx);
   if (n < 1) return RTG_EINVAL;
-  RTG_LAUNCH(lrelu_bwd_kernel, grid_for(n), RTG_THREADS, 0, stream, dy, ref, dx, n, slope);
+  if (vec4_ok(n, dy, ref, dx)) {
+    RTG_LAUNCH(lrelu_bwd_kernel<4>, grid_for(n / 4, 2), RTG_THREADS, 0, stream, dy, ref, dx, n, slope);
+  }
+  RTG_LAUNCH(lrelu_bwd_kernel<1>, grid_for(n), RTG_THREADS, 0, stream, dy, ref, dx, n, slope);
 }
 
 extern "C" int rtg_avgpool4s2_fwd(const float* x, float* out, int rows, int L, void* stream) {

@@ -221,19 +221,19 @@ extern "C" int rtg_resstack_ok(const RtgResStackDesc* d) {
   for (int i = 0; i < 6; ++i)
     if (d->dil[i] < 1 || d->dil[i] > kHalo) return 0;
   if ((long long)d->B * ((d->L + 95) / 96) > (1 << 24)) return 0;
+  // -> the instance that serves the shape (1: (128, 32), 2: (64, L >= 64), 3: (32, L >= 128)), 0: none.  Which instances a
+  // caller USES is its choice (rtg/ops.py: RTG_RESSTACK_KINDS, default instance 1 only).  Measured at batch 32 inside the
+  // train step (us per stack, forward / backward, against six launches of the general kernel): (128, 32) 73 / 115 vs 150 /
+  // 170; (64, 256) 79 / 113 vs 102 / 120 and (32, 2048) 93 / 130 vs 96 / 114 (stand-alone) — no gain: a block per clip
+  // (tile) leaves most of the chip idle or, tiled, moves 58-108 MB through 4-byte epilogue accesses.
   const int kind = stack_kind(d);
-  // RTG_RESSTACK_KINDS: bit mask of the served instances.  Measured at batch 32 inside the train step (us per stack, forward
-  // / backward, against six launches of the general kernel): (128, 32) 73 / 115 vs 150 / 170 — served; (64, 256) 79 / 113 vs
-  // 102 / 120 and (32, 2048) 93 / 130 vs 96 / 114 (stand-alone) — no gain: a block per clip (tile) leaves most of the chip
-  // idle or, tiled, moves 58-108 MB through 4-byte epilogue accesses.  Both are built and tested but not served.
-  const int served = RTG_ENV_INT("RTG_RESSTACK_KINDS", 1);
-  return (kind > 0 && (served & (1 << (kind - 1)))) ? 1 : 0;
+  return kind > 0 ? kind : 0;
 }
 
 extern "C" int rtg_resstack_forward(const RtgResStackDesc* d, const float* x, const float* const* wp,
                                     const float* const* bias, float* const* outs, void* stream) {
   if (!d || !x || !wp || !bias || !outs) return RTG_ENULL;
-  if (rtg_resstack_ok(d) != 1) return RTG_EINVAL;
+  if (rtg_resstack_ok(d) < 1) return RTG_EINVAL;
   StackArgs a;
   a.in = x; a.pro_aux = nullptr;
   for (int i = 0; i < 6; ++i) {
@@ -247,7 +247,7 @@ extern "C" int rtg_resstack_forward(const RtgResStackDesc* d, const float* x, co
 extern "C" int rtg_resstack_backward(const RtgResStackDesc* d, const float* dy, const float* y, const float* const* wpb,
                                      const float* const* masks, float* const* gouts, void* stream) {
   if (!d || !dy || !wpb || !masks || !gouts) return RTG_ENULL;
-  if (rtg_resstack_ok(d) != 1) return RTG_EINVAL;
+  if (rtg_resstack_ok(d) < 1) return RTG_EINVAL;
   if (d->final_act && !y) return RTG_ENULL;
   StackArgs a;
   a.in = dy; a.pro_aux = d->final_act ? y : nullptr;

@@ -69,17 +69,21 @@ __device__ __forceinline__ float pack_logical(const RtgPackJob& j, const float* 
   return val;
 }
 
+// Every image is a sequence of 256-float (frag16) or 16 * tile_m-float steps, one per (row tile, chunk, tap) — or per (row
+// tile, k-step group) in the tap-major order — whose inner index is a power of two.  A wave packs 64 consecutive elements
+// of ONE step, so the step's coordinates (three divisions by run-time values: 64-bit divisions per element were most of
+// this kernel's time in round 1, 32-bit ones per element still 3/4 of it in round 2) are computed once per wave on the
+// scalar unit and a lane only splits its index within the step with shifts.
 __global__ __launch_bounds__(RTG_THREADS) void pack_kernel(const RtgPackJob* jobs, const float* params,
                                                            const float* scales, float* packed) {
   const RtgPackJob j = jobs[blockIdx.y];
   const int TM = j.tile_m, KK = 64 / TM, CPN = RTG_CK / KK;
   const int n_mt = (j.Mg + TM - 1) / TM, n_cc = (j.Cg + RTG_CK - 1) / RTG_CK;
-  // (32-bit index arithmetic: dst_size < 2^31, checked on the host — the 64-bit divisions of the index decode were most of
-  // this kernel's time)
   const unsigned n_e = (unsigned)j.dst_size;
-  for (unsigned e = blockIdx.x * RTG_THREADS + threadIdx.x; e < n_e; e += gridDim.x * RTG_THREADS) {
-    if (j.bf16) {
-      // two bf16 per 32-bit slot: elements (2e, 2e+1) of [g][mt][cc][tap][mfma][lane][4]
+  const int lane = threadIdx.x & 63;
+  if (j.bf16) {
+    // two bf16 per 32-bit slot: elements (2e, 2e+1) of [g][mt][cc][tap][mfma][lane][4]
+    for (unsigned e = blockIdx.x * RTG_THREADS + threadIdx.x; e < n_e; e += gridDim.x * RTG_THREADS) {
       const int NMF = TM == 32 ? 2 : 1;
       unsigned bits = 0;
       for (int h = 0; h < 2; ++h) {
@@ -98,47 +102,54 @@ __global__ __launch_bounds__(RTG_THREADS) void pack_kernel(const RtgPackJob* job
         bits |= (unsigned)b << (16 * h);
       }
       packed[j.dst_off + e] = __builtin_bit_cast(float, bits);
-      continue;
     }
+    return;
+  }
+  // fp32 images: wave-sized pieces of 64 consecutive elements
+  const unsigned step_sz = j.frag16 ? 256u : (unsigned)(RTG_CK * TM);        // 256, 512: a multiple of 64
+  const unsigned n_w = n_e >> 6;                                             // (dst_size is a multiple of the step size)
+  const unsigned wave0 = (blockIdx.x * RTG_THREADS + threadIdx.x) >> 6, wstride = (gridDim.x * RTG_THREADS) >> 6;
+  for (unsigned wv = wave0; wv < n_w; wv += wstride) {
+    const unsigned wu = __builtin_amdgcn_readfirstlane(wv);
+    const unsigned e0 = wu << 6;
+    unsigned t = e0 / step_sz;                         // the step (scalar)
+    const unsigned in0 = e0 - t * step_sz;             // first inner index of this wave's piece
+    const unsigned in = in0 + lane;
+    int tap, c, mt, g, m;
     if (j.frag16) {
-      // b128-fragment image of rtg_dconv.hip: [g][16-row tile][chunk][tap][kgrp 4][m 16][kq 4], channel = 4 * kq + kgrp —
-      // lane (kgrp, m) of a v_mfma_f32_16x16x4_f32 reads its A operands of the chunk's four k-steps with ONE 16-byte load
-      unsigned t2 = e;
-      const int kq = (int)(t2 % 4); t2 /= 4;
-      const int m2 = (int)(t2 % 16); t2 /= 16;
-      const int kgrp = (int)(t2 % 4); t2 /= 4;
-      const int tap2 = (int)(t2 % j.K); t2 /= j.K;
-      const int cc2 = (int)(t2 % n_cc); t2 /= n_cc;
-      const int n_mt16 = (j.Mg + 15) / 16;
-      const int mt2 = (int)(t2 % n_mt16); t2 /= n_mt16;
-      packed[j.dst_off + e] = pack_logical(j, params, scales, (int)t2, mt2 * 16 + m2, cc2 * RTG_CK + 4 * kq + kgrp, tap2);
-      continue;
-    }
-    unsigned t = e;
-    const int m = (int)(t % TM); t /= TM;
-    const int kk = (int)(t % KK); t /= KK;
-    const int cp = (int)(t % CPN); t /= CPN;
-    int tap, c, mt, g;
-    if (j.tap_major) {
-      // [g][mt][group][cp][kk][m]: k-step = group*CPN + cp = (channel, tap group); tap = tap group * KK + kk
-      const int TG = (j.K + KK - 1) / KK;
-      const int n_grp = (j.Cg * TG + CPN - 1) / CPN;
-      const int grp = (int)(t % n_grp); t /= n_grp;
-      mt = (int)(t % n_mt); t /= n_mt;
-      g = (int)t;
-      const int ks = grp * CPN + cp;
-      c = ks / TG;
-      tap = (ks - c * TG) * KK + kk;
-      if (tap >= j.K) c = j.Cg;            // padding taps: zero
-    } else {
+      // [16-row tile][chunk][tap][kgrp 4][m 16][kq 4], channel = 4 * kq + kgrp of the chunk (rtg_dconv.hip)
+      const int kq = in & 3, kgrp = in >> 6;
+      m = (in >> 2) & 15;
       tap = (int)(t % j.K); t /= j.K;
       const int cc = (int)(t % n_cc); t /= n_cc;
-      mt = (int)(t % n_mt); t /= n_mt;
-      g = (int)t;
-      c = cc * RTG_CK + cp * KK + kk;
+      const int n_mt16 = (j.Mg + 15) / 16;
+      mt = (int)(t % n_mt16);
+      g = 0;
+      m += mt * 16;
+      c = cc * RTG_CK + 4 * kq + kgrp;
+    } else {
+      const int mm = in & (TM - 1), kk = (in / TM) & (KK - 1), cp = in / (TM * KK);
+      if (j.tap_major) {
+        // [g][mt][group][cp][kk][m]: k-step = group*CPN + cp = (channel, tap group); tap = tap group * KK + kk
+        const int TG = (j.K + KK - 1) / KK;
+        const int n_grp = (j.Cg * TG + CPN - 1) / CPN;
+        const int grp = (int)(t % n_grp); t /= n_grp;
+        mt = (int)(t % n_mt); t /= n_mt;
+        g = (int)t;
+        const int ks = grp * CPN + cp;
+        c = ks / TG;
+        tap = (ks - c * TG) * KK + kk;
+        if (tap >= j.K) c = j.Cg;            // padding taps: zero
+      } else {
+        tap = (int)(t % j.K); t /= j.K;
+        const int cc = (int)(t % n_cc); t /= n_cc;
+        mt = (int)(t % n_mt); t /= n_mt;
+        g = (int)t;
+        c = cc * RTG_CK + cp * KK + kk;
+      }
+      m = mt * TM + mm;
     }
-    const float val = pack_logical(j, params, scales, g, mt * TM + m, c, tap);
-    packed[j.dst_off + e] = val;
+    packed[j.dst_off + e0 + lane] = pack_logical(j, params, scales, g, m, c, tap);
   }
 }
 

@@ -102,14 +102,14 @@ class ConvLayer:
         def ok(op, tap):
             return bool(want_bf and not tap and op[2] > 1 and op[3] > 1)
         # the dense-layer kernel (rtg_dconv.hip, block-shape codes 8xxx) reads 16-byte operand fragments: layers it can serve
-        # (>= 128 channels on both sides, dilation 1, k5 at stride 1 / 3 forward, the k5 stride-1 or 2-tap polyphase
+        # (>= 32 input channels, >= 96 output rows, dilation 1, k5 at stride 1 / 3 forward, the k5 stride-1 or 2-tap polyphase
         # backward-data operator) carry a second image of their weights behind the standard one (RtgPackJob.frag16,
         # RtgConv1dDesc.wp16); the tuner then times both kernels per problem.  RTG_DCONV=0: never (A/B knob).
         def dense(op, fwd):
             mode, g, mg, cg, k, s = op
             if os.environ.get('RTG_DCONV', '1') == '0' or want_bf or self.kind != 'conv' or self.dil != 1:
                 return 0
-            if g != 1 or cg % L.CK != 0 or cg < 128 or mg < 128:
+            if g != 1 or cg % L.CK != 0 or cg < 32 or mg < 96:
                 return 0
             if fwd:
                 return int(k == 5 and self.stride in (1, 3))

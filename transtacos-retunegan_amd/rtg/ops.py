@@ -417,8 +417,9 @@ class ConvFn(torch.autograd.Function):
                                                      _conv_flop(ly, B, lc), f'wgrad {ly.name} B{B} L{L_in}',
                                                      f'conv1d wgrad {ly.name}')
                 if ly.kind == 'convT':   # bias gradient of a transposed conv: plain channel sum of dy
+                    ws = torch.empty(32 * ly.cout, device=dy.device)
                     check(lib.rtg_channel_sum(_p(dy), C.c_void_p(bank.gflat.data_ptr() + 4 * ly.b_off), B, ly.cout, L_out,
-                                              st), 'channel_sum')
+                                              _p(ws), st), 'channel_sum')
                 if immediate:
                     bank.flush_one(ly, part, splits)
         return None, dx1, dx2, dres, None, None, None, None, None, None
@@ -428,6 +429,9 @@ class ConvFn(torch.autograd.Function):
 # ResidualStack in one launch per direction (rtg_resstack.hip)
 # ---------------------------------------------------------------------------------------------------------------
 RESSTACK = _os.environ.get('RTG_RESSTACK', '1') == '1'          # A/B knob: 0 = six conv launches per direction
+# bit mask of the fused-stack instances used (rtg_resstack_ok's instance numbers): only (128 channels, 32 samples) beat six
+# launches of the general kernel inside the train step; the 64- and 32-channel instances are built and tested, not served
+RESSTACK_KINDS = int(_os.environ.get('RTG_RESSTACK_KINDS', '1'))
 
 
 def _stack_desc(lys, B, Lx, pre_slope, final_act_slope, reverse=False):
@@ -453,7 +457,8 @@ def resstack_ok(lys, x):
         return False
     B, c, Lx = x.shape
     d = L.ResStackDesc(B, c, Lx, (C.c_int * 6)(*[ly.dil for ly in lys]), 0.01, 0, 1.0)
-    return lib.rtg_resstack_ok(C.byref(d)) == 1
+    kind = lib.rtg_resstack_ok(C.byref(d))
+    return kind >= 1 and bool(RESSTACK_KINDS >> (kind - 1) & 1)
 
 
 class ResStackFn(torch.autograd.Function):
@@ -888,7 +893,7 @@ def mrf_group_ok(lys, x):
 # GaussianNoise
 # ---------------------------------------------------------------------------------------------------------------
 class NoiseFn(torch.autograd.Function):
-    N_BLOCKS = 256
+    N_BLOCKS = 2048         # (256: one block per CU streamed 1.2 TB/s; the kernel is a pure 12-byte-per-element stream)
 
     @staticmethod
     def forward(ctx, x, w, u_in, slope, seed, salt):
