@@ -92,6 +92,34 @@ def test_reswgrad_kernel(case):
     _check_case(case, shape_cfg=8, act='none')
 
 
+DENSE_CASES = [
+    (22, 512, 512, 10, 5, 1, 1, 2, 1),       # DiscriminatorP convs.4: rows of 10, clips straddle the 64-wide reduction tiles
+    (7, 512, 512, 34, 5, 1, 1, 2, 1),
+    (3, 512, 512, 128, 5, 1, 1, 2, 1),       # DiscriminatorS convs.5
+    (14, 256, 512, 44, 5, 3, 1, 2, 1),       # convs.3: stride 3
+    (6, 128, 256, 304, 5, 3, 1, 2, 1),       # convs.2
+    (5, 32, 128, 911, 5, 3, 1, 2, 1),        # convs.1: two channel chunks
+    (1, 64, 128, 50, 5, 1, 1, 2, 1),         # a single partial tile
+]
+
+
+@pytest.mark.parametrize('case', DENSE_CASES)
+def test_dense_wgrad_kernel(case):
+    """rtg_dwgrad.hip (shape codes 10, 11): weight / bias gradients of the dense discriminator layers with 16-byte operand
+    fragments (both tiles staged in matrix-core order, the column tile as the im2col of the reduction tile), through the
+    weight-norm chain, against torch autograd; listed as a candidate for exactly these shapes."""
+    from rtg.lib import lib, WgradDesc
+    B, Cin, Cout, L, K, s, d, p, g = case
+    Lo = (L + 2 * p - d * (K - 1) - 1) // s + 1
+    probe = WgradDesc(B=B, C1=Cin, C2=0, L_in=L, groups=g, Cg=Cin // g, Mg=Cout // g, K=K, stride=s, dil=d, pad=p, Q=Lo,
+                      dy_L=Lo, pre_mode=1, pre_slope=0.15, gy_mode=0, gy_slope=1.0, gy_scale=1.0, splits=1, part_stride=0)
+    cands = (C.c_int * 12)()
+    n = lib.rtg_wgrad_shape_candidates(C.byref(probe), cands, 12)
+    assert 10 in list(cands[:n]) and 11 in list(cands[:n])          # 128-row and 64-row blocks
+    _check_case(case, shape_cfg=10, act='none')
+    _check_case(case, shape_cfg=11, act='none')
+
+
 def _check_case(case, shape_cfg=0, act='lrelu'):
     from rtg.lib import lib, WgradDesc, WnBwdJob, NormJob, check
     B, Cin, Cout, L, K, s, d, p, g = case

@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.join(REPO, 'tests'))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import packref  # noqa: E402
-from rtg.lib import lib, Conv1dDesc  # noqa: E402
+from rtg.lib import lib, Conv1dDesc, WgradDesc  # noqa: E402
 
 
 def P(t):
@@ -31,7 +31,47 @@ def timeit(f, iters=20):
     return e0.elapsed_time(e1) / iters
 
 
+def bench_wgrad(B, Cin, Cout, L, s):
+    K, p = 5, 2
+    Lo = (L + 2 * p - K) // s + 1
+    x = torch.randn(B, Cin, L, device='cuda')
+    dy = torch.randn(B, Cout, Lo, device='cuda')
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    need = Cout * (Cin * K + 1)
+    flop = 2.0 * B * Lo * Cout * Cin * K
+    probe = WgradDesc(B=B, C1=Cin, C2=0, L_in=L, groups=1, Cg=Cin, Mg=Cout, K=K, stride=s, dil=1, pad=p, Q=Lo, dy_L=Lo,
+                      pre_mode=1, pre_slope=0.15, gy_mode=0, gy_slope=1.0, gy_scale=1.0, splits=1, part_stride=0)
+    cands = (C.c_int * 12)()
+    n = lib.rtg_wgrad_shape_candidates(C.byref(probe), cands, 12)
+    res, ref = [], None
+    for c in list(cands[:n]):
+        wd = WgradDesc(B=B, C1=Cin, C2=0, L_in=L, groups=1, Cg=Cin, Mg=Cout, K=K, stride=s, dil=1, pad=p, Q=Lo, dy_L=Lo,
+                       pre_mode=1, pre_slope=0.15, gy_mode=0, gy_slope=1.0, gy_scale=1.0, splits=1, part_stride=0, shape_cfg=c)
+        splits = lib.rtg_wgrad_splits(C.byref(wd))
+        if splits < 1:
+            continue
+        part = torch.empty(splits * need, device='cuda')
+        wd.splits, wd.part_stride = splits, need
+        if lib.rtg_conv1d_wgrad(C.byref(wd), P(x), None, P(dy), None, P(part), st):
+            continue
+        torch.cuda.synchronize()
+        tot = part.view(splits, need).double().sum(0)
+        if ref is None:
+            ref = tot
+        err = ((tot - ref).abs().max() / ref.abs().max()).item()
+        ms = timeit(lambda: lib.rtg_conv1d_wgrad(C.byref(wd), P(x), None, P(dy), None, P(part), st))
+        res.append((c, ms, splits, err))
+    gen = min((r for r in res if r[0] < 10), key=lambda r: r[1])
+    dn = [r for r in res if r[0] >= 10]
+    line = f'wgrad B{B:4d} {Cin}->{Cout} L{L:4d} s{s}: general best s{gen[0]} x{gen[2]:3d} {gen[1] * 1e3:7.1f} us {flop / gen[1] / 1e9:6.1f} TF/s'
+    for d in dn:
+        line += f' | s{d[0]} x{d[2]:3d} {d[1] * 1e3:7.1f} us {flop / d[1] / 1e9:6.1f} TF/s  x{gen[1] / d[1]:.2f}  relerr {d[3]:.1e}'
+    print(line, flush=True)
+
+
 def bench(kind, B, Cin, Cout, L, s):
+    if kind == 'wgrad':
+        return bench_wgrad(B, Cin, Cout, L, s)
     K, p = 5, 2
     w = (np.random.RandomState(1).randn(Cout, Cin, K) / np.sqrt(Cin * K)).astype(np.float32)
     Lo = (L + 2 * p - K) // s + 1
@@ -99,6 +139,10 @@ SHAPES = [
     ('dgrad', 704, 512, 512, 10, 1), ('dgrad', 192, 512, 512, 34, 1), ('dgrad', 352, 512, 512, 10, 1), ('dgrad', 64, 512, 512, 128, 1),
     ('fwd', 704, 256, 512, 28, 3), ('fwd', 192, 256, 512, 102, 3), ('fwd', 704, 128, 256, 83, 3), ('fwd', 192, 128, 256, 304, 3),
     ('poly', 704, 256, 512, 28, 3), ('poly', 192, 256, 512, 102, 3), ('poly', 704, 128, 256, 83, 3), ('poly', 192, 128, 256, 304, 3),
+    ('fwd', 704, 32, 128, 249, 3), ('fwd', 192, 32, 128, 911, 3), ('poly', 704, 32, 128, 249, 3), ('poly', 192, 32, 128, 911, 3),
+    ('wgrad', 704, 512, 512, 10, 1), ('wgrad', 192, 512, 512, 34, 1), ('wgrad', 64, 512, 512, 128, 1), ('wgrad', 64, 512, 512, 32, 1),
+    ('wgrad', 704, 256, 512, 28, 3), ('wgrad', 192, 256, 512, 102, 3), ('wgrad', 704, 128, 256, 83, 3), ('wgrad', 192, 128, 256, 304, 3),
+    ('wgrad', 704, 32, 128, 249, 3), ('wgrad', 192, 32, 128, 911, 3),
 ]
 
 if __name__ == '__main__':

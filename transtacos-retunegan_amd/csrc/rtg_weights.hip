@@ -69,11 +69,12 @@ __device__ __forceinline__ float pack_logical(const RtgPackJob& j, const float* 
   return val;
 }
 
-// Every image is a sequence of 256-float (frag16) or 16 * tile_m-float steps, one per (row tile, chunk, tap) — or per (row
-// tile, k-step group) in the tap-major order — whose inner index is a power of two.  A wave packs 64 consecutive elements
-// of ONE step, so the step's coordinates (three divisions by run-time values: 64-bit divisions per element were most of
-// this kernel's time in round 1, 32-bit ones per element still 3/4 of it in round 2) are computed once per wave on the
-// scalar unit and a lane only splits its index within the step with shifts.
+// Every fp32 image is a sequence of 256-float (frag16) or 16 * tile_m-float steps, one per (row tile, chunk, tap) — or per
+// (row tile, k-step group) in the tap-major order — whose inner index is a power of two.  A wave packs one whole step per
+// iteration: the step's coordinates (three divisions by run-time values) are computed once per 256 / 512 elements, an
+// element splits its index within the step with shifts and finds its source in 32-bit arithmetic.  (Round 1: 64-bit
+// divisions per element were most of this kernel's time; round 2: 32-bit ones still 3/4 of it, ~110 instructions per
+// element at 1.2 TB/s.)
 __global__ __launch_bounds__(RTG_THREADS) void pack_kernel(const RtgPackJob* jobs, const float* params,
                                                            const float* scales, float* packed) {
   const RtgPackJob j = jobs[blockIdx.y];
@@ -105,51 +106,94 @@ __global__ __launch_bounds__(RTG_THREADS) void pack_kernel(const RtgPackJob* job
     }
     return;
   }
-  // fp32 images: wave-sized pieces of 64 consecutive elements
-  const unsigned step_sz = j.frag16 ? 256u : (unsigned)(RTG_CK * TM);        // 256, 512: a multiple of 64
-  const unsigned n_w = n_e >> 6;                                             // (dst_size is a multiple of the step size)
+  // fp32 images: a wave packs one whole step per iteration (4 or 8 pieces of 64 consecutive elements)
+  const unsigned step_sz = j.frag16 ? 256u : (unsigned)(RTG_CK * TM);        // 256 or 512
+  const unsigned n_steps = n_e / step_sz;                                    // (dst_size is a multiple of the step size)
   const unsigned wave0 = (blockIdx.x * RTG_THREADS + threadIdx.x) >> 6, wstride = (gridDim.x * RTG_THREADS) >> 6;
-  for (unsigned wv = wave0; wv < n_w; wv += wstride) {
-    const unsigned wu = __builtin_amdgcn_readfirstlane(wv);
-    const unsigned e0 = wu << 6;
-    unsigned t = e0 / step_sz;                         // the step (scalar)
-    const unsigned in0 = e0 - t * step_sz;             // first inner index of this wave's piece
-    const unsigned in = in0 + lane;
-    int tap, c, mt, g, m;
+  const int TG = (j.K + KK - 1) / KK;                                        // tap-major: tap groups per channel
+  const int n_grp = (j.Cg * TG + CPN - 1) / CPN;
+  const int n_mt16 = (j.Mg + 15) / 16;
+  const float invS = 1.0f / (float)(j.S > 0 ? j.S : 1);
+  const int inner = j.src_inner_c * j.src_K;
+  const int n_co = j.KH > 0 ? j.Cg / j.KH : j.Cg;
+  const float inv_nco = 1.0f / (float)(n_co > 0 ? n_co : 1);
+  for (unsigned st = wave0; st < n_steps; st += wstride) {
+    unsigned t = __builtin_amdgcn_readfirstlane(st);
+    // ---- the step's coordinates, once per wave
+    int tap = 0, cc = 0, mt, g = 0, grp = 0;
     if (j.frag16) {
-      // [16-row tile][chunk][tap][kgrp 4][m 16][kq 4], channel = 4 * kq + kgrp of the chunk (rtg_dconv.hip)
-      const int kq = in & 3, kgrp = in >> 6;
-      m = (in >> 2) & 15;
       tap = (int)(t % j.K); t /= j.K;
-      const int cc = (int)(t % n_cc); t /= n_cc;
-      const int n_mt16 = (j.Mg + 15) / 16;
+      cc = (int)(t % n_cc); t /= n_cc;
       mt = (int)(t % n_mt16);
-      g = 0;
-      m += mt * 16;
-      c = cc * RTG_CK + 4 * kq + kgrp;
+    } else if (j.tap_major) {
+      grp = (int)(t % n_grp); t /= n_grp;
+      mt = (int)(t % n_mt); t /= n_mt;
+      g = (int)t;
     } else {
-      const int mm = in & (TM - 1), kk = (in / TM) & (KK - 1), cp = in / (TM * KK);
-      if (j.tap_major) {
-        // [g][mt][group][cp][kk][m]: k-step = group*CPN + cp = (channel, tap group); tap = tap group * KK + kk
-        const int TG = (j.K + KK - 1) / KK;
-        const int n_grp = (j.Cg * TG + CPN - 1) / CPN;
-        const int grp = (int)(t % n_grp); t /= n_grp;
-        mt = (int)(t % n_mt); t /= n_mt;
-        g = (int)t;
-        const int ks = grp * CPN + cp;
-        c = ks / TG;
-        tap = (ks - c * TG) * KK + kk;
-        if (tap >= j.K) c = j.Cg;            // padding taps: zero
-      } else {
-        tap = (int)(t % j.K); t /= j.K;
-        const int cc = (int)(t % n_cc); t /= n_cc;
-        mt = (int)(t % n_mt); t /= n_mt;
-        g = (int)t;
-        c = cc * RTG_CK + cp * KK + kk;
-      }
-      m = mt * TM + mm;
+      tap = (int)(t % j.K); t /= j.K;
+      cc = (int)(t % n_cc); t /= n_cc;
+      mt = (int)(t % n_mt); t /= n_mt;
+      g = (int)t;
     }
-    packed[j.dst_off + e0 + lane] = pack_logical(j, params, scales, g, m, c, tap);
+    float* dst = packed + j.dst_off + (size_t)st * step_sz;
+    for (unsigned in = lane; in < step_sz; in += 64) {
+      // ---- the element's (row, channel, tap) within the step: shifts only
+      int m, c, tp = tap;
+      if (j.frag16) {
+        // [kgrp 4][m 16][kq 4], channel = 4 * kq + kgrp of the chunk (rtg_dconv.hip)
+        m = mt * 16 + ((in >> 2) & 15);
+        c = cc * RTG_CK + 4 * (in & 3) + (in >> 6);
+      } else {
+        const int mm = in & (TM - 1), kk = (in / TM) & (KK - 1), cp = in / 64;
+        m = mt * TM + mm;
+        if (j.tap_major) {
+          // k-step = group * CPN + cp = (channel, tap group); tap = tap group * KK + kk
+          const int ks = grp * CPN + cp;
+          c = ks / TG;
+          tp = (ks - c * TG) * KK + kk;
+          if (tp >= j.K) c = j.Cg;             // padding taps: zero
+        } else {
+          c = cc * RTG_CK + cp * KK + kk;
+        }
+      }
+      // ---- the source element (pack_logical in 32-bit arithmetic; divisions by the stride / the kernel rows through the
+      // float reciprocal, exact for operands below 2^24 after one correction step)
+      float val = 0.f;
+      if (m < j.Mg && c < j.Cg) {
+        int srow = -1, sin = 0;
+        if (j.mode == RTG_PACK_FWD) {
+          srow = g * j.Mg + m;
+          sin = c * j.src_K + tp;
+        } else if (j.mode == RTG_PACK_DGRAD_S1) {
+          srow = g * j.Cg + c;
+          sin = m * j.src_K + (j.src_K - 1 - tp);
+        } else {
+          int ch = (int)((float)m * invS);
+          int r = m - ch * j.S;
+          if (r < 0) { --ch; r += j.S; }
+          else if (r >= j.S) { ++ch; r -= j.S; }
+          const int jj = r + (j.K - 1 - tp) * j.S;
+          if (jj < j.src_K) {
+            if (j.mode == RTG_PACK_DGRAD_2D) {
+              int kh = (int)((float)c * inv_nco);
+              int co = c - kh * n_co;
+              if (co < 0) { --kh; co += n_co; }
+              else if (co >= n_co) { ++kh; co -= n_co; }
+              srow = co;
+              sin = (ch * j.KH + kh) * j.src_K + jj;
+            } else if (j.mode == RTG_PACK_DGRAD_POLY) {
+              srow = g * j.Cg + c;
+              sin = ch * j.src_K + jj;
+            } else {                           // RTG_PACK_CONVT_POLY (groups == 1): source [C_in][C_out][K]
+              srow = c;
+              sin = ch * j.src_K + jj;
+            }
+          }
+        }
+        if (srow >= 0) val = params[j.v_off + (long long)srow * inner + sin] * scales[j.scale_off + srow];
+      }
+      dst[in] = val;
+    }
   }
 }
 
