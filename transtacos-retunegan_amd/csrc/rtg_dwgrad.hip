@@ -3,19 +3,24 @@
 //
 //   dW[m][c][t] = sum over (clip, q) of gy[clip, m, q] * lrelu(x[clip, c, q * S + t - pad]),   db[m] = sum gy[clip, m, q]
 //
-// GEMM view: rows = output channels, columns = (input channel, tap) pairs of a 16-channel chunk (80 columns at k = 5), the
-// reduction runs over the dense (clip, q) sequence n = clip * Q + q in tiles of 64.  Both operand tiles are staged in LDS
-// in the order the matrix cores read them: [16 reductions n][row or column][n % 16], so that lane (kgrp, r) of a
-// v_mfma_f32_16x16x4_f32 fetches its operands of FOUR k-steps (n = 16 g + 4 kgrp + 0..3) with one aligned ds_read_b128
-// from either image — the column image is the im2col of the tile ([tap] shifted copies of the input rows), which is what
-// makes the shifted reads of the taps aligned.  The general kernel (rtg_wgrad_kernel.h) reads one float per matrix
-// instruction and operand from a [row][64] tile and the raw patch.
-// A block (8 waves, one 16-row tile each, all five column tiles) owns 128 rows x one channel chunk x one split of the
-// reduction; the tiles of its split are double buffered in LDS (global -> registers during the multiplications, registers
-// -> LDS behind them, ONE barrier per tile).  Chunk 0's blocks also accumulate the bias gradient (a ones operand).
-// Exposed as shape code 10 of RtgWgradDesc.shape_cfg: the tuner times it against the general shapes.  Its summation
-// order differs from theirs (rounding level), results are reproducible run to run (no atomics; splits are summed in fixed
-// order by rtg_weightnorm_backward).
+// GEMM view: rows = output channels, columns = (input channel, tap) pairs of NCH 16-channel chunks (80 columns each at
+// k = 5), the reduction runs over the dense (clip, q) sequence n = clip * Q + q in tiles of 64.  Lane (kgrp, r) of a
+// v_mfma_f32_16x16x4_f32 takes its operands of FOUR k-steps (n = 16 g + 4 kgrp + 0..3) from one 16-byte fetch:
+//   rows     gy is read by exactly one wave (waves are stacked along the rows), so it never passes through LDS: a lane
+//            loads its four consecutive n of row r straight from global memory (one 16-byte load; a second one from the
+//            next clip's row where the four straddle a clip boundary, merged by selects), a tile ahead;
+//   columns  the tile's im2col ([tap] shifted copies of the input rows, leaky-relu applied) is staged in LDS as
+//            [16 reductions][column][n % 16] — what makes the shifted reads of the taps aligned 16-byte reads — double
+//            buffered, ONE barrier per tile.
+// The general kernel (rtg_wgrad_kernel.h) reads one float per matrix instruction and operand from a [row][64] gy tile
+// and the raw patch, both in LDS.  Measured on the way (ablation builds, tools/dbg/abl_dwgrad.sh; 512 -> 512, k5): with gy
+// staged through LDS like the columns the kernel ran 72-81 TFLOP/s, 98-102 without its 26 global loads per wave and
+// tile (82 with the loads issued but out of range: the ISSUE of a vector-memory instruction costs a wave ~60 cycles,
+// whatever it fetches) and 113-118 without the LDS writes as well — hence 16-byte loads and nothing staged twice.
+// A block = kWB waves of one 16-row tile each x NCH channel chunks x one split of the reduction.  Chunk 0's blocks also
+// accumulate the bias gradient (a ones operand).  Exposed as shape codes 10.. of RtgWgradDesc.shape_cfg; the tuner times
+// them against the general shapes.  The summation order differs from theirs (rounding level); results are reproducible
+// run to run (no atomics; splits are summed in fixed order by rtg_weightnorm_backward).
 #include <type_traits>
 
 #include "rtg_common.h"
@@ -23,9 +28,10 @@
 namespace {
 
 using rsrc_t = __amdgpu_buffer_rsrc_t;
+using u32x4 = unsigned __attribute__((ext_vector_type(4)));
 #define DW_OOB 0x80000000u
 constexpr int kCch = 16, kK = 5, kCols = kCch * kK, kNCT = kCols / 16, kTT = 64, kNG = kTT / 16;
-constexpr int kBF = kNG * kCols * 16;                                // floats per buffer of the column image
+constexpr int kBF = kNG * kCols * 16;                                // floats of one chunk's column image (one buffer)
 
 struct WArgs {
   const float *x, *dy;
@@ -41,118 +47,166 @@ struct WArgs {
 __device__ __forceinline__ float dw_load(rsrc_t r, unsigned voff, unsigned soff) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
+__device__ __forceinline__ f32x4 dw_load4(rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
 
-// S: stride; kWB waves of one 16-row tile each (8: 128 rows, one block per CU; 4: 64 rows, two blocks per CU whose barrier
-// and staging phases overlap each other's multiplications, at twice the input staging per row)
-template <int S, int kWB>
+// S: stride; kWB: waves; RW: 16-row tiles per wave; NCH: channel chunks per block
+template <int S, int kWB, int NCH, int RW>
 __global__ __launch_bounds__(kWB * 64, 2) void dwgrad_kernel(const WArgs a) {
-  constexpr int kRows = kWB * 16;
-  constexpr int kAF = kNG * kRows * 16;                                // floats per buffer of the row image
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* const la = lds;                       // [2][kNG][kRows][16]
-  float* const lb = lds + 2 * kAF;             // [2][kNG][kCols][16]
+  constexpr int kRows = kWB * RW * 16;
+  constexpr int CPW = NCH * kCch / kWB;                               // input channels a wave stages per tile
+  static_assert(NCH * kCch % kWB == 0, "channels split evenly over the waves");
+  extern __shared__ __attribute__((aligned(16))) float lds[];      // [2][NCH][kNG][kCols][16]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // block -> (split, row block, channel chunk): each XCD walks a contiguous range of items; the chunks of one (split,
-  // row block) are neighbours (same gy tiles), the row blocks of one split next (same input tiles)
+  // block -> (split, row block, group of NCH channel chunks): each XCD walks a contiguous range of items; the chunk
+  // groups of one (split, row block) are neighbours (same gy rows), the row blocks of one split next (same input tiles)
   const int item = (int)(blockIdx.x & 7u) * a.per_xcd + (int)(blockIdx.x >> 3);
   if (item >= a.n_items) return;
   const int split = item / a.per_split;
   int rem = item - split * a.per_split;
   const int cch = rem % a.n_cch, mb = rem / a.n_cch;
-  const int m0 = mb * kRows, c0 = cch * kCch;
+  const int m0 = mb * kRows, c0 = cch * NCH * kCch;
 
   const rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
   const rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.dy_bytes, 0x00020000);
-  const unsigned rowb_d = (unsigned)a.dy_L * 4u, rowb_x = (unsigned)a.L_in * 4u;
+  const unsigned rowb_x = (unsigned)a.L_in * 4u;
+  const int r16 = lane & 15, kgrp = lane >> 4;
 
-  // ---- staging: the lane is reduction index n of the tile; the wave fetches rows wave, wave + 8, ... of gy and the K
-  // shifted copies of channels wave, wave + 8 of the chunk
-  float sa[kRows / kWB], sb[kCch / kWB][kK];
-  auto stage_load = [&](int tile) __attribute__((always_inline)) {
-    const int n = tile * kTT + lane;
-    int clip = (int)((float)n * a.inv_Q);
-    int q = n - clip * a.Q;
-    if (q < 0) { --clip; q += a.Q; }
-    else if (q >= a.Q) { ++clip; q -= a.Q; }
-    const bool valid = n < a.n_red;
-    const unsigned va = valid ? ((unsigned)clip * (unsigned)a.Mg * (unsigned)a.dy_L + (unsigned)q) * 4u : DW_OOB;
+  auto divq = [&](int n, int& q) __attribute__((always_inline)) {      // n / Q (n < 2^23) through the float reciprocal
+    int c = (int)((float)n * a.inv_Q);
+    q = n - c * a.Q;
+    if (q < 0) { --c; q += a.Q; }
+    else if (q >= a.Q) { ++c; q -= a.Q; }
+    return c;
+  };
+
+  // ---- rows: this lane's four consecutive reductions of row (wave's tile, r16) for each 16-reduction group of a tile
+  f32x4 l1[RW][kNG], l2[RW][kNG];
+  int arem[kNG], aval[kNG];                    // elements before the clip boundary; valid elements (n < n_red)
+  const unsigned arow = (unsigned)(m0 + wave * RW * 16 + r16) * (unsigned)a.dy_L * 4u;
+  const unsigned atile = 16u * (unsigned)a.dy_L * 4u;        // bytes between the wave's row tiles
+  auto a_load = [&](int tile) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < kRows / kWB; ++i) sa[i] = dw_load(rd, va, (unsigned)(m0 + wave + kWB * i) * rowb_d);
+    for (int g = 0; g < kNG; ++g) {
+      const int n0 = tile * kTT + g * 16 + kgrp * 4;
+      int q0;
+      const int clip = divq(n0, q0);
+      const int left = a.n_red - n0;
+      aval[g] = left < 0 ? 0 : left;
+      arem[g] = a.Q - q0;
+      const unsigned cb = (unsigned)clip * (unsigned)a.Mg * (unsigned)a.dy_L * 4u;
+      const unsigned o1 = left > 0 ? cb + arow + (unsigned)q0 * 4u : DW_OOB;
+      // the part behind a clip boundary: row r of the NEXT clip, element e at position e - arem
+      const unsigned o2 = (left > arem[g] && arem[g] < 4)
+                              ? cb + (unsigned)a.Mg * (unsigned)a.dy_L * 4u + arow - (unsigned)arem[g] * 4u : DW_OOB;
+#pragma unroll
+      for (int i = 0; i < RW; ++i) {
+        l1[i][g] = dw_load4(rd, o1, i * atile);
+        l2[i][g] = dw_load4(rd, o2, i * atile);
+      }
+    }
+  };
+  auto a_frag = [&](int i, int g) __attribute__((always_inline)) {
+    f32x4 f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float v = e < arem[g] ? l1[i][g][e] : l2[i][g][e];
+      f[e] = e < aval[g] ? v : 0.f;
+    }
+    return f;
+  };
+
+  // ---- columns: the lane is reduction index n of the tile; a wave stages the K shifted copies of CPW channels
+  float sb[CPW][kK];
+  auto b_load = [&](int tile) __attribute__((always_inline)) {
+    const int n = tile * kTT + lane;
+    int q;
+    const int clip = divq(n, q);
+    const bool valid = n < a.n_red;
     const unsigned xclip = (unsigned)clip * (unsigned)a.Cg * (unsigned)a.L_in;
 #pragma unroll
     for (int t = 0; t < kK; ++t) {
       const int pos = q * S + t - a.pad;
       const unsigned vb = (valid && pos >= 0 && pos < a.L_in) ? (xclip + (unsigned)pos) * 4u : DW_OOB;
 #pragma unroll
-      for (int j = 0; j < kCch / kWB; ++j) sb[j][t] = dw_load(rx, vb, (unsigned)(c0 + wave + kWB * j) * rowb_x);
+      for (int j = 0; j < CPW; ++j) sb[j][t] = dw_load(rx, vb, (unsigned)(c0 + wave + kWB * j) * rowb_x);
     }
   };
-  auto stage_write = [&](int buf) __attribute__((always_inline)) {
-    float* pa = la + buf * kAF + (lane >> 4) * kRows * 16 + (lane & 15) + wave * 16;
+  auto b_write = [&](int buf) __attribute__((always_inline)) {
+    // channel c = wave + kWB * j of the block's NCH * 16: chunk c / 16, column (c % 16) * K + t
+    float* pb = lds + buf * (NCH * kBF) + (lane >> 4) * kCols * 16 + (lane & 15);
 #pragma unroll
-    for (int i = 0; i < kRows / kWB; ++i) {
-      float v = sa[i];
-      asm volatile("" : "+v"(v));                   // keep the consumption (and its wait) here, below the multiplications
-      pa[i * kWB * 16] = v * a.gy_scale;
-    }
-    float* pb = lb + buf * kBF + (lane >> 4) * kCols * 16 + (lane & 15) + wave * kK * 16;
-#pragma unroll
-    for (int j = 0; j < kCch / kWB; ++j)
+    for (int j = 0; j < CPW; ++j) {
+      const int c = wave + kWB * j;
 #pragma unroll
       for (int t = 0; t < kK; ++t) {
         float v = sb[j][t];
-        asm volatile("" : "+v"(v));
-        pb[(j * kWB * kK + t) * 16] = v > 0.f ? v : v * a.xslope;
+        asm volatile("" : "+v"(v));                 // keep the consumption (and its wait) here, below the multiplications
+        pb[(c >> 4) * kBF + ((c & 15) * kK + t) * 16] = v > 0.f ? v : v * a.xslope;
       }
+    }
   };
 
-  // ---- operands of this wave: row tile `wave`, every column tile
-  const int r16 = lane & 15, kgrp = lane >> 4;
-  const int aoff = (wave * 16 + r16) * 16 + kgrp * 4;
   const int boff = r16 * 16 + kgrp * 4;
-  f32x4 acc[kNCT], accb = {0.f, 0.f, 0.f, 0.f};
+  f32x4 acc[RW][NCH][kNCT], accb[RW];
 #pragma unroll
-  for (int j = 0; j < kNCT; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < RW; ++i) {
+    accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int h = 0; h < NCH; ++h)
+#pragma unroll
+      for (int j = 0; j < kNCT; ++j) acc[i][h][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   const bool with_bias = cch == 0;
 
   struct Frag {
-    f32x4 a, b[kNCT];
+    f32x4 b[NCH][kNCT];
   };
   int tile = split;
-  if (tile < a.n_tiles) {
-    stage_load(tile);
-    stage_write(0);
-  }
+  b_load(tile < a.n_tiles ? tile : (1 << 24));
+  b_write(0);
+  a_load(tile < a.n_tiles ? tile : (1 << 24));
   __syncthreads();
-  // BIAS (chunk 0's blocks): one more matrix instruction per k-step against a ones operand — two copies of the loop, so
-  // that the other blocks carry no branch inside the multiplications
+  // BIAS (chunk group 0's blocks): one more matrix instruction per k-step against a ones operand — two copies of the
+  // loop, so that the other blocks carry no branch inside the multiplications
   auto run = [&](auto bias_tag) __attribute__((always_inline)) {
     constexpr bool BIAS = decltype(bias_tag)::value;
     int cur = 0;
     for (; tile < a.n_tiles; tile += a.splits) {
-      const int nxt = tile + a.splits;
-      // (unconditional: past the last tile every offset is out of range, the loads return zeros nobody writes — a branch
-      // around them would make the compiler wait for ALL loads at the join)
-#ifndef RTG_EXP_DW_NOLOAD
-      stage_load(nxt < a.n_tiles ? nxt : (1 << 24));
-#endif
-      const float* pa = la + cur * kAF + aoff;
-      const float* pb = lb + cur * kBF + boff;
+      const int nxt = tile + a.splits < a.n_tiles ? tile + a.splits : (1 << 24);
+      // this tile's row fragments (requested a tile ago), then the requests of the next tile: past the last tile every
+      // offset is out of range and the loads return zeros nobody uses (no branch: the compiler's wait counts stay exact)
+      f32x4 fa[RW][kNG];
+#pragma unroll
+      for (int i = 0; i < RW; ++i)
+#pragma unroll
+        for (int g = 0; g < kNG; ++g) fa[i][g] = a_frag(i, g);
+      a_load(nxt);
+      b_load(nxt);
+      const float* pb = lds + cur * (NCH * kBF) + boff;
       auto fetch = [&](Frag& f, int g) __attribute__((always_inline)) {
-        f.a = *reinterpret_cast<const f32x4*>(pa + g * kRows * 16);
 #pragma unroll
-        for (int j = 0; j < kNCT; ++j) f.b[j] = *reinterpret_cast<const f32x4*>(pb + (g * kCols + j * 16) * 16);
+        for (int h = 0; h < NCH; ++h)
+#pragma unroll
+          for (int j = 0; j < kNCT; ++j)
+            f.b[h][j] = *reinterpret_cast<const f32x4*>(pb + h * kBF + (g * kCols + j * 16) * 16);
       };
-      auto mma = [&](const Frag& f) __attribute__((always_inline)) {
+      auto mma = [&](const Frag& f, int g) __attribute__((always_inline)) {
 #pragma unroll
-        for (int kq = 0; kq < 4; ++kq) {
+        for (int kq = 0; kq < 4; ++kq)
 #pragma unroll
-          for (int j = 0; j < kNCT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[kq], f.b[j][kq], acc[j], 0, 0, 0);
-          if constexpr (BIAS) accb = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[kq], 1.0f, accb, 0, 0, 0);
-        }
+          for (int i = 0; i < RW; ++i) {
+#pragma unroll
+            for (int h = 0; h < NCH; ++h)
+#pragma unroll
+              for (int j = 0; j < kNCT; ++j)
+                acc[i][h][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][g][kq], f.b[h][j][kq], acc[i][h][j], 0, 0, 0);
+            if constexpr (BIAS) accb[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][g][kq], 1.0f, accb[i], 0, 0, 0);
+          }
       };
-      // the fragments of 16-reduction group g + 1 are requested before group g is multiplied
+      // the column fragments of 16-reduction group g + 1 are requested before group g is multiplied
       Frag f0, f1;
       fetch(f0, 0);
 #pragma unroll
@@ -161,12 +215,10 @@ __global__ __launch_bounds__(kWB * 64, 2) void dwgrad_kernel(const WArgs a) {
         Frag& fn = (g & 1) ? f0 : f1;
         if (g + 1 < kNG) fetch(fn, g + 1);
         __builtin_amdgcn_sched_barrier(0);
-        mma(fc);
+        mma(fc, g);
         __builtin_amdgcn_sched_barrier(0);
       }
-#ifndef RTG_EXP_DW_NOWRITE
-      if (nxt < a.n_tiles) stage_write(cur ^ 1);
-#endif
+      if (nxt < a.n_tiles) b_write(cur ^ 1);
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
       cur ^= 1;
@@ -175,31 +227,46 @@ __global__ __launch_bounds__(kWB * 64, 2) void dwgrad_kernel(const WArgs a) {
   if (with_bias) run(std::true_type{});
   else run(std::false_type{});
 
-  // ---- this split's partial: [rows][Cg * K] then the bias partials
+  // ---- this split's partial: [rows][Cg * K] then the bias partials (gy_scale applied here: the sums are linear in gy)
   float* wpart = a.part + (size_t)split * a.part_stride;
   const int ck = a.Cg * kK;
 #pragma unroll
-  for (int j = 0; j < kNCT; ++j)
+  for (int i = 0; i < RW; ++i)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int m = m0 + wave * 16 + kgrp * 4 + r;
-      wpart[(size_t)m * ck + c0 * kK + j * 16 + r16] = acc[j][r];
-    }
+    for (int h = 0; h < NCH; ++h)
+#pragma unroll
+      for (int j = 0; j < kNCT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = m0 + (wave * RW + i) * 16 + kgrp * 4 + r;
+          wpart[(size_t)m * ck + (c0 + h * kCch) * kK + j * 16 + r16] = acc[i][h][j][r] * a.gy_scale;
+        }
   if (with_bias && r16 == 0) {
     float* bpart = wpart + (size_t)a.Mg * ck;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) bpart[m0 + wave * 16 + kgrp * 4 + r] = accb[r];
+    for (int i = 0; i < RW; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bpart[m0 + (wave * RW + i) * 16 + kgrp * 4 + r] = accb[i][r] * a.gy_scale;
   }
 }
 
-constexpr int kRowsOf[2] = {128, 64};                                  // shape code 10, 11
+// shape codes 10, 11: (waves, channel chunks per block, 16-row tiles per wave).  Measured and dropped: 4-wave blocks
+// (two per CU: 5-15 % slower than the 8-wave block of the same tile) and 32 rows per wave (RW = 2: the two pending
+// 16-byte loads per fragment and row tile push the kernel past 256 registers)
+struct DwShape {
+  int wb, nch, rw;
+};
+constexpr DwShape kDw[] = {{8, 1, 1}, {8, 2, 1}};
+constexpr int kNumDw = sizeof(kDw) / sizeof(DwShape);
 
-bool eligible(const RtgWgradDesc* d, int kRows = 128) {
+bool eligible(const RtgWgradDesc* d, int variant) {
+  if (variant < 0 || variant >= kNumDw) return false;
+  const int kRows = kDw[variant].wb * kDw[variant].rw * 16;
   if (d->groups != 1 || d->C2 != 0 || d->h_k > 1 || d->h_n > 1 || d->bf16) return false;
   if (d->K != kK || d->dil != 1 || (d->stride != 1 && d->stride != 3)) return false;
-  if (d->Cg != d->C1 || d->Cg % kCch != 0 || d->Mg % kRows != 0) return false;
+  if (d->Cg != d->C1 || d->Cg % (kCch * kDw[variant].nch) != 0 || d->Mg % kRows != 0) return false;
   if (d->gy_mode != RTG_PRE_NONE || (d->pre_mode != RTG_PRE_NONE && d->pre_mode != RTG_PRE_LRELU)) return false;
-  if (d->Q < 1 || d->Q > d->dy_L) return false;
+  if (d->Q < 4 || d->Q > d->dy_L) return false;                               // (four consecutive reductions span <= 2 clips)
   const long long n = (long long)d->B * d->Q;
   if (n >= (1ll << 23)) return false;                                         // float-reciprocal division of n by Q
   if ((long long)d->B * d->C1 * d->L_in * 4 >= (1ll << 31) || (long long)d->B * d->Mg * d->dy_L * 4 >= (1ll << 31)) return false;
@@ -208,19 +275,19 @@ bool eligible(const RtgWgradDesc* d, int kRows = 128) {
 
 }  // namespace
 
-// variant 0: 128-row blocks (shape code 10), 1: 64-row blocks (11)
-int rtg_dwgrad_ok(const RtgWgradDesc* d, int variant) { return (variant == 0 || variant == 1) && eligible(d, kRowsOf[variant]) ? 1 : 0; }
+int rtg_dwgrad_variants(void) { return kNumDw; }
+int rtg_dwgrad_ok(const RtgWgradDesc* d, int variant) { return eligible(d, variant) ? 1 : 0; }
 
-// split count: one block per CU (104 KB of LDS, 8 waves); a launch lasts (rounds of the chip) x (tiles per block) tile times
-// plus the write and the fixed-order read-back of one partial per split
+// split count: a launch lasts (rounds of the chip) x (tiles per block) tile times plus the write and the fixed-order
+// read-back of one partial per split
 int rtg_dwgrad_splits(const RtgWgradDesc* d, int variant) {
-  if (!rtg_dwgrad_ok(d, variant)) return RTG_EINVAL;
-  const int kRows = kRowsOf[variant];
-  const long long base = (long long)(d->Mg / kRows) * (d->Cg / kCch);
+  if (!eligible(d, variant)) return RTG_EINVAL;
+  const DwShape sh = kDw[variant];
+  const long long base = (long long)(d->Mg / (sh.wb * sh.rw * 16)) * (d->Cg / (kCch * sh.nch));
   const long long tiles = ((long long)d->B * d->Q + kTT - 1) / kTT;
-  const double t_tile = variant == 0 ? 2.4 : 1.3, t_fixed = 6.0;
-  const long long slots = variant == 0 ? 256 : 512;
+  const double t_tile = 0.27 * sh.wb * sh.nch * sh.rw + 0.3, t_fixed = 6.0;
   const double t_flush = (double)d->Mg * ((double)d->Cg * d->K + 1) * 8.0 / 3.0e6;
+  const long long slots = sh.wb == 8 ? 256 : 512;
   double best = 1e30;
   long long best_s = 1;
   const long long s_max = tiles < 512 ? tiles : 512;
@@ -232,10 +299,24 @@ int rtg_dwgrad_splits(const RtgWgradDesc* d, int variant) {
   return (int)best_s;
 }
 
+template <int S, int WB, int NCH, int RW>
+static int dw_launch(const WArgs& a, hipStream_t s) {
+  auto k = dwgrad_kernel<S, WB, NCH, RW>;
+  const size_t lds_bytes = (size_t)2 * NCH * kBF * sizeof(float);
+  static bool attr_set = false;
+  if (lds_bytes > 64 * 1024 && !attr_set) {
+    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return RTG_ERANGE;
+    attr_set = true;
+  }
+  RTG_KLAUNCH(k, dim3((unsigned)(8 * a.per_xcd)), dim3(WB * 64), lds_bytes, s, a);
+  return rtg_launch_status();
+}
+
 int rtg_dwgrad_launch(const RtgWgradDesc* d, int variant, const float* x, const float* dy, float* part, hipStream_t s) {
-  if (!rtg_dwgrad_ok(d, variant)) return RTG_EINVAL;
-  const int kRows = kRowsOf[variant], kWB = kRows / 16;
+  if (!eligible(d, variant)) return RTG_EINVAL;
   if (!x || !dy || !part) return RTG_ENULL;
+  if ((reinterpret_cast<uintptr_t>(dy) & 3) != 0) return RTG_EINVAL;
+  const DwShape sh = kDw[variant];
   WArgs a;
   a.x = x; a.dy = dy; a.part = part;
   a.B = d->B; a.Cg = d->Cg; a.L_in = d->L_in; a.Mg = d->Mg; a.Q = d->Q; a.dy_L = d->dy_L; a.pad = d->pad;
@@ -245,7 +326,7 @@ int rtg_dwgrad_launch(const RtgWgradDesc* d, int variant, const float* x, const 
   a.splits = d->splits; a.part_stride = d->part_stride;
   a.n_red = d->B * d->Q;
   a.n_tiles = rtg_ceil_div(a.n_red, kTT);
-  a.n_mb = d->Mg / kRows; a.n_cch = d->Cg / kCch;
+  a.n_mb = d->Mg / (sh.wb * sh.rw * 16); a.n_cch = d->Cg / (kCch * sh.nch);
   a.per_split = a.n_mb * a.n_cch;
   const long long n_items = (long long)a.per_split * d->splits;
   if (n_items > (1ll << 28)) return RTG_ERANGE;
@@ -253,15 +334,7 @@ int rtg_dwgrad_launch(const RtgWgradDesc* d, int variant, const float* x, const 
   a.per_xcd = (int)((n_items + 7) / 8);
   a.x_bytes = d->B * d->C1 * d->L_in * 4;
   a.dy_bytes = d->B * d->Mg * d->dy_L * 4;
-  const size_t lds_bytes = (size_t)2 * (kNG * kRows * 16 + kBF) * sizeof(float);
-  static bool attr_set[4] = {false, false, false, false};
-  auto k = variant == 0 ? (d->stride == 1 ? dwgrad_kernel<1, 8> : dwgrad_kernel<3, 8>)
-                        : (d->stride == 1 ? dwgrad_kernel<1, 4> : dwgrad_kernel<3, 4>);
-  bool& set = attr_set[variant * 2 + (d->stride == 1 ? 0 : 1)];
-  if (!set) {
-    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return RTG_ERANGE;
-    set = true;
-  }
-  RTG_KLAUNCH(k, dim3((unsigned)(8 * a.per_xcd)), dim3(kWB * 64), lds_bytes, s, a);
-  return rtg_launch_status();
+  const int S = d->stride;
+  if (variant == 0) return S == 1 ? dw_launch<1, 8, 1, 1>(a, s) : dw_launch<3, 8, 1, 1>(a, s);
+  return S == 1 ? dw_launch<1, 8, 2, 1>(a, s) : dw_launch<3, 8, 2, 1>(a, s);
 }
