@@ -207,10 +207,14 @@ def spec_to_natural_scale(spec):
 
 
 def augment_spec(S, time_mask=True, freq_mask=True, prob=0.2, rounds=3, freq_width=9, time_width=3, rng=None):
-    """audio.py:72-99: random frequency / time band masks then a 3x3 mean blur (zero padded, count includes padding)."""
+    """audio.py:72-99: random frequency / time band masks then a 3x3 mean blur (zero padded, count includes padding).
+    Kept from the reference: its masks are written through `torch.from_numpy(S)`, i.e. INTO THE CALLER'S ARRAY (a float32
+    ndarray shares its memory with the tensor) — the caller's `mel / 2 + mel_aug / 2` (data.py:71-72) therefore blends
+    the MASKED mel with its blur.  Pinned by tests/test_data_golden_cpu.py against the reference's own Dataset."""
     R = rng or np.random
     F, T = S.shape
-    S = np.array(S, dtype=np.float32, copy=True)
+    if not (isinstance(S, np.ndarray) and S.dtype == np.float32 and S.flags.writeable):
+        S = np.array(S, dtype=np.float32, copy=True)
     for _ in range(rounds):
         if freq_mask and R.random() < prob:
             s, r = R.randint(0, F - freq_width), R.randint(1, freq_width)

@@ -11,7 +11,10 @@ Everything here is numpy / scipy on the host.  librosa (wav decoding with 'kaise
 pitch-shift / time-stretch augmentation) is absent from this image and from /root/reference: `load_wav` reads PCM / float
 wav files with scipy and resamples with a polyphase filter when the rate differs, `trim_silence` restates
 librosa.effects.trim, and the two librosa augmentations of retunegan/audio.py:44-69 are left out (the dynamic-range one
-is kept).  PARITY UNPINNED for those (no reference fixture exists); the crop / pad / cache logic is tested directly.
+is kept).  Parity: the Dataset contract (finetune and plain feed, per-utterance cache, training crops, evaluation items),
+the TransTacoS de-normalisation, the mel projection and the augmentation blend are PINNED by fixtures the reference's own
+data.py / audio.py produced on a synthetic corpus (oracle/gen_golden_data.py, tests/test_data_golden_cpu.py); librosa's
+Griffin-Lim, STFT pair, silence trimmer and resampler were stand-ins there (oracle/stubs/librosa) and stay unpinned.
 """
 import os
 import threading
@@ -120,7 +123,9 @@ class Dataset(_TorchDataset):
             mag = A.spec_to_natural_scale(np.load(os.path.join(self.data_dp, f'mag-{name}.npy')))
         mel = A.mag_to_mel(mag)
         if self.is_train:
-            mel = mel / 2 + A.augment_spec(mel, rounds=5) / 2
+            # (in this order: augment_spec writes its masks into `mel` itself, as the reference's does — audio.augment_spec)
+            mel_aug = A.augment_spec(mel, rounds=5)
+            mel = mel / 2 + mel_aug / 2
         wav_tmpl = np.pad(A.inv_mag(mag, wavlen=wavlen - 1), (0, 1))       # data.py:76-77
         if hp.ref_wav == 'dy':
             wav_tmpl = np.diff(np.pad(wav_tmpl, (0, 1)))
