@@ -187,3 +187,68 @@ def test_pack_kernel_writes_the_fragment_image():
         assert lib.rtg_weights_pack(_ptr(job_d), 1, size, _ptr(params), _ptr(scales), _ptr(packed), st) == 0
         torch.cuda.synchronize()
         np.testing.assert_allclose(packed.cpu().numpy(), ref, rtol=1e-6, atol=1e-7)
+
+
+CONV2D = [
+    # B, Cin, Cout, H, W, (kh, kw), (sh, sw), (ph, pw)        StftDiscriminator layers (discrminator.py:255-262)
+    (2, 64, 256, 40, 18, (5, 3), (3, 2), (2, 1)),
+    (3, 256, 512, 22, 9, (5, 3), (3, 2), (2, 1)),
+    (2, 512, 512, 8, 5, (3, 3), (1, 1), (1, 1)),
+    (2, 32, 96, 33, 35, (3, 3), (2, 2), (1, 1)),
+    (1, 64, 128, 13, 69, (3, 3), (1, 1), (1, 1)),
+]
+
+
+@pytest.mark.parametrize('case', CONV2D)
+def test_conv2d_forward_codes(case):
+    """the second dimension of the dense-layer kernel: clips = (item, output row), channels = (channel, kernel row), the
+    patch row of a clip gathered per kernel row; bit-identical to the general kernel's 2-D mode, close to torch.conv2d"""
+    B, Cin, Cout, H, W, (kh, kw), (sh, sw), (ph, pw) = case
+    gen = torch.Generator().manual_seed(29)
+    x = torch.randn(B, Cin, H, W, generator=gen)
+    w = torch.randn(Cout, Cin, kh, kw, generator=gen) / np.sqrt(Cin * kh * kw)
+    bias = torch.randn(Cout, generator=gen)
+    ref = F.conv2d(F.leaky_relu(x, 0.15).double(), w.double(), bias.double(), (sh, sw), (ph, pw)).float()
+    Ho, Wo = ref.shape[-2:]
+    Wl = w.numpy().reshape(1, Cout, Cin * kh, kw)                  # virtual channel = ci * kh + row
+    wp = torch.from_numpy(_both_images(Wl)).cuda()
+    kw_ = _desc(B * Ho, Cin * kh, W, Cout, kw, sw, pw, Wo, Cout, Wo, pre_mode=1, pre_slope=0.15, h_in=H, h_k=kh,
+                h_stride=sh, h_pad=ph, h_n=Ho, h_mode=0)
+    xd, bd = x.cuda(), bias.cuda()
+    rc, base = _run(kw_, xd, wp, bias=bd, out_shape=(B, Cout, Ho, Wo))
+    assert rc == 0
+    np.testing.assert_allclose(base.cpu().numpy(), ref.numpy(), rtol=1e-4, atol=3e-5)
+    codes = _codes(kw_)
+    assert codes, 'no dense-layer code listed for the 2-D problem'
+    for c in codes:
+        rc, out = _run(kw_, xd, wp, bias=bd, out_shape=(B, Cout, Ho, Wo), cfg=c)
+        assert rc == 0, c
+        assert torch.equal(out, base), (c, (out - base).abs().max().item())
+
+
+@pytest.mark.parametrize('case', [(2, 512, 512, 8, 5), (1, 64, 128, 13, 69)])
+def test_conv2d_dgrad_stride1_codes(case):
+    """backward-data of the 3x3 stride-(1, 1) layer: channels ordered (kernel row, output channel), rows r + pad - kh"""
+    B, Cin, Cout, H, W = case
+    k, p = 3, 1
+    gen = torch.Generator().manual_seed(31)
+    x = torch.randn(B, Cin, H, W, generator=gen, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(Cout, Cin, k, k, generator=gen) / np.sqrt(Cin * k * k)
+    y = F.conv2d(F.leaky_relu(x, 0.15), w.double(), None, 1, p)
+    dy = torch.randn(y.shape, generator=gen)
+    y.backward(dy.double())
+    ref = x.grad.float()
+    # rows = input channels, channels = (kh, co), taps along W flipped (RTG_PACK_DGRAD_2D with stride 1)
+    Wl = np.ascontiguousarray(w.numpy().transpose(1, 2, 0, 3)[..., ::-1]).reshape(1, Cin, k * Cout, k)
+    wp = torch.from_numpy(_both_images(Wl)).cuda()
+    kw_ = _desc(B * H, Cout * k, W, Cin, k, 1, (k - 1) - p, W, Cin, W, mask_slope=0.15, h_in=H, h_k=k, h_stride=1,
+                h_pad=p, h_n=H, h_mode=1)
+    xm, dyd = x.detach().float().cuda(), dy.cuda()
+    rc, base = _run(kw_, dyd, wp, mask=xm, out_shape=(B, Cin, H, W))
+    assert rc == 0
+    np.testing.assert_allclose(base.cpu().numpy(), ref.numpy(), rtol=1e-4, atol=3e-5)
+    codes = _codes(kw_)
+    assert codes
+    for c in codes:
+        rc, out = _run(kw_, dyd, wp, mask=xm, out_shape=(B, Cin, H, W), cfg=c)
+        assert rc == 0 and torch.equal(out, base), c

@@ -69,6 +69,44 @@ def bench_wgrad(B, Cin, Cout, L, s):
     print(line, flush=True)
 
 
+def bench_2d(B, Cin, Cout, H, W, kh, sh, sw):
+    """StftDiscriminator layer forward: (kh, 3) kernel, stride (sh, sw), 'same'-style padding"""
+    kw, ph, pw = 3, kh // 2, 1
+    Ho, Wo = (H + 2 * ph - kh) // sh + 1, (W + 2 * pw - kw) // sw + 1
+    w = (np.random.RandomState(1).randn(Cout, Cin, kh, kw) / np.sqrt(Cin * kh * kw)).astype(np.float32)
+    Wl = w.reshape(1, Cout, Cin * kh, kw)
+    wp = torch.from_numpy(np.concatenate([packref.pack_logical(Wl, 32), packref.pack_frag16(Wl)])).cuda()
+    x = torch.randn(B, Cin, H, W, device='cuda')
+    out = torch.empty(B, Cout, Ho, Wo, device='cuda')
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    d = Conv1dDesc(B=B * Ho, C1=Cin * kh, C2=0, L_in=W, groups=1, Cg=Cin * kh, Mg=Cout, K=kw, stride=sw, dil=1, pad=pw, Q=Wo,
+                   out_C=Cout, out_L=Wo, shuf_S=1, shuf_P=0, pre_mode=1, pre_slope=0.15, mask_slope=1.0, out_scale=1.0,
+                   act=0, act_slope=1.0, accumulate=0, tile_m=32, out_split=0, wp16=1, h_in=H, h_k=kh, h_stride=sh,
+                   h_pad=ph, h_n=Ho, h_mode=0)
+    flop = 2.0 * B * Ho * Wo * Cout * Cin * kh * kw
+    cands = (C.c_int * 48)()
+    n = lib.rtg_conv1d_tile_candidates(C.byref(d), cands, 48)
+    res, ref = [], None
+    for c in list(cands[:n]):
+        d.tile_cfg = c
+        if lib.rtg_conv1d(C.byref(d), P(x), None, None, P(wp), None, None, None, P(out), None, st):
+            continue
+        torch.cuda.synchronize()
+        if ref is None:
+            ref = out.clone()
+        same = torch.equal(out, ref)
+        ms = timeit(lambda: lib.rtg_conv1d(C.byref(d), P(x), None, None, P(wp), None, None, None, P(out), None, st))
+        res.append((c, ms, same))
+    gen = min((r for r in res if r[0] < 8000), key=lambda r: r[1])
+    dc = [r for r in res if r[0] > 8000]
+    line = f'fwd2d B{B} {Cin}->{Cout} {H}x{W} k({kh},3) s({sh},{sw}): general best {gen[0]} {gen[1] * 1e3:7.1f} us {flop / gen[1] / 1e9:6.1f} TF/s'
+    if dc:
+        bd = min(dc, key=lambda r: r[1])
+        line += f' | dconv best {bd[0]} {bd[1] * 1e3:7.1f} us {flop / bd[1] / 1e9:6.1f} TF/s  x{gen[1] / bd[1]:.2f}'
+    bad = [r[0] for r in res if not r[2]]
+    print(line + (f'  MISMATCH {bad}' if bad else ''), flush=True)
+
+
 def bench(kind, B, Cin, Cout, L, s):
     if kind == 'wgrad':
         return bench_wgrad(B, Cin, Cout, L, s)
@@ -145,7 +183,16 @@ SHAPES = [
     ('wgrad', 704, 32, 128, 249, 3), ('wgrad', 192, 32, 128, 911, 3),
 ]
 
+MTD = [  # B = 64 (real + generated clips), resolution 0 (1025 x 35) and 2 (257 x 137)
+    (64, 64, 256, 257, 18, 5, 3, 2), (64, 256, 512, 86, 9, 5, 3, 2), (64, 512, 512, 29, 5, 3, 1, 1), (64, 32, 64, 513, 35, 3, 2, 2),
+    (64, 64, 256, 65, 69, 5, 3, 2), (64, 256, 512, 22, 35, 5, 3, 2), (64, 512, 512, 8, 18, 3, 1, 1),
+]
+
 if __name__ == '__main__':
+    if sys.argv[1:] == ['2d']:
+        for sh in MTD:
+            bench_2d(*sh)
+        sys.exit(0)
     kinds = sys.argv[1:]
     for sh in SHAPES:
         if not kinds or sh[0] in kinds:

@@ -44,13 +44,17 @@ struct DArgs {
   int n_mb, total, per_xcd;   // row blocks, work items, work items per XCD
   int PW;                     // staged positions per buffer
   int x_bytes, out_bytes;
+  // second dimension (RtgConv1dDesc.h_*): a clip is an (item, output row) pair, a channel a (channel, kernel row) pair
+  int h_in, h_k, h_stride, h_pad, h_n, h_mode, n_co;
 };
 
 __device__ __forceinline__ float dc_load(rsrc_t r, unsigned off) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
 }
 
-constexpr int kMinQ = 8;                  // shortest row served (bounds the clip boundaries a column tile can straddle)
+// shortest row served (bounds the clip boundaries a column tile can straddle, hence the staging registers): 8 for the k5 /
+// 2-tap 1-D layers, 4 for the 3-tap rows of the spectrogram discriminators (5 columns after their strided layers)
+constexpr int min_q(int K) { return K == 3 ? 4 : 8; }
 
 // positions a column tile of `cols` columns reads: the span of its columns' virtual positions plus the taps; every clip
 // boundary inside the tile adds the gap between two clips' segments (seg_pw - Q * S = K - S)
@@ -60,13 +64,15 @@ constexpr int window_positions(int cols, int Q, int S, int K) {
 }
 
 // RW16: 16-row tiles per wave; WB: waves per block (stacked along the rows); NT16: 16-column tiles per block (= per wave);
-// S: stride of the B-operand walk (1 or 3); K: taps
-template <int RW16, int WB, int NT16, int S, int K>
+// S: stride of the B-operand walk; K: taps; TWO_D: the Conv2d layers of StftDiscriminator run along their last axis
+// (discrminator.py:255-262), the patch row of clip (item, r) and channel (c, kh) being input row r * h_stride - h_pad + kh
+// (forward) or r + h_pad - kh (backward-data of a row-stride-1 layer, channels ordered (kh, c))
+template <int RW16, int WB, int NT16, int S, int K, bool TWO_D>
 __global__ __launch_bounds__(WB * 64, 2) void dconv_kernel(const DArgs a) {
   constexpr int BN = NT16 * 16;
-  // positions staged per lane: enough for the widest window of the shape (rows of kMinQ positions); iterations past the
-  // actual window load nothing (out-of-range offsets) and write nothing
-  constexpr int MAXIT = (window_positions(BN, kMinQ, S, K) + 64 * (WB / 4) - 1) / (64 * (WB / 4));
+  // positions staged per lane: enough for the widest window of the shape (rows of min_q(K) positions); iterations past
+  // the actual window load nothing (out-of-range offsets) and write nothing
+  constexpr int MAXIT = (window_positions(BN, min_q(K), S, K) + 64 * (WB / 4) - 1) / (64 * (WB / 4));
   constexpr int SPI = 64 * (WB / 4);                 // positions staged per iteration by the WB / 4 waves of a channel group
   constexpr int TW = K >= 3 ? K - 2 : 0;             // tap after which the next chunk's patch is written and published
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -87,6 +93,7 @@ __global__ __launch_bounds__(WB * 64, 2) void dconv_kernel(const DArgs a) {
   // the chunk (one 16-byte LDS row segment per position)
   const int skgrp = wave & 3;
   unsigned soff[MAXIT];                              // byte offset of (clip, channel 0, position) in x, or out of range
+  int srow[TWO_D ? MAXIT : 1];                       // 2-D: the input row kernel row 0 reads for this position's clip
 #pragma unroll
   for (int it = 0; it < MAXIT; ++it) {
     const int o = (wave >> 2) * 64 + lane + SPI * it;
@@ -94,7 +101,14 @@ __global__ __launch_bounds__(WB * 64, 2) void dconv_kernel(const DArgs a) {
     const int seg = G / a.seg_pw, w = G - seg * a.seg_pw;
     const int clip = clip0 + seg, pos = w - a.pad;
     const bool ok = o < a.PW && clip < a.B && pos >= 0 && pos < a.L_in;
-    soff[it] = ok ? ((unsigned)clip * (unsigned)a.C * (unsigned)a.L_in + (unsigned)pos) * 4u : DC_OOB;
+    if constexpr (TWO_D) {
+      const int item = clip / a.h_n, ho = clip - item * a.h_n;
+      srow[it] = a.h_mode == 0 ? ho * a.h_stride - a.h_pad : ho + a.h_pad;
+      // (item, channel 0, row 0, position); the channel's rows and the kernel row are added per chunk
+      soff[it] = ok ? ((unsigned)item * (unsigned)a.C * (unsigned)a.h_in * (unsigned)a.L_in + (unsigned)pos) * 4u : DC_OOB;
+    } else {
+      soff[it] = ok ? ((unsigned)clip * (unsigned)a.C * (unsigned)a.L_in + (unsigned)pos) * 4u : DC_OOB;
+    }
   }
   const rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
   const unsigned chb = (unsigned)a.L_in * 4u;        // bytes per channel row
@@ -105,9 +119,24 @@ __global__ __launch_bounds__(WB * 64, 2) void dconv_kernel(const DArgs a) {
     const unsigned past = cc < a.n_cc ? 0u : DC_OOB;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const unsigned coff = (unsigned)(cc * RTG_CK + skgrp + 4 * i) * chb | past;
+      const int vc = cc * RTG_CK + skgrp + 4 * i;
+      if constexpr (TWO_D) {
+        // virtual channel -> (channel, kernel row): (c, kh) forward, (kh, c) backward-data; the row moves with kh
+        int c, dr;
+        if (a.h_mode == 0) { c = vc / a.h_k; dr = vc - c * a.h_k; }
+        else { const int kh = vc / a.n_co; c = vc - kh * a.n_co; dr = -kh; }
+        const unsigned coff = (unsigned)(c * a.h_in) * chb | past;
 #pragma unroll
-      for (int it = 0; it < MAXIT; ++it) st[i][it] = dc_load(rx, (soff[it] + coff) | (soff[it] & DC_OOB));
+        for (int it = 0; it < MAXIT; ++it) {
+          const int row = srow[it] + dr;
+          const unsigned off = (unsigned)row < (unsigned)a.h_in ? soff[it] + coff + (unsigned)row * chb : DC_OOB;
+          st[i][it] = dc_load(rx, off | (soff[it] & DC_OOB) | past);
+        }
+      } else {
+        const unsigned coff = (unsigned)vc * chb | past;
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) st[i][it] = dc_load(rx, (soff[it] + coff) | (soff[it] & DC_OOB));
+      }
     }
   };
   const float wslope = a.pre ? a.pre_slope : 1.f;
@@ -249,7 +278,7 @@ __global__ __launch_bounds__(WB * 64, 2) void dconv_kernel(const DArgs a) {
         ph -= a.shuf_P;
       }
       const bool rok = m < a.Mg;
-      rowoff[r] = (unsigned)(ch * a.out_L + ph) * 4u;
+      rowoff[r] = (unsigned)(ch * a.h_n * a.out_L + ph) * 4u;          // (h_n == 1 in 1-D)
       rowph[r] = rok ? ph : -(1 << 28);
       bv[r] = dc_load(rb, rok ? (unsigned)ch * 4u : DC_OOB);
     }
@@ -258,7 +287,13 @@ __global__ __launch_bounds__(WB * 64, 2) void dconv_kernel(const DArgs a) {
       const int n = n0 + j * 16 + n16;
       const int clip = n / a.Q, q = n - clip * a.Q;
       const int qs = n < a.n_cols ? q * So : -(1 << 28);
-      const unsigned col = ((unsigned)(clip * a.out_C) * (unsigned)a.out_L + (unsigned)(q * So)) * 4u;
+      unsigned col;
+      if constexpr (TWO_D) {                               // clip -> (item, output row) of [items, out_C, h_n, out_L]
+        const int item = clip / a.h_n, ho = clip - item * a.h_n;
+        col = ((unsigned)(item * a.out_C * a.h_n + ho) * (unsigned)a.out_L + (unsigned)(q * So)) * 4u;
+      } else {
+        col = ((unsigned)(clip * a.out_C) * (unsigned)a.out_L + (unsigned)(q * So)) * 4u;
+      }
       unsigned off[4];
       float mv[4], rv[4], av[4];
 #pragma unroll
@@ -305,21 +340,30 @@ constexpr DShape kShapes[] = {{2, 4}, {1, 8}, {1, 4}, {2, 8}};       // code dig
 constexpr int kNT[] = {4, 6, 7, 8};
 
 bool dconv_eligible(const RtgConv1dDesc* d) {
-  if (!d->wp16 || d->groups != 1 || d->C2 != 0 || d->out_split != 0 || d->h_k > 1 || d->h_n > 1 || d->tap_major || d->bf16)
-    return false;
-  if (d->dil != 1 || (d->stride != 1 && d->stride != 3)) return false;
-  if (!((d->K == 5) || (d->K == 2 && d->stride == 1))) return false;
-  if (d->Cg != d->C1 || d->Cg % RTG_CK != 0 || d->Cg < 32 || d->Mg < 64 || d->Q < kMinQ) return false;
+  if (!d->wp16 || d->groups != 1 || d->C2 != 0 || d->out_split != 0 || d->tap_major || d->bf16) return false;
+  const bool two_d = d->h_k > 1 || d->h_n > 1;
+  if (two_d) {
+    // forward of the Conv2d layers, backward-data of the row-stride-1 ones; 3 taps along the last axis
+    if (d->K != 3 || d->dil != 1 || (d->stride != 1 && d->stride != 2) || d->shuf_S != 1) return false;
+    if (d->h_in < 1 || d->h_k < 1 || d->h_n < 1 || d->h_pad < 0 || d->C1 % d->h_k != 0 || d->B % d->h_n != 0) return false;
+    if (d->h_mode == 1 ? d->h_stride != 1 : (d->h_mode != 0 || d->h_stride < 1)) return false;
+    if ((long long)(d->B / d->h_n) * (d->C1 / d->h_k) * d->h_in * d->L_in * 4 >= (1ll << 31)) return false;
+    if ((long long)(d->B / d->h_n) * d->out_C * d->h_n * d->out_L * 4 >= (1ll << 31)) return false;
+  } else {
+    if (d->dil != 1 || (d->stride != 1 && d->stride != 3)) return false;
+    if (!((d->K == 5) || (d->K == 2 && d->stride == 1))) return false;
+    if ((long long)d->B * d->C1 * d->L_in * 4 >= (1ll << 31) || (long long)d->B * d->out_C * d->out_L * 4 >= (1ll << 31)) return false;
+  }
+  if (d->Cg != d->C1 || d->Cg % RTG_CK != 0 || d->Cg < 32 || d->Mg < 64 || d->Q < min_q(d->K)) return false;
   if (d->pre_mode != RTG_PRE_NONE && d->pre_mode != RTG_PRE_LRELU) return false;
   if ((long long)d->groups * d->Mg != (long long)d->out_C * d->shuf_S) return false;
-  if ((long long)d->B * d->C1 * d->L_in * 4 >= (1ll << 31) || (long long)d->B * d->out_C * d->out_L * 4 >= (1ll << 31)) return false;
   if ((long long)d->B * d->Q >= (1ll << 30)) return false;
   return true;
 }
 
-template <int RW16, int WB, int NT16, int S, int K>
+template <int RW16, int WB, int NT16, int S, int K, bool TWO_D>
 int launch(const DArgs& a, unsigned blocks, size_t lds_bytes, hipStream_t s) {
-  auto k = dconv_kernel<RW16, WB, NT16, S, K>;
+  auto k = dconv_kernel<RW16, WB, NT16, S, K, TWO_D>;
   if (lds_bytes > 64 * 1024) {
     static bool attr_set = false;                      // (> 64 KB of dynamic LDS needs the opt-in once per kernel)
     if (!attr_set) {
@@ -333,10 +377,15 @@ int launch(const DArgs& a, unsigned blocks, size_t lds_bytes, hipStream_t s) {
 }
 
 template <int RW16, int WB, int NT16>
-int launch_sk(const DArgs& a, int S, int K, unsigned blocks, size_t lds_bytes, hipStream_t s) {
-  if (S == 1 && K == 5) return launch<RW16, WB, NT16, 1, 5>(a, blocks, lds_bytes, s);
-  if (S == 3 && K == 5) return launch<RW16, WB, NT16, 3, 5>(a, blocks, lds_bytes, s);
-  if (S == 1 && K == 2) return launch<RW16, WB, NT16, 1, 2>(a, blocks, lds_bytes, s);
+int launch_sk(const DArgs& a, int S, int K, bool two_d, unsigned blocks, size_t lds_bytes, hipStream_t s) {
+  if (two_d) {
+    if (S == 1 && K == 3) return launch<RW16, WB, NT16, 1, 3, true>(a, blocks, lds_bytes, s);
+    if (S == 2 && K == 3) return launch<RW16, WB, NT16, 2, 3, true>(a, blocks, lds_bytes, s);
+    return RTG_EINVAL;
+  }
+  if (S == 1 && K == 5) return launch<RW16, WB, NT16, 1, 5, false>(a, blocks, lds_bytes, s);
+  if (S == 3 && K == 5) return launch<RW16, WB, NT16, 3, 5, false>(a, blocks, lds_bytes, s);
+  if (S == 1 && K == 2) return launch<RW16, WB, NT16, 1, 2, false>(a, blocks, lds_bytes, s);
   return RTG_EINVAL;
 }
 
@@ -360,6 +409,10 @@ int rtg_dconv_candidates(const RtgConv1dDesc* d, int* codes, int max) {
     const int n_mb = rtg_ceil_div(n_mt16, mb16);
     for (int ni = 0; ni < 4; ++ni) {
       const int BN = kNT[ni] * 16;
+      // instances that need more than 256 registers at two waves per SIMD (they spill): 32 rows per wave with >= 6
+      // column tiles; 8 column tiles with a strided walk in the 4-wave blocks (twice the staging registers per wave)
+      if (kShapes[si].rw16 == 2 && kNT[ni] >= 6) continue;
+      if (kNT[ni] == 8 && d->stride > 1 && kShapes[si].wb == 4) continue;
       const int pw = window_positions((int)(n_cols < BN ? n_cols : BN), d->Q, d->stride, d->K);
       if (2ll * pw * kRowF * 4 > 150 * 1024) continue;
       const long long blocks = (long long)n_mb * ((n_cols + BN - 1) / BN);
@@ -399,7 +452,11 @@ int rtg_dconv_launch(const RtgConv1dDesc* d, int code, const float* x, const flo
   const long long std_size = rtg_packed_size(1, d->Mg, d->Cg, d->K, d->tile_m);
   if (std_size < 0 || (std_size & 3) != 0) return RTG_EINVAL;
   a.x = x; a.wp = wp + std_size; a.bias = bias; a.mask = mask; a.res = res; a.out = out;
-  a.B = d->B; a.C = d->C1; a.L_in = d->L_in; a.Mg = d->Mg; a.n_cc = d->Cg / RTG_CK; a.Q = d->Q; a.pad = d->pad;
+  const bool two_d = d->h_k > 1 || d->h_n > 1;
+  a.h_in = two_d ? d->h_in : 1; a.h_k = two_d ? d->h_k : 1; a.h_stride = two_d ? d->h_stride : 1;
+  a.h_pad = two_d ? d->h_pad : 0; a.h_n = two_d ? d->h_n : 1; a.h_mode = two_d ? d->h_mode : 0;
+  a.n_co = d->C1 / a.h_k;                            // real channels (backward-data: output channels of the layer)
+  a.B = d->B; a.C = d->C1 / a.h_k; a.L_in = d->L_in; a.Mg = d->Mg; a.n_cc = d->Cg / RTG_CK; a.Q = d->Q; a.pad = d->pad;
   a.out_C = d->out_C; a.out_L = d->out_L; a.shuf_S = d->shuf_S; a.shuf_P = d->shuf_P;
   a.pre = d->pre_mode == RTG_PRE_LRELU ? 1 : 0; a.act = d->act; a.accumulate = d->accumulate;
   a.pre_slope = d->pre_slope; a.mask_slope = d->mask_slope; a.out_scale = d->out_scale; a.act_slope = d->act_slope;
@@ -412,14 +469,14 @@ int rtg_dconv_launch(const RtgConv1dDesc* d, int code, const float* x, const flo
   a.total = (int)total;
   a.per_xcd = rtg_ceil_div(total, 8);
   a.PW = window_positions(a.n_cols < BN ? a.n_cols : BN, d->Q, d->stride, d->K);
-  a.x_bytes = d->B * d->C1 * d->L_in * 4;
-  a.out_bytes = d->B * d->out_C * d->out_L * 4;
+  a.x_bytes = (d->B / a.h_n) * a.C * a.h_in * d->L_in * 4;       // 1-D: h_n = h_in = 1
+  a.out_bytes = d->B * d->out_C * d->out_L * 4;                   // (B = items * h_n)
   const size_t lds_bytes = (size_t)2 * a.PW * kRowF * sizeof(float);
   if (lds_bytes > 150 * 1024) return RTG_ERANGE;
   const unsigned blocks = (unsigned)(8 * a.per_xcd);
 #define RTG_DC(S_, N_)                                                                                                  \
   if (si == S_ - 1 && nt16 == N_)                                                                                         \
-    return launch_sk<kShapes[S_ - 1].rw16, kShapes[S_ - 1].wb, N_>(a, d->stride, d->K, blocks, lds_bytes, s);
+    return launch_sk<kShapes[S_ - 1].rw16, kShapes[S_ - 1].wb, N_>(a, d->stride, d->K, two_d, blocks, lds_bytes, s);
   RTG_DC(1, 4) RTG_DC(1, 6) RTG_DC(1, 7) RTG_DC(1, 8)
   RTG_DC(2, 4) RTG_DC(2, 6) RTG_DC(2, 7) RTG_DC(2, 8)
   RTG_DC(3, 4) RTG_DC(3, 6) RTG_DC(3, 7) RTG_DC(3, 8)

@@ -102,14 +102,21 @@ class ConvLayer:
         def ok(op, tap):
             return bool(want_bf and not tap and op[2] > 1 and op[3] > 1)
         # the dense-layer kernel (rtg_dconv.hip, block-shape codes 8xxx) reads 16-byte operand fragments: layers it can serve
-        # (>= 32 input channels, >= 96 output rows, dilation 1, k5 at stride 1 / 3 forward, the k5 stride-1 or 2-tap polyphase
-        # backward-data operator) carry a second image of their weights behind the standard one (RtgPackJob.frag16,
+        # (>= 32 input channels, >= 96 output rows, dilation 1; 1-D: k5 at stride 1 / 3 forward, the k5 stride-1 or 2-tap
+        # polyphase backward-data operator; Conv2d of the spectrogram discriminators: forward, stride-1 backward-data) carry a second image of their weights behind the standard one (RtgPackJob.frag16,
         # RtgConv1dDesc.wp16); the tuner then times both kernels per problem.  RTG_DCONV=0: never (A/B knob).
         def dense(op, fwd):
             mode, g, mg, cg, k, s = op
-            if os.environ.get('RTG_DCONV', '1') == '0' or want_bf or self.kind != 'conv' or self.dil != 1:
+            if os.environ.get('RTG_DCONV', '1') == '0' or want_bf or self.dil != 1:
                 return 0
             if g != 1 or cg % L.CK != 0 or cg < 32 or mg < 96:
+                return 0
+            if self.kind == 'conv2d':
+                # StftDiscriminator (3 taps along the last axis): forward, and the backward-data of the stride-(1, 1) layer
+                if fwd:
+                    return int(k == 3 and self.stride in (1, 2))
+                return int(mode == L.PACK_DGRAD_2D and k == 3 and s == 1 and self.sh == 1)
+            if self.kind != 'conv':
                 return 0
             if fwd:
                 return int(k == 5 and self.stride in (1, 3))

@@ -589,7 +589,7 @@ class Conv2dFn(torch.autograd.Function):
         pre_mode = L.PRE_LRELU if pre_slope != 1.0 else L.PRE_NONE
         d = _desc(B=B * Ho, C1=Cin * ly.kh, L_in=W, groups=1, Cg=Cin * ly.kh, Mg=ly.cout, K=ly.k, stride=ly.stride,
                   pad=ly.pad, Q=Wo, out_C=ly.cout, out_L=Wo, pre_mode=pre_mode, pre_slope=pre_slope, tile_m=ly.fwd_tm,
-                  h_in=H, h_k=ly.kh, h_stride=ly.sh, h_pad=ly.ph, h_n=Ho, h_mode=0, bf16=ly.fwd_bf)
+                  h_in=H, h_k=ly.kh, h_stride=ly.sh, h_pad=ly.ph, h_n=Ho, h_mode=0, bf16=ly.fwd_bf, wp16=ly.fwd16)
         flop = 2.0 * B * Ho * Wo * ly.cout * Cin * ly.kh * ly.k
         _run_conv(d, (_p(x), None, None, bank.fwd_ptr(ly), bank.bias_ptr(ly), None, None, _p(out), None, _stream()),
                   flop, f'fwd2d {ly.name} B{B} {H}x{W}', f'conv2d fwd {ly.name}')
@@ -616,7 +616,7 @@ class Conv2dFn(torch.autograd.Function):
             mask = x if pre_slope != 1.0 else None
             common = dict(B=B * H, C1=ly.cout * ly.kh, L_in=Wo, groups=1, Cg=cg, Mg=mg, K=k, out_C=Cin, out_L=W,
                           mask_slope=pre_slope, tile_m=ly.bwd_tm, h_in=Ho, h_k=ly.kh, h_stride=ly.sh, h_pad=ly.ph,
-                          h_n=H, h_mode=1, bf16=ly.bwd_bf)
+                          h_n=H, h_mode=1, bf16=ly.bwd_bf, wp16=ly.bwd16)
             if ly.stride == 1:
                 d = _desc(stride=1, pad=(ly.k - 1) - ly.pad, Q=W, **common)
             else:
