@@ -25,10 +25,26 @@ class _Net(nn.Module):
     pass
 
 
+@pytest.mark.parametrize('force', [0, 10, 11])
 @pytest.mark.parametrize('case', CASES)
-def test_conv2d_layer_forward_backward(case):
+def test_conv2d_layer_forward_backward(case, force, monkeypatch):
+    """force: the weight-gradient block shape the tuner would have to pick (0: the library's heuristic; 10, 11: the dense
+    kernel of rtg_dwgrad.hip in its 2-D mode, where it serves the layer)"""
+    import ctypes as C
     from models.layers import WNConv, BankedModel, conv
+    from rtg import tune
+    from rtg.lib import lib
     B, Cin, Cout, H, W, k, s, p = case
+    used = []
+    if force:
+        def forced(wd, run):
+            wd.shape_cfg, wd.splits, wd.part_stride = 0, 1, 0
+            cands = (C.c_int * 16)()
+            n = lib.rtg_wgrad_shape_candidates(C.byref(wd), cands, 16)
+            pick = force if force in list(cands[:n]) else 0
+            used.append(pick)
+            return pick
+        monkeypatch.setattr(tune, 'wgrad_cfg', forced)
 
     class Net(BankedModel):
         def __init__(self):
@@ -66,6 +82,8 @@ def test_conv2d_layer_forward_backward(case):
     close(net.c.weight_v.grad, v.grad, 'dv')
     close(net.c.weight_g.grad, g.grad, 'dg')
     close(net.c.bias.grad, bias.grad, 'dbias')
+    if force and Cout % 128 == 0 and (Cin * k[0]) % (32 if force == 11 else 16) == 0 and out.shape[-1] >= 4:
+        assert used == [force], used              # the dense kernel really ran
 
 
 def _stats(t):

@@ -252,3 +252,40 @@ def test_conv2d_dgrad_stride1_codes(case):
     for c in codes:
         rc, out = _run(kw_, dyd, wp, mask=xm, out_shape=(B, Cin, H, W), cfg=c)
         assert rc == 0 and torch.equal(out, base), c
+
+
+@pytest.mark.parametrize('case', [(2, 64, 256, 40, 18, (5, 3), (3, 2), (2, 1)), (3, 256, 512, 22, 9, (5, 3), (3, 2), (2, 1)),
+                                  (2, 32, 64, 33, 35, (3, 3), (2, 2), (1, 1)), (1, 128, 96, 17, 20, (5, 3), (3, 2), (2, 1))])
+def test_conv2d_dgrad_strided_codes(case):
+    """backward-data of the row-strided Conv2d layers: clips in residue-class order of their rows (a tile inside one class
+    walks only that class's kernel rows), polyphase walk and interleaving store along the last axis"""
+    B, Cin, Cout, H, W, (kh, kw), (sh, sw), (ph, pw) = case
+    gen = torch.Generator().manual_seed(37)
+    x = torch.randn(B, Cin, H, W, generator=gen, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(Cout, Cin, kh, kw, generator=gen) / np.sqrt(Cin * kh * kw)
+    y = F.conv2d(F.leaky_relu(x, 0.15), w.double(), None, (sh, sw), (ph, pw))
+    Ho, Wo = y.shape[-2:]
+    dy = torch.randn(y.shape, generator=gen)
+    y.backward(dy.double())
+    ref = x.grad.float()
+    nt = -(-kw // sw)
+    wn = w.numpy()
+    Wl = np.zeros((1, Cin * sw, kh * Cout, nt), dtype=np.float32)      # rows (ci, phase), channels (kh, co): RTG_PACK_DGRAD_2D
+    for r in range(sw):
+        for tap in range(nt):
+            jj = r + (nt - 1 - tap) * sw
+            if jj < kw:
+                Wl[0, r::sw, :, tap] = wn[:, :, :, jj].transpose(1, 2, 0).reshape(Cin, kh * Cout)
+    wp = torch.from_numpy(_both_images(Wl)).cuda()
+    nq = (W - 1 + pw) // sw + 1
+    kw_ = _desc(B * H, Cout * kh, Wo, Cin * sw, nt, 1, nt - 1, nq, Cin, W, shuf_S=sw, shuf_P=pw, mask_slope=0.15, h_in=Ho,
+                h_k=kh, h_stride=sh, h_pad=ph, h_n=H, h_mode=1)
+    xm, dyd = x.detach().float().cuda(), dy.cuda()
+    rc, base = _run(kw_, dyd, wp, mask=xm, out_shape=(B, Cin, H, W))
+    assert rc == 0
+    np.testing.assert_allclose(base.cpu().numpy(), ref.numpy(), rtol=1e-4, atol=3e-5)
+    codes = _codes(kw_)
+    assert codes
+    for c in codes:
+        rc, out = _run(kw_, dyd, wp, mask=xm, out_shape=(B, Cin, H, W), cfg=c)
+        assert rc == 0 and torch.equal(out, base), c

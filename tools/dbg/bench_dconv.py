@@ -183,6 +183,46 @@ SHAPES = [
     ('wgrad', 704, 32, 128, 249, 3), ('wgrad', 192, 32, 128, 911, 3),
 ]
 
+def bench_wgrad_2d(B, Cin, Cout, H, W, kh, sh, sw):
+    kw, ph, pw = 3, kh // 2, 1
+    Ho, Wo = (H + 2 * ph - kh) // sh + 1, (W + 2 * pw - kw) // sw + 1
+    x = torch.randn(B, Cin, H, W, device='cuda')
+    dy = torch.randn(B, Cout, Ho, Wo, device='cuda')
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    need = Cout * (Cin * kh * kw + 1)
+    flop = 2.0 * B * Ho * Wo * Cout * Cin * kh * kw
+
+    def desc(c):
+        return WgradDesc(B=B * Ho, C1=Cin * kh, C2=0, L_in=W, groups=1, Cg=Cin * kh, Mg=Cout, K=kw, stride=sw, dil=1, pad=pw,
+                         Q=Wo, dy_L=Wo, pre_mode=1, pre_slope=0.15, gy_mode=0, gy_slope=1.0, gy_scale=1.0, splits=1,
+                         part_stride=0, h_in=H, h_k=kh, h_stride=sh, h_pad=ph, h_n=Ho, shape_cfg=c)
+    cands = (C.c_int * 16)()
+    probe = desc(0)
+    n = lib.rtg_wgrad_shape_candidates(C.byref(probe), cands, 16)
+    res, ref = [], None
+    for c in list(cands[:n]):
+        wd = desc(c)
+        splits = lib.rtg_wgrad_splits(C.byref(wd))
+        if splits < 1:
+            continue
+        part = torch.empty(splits * need, device='cuda')
+        wd.splits, wd.part_stride = splits, need
+        if lib.rtg_conv1d_wgrad(C.byref(wd), P(x), None, P(dy), None, P(part), st):
+            continue
+        torch.cuda.synchronize()
+        tot = part.view(splits, need).double().sum(0)
+        if ref is None:
+            ref = tot
+        err = ((tot - ref).abs().max() / ref.abs().max()).item()
+        ms = timeit(lambda: lib.rtg_conv1d_wgrad(C.byref(wd), P(x), None, P(dy), None, P(part), st))
+        res.append((c, ms, splits, err))
+    gen = min((r for r in res if r[0] < 10), key=lambda r: r[1])
+    line = f'wgrad2d B{B} {Cin}->{Cout} {H}x{W} k({kh},3) s({sh},{sw}): general best s{gen[0]} x{gen[2]:3d} {gen[1] * 1e3:7.1f} us {flop / gen[1] / 1e9:6.1f} TF/s'
+    for d in (r for r in res if r[0] >= 10):
+        line += f' | s{d[0]} x{d[2]:3d} {d[1] * 1e3:7.1f} us {flop / d[1] / 1e9:6.1f} TF/s  x{gen[1] / d[1]:.2f} err {d[3]:.0e}'
+    print(line, flush=True)
+
+
 MTD = [  # B = 64 (real + generated clips), resolution 0 (1025 x 35) and 2 (257 x 137)
     (64, 64, 256, 257, 18, 5, 3, 2), (64, 256, 512, 86, 9, 5, 3, 2), (64, 512, 512, 29, 5, 3, 1, 1), (64, 32, 64, 513, 35, 3, 2, 2),
     (64, 64, 256, 65, 69, 5, 3, 2), (64, 256, 512, 22, 35, 5, 3, 2), (64, 512, 512, 8, 18, 3, 1, 1),
@@ -192,6 +232,8 @@ if __name__ == '__main__':
     if sys.argv[1:] == ['2d']:
         for sh in MTD:
             bench_2d(*sh)
+        for sh in MTD:
+            bench_wgrad_2d(*sh)
         sys.exit(0)
     kinds = sys.argv[1:]
     for sh in SHAPES:

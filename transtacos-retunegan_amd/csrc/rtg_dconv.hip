@@ -46,6 +46,11 @@ struct DArgs {
   int x_bytes, out_bytes;
   // second dimension (RtgConv1dDesc.h_*): a clip is an (item, output row) pair, a channel a (channel, kernel row) pair
   int h_in, h_k, h_stride, h_pad, h_n, h_mode, n_co;
+  // class-ordered clips (backward-data over a row-strided layer): output row r only receives kernel rows kh == (r + h_pad)
+  // (mod h_stride), so the clip sequence lists the rows of residue class 0 of every item first, then class 1, ...: a
+  // column tile inside one class walks only that class's kernel rows.  Class c: first row cls_f, cls_n rows per item,
+  // clips [cls_base, ...); cpk = 16-channel chunks per kernel row
+  int cls_f[4], cls_n[4], cls_base[4], cpk;
 };
 
 __device__ __forceinline__ float dc_load(rsrc_t r, unsigned off) {
@@ -54,7 +59,7 @@ __device__ __forceinline__ float dc_load(rsrc_t r, unsigned off) {
 
 // shortest row served (bounds the clip boundaries a column tile can straddle, hence the staging registers): 8 for the k5 /
 // 2-tap 1-D layers, 4 for the 3-tap rows of the spectrogram discriminators (5 columns after their strided layers)
-constexpr int min_q(int K) { return K == 3 ? 4 : 8; }
+constexpr int min_q(int K, bool two_d = false) { return (K == 3 || two_d) ? 4 : 8; }
 
 // positions a column tile of `cols` columns reads: the span of its columns' virtual positions plus the taps; every clip
 // boundary inside the tile adds the gap between two clips' segments (seg_pw - Q * S = K - S)
@@ -67,12 +72,13 @@ constexpr int window_positions(int cols, int Q, int S, int K) {
 // S: stride of the B-operand walk; K: taps; TWO_D: the Conv2d layers of StftDiscriminator run along their last axis
 // (discrminator.py:255-262), the patch row of clip (item, r) and channel (c, kh) being input row r * h_stride - h_pad + kh
 // (forward) or r + h_pad - kh (backward-data of a row-stride-1 layer, channels ordered (kh, c))
-template <int RW16, int WB, int NT16, int S, int K, bool TWO_D>
+template <int RW16, int WB, int NT16, int S, int K, bool TWO_D, bool CLS>
 __global__ __launch_bounds__(WB * 64, 2) void dconv_kernel(const DArgs a) {
+  static_assert(!CLS || TWO_D, "class-ordered clips belong to the 2-D backward-data");
   constexpr int BN = NT16 * 16;
-  // positions staged per lane: enough for the widest window of the shape (rows of min_q(K) positions); iterations past
+  // positions staged per lane: enough for the widest window of the shape (rows of min_q(K, TWO_D) positions); iterations past
   // the actual window load nothing (out-of-range offsets) and write nothing
-  constexpr int MAXIT = (window_positions(BN, min_q(K), S, K) + 64 * (WB / 4) - 1) / (64 * (WB / 4));
+  constexpr int MAXIT = (window_positions(BN, min_q(K, TWO_D), S, K) + 64 * (WB / 4) - 1) / (64 * (WB / 4));
   constexpr int SPI = 64 * (WB / 4);                 // positions staged per iteration by the WB / 4 waves of a channel group
   constexpr int TW = K >= 3 ? K - 2 : 0;             // tap after which the next chunk's patch is written and published
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -92,8 +98,24 @@ __global__ __launch_bounds__(WB * 64, 2) void dconv_kernel(const DArgs a) {
   // ---- staging geometry: LDS position o <-> (clip, input position); a wave stages channels kgrp, kgrp + 4, + 8, + 12 of
   // the chunk (one 16-byte LDS row segment per position)
   const int skgrp = wave & 3;
+  // clip of the (possibly class-ordered) sequence -> (item, row of the output tensor, residue class)
+  auto decode = [&](int cl, int& item, int& r, int& cls) __attribute__((always_inline)) {
+    cls = 0;
+    if constexpr (CLS) {
+#pragma unroll
+      for (int c = 1; c < 4; ++c)
+        if (c < a.h_stride && cl >= a.cls_base[c]) cls = c;
+      const int idx = cl - a.cls_base[cls];
+      item = idx / a.cls_n[cls];
+      r = a.cls_f[cls] + (idx - item * a.cls_n[cls]) * a.h_stride;
+    } else {
+      item = cl / a.h_n;
+      r = cl - item * a.h_n;
+    }
+  };
   unsigned soff[MAXIT];                              // byte offset of (clip, channel 0, position) in x, or out of range
   int srow[TWO_D ? MAXIT : 1];                       // 2-D: the input row kernel row 0 reads for this position's clip
+  int scls[CLS ? MAXIT : 1];                         // class-ordered: the residue class of this position's row
 #pragma unroll
   for (int it = 0; it < MAXIT; ++it) {
     const int o = (wave >> 2) * 64 + lane + SPI * it;
@@ -102,8 +124,14 @@ __global__ __launch_bounds__(WB * 64, 2) void dconv_kernel(const DArgs a) {
     const int clip = clip0 + seg, pos = w - a.pad;
     const bool ok = o < a.PW && clip < a.B && pos >= 0 && pos < a.L_in;
     if constexpr (TWO_D) {
-      const int item = clip / a.h_n, ho = clip - item * a.h_n;
+      int item, ho, cls;
+      decode(clip, item, ho, cls);
       srow[it] = a.h_mode == 0 ? ho * a.h_stride - a.h_pad : ho + a.h_pad;
+      if constexpr (CLS) {
+        // rows of class cls take kernel rows cls, cls + h_stride, ...: kernel row cls + m * h_stride reads row srow - m
+        srow[it] = (ho + a.h_pad - cls) / a.h_stride;
+        scls[it] = cls;
+      }
       // (item, channel 0, row 0, position); the channel's rows and the kernel row are added per chunk
       soff[it] = ok ? ((unsigned)item * (unsigned)a.C * (unsigned)a.h_in * (unsigned)a.L_in + (unsigned)pos) * 4u : DC_OOB;
     } else {
@@ -122,14 +150,21 @@ __global__ __launch_bounds__(WB * 64, 2) void dconv_kernel(const DArgs a) {
       const int vc = cc * RTG_CK + skgrp + 4 * i;
       if constexpr (TWO_D) {
         // virtual channel -> (channel, kernel row): (c, kh) forward, (kh, c) backward-data; the row moves with kh
-        int c, dr;
+        int c, dr, kc = 0;
         if (a.h_mode == 0) { c = vc / a.h_k; dr = vc - c * a.h_k; }
-        else { const int kh = vc / a.n_co; c = vc - kh * a.n_co; dr = -kh; }
+        else {
+          const int kh = vc / a.n_co;
+          c = vc - kh * a.n_co;
+          dr = -kh;
+          if constexpr (CLS) { dr = -(kh / a.h_stride); kc = kh - (kh / a.h_stride) * a.h_stride; }
+        }
         const unsigned coff = (unsigned)(c * a.h_in) * chb | past;
 #pragma unroll
         for (int it = 0; it < MAXIT; ++it) {
           const int row = srow[it] + dr;
-          const unsigned off = (unsigned)row < (unsigned)a.h_in ? soff[it] + coff + (unsigned)row * chb : DC_OOB;
+          bool ok = (unsigned)row < (unsigned)a.h_in;
+          if constexpr (CLS) ok = ok && scls[it] == kc;          // a kernel row of another residue class: zeros
+          const unsigned off = ok ? soff[it] + coff + (unsigned)row * chb : DC_OOB;
           st[i][it] = dc_load(rx, off | (soff[it] & DC_OOB) | past);
         }
       } else {
@@ -175,7 +210,37 @@ __global__ __launch_bounds__(WB * 64, 2) void dconv_kernel(const DArgs a) {
     if (mt > n_mt16 - 1) mt = n_mt16 - 1;            // clamped duplicate tile, dropped in the epilogue
     aptr[i] = reinterpret_cast<const f32x4*>(a.wp) + (size_t)mt * a.n_cc * K * 64 + lane;
   }
-  const int n_steps = a.n_cc * K;
+  // the chunks this block walks: all of them, or (class-ordered clips, every column of the tile in ONE residue class) only
+  // the kernel rows of that class — channels are ordered (kernel row, channel), so those are whole chunk ranges
+  int n_v = a.n_cc;
+  [[maybe_unused]] int cls_blk = 0;
+  [[maybe_unused]] bool pure = false;
+  if constexpr (CLS) {
+    int it0, r0, c0, it1, r1, c1;
+    const int n_last = (n0 + BN < a.n_cols ? n0 + BN : a.n_cols) - 1;
+    decode(clip0, it0, r0, c0);
+    decode(n_last / a.Q, it1, r1, c1);
+    pure = c0 == c1;
+    cls_blk = c0;
+    if (pure) n_v = (c0 < a.h_k ? (a.h_k - c0 + a.h_stride - 1) / a.h_stride : 0) * a.cpk;
+  }
+  // generator of the walk: the real chunk of virtual chunk 0, 1, 2, ... (n_cc once past the end)
+  int gv = 0;
+  [[maybe_unused]] int gk = 0, gw = 0;
+  auto gen = [&]() __attribute__((always_inline)) {
+    int rc = a.n_cc;
+    if (gv < n_v) {
+      rc = gv;
+      if constexpr (CLS) {
+        if (pure) {
+          rc = (cls_blk + gk * a.h_stride) * a.cpk + gw;
+          if (++gw == a.cpk) { gw = 0; ++gk; }
+        }
+      }
+    }
+    ++gv;
+    return rc;
+  };
 
   f32x4 acc[RW16][NT16];
 #pragma unroll
@@ -186,7 +251,9 @@ __global__ __launch_bounds__(WB * 64, 2) void dconv_kernel(const DArgs a) {
   struct Frag {
     f32x4 a[RW16], b[NT16];
   };
-  // the fragments of (chunk, tap) step s: RW16 coalesced 1-KB weight loads from L2, NT16 16-byte LDS reads
+  // the fragments of (chunk rc, tap t) — step s = rc * K + t of the weight image: RW16 coalesced 1-KB weight loads from
+  // L2, NT16 16-byte LDS reads
+  const int n_steps = a.n_cc * K;
   auto fetch = [&](Frag& f, int s, const float* bsrc) __attribute__((always_inline)) {
     const int sc = s < n_steps ? s : n_steps - 1;    // (past the end: re-read the last step, never used)
 #pragma unroll
@@ -205,48 +272,51 @@ __global__ __launch_bounds__(WB * 64, 2) void dconv_kernel(const DArgs a) {
   };
 
   // ---- prologue: chunk 0 staged and published, chunk 1 requested, fragments of step 0 fetched
-  stage_issue(0);
+  int rc0 = gen(), rc1 = gen(), rc2 = gen();          // real chunk of the current virtual chunk, the next, the one after
+  stage_issue(rc0);
   stage_write(lds);
   __syncthreads();
-  stage_issue(1);
+  stage_issue(rc1);
   Frag f0, f1;
-  fetch(f0, 0, lds);
+  fetch(f0, rc0 * K, lds);
 
-  // one chunk: K taps; `cur` holds the fragments of tap 0 on entry, and of the next chunk's tap 0 on exit (in `cur` again
-  // when K is even, in `oth` when K is odd: the caller alternates)
-  auto chunk = [&](int cc, Frag& cur, Frag& oth) __attribute__((always_inline)) {
-    const float* bufc = lds + (cc & 1) * bufF;
-    float* bufn = lds + ((cc + 1) & 1) * bufF;
+  // one chunk (virtual index v): K taps; `cur` holds the fragments of tap 0 on entry, and of the next chunk's tap 0 on
+  // exit (in `cur` again when K is even, in `oth` when K is odd: the caller alternates)
+  auto chunk = [&](int v, Frag& cur, Frag& oth) __attribute__((always_inline)) {
+    const float* bufc = lds + (v & 1) * bufF;
+    float* bufn = lds + ((v + 1) & 1) * bufF;
 #pragma unroll
     for (int t = 0; t < K; ++t) {
       Frag& fc = (t & 1) ? oth : cur;
       Frag& fn = (t & 1) ? cur : oth;
       // request the next step's fragments, THEN (last tap) the patch of the chunk after the next: the wait for the
       // fragments one step later does not include the patch loads (vmcnt retires in order)
-      fetch(fn, cc * K + t + 1, t + 1 < K ? bufc + (t + 1) * kRowF : bufn);
-      if (t == K - 1) stage_issue(cc + 2);
+      if (t + 1 < K) fetch(fn, rc0 * K + t + 1, bufc + (t + 1) * kRowF);
+      else fetch(fn, rc1 * K, bufn);
+      if (t == K - 1) stage_issue(rc2);
       __builtin_amdgcn_sched_barrier(0);
       mma(fc);
       __builtin_amdgcn_sched_barrier(0);
       if (t == TW) {
         // publish the next chunk's patch: its buffer was last read by fragment fetches that completed before the
         // previous chunk's barrier; the reads of this chunk's last tap (just requested) are waited for here too
-        if (cc + 1 < a.n_cc) stage_write(bufn);
+        if (v + 1 < n_v) stage_write(bufn);
         // (one asm statement: nothing can be scheduled between the wait and the barrier, no memory access across it)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    rc0 = rc1; rc1 = rc2; rc2 = gen();
   };
   int cc = 0;
   if constexpr (K & 1) {
-    for (; cc + 1 < a.n_cc; cc += 2) {
+    for (; cc + 1 < n_v; cc += 2) {
       chunk(cc, f0, f1);
       chunk(cc + 1, f1, f0);
     }
-    if (cc < a.n_cc) chunk(cc, f0, f1);
+    if (cc < n_v) chunk(cc, f0, f1);
   } else {
-    for (; cc < a.n_cc; ++cc) chunk(cc, f0, f1);
+    for (; cc < n_v; ++cc) chunk(cc, f0, f1);
   }
 
   // ---- epilogue: out = act(((acc + bias) * dmask + res) * out_scale) (+ out), the arithmetic and rounding of the general
@@ -289,7 +359,8 @@ __global__ __launch_bounds__(WB * 64, 2) void dconv_kernel(const DArgs a) {
       const int qs = n < a.n_cols ? q * So : -(1 << 28);
       unsigned col;
       if constexpr (TWO_D) {                               // clip -> (item, output row) of [items, out_C, h_n, out_L]
-        const int item = clip / a.h_n, ho = clip - item * a.h_n;
+        int item, ho, cls;
+        decode(clip, item, ho, cls);
         col = ((unsigned)(item * a.out_C * a.h_n + ho) * (unsigned)a.out_L + (unsigned)(q * So)) * 4u;
       } else {
         col = ((unsigned)(clip * a.out_C) * (unsigned)a.out_L + (unsigned)(q * So)) * 4u;
@@ -344,9 +415,14 @@ bool dconv_eligible(const RtgConv1dDesc* d) {
   const bool two_d = d->h_k > 1 || d->h_n > 1;
   if (two_d) {
     // forward of the Conv2d layers, backward-data of the row-stride-1 ones; 3 taps along the last axis
-    if (d->K != 3 || d->dil != 1 || (d->stride != 1 && d->stride != 2) || d->shuf_S != 1) return false;
+    // ... and of the row-strided ones (class-ordered clips, 2 taps of the polyphase walk along the last axis)
     if (d->h_in < 1 || d->h_k < 1 || d->h_n < 1 || d->h_pad < 0 || d->C1 % d->h_k != 0 || d->B % d->h_n != 0) return false;
-    if (d->h_mode == 1 ? d->h_stride != 1 : (d->h_mode != 0 || d->h_stride < 1)) return false;
+    if (d->dil != 1 || d->h_stride < 1 || (d->h_mode != 0 && d->h_mode != 1)) return false;
+    if (d->h_mode == 1 && d->h_stride > 1) {
+      if (d->K != 2 || d->stride != 1 || d->h_stride > 4 || (d->C1 / d->h_k) % RTG_CK != 0) return false;
+    } else {
+      if (d->K != 3 || (d->stride != 1 && d->stride != 2) || d->shuf_S != 1) return false;
+    }
     if ((long long)(d->B / d->h_n) * (d->C1 / d->h_k) * d->h_in * d->L_in * 4 >= (1ll << 31)) return false;
     if ((long long)(d->B / d->h_n) * d->out_C * d->h_n * d->out_L * 4 >= (1ll << 31)) return false;
   } else {
@@ -354,16 +430,16 @@ bool dconv_eligible(const RtgConv1dDesc* d) {
     if (!((d->K == 5) || (d->K == 2 && d->stride == 1))) return false;
     if ((long long)d->B * d->C1 * d->L_in * 4 >= (1ll << 31) || (long long)d->B * d->out_C * d->out_L * 4 >= (1ll << 31)) return false;
   }
-  if (d->Cg != d->C1 || d->Cg % RTG_CK != 0 || d->Cg < 32 || d->Mg < 64 || d->Q < min_q(d->K)) return false;
+  if (d->Cg != d->C1 || d->Cg % RTG_CK != 0 || d->Cg < 32 || d->Mg < 64 || d->Q < min_q(d->K, two_d)) return false;
   if (d->pre_mode != RTG_PRE_NONE && d->pre_mode != RTG_PRE_LRELU) return false;
   if ((long long)d->groups * d->Mg != (long long)d->out_C * d->shuf_S) return false;
   if ((long long)d->B * d->Q >= (1ll << 30)) return false;
   return true;
 }
 
-template <int RW16, int WB, int NT16, int S, int K, bool TWO_D>
+template <int RW16, int WB, int NT16, int S, int K, bool TWO_D, bool CLS = false>
 int launch(const DArgs& a, unsigned blocks, size_t lds_bytes, hipStream_t s) {
-  auto k = dconv_kernel<RW16, WB, NT16, S, K, TWO_D>;
+  auto k = dconv_kernel<RW16, WB, NT16, S, K, TWO_D, CLS>;
   if (lds_bytes > 64 * 1024) {
     static bool attr_set = false;                      // (> 64 KB of dynamic LDS needs the opt-in once per kernel)
     if (!attr_set) {
@@ -379,6 +455,7 @@ int launch(const DArgs& a, unsigned blocks, size_t lds_bytes, hipStream_t s) {
 template <int RW16, int WB, int NT16>
 int launch_sk(const DArgs& a, int S, int K, bool two_d, unsigned blocks, size_t lds_bytes, hipStream_t s) {
   if (two_d) {
+    if (a.h_mode == 1 && a.h_stride > 1) return launch<RW16, WB, NT16, 1, 2, true, true>(a, blocks, lds_bytes, s);
     if (S == 1 && K == 3) return launch<RW16, WB, NT16, 1, 3, true>(a, blocks, lds_bytes, s);
     if (S == 2 && K == 3) return launch<RW16, WB, NT16, 2, 3, true>(a, blocks, lds_bytes, s);
     return RTG_EINVAL;
@@ -456,6 +533,14 @@ int rtg_dconv_launch(const RtgConv1dDesc* d, int code, const float* x, const flo
   a.h_in = two_d ? d->h_in : 1; a.h_k = two_d ? d->h_k : 1; a.h_stride = two_d ? d->h_stride : 1;
   a.h_pad = two_d ? d->h_pad : 0; a.h_n = two_d ? d->h_n : 1; a.h_mode = two_d ? d->h_mode : 0;
   a.n_co = d->C1 / a.h_k;                            // real channels (backward-data: output channels of the layer)
+  a.cpk = a.n_co / RTG_CK;
+  for (int c = 0, base = 0; c < 4; ++c) {
+    int f = (c - a.h_pad) % a.h_stride;
+    if (f < 0) f += a.h_stride;
+    const int n = (c < a.h_stride && f < a.h_n) ? (a.h_n - f + a.h_stride - 1) / a.h_stride : 0;
+    a.cls_f[c] = f; a.cls_n[c] = n > 0 ? n : 1; a.cls_base[c] = base;
+    base += (d->B / a.h_n) * n;
+  }
   a.B = d->B; a.C = d->C1 / a.h_k; a.L_in = d->L_in; a.Mg = d->Mg; a.n_cc = d->Cg / RTG_CK; a.Q = d->Q; a.pad = d->pad;
   a.out_C = d->out_C; a.out_L = d->out_L; a.shuf_S = d->shuf_S; a.shuf_P = d->shuf_P;
   a.pre = d->pre_mode == RTG_PRE_LRELU ? 1 : 0; a.act = d->act; a.accumulate = d->accumulate;

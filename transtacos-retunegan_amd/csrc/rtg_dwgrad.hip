@@ -30,8 +30,7 @@ namespace {
 using rsrc_t = __amdgpu_buffer_rsrc_t;
 using u32x4 = unsigned __attribute__((ext_vector_type(4)));
 #define DW_OOB 0x80000000u
-constexpr int kCch = 16, kK = 5, kCols = kCch * kK, kNCT = kCols / 16, kTT = 64, kNG = kTT / 16;
-constexpr int kBF = kNG * kCols * 16;                                // floats of one chunk's column image (one buffer)
+constexpr int kCch = 16, kTT = 64, kNG = kTT / 16;
 
 struct WArgs {
   const float *x, *dy;
@@ -42,6 +41,9 @@ struct WArgs {
   long long part_stride;
   int n_red, n_tiles, n_mb, n_cch, per_split, n_items, per_xcd;
   int x_bytes, dy_bytes;
+  // second dimension (RtgWgradDesc.h_*; forward geometry): a clip is an (item, output row) pair, a channel a (channel,
+  // kernel row) pair; x is [items, Cg / h_k, h_in, L_in], dy [items, Mg, h_n, dy_L]
+  int h_in, h_k, h_stride, h_pad, h_n;
 };
 
 __device__ __forceinline__ float dw_load(rsrc_t r, unsigned voff, unsigned soff) {
@@ -51,9 +53,12 @@ __device__ __forceinline__ f32x4 dw_load4(rsrc_t r, unsigned voff, unsigned soff
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
 
-// S: stride; kWB: waves; RW: 16-row tiles per wave; NCH: channel chunks per block
-template <int S, int kWB, int NCH, int RW>
+// S: stride; kWB: waves; RW: 16-row tiles per wave; NCH: channel chunks per block; kK: taps; TWO_D: the Conv2d layers of
+// StftDiscriminator (discrminator.py:255-262) along their last axis
+template <int S, int kWB, int NCH, int RW, int kK, bool TWO_D>
 __global__ __launch_bounds__(kWB * 64, 2) void dwgrad_kernel(const WArgs a) {
+  constexpr int kCols = kCch * kK, kNCT = kCols / 16;                 // columns / column tiles of one chunk
+  constexpr int kBF = kNG * kCols * 16;                               // floats of one chunk's column image (one buffer)
   constexpr int kRows = kWB * RW * 16;
   constexpr int CPW = NCH * kCch / kWB;                               // input channels a wave stages per tile
   static_assert(NCH * kCch % kWB == 0, "channels split evenly over the waves");
@@ -85,8 +90,17 @@ __global__ __launch_bounds__(kWB * 64, 2) void dwgrad_kernel(const WArgs a) {
   // ---- rows: this lane's four consecutive reductions of row (wave's tile, r16) for each 16-reduction group of a tile
   f32x4 l1[RW][kNG], l2[RW][kNG];
   int arem[kNG], aval[kNG];                    // elements before the clip boundary; valid elements (n < n_red)
-  const unsigned arow = (unsigned)(m0 + wave * RW * 16 + r16) * (unsigned)a.dy_L * 4u;
-  const unsigned atile = 16u * (unsigned)a.dy_L * 4u;        // bytes between the wave's row tiles
+  const unsigned arow = (unsigned)(m0 + wave * RW * 16 + r16) * (unsigned)(a.h_n * a.dy_L) * 4u;     // (h_n == 1 in 1-D)
+  const unsigned atile = 16u * (unsigned)(a.h_n * a.dy_L) * 4u;  // bytes between the wave's row tiles
+  // byte offset of (clip, row 0, position 0) in dy: clip = item (1-D) or (item, output row)
+  auto dy_clip = [&](int clip) __attribute__((always_inline)) {
+    if constexpr (TWO_D) {
+      const int item = clip / a.h_n, ho = clip - item * a.h_n;
+      return ((unsigned)item * (unsigned)a.Mg * (unsigned)a.h_n + (unsigned)ho) * (unsigned)a.dy_L * 4u;
+    } else {
+      return (unsigned)clip * (unsigned)a.Mg * (unsigned)a.dy_L * 4u;
+    }
+  };
   auto a_load = [&](int tile) __attribute__((always_inline)) {
 #pragma unroll
     for (int g = 0; g < kNG; ++g) {
@@ -96,11 +110,9 @@ __global__ __launch_bounds__(kWB * 64, 2) void dwgrad_kernel(const WArgs a) {
       const int left = a.n_red - n0;
       aval[g] = left < 0 ? 0 : left;
       arem[g] = a.Q - q0;
-      const unsigned cb = (unsigned)clip * (unsigned)a.Mg * (unsigned)a.dy_L * 4u;
-      const unsigned o1 = left > 0 ? cb + arow + (unsigned)q0 * 4u : DW_OOB;
+      const unsigned o1 = left > 0 ? dy_clip(clip) + arow + (unsigned)q0 * 4u : DW_OOB;
       // the part behind a clip boundary: row r of the NEXT clip, element e at position e - arem
-      const unsigned o2 = (left > arem[g] && arem[g] < 4)
-                              ? cb + (unsigned)a.Mg * (unsigned)a.dy_L * 4u + arow - (unsigned)arem[g] * 4u : DW_OOB;
+      const unsigned o2 = (left > arem[g] && arem[g] < 4) ? dy_clip(clip + 1) + arow - (unsigned)arem[g] * 4u : DW_OOB;
 #pragma unroll
       for (int i = 0; i < RW; ++i) {
         l1[i][g] = dw_load4(rd, o1, i * atile);
@@ -125,13 +137,34 @@ __global__ __launch_bounds__(kWB * 64, 2) void dwgrad_kernel(const WArgs a) {
     int q;
     const int clip = divq(n, q);
     const bool valid = n < a.n_red;
-    const unsigned xclip = (unsigned)clip * (unsigned)a.Cg * (unsigned)a.L_in;
+    if constexpr (TWO_D) {
+      // channel vc = (c, kh): input row ho * h_stride - h_pad + kh of channel c
+      const int item = clip / a.h_n, ho = clip - item * a.h_n;
+      const int row0 = ho * a.h_stride - a.h_pad;
+      const int cin = a.Cg / a.h_k;
+      const unsigned xitem = (unsigned)item * (unsigned)cin * (unsigned)a.h_in * (unsigned)a.L_in;
 #pragma unroll
-    for (int t = 0; t < kK; ++t) {
-      const int pos = q * S + t - a.pad;
-      const unsigned vb = (valid && pos >= 0 && pos < a.L_in) ? (xclip + (unsigned)pos) * 4u : DW_OOB;
+      for (int j = 0; j < CPW; ++j) {
+        const int vc = c0 + wave + kWB * j;
+        const int c = vc / a.h_k, kh = vc - c * a.h_k;
+        const int row = row0 + kh;
+        const bool rok = valid && (unsigned)row < (unsigned)a.h_in;
+        const unsigned rb = xitem + (unsigned)(c * a.h_in + row) * (unsigned)a.L_in;
 #pragma unroll
-      for (int j = 0; j < CPW; ++j) sb[j][t] = dw_load(rx, vb, (unsigned)(c0 + wave + kWB * j) * rowb_x);
+        for (int t = 0; t < kK; ++t) {
+          const int pos = q * S + t - a.pad;
+          sb[j][t] = dw_load(rx, (rok && pos >= 0 && pos < a.L_in) ? (rb + (unsigned)pos) * 4u : DW_OOB, 0);
+        }
+      }
+    } else {
+      const unsigned xclip = (unsigned)clip * (unsigned)a.Cg * (unsigned)a.L_in;
+#pragma unroll
+      for (int t = 0; t < kK; ++t) {
+        const int pos = q * S + t - a.pad;
+        const unsigned vb = (valid && pos >= 0 && pos < a.L_in) ? (xclip + (unsigned)pos) * 4u : DW_OOB;
+#pragma unroll
+        for (int j = 0; j < CPW; ++j) sb[j][t] = dw_load(rx, vb, (unsigned)(c0 + wave + kWB * j) * rowb_x);
+      }
     }
   };
   auto b_write = [&](int buf) __attribute__((always_inline)) {
@@ -206,17 +239,27 @@ __global__ __launch_bounds__(kWB * 64, 2) void dwgrad_kernel(const WArgs a) {
             if constexpr (BIAS) accb[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][g][kq], 1.0f, accb[i], 0, 0, 0);
           }
       };
-      // the column fragments of 16-reduction group g + 1 are requested before group g is multiplied
-      Frag f0, f1;
-      fetch(f0, 0);
+      // the column fragments of 16-reduction group g + 1 are requested before group g is multiplied (two register sets;
+      // one set where twelve fragments are already 48 registers: the 4-chunk shape)
+      if constexpr (NCH * kNCT <= 10) {
+        Frag f0, f1;
+        fetch(f0, 0);
 #pragma unroll
-      for (int g = 0; g < kNG; ++g) {
-        Frag& fc = (g & 1) ? f1 : f0;
-        Frag& fn = (g & 1) ? f0 : f1;
-        if (g + 1 < kNG) fetch(fn, g + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(fc, g);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int g = 0; g < kNG; ++g) {
+          Frag& fc = (g & 1) ? f1 : f0;
+          Frag& fn = (g & 1) ? f0 : f1;
+          if (g + 1 < kNG) fetch(fn, g + 1);
+          __builtin_amdgcn_sched_barrier(0);
+          mma(fc, g);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+        Frag f;
+#pragma unroll
+        for (int g = 0; g < kNG; ++g) {
+          fetch(f, g);
+          mma(f, g);
+        }
       }
       if (nxt < a.n_tiles) b_write(cur ^ 1);
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -229,7 +272,7 @@ __global__ __launch_bounds__(kWB * 64, 2) void dwgrad_kernel(const WArgs a) {
 
   // ---- this split's partial: [rows][Cg * K] then the bias partials (gy_scale applied here: the sums are linear in gy)
   float* wpart = a.part + (size_t)split * a.part_stride;
-  const int ck = a.Cg * kK;
+  const int ck = a.Cg * kK;                       // (2-D: Cg = channels x kernel rows)
 #pragma unroll
   for (int i = 0; i < RW; ++i)
 #pragma unroll
@@ -256,20 +299,30 @@ __global__ __launch_bounds__(kWB * 64, 2) void dwgrad_kernel(const WArgs a) {
 struct DwShape {
   int wb, nch, rw;
 };
-constexpr DwShape kDw[] = {{8, 1, 1}, {8, 2, 1}};
+constexpr DwShape kDw[] = {{8, 1, 1}, {8, 2, 1}, {8, 4, 1}};      // (the 4-chunk shape: 3-tap layers only, 192 columns)
 constexpr int kNumDw = sizeof(kDw) / sizeof(DwShape);
 
 bool eligible(const RtgWgradDesc* d, int variant) {
   if (variant < 0 || variant >= kNumDw) return false;
   const int kRows = kDw[variant].wb * kDw[variant].rw * 16;
-  if (d->groups != 1 || d->C2 != 0 || d->h_k > 1 || d->h_n > 1 || d->bf16) return false;
-  if (d->K != kK || d->dil != 1 || (d->stride != 1 && d->stride != 3)) return false;
+  if (d->groups != 1 || d->C2 != 0 || d->bf16 || d->dil != 1) return false;
+  const bool two_d = d->h_k > 1 || d->h_n > 1;
+  if (two_d) {
+    if (d->K != 3 || (d->stride != 1 && d->stride != 2)) return false;
+    if (d->h_in < 1 || d->h_k < 1 || d->h_stride < 1 || d->h_pad < 0 || d->h_n < 1 || d->C1 % d->h_k != 0 || d->B % d->h_n != 0)
+      return false;
+    if ((long long)(d->B / d->h_n) * (d->C1 / d->h_k) * d->h_in * d->L_in * 4 >= (1ll << 31)) return false;
+  } else {
+    if (d->K != 5 || (d->stride != 1 && d->stride != 3)) return false;
+    if ((long long)d->B * d->C1 * d->L_in * 4 >= (1ll << 31)) return false;
+  }
   if (d->Cg != d->C1 || d->Cg % (kCch * kDw[variant].nch) != 0 || d->Mg % kRows != 0) return false;
+  if (kDw[variant].nch == 4 && d->K != 3) return false;
   if (d->gy_mode != RTG_PRE_NONE || (d->pre_mode != RTG_PRE_NONE && d->pre_mode != RTG_PRE_LRELU)) return false;
   if (d->Q < 4 || d->Q > d->dy_L) return false;                               // (four consecutive reductions span <= 2 clips)
   const long long n = (long long)d->B * d->Q;
   if (n >= (1ll << 23)) return false;                                         // float-reciprocal division of n by Q
-  if ((long long)d->B * d->C1 * d->L_in * 4 >= (1ll << 31) || (long long)d->B * d->Mg * d->dy_L * 4 >= (1ll << 31)) return false;
+  if ((long long)d->B * d->Mg * d->dy_L * 4 >= (1ll << 31)) return false;
   return true;
 }
 
@@ -285,7 +338,7 @@ int rtg_dwgrad_splits(const RtgWgradDesc* d, int variant) {
   const DwShape sh = kDw[variant];
   const long long base = (long long)(d->Mg / (sh.wb * sh.rw * 16)) * (d->Cg / (kCch * sh.nch));
   const long long tiles = ((long long)d->B * d->Q + kTT - 1) / kTT;
-  const double t_tile = 0.27 * sh.wb * sh.nch * sh.rw + 0.3, t_fixed = 6.0;
+  const double t_tile = 0.27 * sh.wb * sh.nch * sh.rw * (d->K / 5.0) + 0.3, t_fixed = 6.0;
   const double t_flush = (double)d->Mg * ((double)d->Cg * d->K + 1) * 8.0 / 3.0e6;
   const long long slots = sh.wb == 8 ? 256 : 512;
   double best = 1e30;
@@ -299,10 +352,10 @@ int rtg_dwgrad_splits(const RtgWgradDesc* d, int variant) {
   return (int)best_s;
 }
 
-template <int S, int WB, int NCH, int RW>
+template <int S, int WB, int NCH, int RW, int K, bool TWO_D>
 static int dw_launch(const WArgs& a, hipStream_t s) {
-  auto k = dwgrad_kernel<S, WB, NCH, RW>;
-  const size_t lds_bytes = (size_t)2 * NCH * kBF * sizeof(float);
+  auto k = dwgrad_kernel<S, WB, NCH, RW, K, TWO_D>;
+  const size_t lds_bytes = (size_t)2 * NCH * (kNG * kCch * K * 16) * sizeof(float);
   static bool attr_set = false;
   if (lds_bytes > 64 * 1024 && !attr_set) {
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return RTG_ERANGE;
@@ -332,9 +385,18 @@ int rtg_dwgrad_launch(const RtgWgradDesc* d, int variant, const float* x, const 
   if (n_items > (1ll << 28)) return RTG_ERANGE;
   a.n_items = (int)n_items;
   a.per_xcd = (int)((n_items + 7) / 8);
-  a.x_bytes = d->B * d->C1 * d->L_in * 4;
-  a.dy_bytes = d->B * d->Mg * d->dy_L * 4;
+  const bool two_d = d->h_k > 1 || d->h_n > 1;
+  a.h_in = two_d ? d->h_in : 1; a.h_k = two_d ? d->h_k : 1; a.h_stride = two_d ? d->h_stride : 1;
+  a.h_pad = two_d ? d->h_pad : 0; a.h_n = two_d ? d->h_n : 1;
+  a.x_bytes = (d->B / a.h_n) * (d->C1 / a.h_k) * a.h_in * d->L_in * 4;
+  a.dy_bytes = d->B * d->Mg * d->dy_L * 4;                            // (B = items * h_n)
   const int S = d->stride;
-  if (variant == 0) return S == 1 ? dw_launch<1, 8, 1, 1>(a, s) : dw_launch<3, 8, 1, 1>(a, s);
-  return S == 1 ? dw_launch<1, 8, 2, 1>(a, s) : dw_launch<3, 8, 2, 1>(a, s);
+  if (two_d) {
+    if (variant == 0) return S == 1 ? dw_launch<1, 8, 1, 1, 3, true>(a, s) : dw_launch<2, 8, 1, 1, 3, true>(a, s);
+    if (variant == 1) return S == 1 ? dw_launch<1, 8, 2, 1, 3, true>(a, s) : dw_launch<2, 8, 2, 1, 3, true>(a, s);
+    return S == 1 ? dw_launch<1, 8, 4, 1, 3, true>(a, s) : dw_launch<2, 8, 4, 1, 3, true>(a, s);
+  }
+  if (variant == 0) return S == 1 ? dw_launch<1, 8, 1, 1, 5, false>(a, s) : dw_launch<3, 8, 1, 1, 5, false>(a, s);
+  if (variant == 1) return S == 1 ? dw_launch<1, 8, 2, 1, 5, false>(a, s) : dw_launch<3, 8, 2, 1, 5, false>(a, s);
+  return RTG_EINVAL;
 }

@@ -112,10 +112,15 @@ class ConvLayer:
             if g != 1 or cg % L.CK != 0 or cg < 32 or mg < 96:
                 return 0
             if self.kind == 'conv2d':
-                # StftDiscriminator (3 taps along the last axis): forward, and the backward-data of the stride-(1, 1) layer
+                # StftDiscriminator (3 taps along the last axis): forward and backward-data
                 if fwd:
                     return int(k == 3 and self.stride in (1, 2))
-                return int(mode == L.PACK_DGRAD_2D and k == 3 and s == 1 and self.sh == 1)
+                if mode != L.PACK_DGRAD_2D:
+                    return 0
+                if s == 1 and self.sh == 1:
+                    return int(k == 3)
+                # row-strided layers: class-ordered clips, 2 taps of the polyphase walk, whole chunks per kernel row
+                return int(k == 2 and s == 2 and 2 <= self.sh <= 4 and self.cout % L.CK == 0)
             if self.kind != 'conv':
                 return 0
             if fwd:
