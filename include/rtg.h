@@ -235,6 +235,8 @@ typedef struct RtgPackJob {      /* one per packed layout of a layer            
   int frag16;                    /* 1 (ABI 6; fp32, channel-major, groups == 1): the 16-byte-fragment image
                                     [16-row tile][chunk][tap][kgrp 4][m 16][kq 4] with channel = 4*kq + kgrp of the chunk
                                     (dst_size = rtg_packed_size_frag16): what rtg_dconv.hip (codes 8xxx) reads           */
+  int first_block, n_blocks;     /* (ABI 6) the job's range of workgroups in the launch: n_blocks = rtg_pack_job_blocks(job),
+                                    first_block = sum of n_blocks of the jobs before it in the table                     */
 } RtgPackJob;
 
 typedef struct RtgWnBwdJob {     /* one per weight-normed tensor                                               */
@@ -248,7 +250,10 @@ typedef struct RtgWnBwdJob {     /* one per weight-normed tensor                
 
 int rtg_weightnorm_scales(const RtgNormJob* jobs_dev, int n_jobs, int max_rows, const float* params, float* scales,
                           void* stream);
-int rtg_weights_pack(const RtgPackJob* jobs_dev, int n_jobs, long long max_dst_size, const float* params,
+/* workgroups job *job (HOST memory; first_block / n_blocks not read) needs in rtg_weights_pack; < 0: invalid job */
+int rtg_pack_job_blocks(const RtgPackJob* job);
+/* total_blocks = sum of the jobs' n_blocks (the table is ordered by first_block) */
+int rtg_weights_pack(const RtgPackJob* jobs_dev, int n_jobs, long long total_blocks, const float* params,
                      const float* scales, float* packed, void* stream);
 /* grads[g_off..], grads[v_off..], grads[b_off..] += weight-norm backward of (sum of partials) */
 int rtg_weightnorm_backward(const RtgWnBwdJob* jobs_dev, int n_jobs, int max_rows, int max_inner, const float* params,

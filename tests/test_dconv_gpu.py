@@ -182,9 +182,10 @@ def test_pack_kernel_writes_the_fragment_image():
         assert size == ref.size
         job = (L.PackJob * 1)(L.PackJob(Cout, 0, 0, size, mode, 1, Mg, Cg, Kp, K, Cin, 3 if mode == L.PACK_DGRAD_POLY else 1,
                                        16, 1, 0, 0, 1))
+        blocks = L.assign_pack_blocks(job)
         job_d = torch.frombuffer(bytearray(bytes(memoryview(job).cast('B'))), dtype=torch.uint8).cuda()
         packed = torch.full((size,), float('nan'), device='cuda')
-        assert lib.rtg_weights_pack(_ptr(job_d), 1, size, _ptr(params), _ptr(scales), _ptr(packed), st) == 0
+        assert lib.rtg_weights_pack(_ptr(job_d), 1, blocks, _ptr(params), _ptr(scales), _ptr(packed), st) == 0
         torch.cuda.synchronize()
         np.testing.assert_allclose(packed.cpu().numpy(), ref, rtol=1e-6, atol=1e-7)
 
@@ -289,3 +290,75 @@ def test_conv2d_dgrad_strided_codes(case):
     for c in codes:
         rc, out = _run(kw_, dyd, wp, mask=xm, out_shape=(B, Cin, H, W), cfg=c)
         assert rc == 0 and torch.equal(out, base), c
+
+
+def _pack_on_gpu(v, g, mode, groups, Mg, Cg, Kp, src_K, src_inner_c, S, tile_m, tap_major=0, frag16=0):
+    """rtg_weightnorm_scales + rtg_weights_pack of ONE tensor through the C ABI -> the packed image (numpy)"""
+    from rtg import lib as L
+    from rtg.lib import lib
+    rows = v.shape[0]
+    inner = int(np.prod(v.shape[1:]))
+    params = torch.cat([g.flatten(), v.flatten()]).cuda()
+    scales = torch.empty(2 * rows, device='cuda')
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def table(job):
+        return torch.frombuffer(bytearray(bytes(memoryview((type(job) * 1)(job)).cast('B'))), dtype=torch.uint8).cuda()
+    assert lib.rtg_weightnorm_scales(_ptr(table(L.NormJob(0, rows, 0, rows, inner))), 1, rows, _ptr(params), _ptr(scales), st) == 0
+    if frag16:
+        size = lib.rtg_packed_size_frag16(Mg, Cg, Kp)
+    elif tap_major:
+        size = lib.rtg_packed_size_tapmajor(groups, Mg, Cg, Kp, tile_m)
+    else:
+        size = lib.rtg_packed_size(groups, Mg, Cg, Kp, tile_m)
+    job = L.PackJob(rows, 0, 0, size, mode, groups, Mg, Cg, Kp, src_K, src_inner_c, S, tile_m, 1, tap_major, 0, frag16)
+    blocks = L.assign_pack_blocks([job])
+    packed = torch.full((size,), float('nan'), device='cuda')
+    assert lib.rtg_weights_pack(_ptr(table(job)), 1, blocks, _ptr(params), _ptr(scales), _ptr(packed), st) == 0
+    torch.cuda.synchronize()
+    return packed.cpu().numpy()
+
+
+PACK = [
+    # kind, C_out (C_in for convT), C_in (C_out), K, stride, groups, tile_m
+    ('fwd', 144, 40, 7, 1, 1, 32),          # ragged rows and channels (staged path)
+    ('fwd', 64, 64, 15, 8, 1, 32),          # long taps (staged: 240-float runs)
+    ('fwd', 128, 32, 41, 2, 4, 16),         # grouped k41: runs too long for the slab -> gather path
+    ('dgrad_s1', 96, 48, 3, 1, 1, 32),
+    ('dgrad_s1', 32, 48, 7, 1, 1, 16),      # 16-row tiles
+    ('dgrad_poly', 512, 256, 5, 3, 1, 32),
+    ('dgrad_poly', 64, 32, 15, 8, 1, 32),
+    ('dgrad_poly', 128, 64, 41, 4, 8, 16),  # grouped, long taps -> gather
+    ('convT', 128, 64, 15, 8, 1, 32),
+]
+
+
+@pytest.mark.parametrize('case', PACK)
+def test_pack_kernel_standard_images(case):
+    """every packed layout of rtg_weights_pack (coalesced slab staging and the gather fallback) against tests/packref.py"""
+    from rtg import lib as L
+    kind, c0, c1, K, s, groups, TM = case
+    gen = torch.Generator().manual_seed(41)
+    if kind == 'convT':
+        v = torch.randn(c0, c1, K, generator=gen)                  # [C_in, C_out, K]
+    else:
+        v = torch.randn(c0, c1 // groups, K, generator=gen)        # [C_out, C_in / groups, K]
+    g = torch.rand(v.shape[0], generator=gen) + 0.5
+    w_eff = (v * (g / v.flatten(1).norm(dim=1)).view(-1, 1, 1)).numpy()
+    if kind == 'fwd':
+        W, mode, S = packref.logical_fwd(w_eff, groups), L.PACK_FWD, 1
+    elif kind == 'dgrad_s1':
+        W, mode, S = packref.logical_dgrad_s1(w_eff, groups), L.PACK_DGRAD_S1, 1
+    elif kind == 'dgrad_poly':
+        W, mode, S = packref.logical_dgrad_poly(w_eff, groups, s), L.PACK_DGRAD_POLY, s
+    else:
+        W, mode, S = packref.logical_convT_poly(w_eff, s), L.PACK_CONVT_POLY, s
+    G, Mg, Cg, Kp = W.shape
+    got = _pack_on_gpu(v, g, mode, G, Mg, Cg, Kp, K, v.shape[1], S, TM)
+    np.testing.assert_allclose(got, packref.pack_logical(W, TM), rtol=1e-6, atol=1e-7)
+    if G == 1 and kind != 'convT':
+        got16 = _pack_on_gpu(v, g, mode, 1, Mg, Cg, Kp, K, v.shape[1], S, 16, frag16=1)
+        np.testing.assert_allclose(got16, packref.pack_frag16(W), rtol=1e-6, atol=1e-7)
+    if kind == 'fwd' and Cg <= 16:
+        gott = _pack_on_gpu(v, g, mode, G, Mg, Cg, Kp, K, v.shape[1], S, TM, tap_major=1)
+        np.testing.assert_allclose(gott, packref.pack_logical_tapmajor(W, TM), rtol=1e-6, atol=1e-7)

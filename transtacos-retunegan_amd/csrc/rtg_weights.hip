@@ -75,16 +75,42 @@ __device__ __forceinline__ float pack_logical(const RtgPackJob& j, const float* 
 // element splits its index within the step with shifts and finds its source in 32-bit arithmetic.  (Round 1: 64-bit
 // divisions per element were most of this kernel's time; round 2: 32-bit ones still 3/4 of it, ~110 instructions per
 // element at 1.2 TB/s.)
-__global__ __launch_bounds__(RTG_THREADS) void pack_kernel(const RtgPackJob* jobs, const float* params,
+// what a job's slabs look like (shared by the kernel and rtg_pack_job_blocks): rows of a row tile, source rows and run
+// length of a slab, whether the slab fits the staging buffer
+constexpr int kPackSlab = 32 * 241;                                          // source rows x (run + 1 float of padding)
+struct PackGeom { int RT, n_rt, n_cc, nrow, run; bool staged; };
+__host__ __device__ inline PackGeom pack_geom(const RtgPackJob& j) {
+  PackGeom p;
+  p.RT = j.frag16 ? 16 : j.tile_m;
+  p.n_rt = (j.Mg + p.RT - 1) / p.RT;
+  p.n_cc = (j.Cg + RTG_CK - 1) / RTG_CK;
+  const int S = j.S > 0 ? j.S : 1;
+  const int chs = (j.mode == RTG_PACK_DGRAD_POLY || j.mode == RTG_PACK_CONVT_POLY) ? (p.RT - 1) / S + 2 : 0;
+  p.run = j.mode == RTG_PACK_FWD ? RTG_CK * j.src_K : (j.mode == RTG_PACK_DGRAD_S1 ? p.RT * j.src_K : chs * j.src_K);
+  p.nrow = j.mode == RTG_PACK_FWD ? p.RT : RTG_CK;
+  p.staged = !j.bf16 && !j.tap_major && j.mode != RTG_PACK_DGRAD_2D && p.nrow * (p.run + 1) <= kPackSlab;
+  return p;
+}
+
+__global__ __launch_bounds__(RTG_THREADS) void pack_kernel(const RtgPackJob* jobs, int n_jobs, const float* params,
                                                            const float* scales, float* packed) {
-  const RtgPackJob j = jobs[blockIdx.y];
+  // the grid is the concatenation of the jobs' block ranges (RtgPackJob.first_block / n_blocks): the job of this block is
+  // the last one that starts at or before it (every thread tests one job; a 2-D grid of (blocks of the largest job) x
+  // jobs spent most of the launch dispatching blocks that had nothing to do)
+  int cnt = 0;
+  for (int base = 0; base < n_jobs; base += RTG_THREADS) {
+    const int i = base + (int)threadIdx.x;
+    cnt += __syncthreads_count(i < n_jobs && jobs[i].first_block <= (int)blockIdx.x);
+  }
+  const RtgPackJob j = jobs[cnt - 1];
+  const unsigned bid = blockIdx.x - (unsigned)j.first_block, nb = (unsigned)j.n_blocks;
   const int TM = j.tile_m, KK = 64 / TM, CPN = RTG_CK / KK;
   const int n_mt = (j.Mg + TM - 1) / TM, n_cc = (j.Cg + RTG_CK - 1) / RTG_CK;
   const unsigned n_e = (unsigned)j.dst_size;
   const int lane = threadIdx.x & 63;
   if (j.bf16) {
     // two bf16 per 32-bit slot: elements (2e, 2e+1) of [g][mt][cc][tap][mfma][lane][4]
-    for (unsigned e = blockIdx.x * RTG_THREADS + threadIdx.x; e < n_e; e += gridDim.x * RTG_THREADS) {
+    for (unsigned e = bid * RTG_THREADS + threadIdx.x; e < n_e; e += nb * RTG_THREADS) {
       const int NMF = TM == 32 ? 2 : 1;
       unsigned bits = 0;
       for (int h = 0; h < 2; ++h) {
@@ -106,10 +132,14 @@ __global__ __launch_bounds__(RTG_THREADS) void pack_kernel(const RtgPackJob* job
     }
     return;
   }
-  // fp32 images: a wave packs one whole step per iteration (4 or 8 pieces of 64 consecutive elements)
+  // ---- fp32 images.  Every image is a sequence of slabs, one per (row tile, 16-channel chunk): K steps of 256 (frag16)
+  // or 16 * tile_m floats, contiguous in the destination.  A slab's SOURCE elements are, per source row, one contiguous run
+  // of the weight tensor ((channel, tap) pairs of the chunk: forward; (row, tap) pairs of the tile: stride-1
+  // backward-data; whole taps of the tile's channels: polyphase), so the block copies those runs into LDS with coalesced
+  // loads and emits the slab in destination order from there — a lane-per-destination gather touched 64 cache lines per
+  // wave-load (the source stride between the rows of a tile is a whole weight row) and ran at 1.2 TB/s.  The tap-major
+  // and 2-D backward-data images (short / strided source runs) keep the gather, one step per wave.
   const unsigned step_sz = j.frag16 ? 256u : (unsigned)(RTG_CK * TM);        // 256 or 512
-  const unsigned n_steps = n_e / step_sz;                                    // (dst_size is a multiple of the step size)
-  const unsigned wave0 = (blockIdx.x * RTG_THREADS + threadIdx.x) >> 6, wstride = (gridDim.x * RTG_THREADS) >> 6;
   const int TG = (j.K + KK - 1) / KK;                                        // tap-major: tap groups per channel
   const int n_grp = (j.Cg * TG + CPN - 1) / CPN;
   const int n_mt16 = (j.Mg + 15) / 16;
@@ -117,6 +147,80 @@ __global__ __launch_bounds__(RTG_THREADS) void pack_kernel(const RtgPackJob* job
   const int inner = j.src_inner_c * j.src_K;
   const int n_co = j.KH > 0 ? j.Cg / j.KH : j.Cg;
   const float inv_nco = 1.0f / (float)(n_co > 0 ? n_co : 1);
+  const int RT = j.frag16 ? 16 : TM;                                         // rows of a row tile
+  const int n_rt = j.frag16 ? n_mt16 : n_mt;
+  __shared__ float slab[kPackSlab];
+  const PackGeom pg = pack_geom(j);
+  if (pg.staged) {
+    // run length per source row and rows per slab: forward: RT rows x 16 K; stride-1 backward-data: 16 rows x RT K;
+    // polyphase: 16 rows x (channels the tile's rows cover) x src_K
+    const int run = pg.run, nrow = pg.nrow, pitch = run + 1;
+    {
+      const unsigned n_slab = (unsigned)j.groups * n_rt * n_cc;
+      for (unsigned sl = bid; sl < n_slab; sl += nb) {
+        unsigned t = sl;
+        const int cc = (int)(t % n_cc); t /= n_cc;
+        const int mt = (int)(t % n_rt); t /= n_rt;
+        const int g = (int)t;
+        const int m0 = mt * RT, c0 = cc * RTG_CK;
+        const int ch0 = m0 / (j.S > 0 ? j.S : 1);                            // polyphase: first channel of the tile's rows
+        // ---- source runs -> LDS (scaled by the row's g / ||v||), zero where the row / channel does not exist
+        for (int f = threadIdx.x; f < nrow * run; f += RTG_THREADS) {
+          const int r = f / run, u = f - r * run;
+          long long srow;
+          int sin;
+          bool ok;
+          if (j.mode == RTG_PACK_FWD) {
+            ok = m0 + r < j.Mg && c0 * j.src_K + u < j.Cg * j.src_K;
+            srow = (long long)g * j.Mg + m0 + r;
+            sin = c0 * j.src_K + u;
+          } else if (j.mode == RTG_PACK_DGRAD_S1) {
+            ok = c0 + r < j.Cg && m0 * j.src_K + u < j.Mg * j.src_K;
+            srow = (long long)g * j.Cg + c0 + r;
+            sin = m0 * j.src_K + u;
+          } else {
+            ok = c0 + r < j.Cg && ch0 * j.src_K + u < inner;
+            srow = j.mode == RTG_PACK_DGRAD_POLY ? (long long)g * j.Cg + c0 + r : (long long)(c0 + r);
+            sin = ch0 * j.src_K + u;
+          }
+          slab[r * pitch + u] = ok ? params[j.v_off + srow * inner + sin] * scales[j.scale_off + srow] : 0.f;
+        }
+        __syncthreads();
+        // ---- the slab in destination order
+        float* dst = packed + j.dst_off + (size_t)sl * j.K * step_sz;
+        const int step_shift = step_sz == 512u ? 9 : 8;
+        for (unsigned e = threadIdx.x; e < (unsigned)j.K * step_sz; e += RTG_THREADS) {
+          const int tap = (int)(e >> step_shift);
+          const unsigned in = e & (step_sz - 1);
+          int ml, cl;
+          if (j.frag16) { ml = (in >> 2) & 15; cl = 4 * (in & 3) + (in >> 6); }
+          else { ml = in & (TM - 1); cl = (in / 64) * KK + ((in / TM) & (KK - 1)); }
+          float val = 0.f;
+          if (m0 + ml < j.Mg && c0 + cl < j.Cg) {
+            if (j.mode == RTG_PACK_FWD) {
+              val = slab[ml * pitch + cl * j.src_K + tap];
+            } else if (j.mode == RTG_PACK_DGRAD_S1) {
+              val = slab[cl * pitch + ml * j.src_K + (j.src_K - 1 - tap)];
+            } else {
+              const int m = m0 + ml;
+              int ch = (int)((float)m * invS);
+              int r = m - ch * j.S;
+              if (r < 0) { --ch; r += j.S; }
+              else if (r >= j.S) { ++ch; r -= j.S; }
+              const int jj = r + (j.K - 1 - tap) * j.S;
+              if (jj < j.src_K) val = slab[cl * pitch + (ch - ch0) * j.src_K + jj];
+            }
+          }
+          dst[e] = val;
+        }
+        __syncthreads();
+      }
+      return;
+    }
+  }
+  // ---- gather path: a wave packs one whole step per iteration (the step's coordinates once per 256 / 512 elements)
+  const unsigned n_steps = n_e / step_sz;                                    // (dst_size is a multiple of the step size)
+  const unsigned wave0 = (bid * RTG_THREADS + threadIdx.x) >> 6, wstride = (nb * RTG_THREADS) >> 6;
   for (unsigned st = wave0; st < n_steps; st += wstride) {
     unsigned t = __builtin_amdgcn_readfirstlane(st);
     // ---- the step's coordinates, once per wave
@@ -327,15 +431,29 @@ extern "C" int rtg_weightnorm_scales(const RtgNormJob* jobs_dev, int n_jobs, int
   return rtg_launch_status();
 }
 
-extern "C" int rtg_weights_pack(const RtgPackJob* jobs_dev, int n_jobs, long long max_dst_size, const float* params,
+extern "C" int rtg_pack_job_blocks(const RtgPackJob* job) {
+  if (!job || job->dst_size < 1 || (job->tile_m != 16 && job->tile_m != 32)) return -1;
+  if (job->dst_size >= (1ll << 30)) return -1;                              // 32-bit index decode in the kernel (2e + 1 must fit)
+  const PackGeom pg = pack_geom(*job);
+  long long n;
+  if (pg.staged) {
+    n = (long long)job->groups * pg.n_rt * pg.n_cc;                          // one slab per block
+  } else if (job->bf16) {
+    n = (job->dst_size + RTG_THREADS * 4 - 1) / (RTG_THREADS * 4);
+  } else {
+    const long long n_steps = job->dst_size / (job->frag16 ? 256 : RTG_CK * job->tile_m);
+    n = (n_steps + 7) / 8;                                                   // two steps per wave
+  }
+  return (int)(n < 1 ? 1 : (n > 4096 ? 4096 : n));
+}
+
+extern "C" int rtg_weights_pack(const RtgPackJob* jobs_dev, int n_jobs, long long total_blocks, const float* params,
                                 const float* scales, float* packed, void* stream) {
   if (!jobs_dev || !params || !scales || !packed) return RTG_ENULL;
-  if (n_jobs < 1 || n_jobs > 65535 || max_dst_size < 1) return RTG_EINVAL;
-  if (max_dst_size >= (1ll << 30)) return RTG_ERANGE;          // 32-bit index decode in the kernel (2e + 1 must fit)
-  long long gx = (max_dst_size + RTG_THREADS * 4 - 1) / (RTG_THREADS * 4);
-  if (gx > 4096) gx = 4096;
-  dim3 grid((unsigned)gx, n_jobs);
-  RTG_KLAUNCH(pack_kernel, grid, dim3(RTG_THREADS), 0, (hipStream_t)stream, jobs_dev, params, scales, packed);
+  if (n_jobs < 1 || n_jobs > 65535 || total_blocks < 1) return RTG_EINVAL;
+  if (total_blocks >= (1ll << 31)) return RTG_ERANGE;
+  RTG_KLAUNCH(pack_kernel, dim3((unsigned)total_blocks), dim3(RTG_THREADS), 0, (hipStream_t)stream, jobs_dev, n_jobs,
+              params, scales, packed);
   return rtg_launch_status();
 }
 

@@ -57,7 +57,7 @@ class PackJob(C.Structure):
     _fields_ = [('v_off', C.c_longlong), ('scale_off', C.c_longlong), ('dst_off', C.c_longlong),
                 ('dst_size', C.c_longlong)] + \
                [(n, C.c_int) for n in ('mode', 'groups', 'Mg', 'Cg', 'K', 'src_K', 'src_inner_c', 'S', 'tile_m', 'KH', 'tap_major', 'bf16',
-                                       'frag16')]
+                                       'frag16', 'first_block', 'n_blocks')]
 
 
 class WnBwdJob(C.Structure):
@@ -117,6 +117,7 @@ PROTOTYPES = {
     'rtg_wgrad_shape_candidates': (_I, [C.POINTER(WgradDesc), C.POINTER(C.c_int), _I]),
     'rtg_weightnorm_scales': (_I, [_P, _I, _I, _P, _P, _P]),
     'rtg_weights_pack': (_I, [_P, _I, _LL, _P, _P, _P, _P]),
+    'rtg_pack_job_blocks': (_I, [_P]),
     'rtg_weightnorm_backward': (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P]),
     'rtg_stft_forward': (_I, [C.POINTER(StftDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'rtg_stft_backward': (_I, [C.POINTER(StftDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
@@ -192,6 +193,18 @@ def check(status, what=''):
 
 
 _raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
+def assign_pack_blocks(jobs):
+    """fill first_block / n_blocks of a list of PackJob (rtg_pack_job_blocks per job) -> the launch's total_blocks"""
+    total = 0
+    for j in jobs:
+        n = lib.rtg_pack_job_blocks(C.byref(j))
+        if n < 1:
+            raise RtgError(f'rtg_pack_job_blocks: invalid pack job (mode {j.mode}, {j.Mg} x {j.Cg} x {j.K})')
+        j.first_block, j.n_blocks = total, n
+        total += n
+    return total
 
 
 def current_stream_ptr():
