@@ -58,11 +58,19 @@ __device__ __forceinline__ f32x4 dw_load4(rsrc_t r, unsigned voff, unsigned soff
 template <int S, int kWB, int NCH, int RW, int kK, bool TWO_D>
 __global__ __launch_bounds__(kWB * 64, 2) void dwgrad_kernel(const WArgs a) {
   constexpr int kCols = kCch * kK, kNCT = kCols / 16;                 // columns / column tiles of one chunk
-  constexpr int kBF = kNG * kCols * 16;                               // floats of one chunk's column image (one buffer)
+  // The column image of one chunk and 16-reduction group: four planes [kgrp][column][4 reductions] (element (column, r) at
+  // plane r / 4, slot r % 4: the four k-steps of lane group kgrp).  ds_read_b128 serves a wave in 16-lane groups that pair columns 0-3, 12-15 of one plane with
+  // columns 4-11 of the next (MI355X_MICROARCH.md, LDS): planes 0/1 and 2/3 a multiple of 256 bytes apart make a group's 16
+  // fragments 16 consecutive columns = all 64 banks once ([column][16 reductions] rows of 64 bytes were 2-way conflicts
+  // throughout).  The 16 bytes between planes 1 and 2 and the 32 bytes between groups keep the staging writes
+  // (ds_write_b32, lane = reduction index, 32 lanes per LDS cycle) at 2-way, which costs them nothing.
+  constexpr int kPS = (kCols * 4 + 63) / 64 * 64;                      // floats between planes 0 / 1 and 2 / 3
+  constexpr int kGS = 4 * kPS + 8;                                    // floats per 16-reduction group
+  constexpr int kBF = kNG * kGS;                                      // floats of one chunk's column image (one buffer)
   constexpr int kRows = kWB * RW * 16;
   constexpr int CPW = NCH * kCch / kWB;                               // input channels a wave stages per tile
   static_assert(NCH * kCch % kWB == 0, "channels split evenly over the waves");
-  extern __shared__ __attribute__((aligned(16))) float lds[];      // [2][NCH][kNG][kCols][16]
+  extern __shared__ __attribute__((aligned(16))) float lds[];      // [2][NCH][kNG][plane 4][kCols][4]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // block -> (split, row block, group of NCH channel chunks): each XCD walks a contiguous range of items; the chunk
@@ -169,7 +177,8 @@ __global__ __launch_bounds__(kWB * 64, 2) void dwgrad_kernel(const WArgs a) {
   };
   auto b_write = [&](int buf) __attribute__((always_inline)) {
     // channel c = wave + kWB * j of the block's NCH * 16: chunk c / 16, column (c % 16) * K + t
-    float* pb = lds + buf * (NCH * kBF) + (lane >> 4) * kCols * 16 + (lane & 15);
+    const int wr = lane & 15;
+    float* pb = lds + buf * (NCH * kBF) + (lane >> 4) * kGS + (wr >> 2) * kPS + (wr >> 3) * 4 + (wr & 3);
 #pragma unroll
     for (int j = 0; j < CPW; ++j) {
       const int c = wave + kWB * j;
@@ -177,12 +186,12 @@ __global__ __launch_bounds__(kWB * 64, 2) void dwgrad_kernel(const WArgs a) {
       for (int t = 0; t < kK; ++t) {
         float v = sb[j][t];
         asm volatile("" : "+v"(v));                 // keep the consumption (and its wait) here, below the multiplications
-        pb[(c >> 4) * kBF + ((c & 15) * kK + t) * 16] = v > 0.f ? v : v * a.xslope;
+        pb[(c >> 4) * kBF + ((c & 15) * kK + t) * 4] = v > 0.f ? v : v * a.xslope;
       }
     }
   };
 
-  const int boff = r16 * 16 + kgrp * 4;
+  const int boff = kgrp * kPS + (kgrp >> 1) * 4 + r16 * 4;
   f32x4 acc[RW][NCH][kNCT], accb[RW];
 #pragma unroll
   for (int i = 0; i < RW; ++i) {
@@ -224,7 +233,7 @@ __global__ __launch_bounds__(kWB * 64, 2) void dwgrad_kernel(const WArgs a) {
         for (int h = 0; h < NCH; ++h)
 #pragma unroll
           for (int j = 0; j < kNCT; ++j)
-            f.b[h][j] = *reinterpret_cast<const f32x4*>(pb + h * kBF + (g * kCols + j * 16) * 16);
+            f.b[h][j] = *reinterpret_cast<const f32x4*>(pb + h * kBF + g * kGS + j * 64);
       };
       auto mma = [&](const Frag& f, int g) __attribute__((always_inline)) {
 #pragma unroll
@@ -355,7 +364,8 @@ int rtg_dwgrad_splits(const RtgWgradDesc* d, int variant) {
 template <int S, int WB, int NCH, int RW, int K, bool TWO_D>
 static int dw_launch(const WArgs& a, hipStream_t s) {
   auto k = dwgrad_kernel<S, WB, NCH, RW, K, TWO_D>;
-  const size_t lds_bytes = (size_t)2 * NCH * (kNG * kCch * K * 16) * sizeof(float);
+  constexpr int kPS = (kCch * K * 4 + 63) / 64 * 64, kGS = 4 * kPS + 8;     // (the kernel's plane / group strides)
+  const size_t lds_bytes = (size_t)2 * NCH * (kNG * kGS) * sizeof(float);
   static bool attr_set = false;
   if (lds_bytes > 64 * 1024 && !attr_set) {
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return RTG_ERANGE;
