@@ -120,6 +120,8 @@ int rtg_conv1d_tile_candidates(const RtgConv1dDesc* d, int* cfgs, int max);
 long long rtg_packed_size(int groups, int Mg, int Cg, int K, int tile_m);
 /* ... of the 16-byte-fragment image (RtgPackJob.frag16; groups == 1): ceil(Mg/16) x ceil(Cg/16) x K x 256 */
 long long rtg_packed_size_frag16(int Mg, int Cg, int K);
+/* ... of its bf16 form (RtgPackJob.frag16 with .bf16): ceil(Mg/16) x ceil(Cg/32) x K x 256 floats (8 bf16 per 16 bytes) */
+long long rtg_packed_size_frag16_bf16(int Mg, int Cg, int K);
 /* the same for the tap-major order, and whether that order needs fewer MFMAs than the channel-major one (1 / 0) */
 long long rtg_packed_size_bf16(int groups, int Mg, int Cg, int K, int tile_m);   /* floats (2 bf16 each) */
 long long rtg_packed_size_tapmajor(int groups, int Mg, int Cg, int K, int tile_m);
@@ -232,9 +234,11 @@ typedef struct RtgPackJob {      /* one per packed layout of a layer            
   int bf16;                      /* 1: bf16 fragments [g][m-tile][chunk][tap][mfma][lane][4] (dst_size in floats =
                                     rtg_packed_size_bf16); lane (kk, m) holds channels 8*mfma + 4*kk .. +3 of the chunk
                                     (tile_m 32, two MFMAs per chunk) or 4*kk .. +3 (tile_m 16, one MFMA)             */
-  int frag16;                    /* 1 (ABI 6; fp32, channel-major, groups == 1): the 16-byte-fragment image
+  int frag16;                    /* 1 (ABI 6; channel-major, groups == 1): the 16-byte-fragment image
                                     [16-row tile][chunk][tap][kgrp 4][m 16][kq 4] with channel = 4*kq + kgrp of the chunk
-                                    (dst_size = rtg_packed_size_frag16): what rtg_dconv.hip (codes 8xxx) reads           */
+                                    (dst_size = rtg_packed_size_frag16): what rtg_dconv.hip (codes 8xxx) reads.  With bf16:
+                                    [16-row tile][32-channel chunk][tap][kgrp 4][m 16][8 bf16], channel = 8*kgrp + element
+                                    (dst_size = rtg_packed_size_frag16_bf16 floats)                                       */
   int first_block, n_blocks;     /* (ABI 6) the job's range of workgroups in the launch: n_blocks = rtg_pack_job_blocks(job),
                                     first_block = sum of n_blocks of the jobs before it in the table                     */
 } RtgPackJob;

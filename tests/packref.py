@@ -93,3 +93,22 @@ def pack_frag16(W):
     P[:Mg, :Cg] = W[0]
     P = P.reshape(n_mt, 16, n_cc, 4, 4, K)                       # mt, m, cc, kq, kgrp, tap
     return np.ascontiguousarray(P.transpose(0, 2, 5, 4, 1, 3)).reshape(-1)
+
+
+def bf16_bits(a):
+    """fp32 array -> bf16 bit patterns (uint16), round to nearest even"""
+    u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+
+
+def pack_frag16_bf16(W):
+    """W: [1, Mg, Cg, K] -> the bf16 fragment image of rtg_dconv.hip (RtgPackJob.frag16 with .bf16), as float32 words:
+    [16-row tile][32-channel chunk][tap][kgrp 4][m 16][8 bf16] with channel = 32 * chunk + 8 * kgrp + element."""
+    G, Mg, Cg, K = W.shape
+    assert G == 1
+    n_mt, n_cc = -(-Mg // 16), -(-Cg // 32)
+    P = np.zeros((n_mt * 16, n_cc * 32, K), dtype=np.float32)
+    P[:Mg, :Cg] = W[0]
+    P = P.reshape(n_mt, 16, n_cc, 4, 8, K)                       # mt, m, cc, kgrp, el, tap
+    bits = bf16_bits(np.ascontiguousarray(P.transpose(0, 2, 5, 3, 1, 4)))
+    return bits.reshape(-1).view(np.float32)

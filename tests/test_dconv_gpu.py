@@ -292,7 +292,7 @@ def test_conv2d_dgrad_strided_codes(case):
         assert rc == 0 and torch.equal(out, base), c
 
 
-def _pack_on_gpu(v, g, mode, groups, Mg, Cg, Kp, src_K, src_inner_c, S, tile_m, tap_major=0, frag16=0):
+def _pack_on_gpu(v, g, mode, groups, Mg, Cg, Kp, src_K, src_inner_c, S, tile_m, tap_major=0, frag16=0, bf16=0):
     """rtg_weightnorm_scales + rtg_weights_pack of ONE tensor through the C ABI -> the packed image (numpy)"""
     from rtg import lib as L
     from rtg.lib import lib
@@ -306,12 +306,12 @@ def _pack_on_gpu(v, g, mode, groups, Mg, Cg, Kp, src_K, src_inner_c, S, tile_m, 
         return torch.frombuffer(bytearray(bytes(memoryview((type(job) * 1)(job)).cast('B'))), dtype=torch.uint8).cuda()
     assert lib.rtg_weightnorm_scales(_ptr(table(L.NormJob(0, rows, 0, rows, inner))), 1, rows, _ptr(params), _ptr(scales), st) == 0
     if frag16:
-        size = lib.rtg_packed_size_frag16(Mg, Cg, Kp)
+        size = (lib.rtg_packed_size_frag16_bf16 if bf16 else lib.rtg_packed_size_frag16)(Mg, Cg, Kp)
     elif tap_major:
         size = lib.rtg_packed_size_tapmajor(groups, Mg, Cg, Kp, tile_m)
     else:
         size = lib.rtg_packed_size(groups, Mg, Cg, Kp, tile_m)
-    job = L.PackJob(rows, 0, 0, size, mode, groups, Mg, Cg, Kp, src_K, src_inner_c, S, tile_m, 1, tap_major, 0, frag16)
+    job = L.PackJob(rows, 0, 0, size, mode, groups, Mg, Cg, Kp, src_K, src_inner_c, S, tile_m, 1, tap_major, bf16, frag16)
     blocks = L.assign_pack_blocks([job])
     packed = torch.full((size,), float('nan'), device='cuda')
     assert lib.rtg_weights_pack(_ptr(table(job)), 1, blocks, _ptr(params), _ptr(scales), _ptr(packed), st) == 0

@@ -14,6 +14,18 @@ import packref  # noqa: E402
 from rtg.lib import lib, Conv1dDesc, WgradDesc  # noqa: E402
 
 
+BF = bool(os.environ.get('BD_BF'))       # bf16 operands (RtgConv1dDesc.bf16): the general bf16 kernel against the dense bf16 codes
+
+
+def images(W):
+    if not BF:
+        return torch.from_numpy(np.concatenate([packref.pack_logical(W, 32), packref.pack_frag16(W)])).cuda()
+    _, Mg, Cg, K = W.shape
+    std = lib.rtg_packed_size_bf16(1, Mg, Cg, K, 32)
+    junk = (np.random.RandomState(3).randn(std) * 0.05).astype(np.float32)      # (timing only: arbitrary bf16 pairs)
+    return torch.from_numpy(np.concatenate([junk, packref.pack_frag16_bf16(W)])).cuda()
+
+
 def P(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
@@ -75,14 +87,14 @@ def bench_2d(B, Cin, Cout, H, W, kh, sh, sw):
     Ho, Wo = (H + 2 * ph - kh) // sh + 1, (W + 2 * pw - kw) // sw + 1
     w = (np.random.RandomState(1).randn(Cout, Cin, kh, kw) / np.sqrt(Cin * kh * kw)).astype(np.float32)
     Wl = w.reshape(1, Cout, Cin * kh, kw)
-    wp = torch.from_numpy(np.concatenate([packref.pack_logical(Wl, 32), packref.pack_frag16(Wl)])).cuda()
+    wp = images(Wl)
     x = torch.randn(B, Cin, H, W, device='cuda')
     out = torch.empty(B, Cout, Ho, Wo, device='cuda')
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     d = Conv1dDesc(B=B * Ho, C1=Cin * kh, C2=0, L_in=W, groups=1, Cg=Cin * kh, Mg=Cout, K=kw, stride=sw, dil=1, pad=pw, Q=Wo,
                    out_C=Cout, out_L=Wo, shuf_S=1, shuf_P=0, pre_mode=1, pre_slope=0.15, mask_slope=1.0, out_scale=1.0,
                    act=0, act_slope=1.0, accumulate=0, tile_m=32, out_split=0, wp16=1, h_in=H, h_k=kh, h_stride=sh,
-                   h_pad=ph, h_n=Ho, h_mode=0)
+                   h_pad=ph, h_n=Ho, h_mode=0, bf16=int(BF))
     flop = 2.0 * B * Ho * Wo * Cout * Cin * kh * kw
     cands = (C.c_int * 48)()
     n = lib.rtg_conv1d_tile_candidates(C.byref(d), cands, 48)
@@ -94,7 +106,7 @@ def bench_2d(B, Cin, Cout, H, W, kh, sh, sw):
         torch.cuda.synchronize()
         if ref is None:
             ref = out.clone()
-        same = torch.equal(out, ref)
+        same = BF or torch.equal(out, ref)
         ms = timeit(lambda: lib.rtg_conv1d(C.byref(d), P(x), None, None, P(wp), None, None, None, P(out), None, st))
         res.append((c, ms, same))
     gen = min((r for r in res if r[0] < 8000), key=lambda r: r[1])
@@ -138,7 +150,8 @@ def bench(kind, B, Cin, Cout, L, s):
         mask = torch.randn(B, Cin, L, device='cuda')
         d = Conv1dDesc(**dict(base, B=B, C1=Cout, L_in=Lo, Cg=Cout, Mg=Cin * s, K=nt, stride=1, pad=nt - 1,
                               Q=(L - 1 + p) // s + 1, out_C=Cin, out_L=L, shuf_S=s, shuf_P=p, mask_slope=0.15))
-    wp = torch.from_numpy(np.concatenate([packref.pack_logical(W, 32), packref.pack_frag16(W)])).cuda()
+    wp = images(W)
+    d.bf16 = int(BF)
     flop = 2.0 * B * Lo * Cout * Cin * K
     cands = (C.c_int * 48)()
     n = lib.rtg_conv1d_tile_candidates(C.byref(d), cands, 48)
@@ -153,7 +166,7 @@ def bench(kind, B, Cin, Cout, L, s):
         torch.cuda.synchronize()
         if ref is None:
             ref = out.clone()
-        same = torch.equal(out, ref)
+        same = BF or torch.equal(out, ref)
         ms = timeit(lambda: lib.rtg_conv1d(C.byref(d), P(x), None, None, P(wp), None, P(mask), None, P(out), None, st))
         res.append((c, ms, same))
     gen = [r for r in res if r[0] < 8000 and r[1]]
@@ -232,7 +245,7 @@ if __name__ == '__main__':
     if sys.argv[1:] == ['2d']:
         for sh in MTD:
             bench_2d(*sh)
-        for sh in MTD:
+        for sh in ([] if BF else MTD):
             bench_wgrad_2d(*sh)
         sys.exit(0)
     kinds = sys.argv[1:]

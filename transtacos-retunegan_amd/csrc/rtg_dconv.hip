@@ -78,9 +78,18 @@ constexpr int window_positions(int cols, int Q, int S, int K) {
 // S: stride of the B-operand walk; K: taps; TWO_D: the Conv2d layers of StftDiscriminator run along their last axis
 // (discrminator.py:255-262), the patch row of clip (item, r) and channel (c, kh) being input row r * h_stride - h_pad + kh
 // (forward) or r + h_pad - kh (backward-data of a row-stride-1 layer, channels ordered (kh, c))
-template <int RW16, int WB, int NT16, int S, int K, bool TWO_D, bool CLS>
+//
+// BF (RtgConv1dDesc.bf16, BASELINE configs[2]): bf16 operands on v_mfma_f32_16x16x32_bf16, fp32 accumulation.  A chunk is 32
+// channels: lane (kgrp, n) holds channels 8 * kgrp .. + 7 of the chunk as ONE 16-byte fragment, so the patch planes, the
+// fragment reads, the weight loads (image [16-row tile][32-channel chunk][tap][kgrp][row][8 bf16]) and the loop are the fp32
+// kernel's with one matrix instruction per fragment pair instead of four; a wave stages 8 channels per position (fp32
+// tensors in HBM, activation applied in fp32, rounded to nearest even when the 16 bytes are written to LDS).
+using bf16x8 = __bf16 __attribute__((ext_vector_type(8)));
+template <int RW16, int WB, int NT16, int S, int K, bool TWO_D, bool CLS, bool BF>
 __global__ __launch_bounds__(WB * 64, 2) void dconv_kernel(const DArgs a) {
   static_assert(!CLS || TWO_D, "class-ordered clips belong to the 2-D backward-data");
+  constexpr int CKC = BF ? 32 : RTG_CK;              // channels per chunk
+  constexpr int NSI = BF ? 8 : 4;                    // channels a wave stages per position
   constexpr int BN = NT16 * 16;
   // positions staged per lane: enough for the widest window of the shape (rows of min_q(K, TWO_D) positions); iterations past
   // the actual window load nothing (out-of-range offsets) and write nothing
@@ -147,14 +156,14 @@ __global__ __launch_bounds__(WB * 64, 2) void dconv_kernel(const DArgs a) {
   }
   const rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
   const unsigned chb = (unsigned)a.L_in * 4u;        // bytes per channel row
-  float st[4][MAXIT];
+  float st[NSI][MAXIT];
   // (unconditional: past the last chunk the loads go out of range and return zeros that nobody writes — a branch around
   // them would make the compiler's vmcnt bookkeeping pessimistic for every weight fetch after the join)
   auto stage_issue = [&](int cc) __attribute__((always_inline)) {
     const unsigned past = cc < a.n_cc ? 0u : DC_OOB;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int vc = cc * RTG_CK + skgrp + 4 * i;
+    for (int i = 0; i < NSI; ++i) {
+      const int vc = cc * CKC + (BF ? 8 * skgrp + i : skgrp + 4 * i);
       if constexpr (TWO_D) {
         // virtual channel -> (channel, kernel row): (c, kh) forward, (kh, c) backward-data; the row moves with kh
         int c, dr, kc = 0;
@@ -188,11 +197,22 @@ __global__ __launch_bounds__(WB * 64, 2) void dconv_kernel(const DArgs a) {
       const int o = (wave >> 2) * 64 + lane + SPI * it;
       if (o < a.PW) {
         f32x4 v;
+        if constexpr (BF) {
+          bf16x8 h;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          float t = st[i][it];
-          asm volatile("" : "+v"(t));                // keep the consumption (and its wait) here, below the multiplications
-          v[i] = t > 0.f ? t : t * wslope;
+          for (int i = 0; i < 8; ++i) {
+            float t = st[i][it];
+            asm volatile("" : "+v"(t));
+            h[i] = (__bf16)(t > 0.f ? t : t * wslope);
+          }
+          v = __builtin_bit_cast(f32x4, h);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float t = st[i][it];
+            asm volatile("" : "+v"(t));                // keep the consumption (and its wait) here, below the multiplications
+            v[i] = t > 0.f ? t : t * wslope;
+          }
         }
         *reinterpret_cast<f32x4*>(buf + skgrp * planeF + o * 4) = v;
       }
@@ -269,13 +289,22 @@ __global__ __launch_bounds__(WB * 64, 2) void dconv_kernel(const DArgs a) {
     for (int j = 0; j < NT16; ++j) f.b[j] = *reinterpret_cast<const f32x4*>(bsrc + bcol[j]);
   };
   auto mma = [&](const Frag& f) __attribute__((always_inline)) {
-#pragma unroll
-    for (int kq = 0; kq < 4; ++kq)
+    if constexpr (BF) {
 #pragma unroll
       for (int i = 0; i < RW16; ++i)
 #pragma unroll
         for (int j = 0; j < NT16; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[i][kq], f.b[j][kq], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, f.a[i]),
+                                                              __builtin_bit_cast(bf16x8, f.b[j]), acc[i][j], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int kq = 0; kq < 4; ++kq)
+#pragma unroll
+        for (int i = 0; i < RW16; ++i)
+#pragma unroll
+          for (int j = 0; j < NT16; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[i][kq], f.b[j][kq], acc[i][j], 0, 0, 0);
+    }
   };
 
   // ---- prologue: chunk 0 staged and published, chunk 1 requested, fragments of step 0 fetched
@@ -418,7 +447,8 @@ constexpr DShape kShapes[] = {{2, 4}, {1, 8}, {1, 4}, {2, 8}};       // code dig
 constexpr int kNT[] = {4, 6, 7, 8};
 
 bool dconv_eligible(const RtgConv1dDesc* d) {
-  if (!d->wp16 || d->groups != 1 || d->C2 != 0 || d->out_split != 0 || d->tap_major || d->bf16) return false;
+  if (!d->wp16 || d->groups != 1 || d->C2 != 0 || d->out_split != 0 || d->tap_major) return false;
+  const int ckc = d->bf16 ? 32 : RTG_CK;             // channels per chunk
   const bool two_d = d->h_k > 1 || d->h_n > 1;
   if (two_d) {
     // forward of the Conv2d layers, backward-data of the row-stride-1 ones; 3 taps along the last axis
@@ -426,7 +456,7 @@ bool dconv_eligible(const RtgConv1dDesc* d) {
     if (d->h_in < 1 || d->h_k < 1 || d->h_n < 1 || d->h_pad < 0 || d->C1 % d->h_k != 0 || d->B % d->h_n != 0) return false;
     if (d->dil != 1 || d->h_stride < 1 || (d->h_mode != 0 && d->h_mode != 1)) return false;
     if (d->h_mode == 1 && d->h_stride > 1) {
-      if (d->K != 2 || d->stride != 1 || d->h_stride > 4 || (d->C1 / d->h_k) % RTG_CK != 0) return false;
+      if (d->K != 2 || d->stride != 1 || d->h_stride > 4 || (d->C1 / d->h_k) % ckc != 0) return false;
     } else {
       if (d->K != 3 || (d->stride != 1 && d->stride != 2) || d->shuf_S != 1) return false;
     }
@@ -437,16 +467,16 @@ bool dconv_eligible(const RtgConv1dDesc* d) {
     if (!((d->K == 5) || (d->K == 2 && d->stride == 1))) return false;
     if ((long long)d->B * d->C1 * d->L_in * 4 >= (1ll << 31) || (long long)d->B * d->out_C * d->out_L * 4 >= (1ll << 31)) return false;
   }
-  if (d->Cg != d->C1 || d->Cg % RTG_CK != 0 || d->Cg < 32 || d->Mg < 64 || d->Q < min_q(d->K, two_d)) return false;
+  if (d->Cg != d->C1 || d->Cg % ckc != 0 || d->Cg < 32 || d->Mg < 64 || d->Q < min_q(d->K, two_d)) return false;
   if (d->pre_mode != RTG_PRE_NONE && d->pre_mode != RTG_PRE_LRELU) return false;
   if ((long long)d->groups * d->Mg != (long long)d->out_C * d->shuf_S) return false;
   if ((long long)d->B * d->Q >= (1ll << 30)) return false;
   return true;
 }
 
-template <int RW16, int WB, int NT16, int S, int K, bool TWO_D, bool CLS = false>
+template <int RW16, int WB, int NT16, int S, int K, bool TWO_D, bool CLS, bool BF>
 int launch(const DArgs& a, unsigned blocks, size_t lds_bytes, hipStream_t s) {
-  auto k = dconv_kernel<RW16, WB, NT16, S, K, TWO_D, CLS>;
+  auto k = dconv_kernel<RW16, WB, NT16, S, K, TWO_D, CLS, BF>;
   if (lds_bytes > 64 * 1024) {
     static bool attr_set = false;                      // (> 64 KB of dynamic LDS needs the opt-in once per kernel)
     if (!attr_set) {
@@ -459,17 +489,17 @@ int launch(const DArgs& a, unsigned blocks, size_t lds_bytes, hipStream_t s) {
   return rtg_launch_status();
 }
 
-template <int RW16, int WB, int NT16>
+template <int RW16, int WB, int NT16, bool BF>
 int launch_sk(const DArgs& a, int S, int K, bool two_d, unsigned blocks, size_t lds_bytes, hipStream_t s) {
   if (two_d) {
-    if (a.h_mode == 1 && a.h_stride > 1) return launch<RW16, WB, NT16, 1, 2, true, true>(a, blocks, lds_bytes, s);
-    if (S == 1 && K == 3) return launch<RW16, WB, NT16, 1, 3, true>(a, blocks, lds_bytes, s);
-    if (S == 2 && K == 3) return launch<RW16, WB, NT16, 2, 3, true>(a, blocks, lds_bytes, s);
+    if (a.h_mode == 1 && a.h_stride > 1) return launch<RW16, WB, NT16, 1, 2, true, true, BF>(a, blocks, lds_bytes, s);
+    if (S == 1 && K == 3) return launch<RW16, WB, NT16, 1, 3, true, false, BF>(a, blocks, lds_bytes, s);
+    if (S == 2 && K == 3) return launch<RW16, WB, NT16, 2, 3, true, false, BF>(a, blocks, lds_bytes, s);
     return RTG_EINVAL;
   }
-  if (S == 1 && K == 5) return launch<RW16, WB, NT16, 1, 5, false>(a, blocks, lds_bytes, s);
-  if (S == 3 && K == 5) return launch<RW16, WB, NT16, 3, 5, false>(a, blocks, lds_bytes, s);
-  if (S == 1 && K == 2) return launch<RW16, WB, NT16, 1, 2, false>(a, blocks, lds_bytes, s);
+  if (S == 1 && K == 5) return launch<RW16, WB, NT16, 1, 5, false, false, BF>(a, blocks, lds_bytes, s);
+  if (S == 3 && K == 5) return launch<RW16, WB, NT16, 3, 5, false, false, BF>(a, blocks, lds_bytes, s);
+  if (S == 1 && K == 2) return launch<RW16, WB, NT16, 1, 2, false, false, BF>(a, blocks, lds_bytes, s);
   return RTG_EINVAL;
 }
 
@@ -497,6 +527,7 @@ int rtg_dconv_candidates(const RtgConv1dDesc* d, int* codes, int max) {
       // column tiles; 8 column tiles with a strided walk in the 4-wave blocks (twice the staging registers per wave)
       if (kShapes[si].rw16 == 2 && kNT[ni] >= 6) continue;
       if (kNT[ni] == 8 && d->stride > 1 && kShapes[si].wb == 4) continue;
+      if (d->bf16 && kNT[ni] == 8 && (d->h_k > 1 || d->h_n > 1) && d->K == 3) continue;   // (8 staged channels per position)
       const int pw = window_positions((int)(n_cols < BN ? n_cols : BN), d->Q, d->stride, d->K);
       if (2ll * 4 * plane_floats(pw, d->stride) * 4 > 150 * 1024) continue;
       const long long blocks = (long long)n_mb * ((n_cols + BN - 1) / BN);
@@ -533,14 +564,16 @@ int rtg_dconv_launch(const RtgConv1dDesc* d, int code, const float* x, const flo
   const int rw16 = kShapes[si].rw16, wb = kShapes[si].wb, BN = nt16 * 16;
   DArgs a;
   // the 16-byte-fragment image follows the standard image of the layer (RtgConv1dDesc.wp16)
-  const long long std_size = rtg_packed_size(1, d->Mg, d->Cg, d->K, d->tile_m);
+  const long long std_size = d->bf16 ? rtg_packed_size_bf16(1, d->Mg, d->Cg, d->K, d->tile_m)
+                                     : rtg_packed_size(1, d->Mg, d->Cg, d->K, d->tile_m);
   if (std_size < 0 || (std_size & 3) != 0) return RTG_EINVAL;
   a.x = x; a.wp = wp + std_size; a.bias = bias; a.mask = mask; a.res = res; a.out = out;
   const bool two_d = d->h_k > 1 || d->h_n > 1;
   a.h_in = two_d ? d->h_in : 1; a.h_k = two_d ? d->h_k : 1; a.h_stride = two_d ? d->h_stride : 1;
   a.h_pad = two_d ? d->h_pad : 0; a.h_n = two_d ? d->h_n : 1; a.h_mode = two_d ? d->h_mode : 0;
   a.n_co = d->C1 / a.h_k;                            // real channels (backward-data: output channels of the layer)
-  a.cpk = a.n_co / RTG_CK;
+  const int ckc = d->bf16 ? 32 : RTG_CK;
+  a.cpk = a.n_co / ckc;
   for (int c = 0, base = 0; c < 4; ++c) {
     int f = (c - a.h_pad) % a.h_stride;
     if (f < 0) f += a.h_stride;
@@ -548,7 +581,7 @@ int rtg_dconv_launch(const RtgConv1dDesc* d, int code, const float* x, const flo
     a.cls_f[c] = f; a.cls_n[c] = n > 0 ? n : 1; a.cls_base[c] = base;
     base += (d->B / a.h_n) * n;
   }
-  a.B = d->B; a.C = d->C1 / a.h_k; a.L_in = d->L_in; a.Mg = d->Mg; a.n_cc = d->Cg / RTG_CK; a.Q = d->Q; a.pad = d->pad;
+  a.B = d->B; a.C = d->C1 / a.h_k; a.L_in = d->L_in; a.Mg = d->Mg; a.n_cc = d->Cg / ckc; a.Q = d->Q; a.pad = d->pad;
   a.out_C = d->out_C; a.out_L = d->out_L; a.shuf_S = d->shuf_S; a.shuf_P = d->shuf_P;
   a.pre = d->pre_mode == RTG_PRE_LRELU ? 1 : 0; a.act = d->act; a.accumulate = d->accumulate;
   a.pre_slope = d->pre_slope; a.mask_slope = d->mask_slope; a.out_scale = d->out_scale; a.act_slope = d->act_slope;
@@ -568,11 +601,12 @@ int rtg_dconv_launch(const RtgConv1dDesc* d, int code, const float* x, const flo
   const unsigned blocks = (unsigned)(8 * a.per_xcd);
 #define RTG_DC(S_, N_)                                                                                                  \
   if (si == S_ - 1 && nt16 == N_)                                                                                         \
-    return launch_sk<kShapes[S_ - 1].rw16, kShapes[S_ - 1].wb, N_>(a, d->stride, d->K, two_d, blocks, lds_bytes, s);
-  RTG_DC(1, 4) RTG_DC(1, 6) RTG_DC(1, 7) RTG_DC(1, 8)
+    return d->bf16 ? launch_sk<kShapes[S_ - 1].rw16, kShapes[S_ - 1].wb, N_, true>(a, d->stride, d->K, two_d, blocks, lds_bytes, s) \
+                   : launch_sk<kShapes[S_ - 1].rw16, kShapes[S_ - 1].wb, N_, false>(a, d->stride, d->K, two_d, blocks, lds_bytes, s);
+  // (32 rows per wave with 6 or more column tiles needs more than 256 registers: never listed, not built)
+  RTG_DC(1, 4) RTG_DC(4, 4)
   RTG_DC(2, 4) RTG_DC(2, 6) RTG_DC(2, 7) RTG_DC(2, 8)
   RTG_DC(3, 4) RTG_DC(3, 6) RTG_DC(3, 7) RTG_DC(3, 8)
-  RTG_DC(4, 4) RTG_DC(4, 6) RTG_DC(4, 7) RTG_DC(4, 8)
 #undef RTG_DC
   return RTG_EINVAL;
 }
@@ -580,4 +614,10 @@ int rtg_dconv_launch(const RtgConv1dDesc* d, int code, const float* x, const flo
 extern "C" long long rtg_packed_size_frag16(int Mg, int Cg, int K) {
   if (Mg < 1 || Cg < 1 || K < 1) return RTG_EINVAL;
   return (long long)((Mg + 15) / 16) * ((Cg + RTG_CK - 1) / RTG_CK) * K * 256;
+}
+
+// bf16 fragments: 1 KB per (16-row tile, 32-channel chunk, tap), in floats
+extern "C" long long rtg_packed_size_frag16_bf16(int Mg, int Cg, int K) {
+  if (Mg < 1 || Cg < 1 || K < 1) return RTG_EINVAL;
+  return (long long)((Mg + 15) / 16) * ((Cg + 31) / 32) * K * 256;
 }

@@ -108,6 +108,25 @@ __global__ __launch_bounds__(RTG_THREADS) void pack_kernel(const RtgPackJob* job
   const int n_mt = (j.Mg + TM - 1) / TM, n_cc = (j.Cg + RTG_CK - 1) / RTG_CK;
   const unsigned n_e = (unsigned)j.dst_size;
   const int lane = threadIdx.x & 63;
+  if (j.bf16 && j.frag16) {
+    // the bf16 fragment image of rtg_dconv.hip: [16-row tile][32-channel chunk][tap][kgrp 4][row 16][8 bf16], channel
+    // 8 * kgrp + i of the chunk in element i; one 32-bit slot = elements (2 * slot, 2 * slot + 1)
+    const int n_c32 = (j.Cg + 31) / 32;
+    for (unsigned e = bid * RTG_THREADS + threadIdx.x; e < n_e; e += nb * RTG_THREADS) {
+      const int slot = (int)(e & 3u), m = (int)((e >> 2) & 15u), kg = (int)((e >> 6) & 3u);
+      unsigned t2 = e >> 8;
+      const int tap2 = (int)(t2 % j.K); t2 /= j.K;
+      const int cc2 = (int)(t2 % n_c32);
+      const int mt2 = (int)(t2 / n_c32);
+      unsigned bits = 0;
+      for (int h = 0; h < 2; ++h) {
+        const float v = pack_logical(j, params, scales, 0, mt2 * 16 + m, cc2 * 32 + 8 * kg + 2 * slot + h, tap2);
+        bits |= (unsigned)__builtin_bit_cast(unsigned short, (__bf16)v) << (16 * h);
+      }
+      packed[j.dst_off + e] = __builtin_bit_cast(float, bits);
+    }
+    return;
+  }
   if (j.bf16) {
     // two bf16 per 32-bit slot: elements (2e, 2e+1) of [g][mt][cc][tap][mfma][lane][4]
     for (unsigned e = bid * RTG_THREADS + threadIdx.x; e < n_e; e += nb * RTG_THREADS) {

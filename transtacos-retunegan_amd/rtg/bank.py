@@ -107,9 +107,10 @@ class ConvLayer:
         # RtgConv1dDesc.wp16); the tuner then times both kernels per problem.  RTG_DCONV=0: never (A/B knob).
         def dense(op, fwd):
             mode, g, mg, cg, k, s = op
-            if os.environ.get('RTG_DCONV', '1') == '0' or want_bf or self.dil != 1:
+            if os.environ.get('RTG_DCONV', '1') == '0' or self.dil != 1:
                 return 0
-            if g != 1 or cg % L.CK != 0 or cg < 32 or mg < 96:
+            ckc = 32 if want_bf else L.CK         # bf16: 32-channel chunks (8 bf16 per 16-byte fragment)
+            if g != 1 or cg % ckc != 0 or cg < 32 or mg < 96:
                 return 0
             if self.kind == 'conv2d':
                 # StftDiscriminator (3 taps along the last axis): forward and backward-data
@@ -120,7 +121,7 @@ class ConvLayer:
                 if s == 1 and self.sh == 1:
                     return int(k == 3)
                 # row-strided layers: class-ordered clips, 2 taps of the polyphase walk, whole chunks per kernel row
-                return int(k == 2 and s == 2 and 2 <= self.sh <= 4 and self.cout % L.CK == 0)
+                return int(k == 2 and s == 2 and 2 <= self.sh <= 4 and self.cout % ckc == 0)
             if self.kind != 'conv':
                 return 0
             if fwd:
@@ -128,6 +129,7 @@ class ConvLayer:
             return int((mode == L.PACK_DGRAD_S1 and k == 5) or (mode == L.PACK_DGRAD_POLY and k == 2 and s == 3))
         self.fwd16 = dense(self.fwd_op, True) if not self.fwd_tap else 0
         self.bwd16 = dense(self.bwd_op, False) if not self.bwd_tap else 0
+        self.frag_bf = int(want_bf)           # the fragment images are bf16 with the layer
         self.fwd_bf = int(ok(self.fwd_op, self.fwd_tap))
         self.wgrad_bf = int(want_bf)          # the weight-gradient kernel has one K order: every layer
         self.bwd_bf = int(ok(self.bwd_op, self.bwd_tap))     # (the class-pure strided 2-D backward-data included)
@@ -144,8 +146,9 @@ class ConvLayer:
         f = fs(self.fwd_op[1], self.fwd_op[2], self.fwd_op[3], self.fwd_op[4], self.fwd_tm)
         b = bs(self.bwd_op[1], self.bwd_op[2], self.bwd_op[3], self.bwd_op[4], self.bwd_tm)
         # (standard image, 16-byte-fragment image behind it) per operator
-        f16 = lib.rtg_packed_size_frag16(self.fwd_op[2], self.fwd_op[3], self.fwd_op[4]) if self.fwd16 else 0
-        b16 = lib.rtg_packed_size_frag16(self.bwd_op[2], self.bwd_op[3], self.bwd_op[4]) if self.bwd16 else 0
+        s16 = lib.rtg_packed_size_frag16_bf16 if self.frag_bf else lib.rtg_packed_size_frag16
+        f16 = s16(self.fwd_op[2], self.fwd_op[3], self.fwd_op[4]) if self.fwd16 else 0
+        b16 = s16(self.bwd_op[2], self.bwd_op[3], self.bwd_op[4]) if self.bwd16 else 0
         return (f, f16), (b, b16)
 
 
@@ -271,7 +274,7 @@ class WeightBank:
                                                         (ly.bwd_op, ly.bwd_off + ly.bwd_size, ly.bwd16_size)):
                 if size:
                     pack.append(L.PackJob(ly.v_off, ly.scale_off, off, size, mode, g, mg, cg, k, ly.k, ly.inner_c, s, 16,
-                                          ly.kh, 0, 0, 1))
+                                          ly.kh, 0, ly.frag_bf, 1))
                     self.max_pack = max(self.max_pack, size)
         self.norm_table = _table(norm, self.device)
         self.pack_blocks = L.assign_pack_blocks(pack)

@@ -102,6 +102,7 @@ PROTOTYPES = {
     'rtg_conv1d_tile_candidates': (_I, [C.POINTER(Conv1dDesc), C.POINTER(C.c_int), _I]),
     'rtg_packed_size': (_LL, [_I, _I, _I, _I, _I]),
     'rtg_packed_size_frag16': (_LL, [_I, _I, _I]),
+    'rtg_packed_size_frag16_bf16': (_LL, [_I, _I, _I]),
     'rtg_packed_size_tapmajor': (_LL, [_I, _I, _I, _I, _I]),
     'rtg_packed_size_bf16': (_LL, [_I, _I, _I, _I, _I]),
     'rtg_tapmajor_pays': (_I, [_I, _I, _I]),
