@@ -242,6 +242,10 @@ MTD = [  # B = 64 (real + generated clips), resolution 0 (1025 x 35) and 2 (257 
 ]
 
 if __name__ == '__main__':
+    if os.environ.get('BD_PICK'):           # e.g. BD_PICK=0,4: only those entries of the lists
+        pick = [int(i) for i in os.environ['BD_PICK'].split(',')]
+        MTD = [MTD[i] for i in pick if i < len(MTD)]
+        SHAPES = [SHAPES[i] for i in pick if i < len(SHAPES)]
     if sys.argv[1:] == ['2d']:
         for sh in MTD:
             bench_2d(*sh)

@@ -59,8 +59,8 @@ struct DArgs {
   int cls_f[4], cls_n[4], cls_base[4], cpk;
 };
 
-__device__ __forceinline__ float dc_load(rsrc_t r, unsigned off) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+__device__ __forceinline__ float dc_load(rsrc_t r, unsigned off, unsigned soff = 0) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, soff, 0));
 }
 
 // shortest row served (bounds the clip boundaries a column tile can straddle, hence the staging registers): 8 for the k5 /
@@ -148,50 +148,108 @@ __global__ __launch_bounds__(WB * 64, 2) void dconv_kernel(const DArgs a) {
         srow[it] = (ho + a.h_pad - cls) / a.h_stride;
         scls[it] = cls;
       }
-      // (item, channel 0, row 0, position); the channel's rows and the kernel row are added per chunk
-      soff[it] = ok ? ((unsigned)item * (unsigned)a.C * (unsigned)a.h_in * (unsigned)a.L_in + (unsigned)pos) * 4u : DC_OOB;
+      // (item, channel 0, row srow, position) — wrapping arithmetic, the row becomes valid once the kernel row is added;
+      // the channel's rows are a wave-uniform offset of the load.  An invalid position has no valid row.
+      soff[it] = ((unsigned)item * (unsigned)a.C * (unsigned)a.h_in * (unsigned)a.L_in + (unsigned)pos) * 4u +
+                 (unsigned)srow[it] * (unsigned)a.L_in * 4u;
+      if (!ok) srow[it] = -(1 << 28);
     } else {
       soff[it] = ok ? ((unsigned)clip * (unsigned)a.C * (unsigned)a.L_in + (unsigned)pos) * 4u : DC_OOB;
     }
   }
   const rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
   const unsigned chb = (unsigned)a.L_in * 4u;        // bytes per channel row
-  float st[NSI][MAXIT];
+  // staging registers: one set (the patch of chunk v + 2 is requested during the last tap of chunk v and written during
+  // chunk v + 1), or two alternating sets (BF: a chunk's matrix instructions last a few hundred cycles, less than the
+  // latency of the loads: chunk v + 3 is requested at the end of chunk v)
+  constexpr int NSET = BF ? 2 : 1;
+  float st[NSET][NSI][MAXIT];
   // (unconditional: past the last chunk the loads go out of range and return zeros that nobody writes — a branch around
   // them would make the compiler's vmcnt bookkeeping pessimistic for every weight fetch after the join)
-  auto stage_issue = [&](int cc) __attribute__((always_inline)) {
-    const unsigned past = cc < a.n_cc ? 0u : DC_OOB;
+  // 2-D: which (channel, kernel row) a staged virtual channel is.  Backward-data orders them (kernel row, channel) with whole
+  // chunks per kernel row: the kernel row is the walk's (Walk::kh, uniform over the chunk).  Forward orders them (channel,
+  // kernel row): sub-channel i of this wave starts at virtual channel base_i and moves CKC channels per chunk — kept as a
+  // (channel, kernel row) pair advanced chunk by chunk (every division here was ~40 vector instructions per staged channel
+  // and chunk: four times the bf16 kernel's matrix time)
+  struct Walk {
+    int rc;                   // real chunk (index into the weight image); n_cc once past the end
+    int kh, khq, khr, cw;     // backward-data: kernel row, kh / h_stride, kh % h_stride, chunk within the kernel row
+  };
+  [[maybe_unused]] int m0c[NSI], m0r[NSI], m0q = 0, m0rem = 0;
+  if constexpr (TWO_D && !CLS) {
+    if (a.h_mode == 0) {
+      m0q = CKC / a.h_k;
+      m0rem = CKC - m0q * a.h_k;
 #pragma unroll
-    for (int i = 0; i < NSI; ++i) {
-      const int vc = cc * CKC + (BF ? 8 * skgrp + i : skgrp + 4 * i);
-      if constexpr (TWO_D) {
-        // virtual channel -> (channel, kernel row): (c, kh) forward, (kh, c) backward-data; the row moves with kh
-        int c, dr, kc = 0;
-        if (a.h_mode == 0) { c = vc / a.h_k; dr = vc - c * a.h_k; }
-        else {
-          const int kh = vc / a.n_co;
-          c = vc - kh * a.n_co;
-          dr = -kh;
-          if constexpr (CLS) { dr = -(kh / a.h_stride); kc = kh - (kh / a.h_stride) * a.h_stride; }
-        }
-        const unsigned coff = (unsigned)(c * a.h_in) * chb | past;
+      for (int i = 0; i < NSI; ++i) {
+        const int vc0 = BF ? 8 * skgrp + i : skgrp + 4 * i;
+        m0c[i] = vc0 / a.h_k;
+        m0r[i] = vc0 - m0c[i] * a.h_k;
+      }
+    }
+  }
+  // (unconditional: past the last chunk the loads go out of range and return zeros that nobody writes — a branch around
+  // them would make the compiler's vmcnt bookkeeping pessimistic for every weight fetch after the join)
+  auto stage_issue = [&](const Walk& w, auto set_tag) __attribute__((always_inline)) {
+    constexpr int SET = decltype(set_tag)::value;
+#ifdef RTG_EXP_DC_NOSTAGE
+    return;
+#endif
+    const bool is_past = w.rc >= a.n_cc;
+    if constexpr (TWO_D) {
+      bool fwd = false;
+      if constexpr (!CLS) fwd = a.h_mode == 0;
+      if (fwd) {
+        if constexpr (!CLS) {
 #pragma unroll
-        for (int it = 0; it < MAXIT; ++it) {
-          const int row = srow[it] + dr;
-          bool ok = (unsigned)row < (unsigned)a.h_in;
-          if constexpr (CLS) ok = ok && scls[it] == kc;          // a kernel row of another residue class: zeros
-          const unsigned off = ok ? soff[it] + coff + (unsigned)row * chb : DC_OOB;
-          st[i][it] = dc_load(rx, off | (soff[it] & DC_OOB) | past);
+          for (int i = 0; i < NSI; ++i) {
+            const int kh = is_past ? (1 << 24) : m0r[i];
+            const unsigned khb = (unsigned)kh * chb, cb = (unsigned)(m0c[i] * a.h_in) * chb;
+#pragma unroll
+            for (int it = 0; it < MAXIT; ++it) {
+              const bool ok = (unsigned)(srow[it] + kh) < (unsigned)a.h_in;
+              st[SET][i][it] = dc_load(rx, ok ? soff[it] + khb : DC_OOB, is_past ? 0u : cb);
+            }
+            m0c[i] += m0q;
+            m0r[i] += m0rem;
+            if (m0r[i] >= a.h_k) { m0r[i] -= a.h_k; ++m0c[i]; }
+          }
         }
       } else {
+        // one kernel row per chunk: the rows (and, class-ordered, whether the row's class takes this kernel row) once
+        const int dr = is_past ? (1 << 24) : (CLS ? -w.khq : -w.kh);
+        unsigned voff[MAXIT];
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) {
+          bool ok = (unsigned)(srow[it] + dr) < (unsigned)a.h_in;
+          if constexpr (CLS) ok = ok && scls[it] == w.khr;       // a kernel row of another residue class: zeros
+          voff[it] = ok ? soff[it] + (unsigned)dr * chb : DC_OOB;
+        }
+#pragma unroll
+        for (int i = 0; i < NSI; ++i) {
+          const int c = w.cw * CKC + (BF ? 8 * skgrp + i : skgrp + 4 * i);
+          const unsigned cb = is_past ? 0u : (unsigned)(c * a.h_in) * chb;
+#pragma unroll
+          for (int it = 0; it < MAXIT; ++it) st[SET][i][it] = dc_load(rx, voff[it], cb);
+        }
+      }
+    } else {
+      const unsigned past = is_past ? DC_OOB : 0u;
+#pragma unroll
+      for (int i = 0; i < NSI; ++i) {
+        const int vc = w.rc * CKC + (BF ? 8 * skgrp + i : skgrp + 4 * i);
         const unsigned coff = (unsigned)vc * chb | past;
 #pragma unroll
-        for (int it = 0; it < MAXIT; ++it) st[i][it] = dc_load(rx, (soff[it] + coff) | (soff[it] & DC_OOB));
+        for (int it = 0; it < MAXIT; ++it) st[SET][i][it] = dc_load(rx, (soff[it] + coff) | (soff[it] & DC_OOB));
       }
     }
   };
   const float wslope = a.pre ? a.pre_slope : 1.f;
-  auto stage_write = [&](float* buf) __attribute__((always_inline)) {
+  auto stage_write = [&](float* buf, auto set_tag) __attribute__((always_inline)) {
+    constexpr int SET = decltype(set_tag)::value;
+#ifdef RTG_EXP_DC_NOSTWRITE
+    return;
+#endif
 #pragma unroll
     for (int it = 0; it < MAXIT; ++it) {
       const int o = (wave >> 2) * 64 + lane + SPI * it;
@@ -201,7 +259,7 @@ __global__ __launch_bounds__(WB * 64, 2) void dconv_kernel(const DArgs a) {
           bf16x8 h;
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
-            float t = st[i][it];
+            float t = st[SET][i][it];
             asm volatile("" : "+v"(t));
             h[i] = (__bf16)(t > 0.f ? t : t * wslope);
           }
@@ -209,7 +267,7 @@ __global__ __launch_bounds__(WB * 64, 2) void dconv_kernel(const DArgs a) {
         } else {
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            float t = st[i][it];
+            float t = st[SET][i][it];
             asm volatile("" : "+v"(t));                // keep the consumption (and its wait) here, below the multiplications
             v[i] = t > 0.f ? t : t * wslope;
           }
@@ -251,22 +309,31 @@ __global__ __launch_bounds__(WB * 64, 2) void dconv_kernel(const DArgs a) {
     cls_blk = c0;
     if (pure) n_v = (c0 < a.h_k ? (a.h_k - c0 + a.h_stride - 1) / a.h_stride : 0) * a.cpk;
   }
-  // generator of the walk: the real chunk of virtual chunk 0, 1, 2, ... (n_cc once past the end)
+  // generator of the walk: virtual chunk 0, 1, 2, ... -> real chunk and (2-D backward-data) its kernel row, kept as
+  // counters (no division per chunk)
   int gv = 0;
-  [[maybe_unused]] int gk = 0, gw = 0;
+  [[maybe_unused]] int gk = 0, gw = 0, gq = 0, gr = 0;
   auto gen = [&]() __attribute__((always_inline)) {
-    int rc = a.n_cc;
+    Walk w{a.n_cc, 0, 0, 0, 0};
     if (gv < n_v) {
-      rc = gv;
-      if constexpr (CLS) {
-        if (pure) {
-          rc = (cls_blk + gk * a.h_stride) * a.cpk + gw;
-          if (++gw == a.cpk) { gw = 0; ++gk; }
+      w.rc = gv;
+      if constexpr (TWO_D) {
+        if (a.h_mode == 1) {
+          w.cw = gw;
+          bool p = false;
+          if constexpr (CLS) p = pure;
+          if (p) { w.kh = cls_blk + gk * a.h_stride; w.khq = gk; w.khr = cls_blk; }
+          else { w.kh = gk; w.khq = gq; w.khr = gr; }
+          w.rc = w.kh * a.cpk + gw;
+          if (++gw == a.cpk) {
+            gw = 0; ++gk;
+            if (++gr == a.h_stride) { gr = 0; ++gq; }
+          }
         }
       }
     }
     ++gv;
-    return rc;
+    return w;
   };
 
   f32x4 acc[RW16][NT16];
@@ -283,12 +350,19 @@ __global__ __launch_bounds__(WB * 64, 2) void dconv_kernel(const DArgs a) {
   const int n_steps = a.n_cc * K;
   auto fetch = [&](Frag& f, int s, const float* bsrc) __attribute__((always_inline)) {
     const int sc = s < n_steps ? s : n_steps - 1;    // (past the end: re-read the last step, never used)
+#ifndef RTG_EXP_DC_NOA
 #pragma unroll
     for (int i = 0; i < RW16; ++i) f.a[i] = aptr[i][(size_t)sc * 64];
+#endif
+#ifndef RTG_EXP_DC_NOB
 #pragma unroll
     for (int j = 0; j < NT16; ++j) f.b[j] = *reinterpret_cast<const f32x4*>(bsrc + bcol[j]);
+#endif
   };
   auto mma = [&](const Frag& f) __attribute__((always_inline)) {
+#ifdef RTG_EXP_DC_NOMMA
+    return;
+#endif
     if constexpr (BF) {
 #pragma unroll
       for (int i = 0; i < RW16; ++i)
@@ -308,17 +382,27 @@ __global__ __launch_bounds__(WB * 64, 2) void dconv_kernel(const DArgs a) {
   };
 
   // ---- prologue: chunk 0 staged and published, chunk 1 requested, fragments of step 0 fetched
-  int rc0 = gen(), rc1 = gen(), rc2 = gen();          // real chunk of the current virtual chunk, the next, the one after
-  stage_issue(rc0);
-  stage_write(lds);
+  using Set0 = std::integral_constant<int, 0>;
+  using Set1 = std::integral_constant<int, NSET - 1>;
+  Walk rc0 = gen(), rc1 = gen(), rc2 = gen();         // the current virtual chunk, the next, the one after
+  [[maybe_unused]] Walk rc3 = rc2;                    // (two sets: and the one after that)
+  if constexpr (NSET == 2) rc3 = gen();
+  stage_issue(rc0, Set0{});
+  stage_write(lds, Set0{});
   __syncthreads();
-  stage_issue(rc1);
+  stage_issue(rc1, Set1{});                           // (one set: into the registers just written out)
+  if constexpr (NSET == 2) stage_issue(rc2, Set0{});
   Frag f0, f1;
-  fetch(f0, rc0 * K, lds);
+#if defined(RTG_EXP_DC_NOA) || defined(RTG_EXP_DC_NOB)
+  for (int i = 0; i < RW16; ++i) f0.a[i] = f1.a[i] = f32x4{1.f, 1.f, 1.f, 1.f};
+  for (int j = 0; j < NT16; ++j) f0.b[j] = f1.b[j] = f32x4{1.f, 1.f, 1.f, 1.f};
+#endif
+  fetch(f0, rc0.rc * K, lds);
 
   // one chunk (virtual index v): K taps; `cur` holds the fragments of tap 0 on entry, and of the next chunk's tap 0 on
   // exit (in `cur` again when K is even, in `oth` when K is odd: the caller alternates)
-  auto chunk = [&](int v, Frag& cur, Frag& oth) __attribute__((always_inline)) {
+  // `nset`: the register set that holds the next chunk's patch (and takes the request issued at the end of this chunk)
+  auto chunk = [&](int v, Frag& cur, Frag& oth, auto nset) __attribute__((always_inline)) {
     const float* bufc = lds + (v & 1) * bufF;
     float* bufn = lds + ((v + 1) & 1) * bufF;
 #pragma unroll
@@ -327,32 +411,42 @@ __global__ __launch_bounds__(WB * 64, 2) void dconv_kernel(const DArgs a) {
       Frag& fn = (t & 1) ? cur : oth;
       // request the next step's fragments, THEN (last tap) the patch of the chunk after the next: the wait for the
       // fragments one step later does not include the patch loads (vmcnt retires in order)
-      if (t + 1 < K) fetch(fn, rc0 * K + t + 1, bufc + (t + 1) * 4);
-      else fetch(fn, rc1 * K, bufn);
-      if (t == K - 1) stage_issue(rc2);
+      if (t + 1 < K) fetch(fn, rc0.rc * K + t + 1, bufc + (t + 1) * 4);
+      else fetch(fn, rc1.rc * K, bufn);
+      if (t == K - 1) stage_issue(NSET == 2 ? rc3 : rc2, nset);
       __builtin_amdgcn_sched_barrier(0);
       mma(fc);
       __builtin_amdgcn_sched_barrier(0);
       if (t == TW) {
         // publish the next chunk's patch: its buffer was last read by fragment fetches that completed before the
         // previous chunk's barrier; the reads of this chunk's last tap (just requested) are waited for here too
-        if (v + 1 < n_v) stage_write(bufn);
+        if (v + 1 < n_v) stage_write(bufn, nset);
         // (one asm statement: nothing can be scheduled between the wait and the barrier, no memory access across it)
+#ifndef RTG_EXP_DC_NOBAR
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    rc0 = rc1; rc1 = rc2; rc2 = gen();
+    if constexpr (NSET == 2) { rc0 = rc1; rc1 = rc2; rc2 = rc3; rc3 = gen(); }
+    else { rc0 = rc1; rc1 = rc2; rc2 = gen(); }
   };
+  // chunk v + 1's patch sits in set (v + 1) % NSET: odd chunks in Set1, even ones in Set0
   int cc = 0;
   if constexpr (K & 1) {
     for (; cc + 1 < n_v; cc += 2) {
-      chunk(cc, f0, f1);
-      chunk(cc + 1, f1, f0);
+      chunk(cc, f0, f1, Set1{});
+      chunk(cc + 1, f1, f0, Set0{});
     }
-    if (cc < n_v) chunk(cc, f0, f1);
+    if (cc < n_v) chunk(cc, f0, f1, Set1{});
+  } else if constexpr (NSET == 2) {
+    for (; cc + 1 < n_v; cc += 2) {
+      chunk(cc, f0, f1, Set1{});
+      chunk(cc + 1, f0, f1, Set0{});
+    }
+    if (cc < n_v) chunk(cc, f0, f1, Set1{});
   } else {
-    for (; cc < n_v; ++cc) chunk(cc, f0, f1);
+    for (; cc < n_v; ++cc) chunk(cc, f0, f1, Set0{});
   }
 
   // ---- epilogue: out = act(((acc + bias) * dmask + res) * out_scale) (+ out), the arithmetic and rounding of the general
@@ -455,8 +549,9 @@ bool dconv_eligible(const RtgConv1dDesc* d) {
     // ... and of the row-strided ones (class-ordered clips, 2 taps of the polyphase walk along the last axis)
     if (d->h_in < 1 || d->h_k < 1 || d->h_n < 1 || d->h_pad < 0 || d->C1 % d->h_k != 0 || d->B % d->h_n != 0) return false;
     if (d->dil != 1 || d->h_stride < 1 || (d->h_mode != 0 && d->h_mode != 1)) return false;
+    if (d->h_mode == 1 && (d->C1 / d->h_k) % ckc != 0) return false;      // whole chunks per kernel row
     if (d->h_mode == 1 && d->h_stride > 1) {
-      if (d->K != 2 || d->stride != 1 || d->h_stride > 4 || (d->C1 / d->h_k) % ckc != 0) return false;
+      if (d->K != 2 || d->stride != 1 || d->h_stride > 4) return false;
     } else {
       if (d->K != 3 || (d->stride != 1 && d->stride != 2) || d->shuf_S != 1) return false;
     }
@@ -526,8 +621,14 @@ int rtg_dconv_candidates(const RtgConv1dDesc* d, int* codes, int max) {
       // instances that need more than 256 registers at two waves per SIMD (they spill): 32 rows per wave with >= 6
       // column tiles; 8 column tiles with a strided walk in the 4-wave blocks (twice the staging registers per wave)
       if (kShapes[si].rw16 == 2 && kNT[ni] >= 6) continue;
-      if (kNT[ni] == 8 && d->stride > 1 && kShapes[si].wb == 4) continue;
-      if (d->bf16 && kNT[ni] == 8 && (d->h_k > 1 || d->h_n > 1) && d->K == 3) continue;   // (8 staged channels per position)
+      const bool two_d = d->h_k > 1 || d->h_n > 1;
+      if (kNT[ni] == 8 && (d->stride > 1 || (two_d && kShapes[si].wb == 4))) continue;
+      // bf16 (8 staged channels per position, two register sets): 16 rows per wave with 8 column tiles, or with 7 on a
+      // strided walk, or with 7 (6 on a strided walk) in the 4-wave blocks
+      if (d->bf16 && kShapes[si].rw16 == 1 &&
+          (kNT[ni] == 8 || (kNT[ni] == 7 && d->stride > 1) ||
+           (kShapes[si].wb == 4 && (kNT[ni] == 7 || (kNT[ni] == 6 && d->stride > 1)))))
+        continue;
       const int pw = window_positions((int)(n_cols < BN ? n_cols : BN), d->Q, d->stride, d->K);
       if (2ll * 4 * plane_floats(pw, d->stride) * 4 > 150 * 1024) continue;
       const long long blocks = (long long)n_mb * ((n_cols + BN - 1) / BN);

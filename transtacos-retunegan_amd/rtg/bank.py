@@ -102,7 +102,7 @@ class ConvLayer:
         def ok(op, tap):
             return bool(want_bf and not tap and op[2] > 1 and op[3] > 1)
         # the dense-layer kernel (rtg_dconv.hip, block-shape codes 8xxx) reads 16-byte operand fragments: layers it can serve
-        # (>= 32 input channels, >= 96 output rows, dilation 1; 1-D: k5 at stride 1 / 3 forward, the k5 stride-1 or 2-tap
+        # (>= 32 input channels, >= 64 output rows, dilation 1; 1-D: k5 at stride 1 / 3 forward, the k5 stride-1 or 2-tap
         # polyphase backward-data operator; Conv2d of the spectrogram discriminators: forward, stride-1 backward-data) carry a second image of their weights behind the standard one (RtgPackJob.frag16,
         # RtgConv1dDesc.wp16); the tuner then times both kernels per problem.  RTG_DCONV=0: never (A/B knob).
         def dense(op, fwd):
@@ -110,7 +110,7 @@ class ConvLayer:
             if os.environ.get('RTG_DCONV', '1') == '0' or self.dil != 1:
                 return 0
             ckc = 32 if want_bf else L.CK         # bf16: 32-channel chunks (8 bf16 per 16-byte fragment)
-            if g != 1 or cg % ckc != 0 or cg < 32 or mg < 96:
+            if g != 1 or cg % ckc != 0 or cg < 32 or mg < 64:
                 return 0
             if self.kind == 'conv2d':
                 # StftDiscriminator (3 taps along the last axis): forward and backward-data
