@@ -146,11 +146,11 @@ def _src_digest():
     return h.hexdigest()[:16]
 
 
-def _pmc_for(prefix):
+def _pmc_for(prefix, workload='config2'):
     """launch-weighted HBM bytes and matrix-pipe busy fraction of the kernels whose name starts with `prefix`, from the
-    newest profiles/*_pmc.json"""
+    newest profiles/*_bench_<workload>_pmc.json (None without a pass of this workload)"""
     import glob
-    files = sorted(glob.glob(os.path.join(REPO, 'profiles', '*_pmc.json')))
+    files = sorted(glob.glob(os.path.join(REPO, 'profiles', f'*_bench_{workload}_pmc.json')))
     if not files:
         return None
     doc = json.load(open(files[-1]))
@@ -168,7 +168,7 @@ def _pmc_for(prefix):
             'stale': bool(stale)}
 
 
-def roofline(trainer, batch, bf16=False):
+def roofline(trainer, batch, bf16=False, workload='config2'):
     """Live per-kernel timing of extra (eager) steps: every conv launch bracketed by HIP events on its launch stream."""
     from rtg import ops
     # an eager step first (the timed steps were graph replays: allocator blocks and caches of the eager path are cold), then
@@ -221,11 +221,11 @@ def roofline(trainer, batch, bf16=False):
     # HBM traffic and matrix-pipe occupancy of that kernel from the committed PMC passes (rocprofv3 --pmc cannot run inside
     # this process): profiles/*_pmc.json, written by tools/pmc_pass.sh + tools/pmc_summary.py from this same command
     if kernel == 'dconv':
-        pmc = _pmc_for('dconv_kernel<')
+        pmc = _pmc_for('dconv_kernel<', workload)
     else:
         pmc = _pmc_for(f'conv1d_mfma_group_kernel<{variant // 100}, {variant // 10 % 10}, {variant % 10},' if kernel == 'conv1d'
-                       else f'wgrad_kernel<{variant},')
-    if pmc and not bf16:                     # the committed PMC passes are of the fp32 instances
+                       else f'wgrad_kernel<{variant},', workload)
+    if pmc:                                  # (a pass of this workload: its instances and arithmetic type)
         out['traffic'] = pmc['traffic']
         out['traffic_unit'] = 'bytes/launch (HBM read + write, PMC FETCH_SIZE x2 + WRITE_SIZE)'
         out['mfma_busy_frac_pmc'] = pmc['mfma_busy']
@@ -375,7 +375,7 @@ def main():
     if not a.no_roofline:
         # every rank runs the instrumented steps (they are train steps: under data parallelism their gradient all-reduces
         # need all ranks), rank 0 reports its own launches
-        roof = roofline(tr, data, bf16=dtype == 'bf16')
+        roof = roofline(tr, data, bf16=dtype == 'bf16', workload=a.workload)
     if world > 1:
         dist.barrier()
     cpu = None

@@ -60,7 +60,14 @@ struct DArgs {
 };
 
 __device__ __forceinline__ float dc_load(rsrc_t r, unsigned off, unsigned soff = 0) {
+#if defined(RTG_EXP_DC_LINEAR)           // ablation: the address math dropped, a coalesced in-range load instead
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (threadIdx.x & 63u) * 4u, 0, 0));
+#elif defined(RTG_EXP_DC_KEEPMATH)       // ablation: the address math kept alive, the load coalesced
+  asm volatile("" ::"v"(off), "s"(soff));
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (threadIdx.x & 63u) * 4u, 0, 0));
+#else
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, soff, 0));
+#endif
 }
 
 // shortest row served (bounds the clip boundaries a column tile can straddle, hence the staging registers): 8 for the k5 /
@@ -85,9 +92,13 @@ constexpr int window_positions(int cols, int Q, int S, int K) {
 // kernel's with one matrix instruction per fragment pair instead of four; a wave stages 8 channels per position (fp32
 // tensors in HBM, activation applied in fp32, rounded to nearest even when the 16 bytes are written to LDS).
 using bf16x8 = __bf16 __attribute__((ext_vector_type(8)));
-template <int RW16, int WB, int NT16, int S, int K, bool TWO_D, bool CLS, bool BF>
+// HB: 2-D backward-data (RtgConv1dDesc.h_mode 1) — a template parameter although it only selects address arithmetic: with
+// both forms in one loop the compiler's wait-count bookkeeping merged their pending loads at every join and waited for the
+// staging loads (and the fragment loads behind them) a chunk early
+template <int RW16, int WB, int NT16, int S, int K, bool TWO_D, bool CLS, bool BF, bool HB>
 __global__ __launch_bounds__(WB * 64, 2) void dconv_kernel(const DArgs a) {
   static_assert(!CLS || TWO_D, "class-ordered clips belong to the 2-D backward-data");
+  static_assert((!CLS || HB) && (!HB || TWO_D), "h_mode 1 is 2-D; class-ordered clips are backward-data");
   constexpr int CKC = BF ? 32 : RTG_CK;              // channels per chunk
   constexpr int NSI = BF ? 8 : 4;                    // channels a wave stages per position
   constexpr int BN = NT16 * 16;
@@ -142,7 +153,7 @@ __global__ __launch_bounds__(WB * 64, 2) void dconv_kernel(const DArgs a) {
     if constexpr (TWO_D) {
       int item, ho, cls;
       decode(clip, item, ho, cls);
-      srow[it] = a.h_mode == 0 ? ho * a.h_stride - a.h_pad : ho + a.h_pad;
+      srow[it] = !HB ? ho * a.h_stride - a.h_pad : ho + a.h_pad;
       if constexpr (CLS) {
         // rows of class cls take kernel rows cls, cls + h_stride, ...: kernel row cls + m * h_stride reads row srow - m
         srow[it] = (ho + a.h_pad - cls) / a.h_stride;
@@ -176,8 +187,8 @@ __global__ __launch_bounds__(WB * 64, 2) void dconv_kernel(const DArgs a) {
     int kh, khq, khr, cw;     // backward-data: kernel row, kh / h_stride, kh % h_stride, chunk within the kernel row
   };
   [[maybe_unused]] int m0c[NSI], m0r[NSI], m0q = 0, m0rem = 0;
-  if constexpr (TWO_D && !CLS) {
-    if (a.h_mode == 0) {
+  if constexpr (TWO_D && !HB) {
+    {
       m0q = CKC / a.h_k;
       m0rem = CKC - m0q * a.h_k;
 #pragma unroll
@@ -197,10 +208,8 @@ __global__ __launch_bounds__(WB * 64, 2) void dconv_kernel(const DArgs a) {
 #endif
     const bool is_past = w.rc >= a.n_cc;
     if constexpr (TWO_D) {
-      bool fwd = false;
-      if constexpr (!CLS) fwd = a.h_mode == 0;
-      if (fwd) {
-        if constexpr (!CLS) {
+      if constexpr (!HB) {
+        {
 #pragma unroll
           for (int i = 0; i < NSI; ++i) {
             const int kh = is_past ? (1 << 24) : m0r[i];
@@ -210,9 +219,10 @@ __global__ __launch_bounds__(WB * 64, 2) void dconv_kernel(const DArgs a) {
               const bool ok = (unsigned)(srow[it] + kh) < (unsigned)a.h_in;
               st[SET][i][it] = dc_load(rx, ok ? soff[it] + khb : DC_OOB, is_past ? 0u : cb);
             }
-            m0c[i] += m0q;
-            m0r[i] += m0rem;
-            if (m0r[i] >= a.h_k) { m0r[i] -= a.h_k; ++m0c[i]; }
+            const int r2 = m0r[i] + m0rem;
+            const bool wrap = r2 >= a.h_k;
+            m0r[i] = wrap ? r2 - a.h_k : r2;
+            m0c[i] += wrap ? m0q + 1 : m0q;
           }
         }
       } else {
@@ -309,28 +319,30 @@ __global__ __launch_bounds__(WB * 64, 2) void dconv_kernel(const DArgs a) {
     cls_blk = c0;
     if (pure) n_v = (c0 < a.h_k ? (a.h_k - c0 + a.h_stride - 1) / a.h_stride : 0) * a.cpk;
   }
+  const int n_vp = ((K & 1) || BF) ? (n_v + 1) & ~1 : n_v;      // chunks the loop walks (an even count where it is unrolled by two)
   // generator of the walk: virtual chunk 0, 1, 2, ... -> real chunk and (2-D backward-data) its kernel row, kept as
   // counters (no division per chunk)
   int gv = 0;
   [[maybe_unused]] int gk = 0, gw = 0, gq = 0, gr = 0;
   auto gen = [&]() __attribute__((always_inline)) {
     Walk w{a.n_cc, 0, 0, 0, 0};
-    if (gv < n_v) {
-      w.rc = gv;
-      if constexpr (TWO_D) {
-        if (a.h_mode == 1) {
-          w.cw = gw;
-          bool p = false;
-          if constexpr (CLS) p = pure;
-          if (p) { w.kh = cls_blk + gk * a.h_stride; w.khq = gk; w.khr = cls_blk; }
-          else { w.kh = gk; w.khq = gq; w.khr = gr; }
-          w.rc = w.kh * a.cpk + gw;
-          if (++gw == a.cpk) {
-            gw = 0; ++gk;
-            if (++gr == a.h_stride) { gr = 0; ++gq; }
-          }
-        }
-      }
+    const bool live = gv < n_v;
+    if constexpr (HB) {
+      bool p = false;
+      if constexpr (CLS) p = pure;
+      w.cw = gw;
+      w.kh = p ? cls_blk + gk * a.h_stride : gk;
+      w.khq = p ? gk : gq;
+      w.khr = p ? cls_blk : gr;
+      w.rc = live ? w.kh * a.cpk + gw : a.n_cc;
+      const bool wrap_w = gw + 1 == a.cpk;
+      const bool wrap_r = wrap_w && gr + 1 == a.h_stride;
+      gw = wrap_w ? 0 : gw + 1;
+      gk += wrap_w ? 1 : 0;
+      gr = wrap_r ? 0 : gr + (wrap_w ? 1 : 0);
+      gq += wrap_r ? 1 : 0;
+    } else {
+      w.rc = live ? gv : a.n_cc;
     }
     ++gv;
     return w;
@@ -363,21 +375,25 @@ __global__ __launch_bounds__(WB * 64, 2) void dconv_kernel(const DArgs a) {
 #ifdef RTG_EXP_DC_NOMMA
     return;
 #endif
+    // (inline asm with the accumulator tied to the destination: left to itself the register allocator lets the bf16 form —
+    // and the strided fp32 instances — write a product into the registers of a dead fragment, copies every accumulator and
+    // fragment back at the loop's back edge and waits for ALL loads there, the staged patch two chunks ahead included)
     if constexpr (BF) {
 #pragma unroll
       for (int i = 0; i < RW16; ++i)
 #pragma unroll
         for (int j = 0; j < NT16; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, f.a[i]),
-                                                              __builtin_bit_cast(bf16x8, f.b[j]), acc[i][j], 0, 0, 0);
+          asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(f.a[i]), "v"(f.b[j]));
     } else {
 #pragma unroll
       for (int kq = 0; kq < 4; ++kq)
 #pragma unroll
         for (int i = 0; i < RW16; ++i)
 #pragma unroll
-          for (int j = 0; j < NT16; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[i][kq], f.b[j][kq], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < NT16; ++j) {
+            const float av = f.a[i][kq], bv = f.b[j][kq];
+            asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(av), "v"(bv));
+          }
     }
   };
 
@@ -420,7 +436,7 @@ __global__ __launch_bounds__(WB * 64, 2) void dconv_kernel(const DArgs a) {
       if (t == TW) {
         // publish the next chunk's patch: its buffer was last read by fragment fetches that completed before the
         // previous chunk's barrier; the reads of this chunk's last tap (just requested) are waited for here too
-        if (v + 1 < n_v) stage_write(bufn, nset);
+        if (v + 1 < n_vp) stage_write(bufn, nset);
         // (one asm statement: nothing can be scheduled between the wait and the barrier, no memory access across it)
 #ifndef RTG_EXP_DC_NOBAR
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -431,24 +447,24 @@ __global__ __launch_bounds__(WB * 64, 2) void dconv_kernel(const DArgs a) {
     if constexpr (NSET == 2) { rc0 = rc1; rc1 = rc2; rc2 = rc3; rc3 = gen(); }
     else { rc0 = rc1; rc1 = rc2; rc2 = gen(); }
   };
-  // chunk v + 1's patch sits in set (v + 1) % NSET: odd chunks in Set1, even ones in Set0
+  // chunk v + 1's patch sits in set (v + 1) % NSET: odd chunks in Set1, even ones in Set0.  The loop body is two chunks
+  // (the fragment sets swap with an odd tap count, the staging sets alternate); an odd walk gets one chunk past the end —
+  // out-of-range loads, a patch of zeros — instead of a tail copy of the body: with a tail the register allocator copied
+  // all accumulators and fragments at the loop header and waited for every load in flight there
   int cc = 0;
-  if constexpr (K & 1) {
-    for (; cc + 1 < n_v; cc += 2) {
+  if constexpr ((K & 1) || NSET == 2) {
+    do {                                    // (n_vp >= 2)
       chunk(cc, f0, f1, Set1{});
-      chunk(cc + 1, f1, f0, Set0{});
-    }
-    if (cc < n_v) chunk(cc, f0, f1, Set1{});
-  } else if constexpr (NSET == 2) {
-    for (; cc + 1 < n_v; cc += 2) {
-      chunk(cc, f0, f1, Set1{});
-      chunk(cc + 1, f0, f1, Set0{});
-    }
-    if (cc < n_v) chunk(cc, f0, f1, Set1{});
+      if constexpr (K & 1) chunk(cc + 1, f1, f0, Set0{});
+      else chunk(cc + 1, f0, f1, Set0{});
+      cc += 2;
+    } while (cc < n_vp);
   } else {
     for (; cc < n_v; ++cc) chunk(cc, f0, f1, Set0{});
   }
 
+  // (the matrix instructions are inline asm: the compiler does not know their results are still in flight)
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
   // ---- epilogue: out = act(((acc + bias) * dmask + res) * out_scale) (+ out), the arithmetic and rounding of the general
   // kernel; 32-bit element offsets through buffer descriptors, invalid rows / columns go to an out-of-range offset the
   // hardware drops.  Row m' of the GEMM is output channel m' / S_out at phase m' % S_out (polyphase backward-data).
@@ -554,6 +570,7 @@ bool dconv_eligible(const RtgConv1dDesc* d) {
       if (d->K != 2 || d->stride != 1 || d->h_stride > 4) return false;
     } else {
       if (d->K != 3 || (d->stride != 1 && d->stride != 2) || d->shuf_S != 1) return false;
+      if (d->h_mode == 1 && d->stride != 1) return false;
     }
     if ((long long)(d->B / d->h_n) * (d->C1 / d->h_k) * d->h_in * d->L_in * 4 >= (1ll << 31)) return false;
     if ((long long)(d->B / d->h_n) * d->out_C * d->h_n * d->out_L * 4 >= (1ll << 31)) return false;
@@ -569,9 +586,9 @@ bool dconv_eligible(const RtgConv1dDesc* d) {
   return true;
 }
 
-template <int RW16, int WB, int NT16, int S, int K, bool TWO_D, bool CLS, bool BF>
+template <int RW16, int WB, int NT16, int S, int K, bool TWO_D, bool CLS, bool BF, bool HB = CLS>
 int launch(const DArgs& a, unsigned blocks, size_t lds_bytes, hipStream_t s) {
-  auto k = dconv_kernel<RW16, WB, NT16, S, K, TWO_D, CLS, BF>;
+  auto k = dconv_kernel<RW16, WB, NT16, S, K, TWO_D, CLS, BF, HB>;
   if (lds_bytes > 64 * 1024) {
     static bool attr_set = false;                      // (> 64 KB of dynamic LDS needs the opt-in once per kernel)
     if (!attr_set) {
@@ -588,8 +605,9 @@ template <int RW16, int WB, int NT16, bool BF>
 int launch_sk(const DArgs& a, int S, int K, bool two_d, unsigned blocks, size_t lds_bytes, hipStream_t s) {
   if (two_d) {
     if (a.h_mode == 1 && a.h_stride > 1) return launch<RW16, WB, NT16, 1, 2, true, true, BF>(a, blocks, lds_bytes, s);
+    if (S == 1 && K == 3 && a.h_mode == 1) return launch<RW16, WB, NT16, 1, 3, true, false, BF, true>(a, blocks, lds_bytes, s);
     if (S == 1 && K == 3) return launch<RW16, WB, NT16, 1, 3, true, false, BF>(a, blocks, lds_bytes, s);
-    if (S == 2 && K == 3) return launch<RW16, WB, NT16, 2, 3, true, false, BF>(a, blocks, lds_bytes, s);
+    if (S == 2 && K == 3 && a.h_mode == 0) return launch<RW16, WB, NT16, 2, 3, true, false, BF>(a, blocks, lds_bytes, s);
     return RTG_EINVAL;
   }
   if (S == 1 && K == 5) return launch<RW16, WB, NT16, 1, 5, false, false, BF>(a, blocks, lds_bytes, s);
