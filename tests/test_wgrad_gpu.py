@@ -291,3 +291,64 @@ def test_gconv_wgrad_on_the_vector_alus(case):
     n = lib.rtg_wgrad_shape_candidates(C.byref(probe), cands, 12)
     assert 9 in list(cands[:n])
     _check_case(case, shape_cfg=9, act='none')
+
+
+def _partials(wd_kw, x, dy, cfg, bf16):
+    """rtg_conv1d_wgrad -> the split partials summed in float64: [rows * (Cg * K + 1)]"""
+    from rtg.lib import lib, WgradDesc
+    wd = WgradDesc(**dict(wd_kw, shape_cfg=cfg, bf16=bf16, splits=1, part_stride=0))
+    splits = lib.rtg_wgrad_splits(C.byref(wd))
+    assert splits >= 1, (cfg, bf16, splits)
+    need = wd.Mg * (wd.Cg * wd.K + 1)
+    part = torch.full((splits * need,), float('nan'), device='cuda')
+    wd.splits, wd.part_stride = splits, need
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert lib.rtg_conv1d_wgrad(C.byref(wd), _ptr(x), None, _ptr(dy), None, _ptr(part), st) == 0
+    torch.cuda.synchronize()
+    return part.view(splits, need).double().sum(0)
+
+
+DENSE_BF16 = [
+    # B, C_in, C_out, L (or H, W), K (or kh), stride (or (sh, sw))
+    ('1d', 22, 512, 512, 10, 5, 1), ('1d', 3, 512, 512, 128, 5, 1), ('1d', 14, 256, 512, 44, 5, 3), ('1d', 3, 32, 128, 7, 5, 1),
+    ('2d', 2, 512, 512, (8, 5), 3, (1, 1)), ('2d', 2, 64, 256, (40, 18), 5, (3, 2)), ('2d', 1, 256, 512, (22, 9), 5, (3, 2)),
+]
+
+
+@pytest.mark.parametrize('case', DENSE_BF16)
+def test_dense_wgrad_kernel_bf16(case):
+    """bf16 form of rtg_dwgrad.hip (RtgWgradDesc.bf16: v_mfma_f32_16x16x32_bf16).  On operands that are exactly representable
+    in bf16 every product is exact in fp32: the bf16 codes must reproduce the fp32 general kernel up to the order of the
+    fp32 additions."""
+    from rtg.lib import lib, WgradDesc
+    kind, B, Cin, Cout, L, K, s = case
+    gen = torch.Generator().manual_seed(11)
+
+    def rb(t):
+        return t.bfloat16().float()
+    if kind == '1d':
+        p = 2
+        Lo = (L + 2 * p - K) // s + 1
+        x, dy = rb(torch.randn(B, Cin, L, generator=gen)), rb(torch.randn(B, Cout, Lo, generator=gen))
+        kw = dict(B=B, C1=Cin, C2=0, L_in=L, groups=1, Cg=Cin, Mg=Cout, K=K, stride=s, dil=1, pad=p, Q=Lo, dy_L=Lo, pre_mode=1,
+                  pre_slope=0.5, gy_mode=0, gy_slope=1.0, gy_scale=0.25)
+    else:
+        (H, W), kh, (sh, sw) = L, K, s
+        kw_, ph, pw = 3, kh // 2, 1
+        Ho, Wo = (H + 2 * ph - kh) // sh + 1, (W + 2 * pw - kw_) // sw + 1
+        x, dy = rb(torch.randn(B, Cin, H, W, generator=gen)), rb(torch.randn(B, Cout, Ho, Wo, generator=gen))
+        kw = dict(B=B * Ho, C1=Cin * kh, C2=0, L_in=W, groups=1, Cg=Cin * kh, Mg=Cout, K=kw_, stride=sw, dil=1, pad=pw, Q=Wo,
+                  dy_L=Wo, pre_mode=1, pre_slope=0.5, gy_mode=0, gy_slope=1.0, gy_scale=0.25, h_in=H, h_k=kh, h_stride=sh,
+                  h_pad=ph, h_n=Ho)
+    xd, dyd = x.cuda(), dy.cuda()
+    ref = _partials(kw, xd, dyd, 0, 0)
+    probe = WgradDesc(**dict(kw, bf16=1, splits=1, part_stride=0))
+    cands = (C.c_int * 16)()
+    n = lib.rtg_wgrad_shape_candidates(C.byref(probe), cands, 16)
+    codes = [c for c in cands[:n] if c >= 10]
+    assert codes, 'no dense code listed for the bf16 descriptor'
+    scale = ref.abs().max().item()
+    for c in codes:
+        got = _partials(kw, xd, dyd, c, 1)
+        err = (got - ref).abs().max().item()
+        assert err <= 3e-5 * scale, (c, err, scale)

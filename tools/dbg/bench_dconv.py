@@ -52,13 +52,13 @@ def bench_wgrad(B, Cin, Cout, L, s):
     need = Cout * (Cin * K + 1)
     flop = 2.0 * B * Lo * Cout * Cin * K
     probe = WgradDesc(B=B, C1=Cin, C2=0, L_in=L, groups=1, Cg=Cin, Mg=Cout, K=K, stride=s, dil=1, pad=p, Q=Lo, dy_L=Lo,
-                      pre_mode=1, pre_slope=0.15, gy_mode=0, gy_slope=1.0, gy_scale=1.0, splits=1, part_stride=0)
+                      pre_mode=1, pre_slope=0.15, gy_mode=0, gy_slope=1.0, gy_scale=1.0, splits=1, part_stride=0, bf16=int(BF))
     cands = (C.c_int * 12)()
     n = lib.rtg_wgrad_shape_candidates(C.byref(probe), cands, 12)
     res, ref = [], None
     for c in list(cands[:n]):
         wd = WgradDesc(B=B, C1=Cin, C2=0, L_in=L, groups=1, Cg=Cin, Mg=Cout, K=K, stride=s, dil=1, pad=p, Q=Lo, dy_L=Lo,
-                       pre_mode=1, pre_slope=0.15, gy_mode=0, gy_slope=1.0, gy_scale=1.0, splits=1, part_stride=0, shape_cfg=c)
+                       pre_mode=1, pre_slope=0.15, gy_mode=0, gy_slope=1.0, gy_scale=1.0, splits=1, part_stride=0, shape_cfg=c, bf16=int(BF))
         splits = lib.rtg_wgrad_splits(C.byref(wd))
         if splits < 1:
             continue
@@ -208,7 +208,7 @@ def bench_wgrad_2d(B, Cin, Cout, H, W, kh, sh, sw):
     def desc(c):
         return WgradDesc(B=B * Ho, C1=Cin * kh, C2=0, L_in=W, groups=1, Cg=Cin * kh, Mg=Cout, K=kw, stride=sw, dil=1, pad=pw,
                          Q=Wo, dy_L=Wo, pre_mode=1, pre_slope=0.15, gy_mode=0, gy_slope=1.0, gy_scale=1.0, splits=1,
-                         part_stride=0, h_in=H, h_k=kh, h_stride=sh, h_pad=ph, h_n=Ho, shape_cfg=c)
+                         part_stride=0, h_in=H, h_k=kh, h_stride=sh, h_pad=ph, h_n=Ho, shape_cfg=c, bf16=int(BF))
     cands = (C.c_int * 16)()
     probe = desc(0)
     n = lib.rtg_wgrad_shape_candidates(C.byref(probe), cands, 16)
@@ -249,7 +249,7 @@ if __name__ == '__main__':
     if sys.argv[1:] == ['2d']:
         for sh in MTD:
             bench_2d(*sh)
-        for sh in ([] if BF else MTD):
+        for sh in MTD:
             bench_wgrad_2d(*sh)
         sys.exit(0)
     kinds = sys.argv[1:]

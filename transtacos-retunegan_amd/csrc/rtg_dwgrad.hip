@@ -44,6 +44,7 @@ struct WArgs {
   // second dimension (RtgWgradDesc.h_*; forward geometry): a clip is an (item, output row) pair, a channel a (channel,
   // kernel row) pair; x is [items, Cg / h_k, h_in, L_in], dy [items, Mg, h_n, dy_L]
   int h_in, h_k, h_stride, h_pad, h_n;
+  int bf;                       // (host side: which instance)
 };
 
 __device__ __forceinline__ float dw_load(rsrc_t r, unsigned voff, unsigned soff) {
@@ -55,8 +56,15 @@ __device__ __forceinline__ f32x4 dw_load4(rsrc_t r, unsigned voff, unsigned soff
 
 // S: stride; kWB: waves; RW: 16-row tiles per wave; NCH: channel chunks per block; kK: taps; TWO_D: the Conv2d layers of
 // StftDiscriminator (discrminator.py:255-262) along their last axis
-template <int S, int kWB, int NCH, int RW, int kK, bool TWO_D>
+//
+// BF (RtgWgradDesc.bf16): bf16 operands on v_mfma_f32_16x16x32_bf16, fp32 accumulation: a lane's fragment is 8 consecutive
+// reductions — two of the 4-element gy groups, converted when the fragment is built; the column image holds bf16 (a tile is
+// two 32-reduction groups of four planes [kgrp][column][8 bf16], the staging writes are 2-byte), the activation is applied
+// in fp32 and rounded to nearest even at the LDS write.  Same loads, same loop; an eighth of the matrix instructions.
+using bf16x8 = __bf16 __attribute__((ext_vector_type(8)));
+template <int S, int kWB, int NCH, int RW, int kK, bool TWO_D, bool BF>
 __global__ __launch_bounds__(kWB * 64, 2) void dwgrad_kernel(const WArgs a) {
+  constexpr int NSTEP = BF ? 2 : kNG;                                 // matrix k-groups per 64-reduction tile
   constexpr int kCols = kCch * kK, kNCT = kCols / 16;                 // columns / column tiles of one chunk
   // The column image of one chunk and 16-reduction group: four planes [kgrp][column][4 reductions] (element (column, r) at
   // plane r / 4, slot r % 4: the four k-steps of lane group kgrp).  ds_read_b128 serves a wave in 16-lane groups that pair columns 0-3, 12-15 of one plane with
@@ -66,7 +74,7 @@ __global__ __launch_bounds__(kWB * 64, 2) void dwgrad_kernel(const WArgs a) {
   // (ds_write_b32, lane = reduction index, 32 lanes per LDS cycle) at 2-way, which costs them nothing.
   constexpr int kPS = (kCols * 4 + 63) / 64 * 64;                      // floats between planes 0 / 1 and 2 / 3
   constexpr int kGS = 4 * kPS + 8;                                    // floats per 16-reduction group
-  constexpr int kBF = kNG * kGS;                                      // floats of one chunk's column image (one buffer)
+  constexpr int kBF = NSTEP * kGS;                                    // floats of one chunk's column image (one buffer)
   constexpr int kRows = kWB * RW * 16;
   constexpr int CPW = NCH * kCch / kWB;                               // input channels a wave stages per tile
   static_assert(NCH * kCch % kWB == 0, "channels split evenly over the waves");
@@ -112,7 +120,8 @@ __global__ __launch_bounds__(kWB * 64, 2) void dwgrad_kernel(const WArgs a) {
   auto a_load = [&](int tile) __attribute__((always_inline)) {
 #pragma unroll
     for (int g = 0; g < kNG; ++g) {
-      const int n0 = tile * kTT + g * 16 + kgrp * 4;
+      // this lane's four consecutive reductions of group g (bf16: halves g & 1 of the 8 reductions of k-group g >> 1)
+      const int n0 = tile * kTT + (BF ? (g >> 1) * 32 + kgrp * 8 + (g & 1) * 4 : g * 16 + kgrp * 4);
       int q0;
       const int clip = divq(n0, q0);
       const int left = a.n_red - n0;
@@ -177,6 +186,21 @@ __global__ __launch_bounds__(kWB * 64, 2) void dwgrad_kernel(const WArgs a) {
   };
   auto b_write = [&](int buf) __attribute__((always_inline)) {
     // channel c = wave + kWB * j of the block's NCH * 16: chunk c / 16, column (c % 16) * K + t
+    if constexpr (BF) {
+      // reduction n = lane: k-group n / 32, plane (n / 8) % 4, element n % 8 of the column's 16 bytes
+      const int kg = (lane >> 3) & 3;
+      __bf16* pb = reinterpret_cast<__bf16*>(lds + buf * (NCH * kBF) + (lane >> 5) * kGS + kg * kPS + (kg >> 1) * 4) + (lane & 7);
+#pragma unroll
+      for (int j = 0; j < CPW; ++j) {
+        const int c = wave + kWB * j;
+#pragma unroll
+        for (int t = 0; t < kK; ++t) {
+          float v = sb[j][t];
+          asm volatile("" : "+v"(v));
+          pb[((c >> 4) * kBF + ((c & 15) * kK + t) * 4) * 2] = (__bf16)(v > 0.f ? v : v * a.xslope);
+        }
+      }
+    } else {
     const int wr = lane & 15;
     float* pb = lds + buf * (NCH * kBF) + (lane >> 4) * kGS + (wr >> 2) * kPS + (wr >> 3) * 4 + (wr & 3);
 #pragma unroll
@@ -188,6 +212,7 @@ __global__ __launch_bounds__(kWB * 64, 2) void dwgrad_kernel(const WArgs a) {
         asm volatile("" : "+v"(v));                 // keep the consumption (and its wait) here, below the multiplications
         pb[(c >> 4) * kBF + ((c & 15) * kK + t) * 4] = v > 0.f ? v : v * a.xslope;
       }
+    }
     }
   };
 
@@ -236,6 +261,28 @@ __global__ __launch_bounds__(kWB * 64, 2) void dwgrad_kernel(const WArgs a) {
             f.b[h][j] = *reinterpret_cast<const f32x4*>(pb + h * kBF + g * kGS + j * 64);
       };
       auto mma = [&](const Frag& f, int g) __attribute__((always_inline)) {
+        if constexpr (BF) {
+#pragma unroll
+          for (int i = 0; i < RW; ++i) {
+            bf16x8 av;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              av[e] = (__bf16)fa[i][2 * g][e];
+              av[4 + e] = (__bf16)fa[i][2 * g + 1][e];
+            }
+#pragma unroll
+            for (int h = 0; h < NCH; ++h)
+#pragma unroll
+              for (int j = 0; j < kNCT; ++j)
+                acc[i][h][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(bf16x8, f.b[h][j]), acc[i][h][j], 0, 0, 0);
+            if constexpr (BIAS) {
+              const __bf16 one = (__bf16)1.0f;
+              const bf16x8 ones = {one, one, one, one, one, one, one, one};
+              accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, ones, accb[i], 0, 0, 0);
+            }
+          }
+          return;
+        }
 #pragma unroll
         for (int kq = 0; kq < 4; ++kq)
 #pragma unroll
@@ -254,10 +301,10 @@ __global__ __launch_bounds__(kWB * 64, 2) void dwgrad_kernel(const WArgs a) {
         Frag f0, f1;
         fetch(f0, 0);
 #pragma unroll
-        for (int g = 0; g < kNG; ++g) {
+        for (int g = 0; g < NSTEP; ++g) {
           Frag& fc = (g & 1) ? f1 : f0;
           Frag& fn = (g & 1) ? f0 : f1;
-          if (g + 1 < kNG) fetch(fn, g + 1);
+          if (g + 1 < NSTEP) fetch(fn, g + 1);
           __builtin_amdgcn_sched_barrier(0);
           mma(fc, g);
           __builtin_amdgcn_sched_barrier(0);
@@ -265,7 +312,7 @@ __global__ __launch_bounds__(kWB * 64, 2) void dwgrad_kernel(const WArgs a) {
       } else {
         Frag f;
 #pragma unroll
-        for (int g = 0; g < kNG; ++g) {
+        for (int g = 0; g < NSTEP; ++g) {
           fetch(f, g);
           mma(f, g);
         }
@@ -308,13 +355,14 @@ __global__ __launch_bounds__(kWB * 64, 2) void dwgrad_kernel(const WArgs a) {
 struct DwShape {
   int wb, nch, rw;
 };
-constexpr DwShape kDw[] = {{8, 1, 1}, {8, 2, 1}, {8, 4, 1}};      // (the 4-chunk shape: 3-tap layers only, 192 columns)
+// (the 4-chunk shape: 3-tap layers, or bf16 — half the fragment registers; the 8-chunk shape: 3-tap bf16 layers)
+constexpr DwShape kDw[] = {{8, 1, 1}, {8, 2, 1}, {8, 4, 1}, {8, 8, 1}};
 constexpr int kNumDw = sizeof(kDw) / sizeof(DwShape);
 
 bool eligible(const RtgWgradDesc* d, int variant) {
   if (variant < 0 || variant >= kNumDw) return false;
   const int kRows = kDw[variant].wb * kDw[variant].rw * 16;
-  if (d->groups != 1 || d->C2 != 0 || d->bf16 || d->dil != 1) return false;
+  if (d->groups != 1 || d->C2 != 0 || (d->bf16 != 0 && d->bf16 != 1) || d->dil != 1) return false;
   const bool two_d = d->h_k > 1 || d->h_n > 1;
   if (two_d) {
     if (d->K != 3 || (d->stride != 1 && d->stride != 2)) return false;
@@ -326,7 +374,8 @@ bool eligible(const RtgWgradDesc* d, int variant) {
     if ((long long)d->B * d->C1 * d->L_in * 4 >= (1ll << 31)) return false;
   }
   if (d->Cg != d->C1 || d->Cg % (kCch * kDw[variant].nch) != 0 || d->Mg % kRows != 0) return false;
-  if (kDw[variant].nch == 4 && d->K != 3) return false;
+  if (kDw[variant].nch == 4 && d->K != 3 && !d->bf16) return false;
+  if (kDw[variant].nch == 8 && (d->K != 3 || !d->bf16)) return false;
   if (d->gy_mode != RTG_PRE_NONE || (d->pre_mode != RTG_PRE_NONE && d->pre_mode != RTG_PRE_LRELU)) return false;
   if (d->Q < 4 || d->Q > d->dy_L) return false;                               // (four consecutive reductions span <= 2 clips)
   const long long n = (long long)d->B * d->Q;
@@ -347,7 +396,8 @@ int rtg_dwgrad_splits(const RtgWgradDesc* d, int variant) {
   const DwShape sh = kDw[variant];
   const long long base = (long long)(d->Mg / (sh.wb * sh.rw * 16)) * (d->Cg / (kCch * sh.nch));
   const long long tiles = ((long long)d->B * d->Q + kTT - 1) / kTT;
-  const double t_tile = 0.27 * sh.wb * sh.nch * sh.rw * (d->K / 5.0) + 0.3, t_fixed = 6.0;
+  // (bf16: the matrix part of a tile is an eighth; the operand loads and the staging stay)
+  const double t_tile = (d->bf16 ? 0.1 : 0.27) * sh.wb * sh.nch * sh.rw * (d->K / 5.0) + 0.3, t_fixed = 6.0;
   const double t_flush = (double)d->Mg * ((double)d->Cg * d->K + 1) * 8.0 / 3.0e6;
   const long long slots = sh.wb == 8 ? 256 : 512;
   double best = 1e30;
@@ -361,11 +411,11 @@ int rtg_dwgrad_splits(const RtgWgradDesc* d, int variant) {
   return (int)best_s;
 }
 
-template <int S, int WB, int NCH, int RW, int K, bool TWO_D>
-static int dw_launch(const WArgs& a, hipStream_t s) {
-  auto k = dwgrad_kernel<S, WB, NCH, RW, K, TWO_D>;
+template <int S, int WB, int NCH, int RW, int K, bool TWO_D, bool BF>
+static int dw_launch_bf(const WArgs& a, hipStream_t s) {
+  auto k = dwgrad_kernel<S, WB, NCH, RW, K, TWO_D, BF>;
   constexpr int kPS = (kCch * K * 4 + 63) / 64 * 64, kGS = 4 * kPS + 8;     // (the kernel's plane / group strides)
-  const size_t lds_bytes = (size_t)2 * NCH * (kNG * kGS) * sizeof(float);
+  const size_t lds_bytes = (size_t)2 * NCH * ((BF ? 2 : kNG) * kGS) * sizeof(float);
   static bool attr_set = false;
   if (lds_bytes > 64 * 1024 && !attr_set) {
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return RTG_ERANGE;
@@ -374,6 +424,10 @@ static int dw_launch(const WArgs& a, hipStream_t s) {
   RTG_KLAUNCH(k, dim3((unsigned)(8 * a.per_xcd)), dim3(WB * 64), lds_bytes, s, a);
   return rtg_launch_status();
 }
+template <int S, int WB, int NCH, int RW, int K, bool TWO_D>
+static int dw_launch(const WArgs& a, hipStream_t s) {
+  return a.bf ? dw_launch_bf<S, WB, NCH, RW, K, TWO_D, true>(a, s) : dw_launch_bf<S, WB, NCH, RW, K, TWO_D, false>(a, s);
+}
 
 int rtg_dwgrad_launch(const RtgWgradDesc* d, int variant, const float* x, const float* dy, float* part, hipStream_t s) {
   if (!eligible(d, variant)) return RTG_EINVAL;
@@ -381,7 +435,7 @@ int rtg_dwgrad_launch(const RtgWgradDesc* d, int variant, const float* x, const 
   if ((reinterpret_cast<uintptr_t>(dy) & 3) != 0) return RTG_EINVAL;
   const DwShape sh = kDw[variant];
   WArgs a;
-  a.x = x; a.dy = dy; a.part = part;
+  a.x = x; a.dy = dy; a.part = part; a.bf = d->bf16;
   a.B = d->B; a.Cg = d->Cg; a.L_in = d->L_in; a.Mg = d->Mg; a.Q = d->Q; a.dy_L = d->dy_L; a.pad = d->pad;
   a.xslope = d->pre_mode == RTG_PRE_LRELU ? d->pre_slope : 1.f;
   a.gy_scale = d->gy_scale;
@@ -404,9 +458,11 @@ int rtg_dwgrad_launch(const RtgWgradDesc* d, int variant, const float* x, const 
   if (two_d) {
     if (variant == 0) return S == 1 ? dw_launch<1, 8, 1, 1, 3, true>(a, s) : dw_launch<2, 8, 1, 1, 3, true>(a, s);
     if (variant == 1) return S == 1 ? dw_launch<1, 8, 2, 1, 3, true>(a, s) : dw_launch<2, 8, 2, 1, 3, true>(a, s);
-    return S == 1 ? dw_launch<1, 8, 4, 1, 3, true>(a, s) : dw_launch<2, 8, 4, 1, 3, true>(a, s);
+    if (variant == 2) return S == 1 ? dw_launch<1, 8, 4, 1, 3, true>(a, s) : dw_launch<2, 8, 4, 1, 3, true>(a, s);
+    return S == 1 ? dw_launch_bf<1, 8, 8, 1, 3, true, true>(a, s) : dw_launch_bf<2, 8, 8, 1, 3, true, true>(a, s);
   }
   if (variant == 0) return S == 1 ? dw_launch<1, 8, 1, 1, 5, false>(a, s) : dw_launch<3, 8, 1, 1, 5, false>(a, s);
   if (variant == 1) return S == 1 ? dw_launch<1, 8, 2, 1, 5, false>(a, s) : dw_launch<3, 8, 2, 1, 5, false>(a, s);
+  if (variant == 2 && a.bf) return S == 1 ? dw_launch_bf<1, 8, 4, 1, 5, false, true>(a, s) : dw_launch_bf<3, 8, 4, 1, 5, false, true>(a, s);
   return RTG_EINVAL;
 }
