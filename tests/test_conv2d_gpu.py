@@ -10,7 +10,9 @@ DEV = 'cuda'
 
 CASES = [
     # B, Cin, Cout, H, W, (kh,kw), (sh,sw), (ph,pw)
-    (2, 2, 32, 65, 35, (3, 3), (2, 1), (1, 1)),
+    (2, 2, 32, 65, 35, (3, 3), (2, 1), (1, 1)),      # the first layer: rtg_thin2d.hip (forward; weight gradient with force 7)
+    (3, 2, 32, 129, 137, (3, 3), (2, 1), (1, 1)),    # several blocks, a partial last one
+    (1, 2, 32, 8, 5, (3, 3), (2, 1), (1, 1)),        # an even row count (the last kernel row of the last output row is padding)
     (2, 32, 64, 33, 35, (3, 3), (2, 2), (1, 1)),
     (2, 64, 256, 40, 18, (5, 3), (3, 2), (2, 1)),
     (3, 256, 512, 22, 9, (5, 3), (3, 2), (2, 1)),
@@ -25,11 +27,12 @@ class _Net(nn.Module):
     pass
 
 
-@pytest.mark.parametrize('force', [0, 10, 11])
+@pytest.mark.parametrize('force', [0, 7, 10, 11])
 @pytest.mark.parametrize('case', CASES)
 def test_conv2d_layer_forward_backward(case, force, monkeypatch):
-    """force: the weight-gradient block shape the tuner would have to pick (0: the library's heuristic; 10, 11: the dense
-    kernel of rtg_dwgrad.hip in its 2-D mode, where it serves the layer)"""
+    """force: the weight-gradient block shape the tuner would have to pick (0: the library's heuristic; 7: the bandwidth
+    kernels of rtg_wgrad_thin.hip / rtg_thin2d.hip; 10, 11: the dense kernel of rtg_dwgrad.hip in its 2-D mode, where it
+    serves the layer)"""
     import ctypes as C
     from models.layers import WNConv, BankedModel, conv
     from rtg import tune
@@ -82,8 +85,10 @@ def test_conv2d_layer_forward_backward(case, force, monkeypatch):
     close(net.c.weight_v.grad, v.grad, 'dv')
     close(net.c.weight_g.grad, g.grad, 'dg')
     close(net.c.bias.grad, bias.grad, 'dbias')
-    if force and Cout % 128 == 0 and (Cin * k[0]) % (32 if force == 11 else 16) == 0 and out.shape[-1] >= 4:
+    if force >= 10 and Cout % 128 == 0 and (Cin * k[0]) % (32 if force == 11 else 16) == 0 and out.shape[-1] >= 4:
         assert used == [force], used              # the dense kernel really ran
+    if force == 7 and Cin == 2:
+        assert used == [7], used                  # the two-channel bandwidth kernel really ran
 
 
 def _stats(t):

@@ -1,0 +1,212 @@
+// rtg_thin2d.hip — bandwidth kernels for the FIRST Conv2d of StftDiscriminator (discrminator.py:256:
+// Conv2d(2, 32, (3, 3), stride (2, 1), padding (1, 1)) over the [B, 2, 1025 / 513 / 257, frames] phase / magnitude maps).
+// 18 multiply-accumulates per output: the layer moves 150-300 MB per pass and computes almost nothing, but on the matrix
+// path (6 virtual channels padded to a 16-channel chunk, rows of 35-137 columns) it ran at 2-12 TFLOP/s: 0.3 ms per pass.
+//   forward          a thread owns two output positions (item, row, column) and all 32 output channels: its 2 x 18 inputs
+//                    in registers, the 18 x 32 weights in LDS read as broadcast 16-byte fragments (one read per 8 FMAs),
+//                    32 coalesced stores per position;
+//   weight gradient  the four waves of a block split the output channels (8 each): a lane walks positions 64 apart with
+//                    8 x 18 + 8 accumulators in registers (8 coalesced dy loads, 18 cached x loads per position), one wave
+//                    reduction per block, one split partial per block in the weight bank's layout (fixed-order reduce in
+//                    rtg_weightnorm_backward).
+// Backward-data of this layer (the generator step's gradient into the STFT) stays on the general kernel.
+// Exposed as thin kind 4 of rtg_conv1d (rtg_thin_kind) and thin kind 4 of the weight-gradient shape code 7.
+#include "rtg_common.h"
+
+namespace {
+
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+constexpr unsigned kOob = 0x80000000u;
+constexpr int kM = 32, kCr = 2, kKH = 3, kKW = 3, kNK = kCr * kKH * kKW;       // 18 products per output
+constexpr int kThreads = 256;
+
+struct T2Args {
+  const float *x, *wp, *bias, *dy;
+  float *out, *part;
+  long long part_stride;
+  int items, H, W, Ho, h_stride, tile_m, splits;
+  float pre_slope, gy_scale;
+  int n_pos;                   // items * Ho * W
+  int x_bytes, y_bytes;        // bytes of x and of the [items, 32, Ho, W] tensor (out / dy)
+};
+
+__device__ __forceinline__ float t2_load(rsrc_t r, unsigned off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+}
+
+// the 18 inputs of output position p = (item, ho, w): x[item][ci][ho * h_stride - 1 + kh][w - 1 + kw], activation applied,
+// zeros outside the map (out-of-range buffer offsets); `yoff`: element offset of (item, channel 0, ho, w) in out / dy
+__device__ __forceinline__ void t2_inputs(const T2Args& a, rsrc_t rx, int p, float (&xv)[kNK], unsigned& yoff) {
+  const bool live = p < a.n_pos;
+  const int hw = a.Ho * a.W;
+  const int b = p / hw, r = p - b * hw;
+  const int ho = r / a.W, w = r - ho * a.W;
+  yoff = live ? (unsigned)(b * kM * hw + r) * 4u : kOob;
+#pragma unroll
+  for (int ci = 0; ci < kCr; ++ci)
+#pragma unroll
+    for (int kh = 0; kh < kKH; ++kh) {
+      const int row = ho * a.h_stride - 1 + kh;
+      const bool rok = live && (unsigned)row < (unsigned)a.H;
+      const unsigned rb = (unsigned)(((b * kCr + ci) * a.H + row) * a.W);
+#pragma unroll
+      for (int kw = 0; kw < kKW; ++kw) {
+        const int col = w - 1 + kw;
+        const float v = t2_load(rx, (rok && (unsigned)col < (unsigned)a.W) ? (rb + (unsigned)col) * 4u : kOob);
+        xv[(ci * kKH + kh) * kKW + kw] = v > 0.f ? v : v * a.pre_slope;
+      }
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void cin2_fwd_kernel(const T2Args a) {
+  __shared__ __attribute__((aligned(16))) float wl[kNK * kM];         // [product k = (ci, kh, kw)][output channel]
+  __shared__ __attribute__((aligned(16))) float bl[kM];
+  // weights from the packed forward image [row tile][chunk 0][tap = kw][channel pair][kk][row], channel = ci * 3 + kh
+  const int KK = 64 / a.tile_m;
+  for (int e = threadIdx.x; e < kNK * kM; e += kThreads) {
+    const int k = e / kM, m = e - k * kM;
+    const int c = k / kKW, tap = k - c * kKW;
+    const int mt = m / a.tile_m, mm = m - mt * a.tile_m;
+    wl[e] = a.wp[(mt * kKW + tap) * (RTG_CK * a.tile_m) + (c / KK) * 64 + (c % KK) * a.tile_m + mm];
+  }
+  if (threadIdx.x < kM) bl[threadIdx.x] = a.bias ? a.bias[threadIdx.x] : 0.f;
+  const rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+  const rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, a.y_bytes, 0x00020000);
+  float xa[kNK], xb[kNK];
+  unsigned oa, ob;
+  const int p0 = (int)blockIdx.x * (2 * kThreads) + (int)threadIdx.x;
+  t2_inputs(a, rx, p0, xa, oa);
+  t2_inputs(a, rx, p0 + kThreads, xb, ob);
+  __syncthreads();
+  const unsigned chb = (unsigned)(a.Ho * a.W) * 4u;                     // bytes per output channel plane
+#pragma unroll
+  for (int g = 0; g < kM / 4; ++g) {
+    float va[4], vb[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) va[r] = vb[r] = bl[4 * g + r];
+#pragma unroll
+    for (int k = 0; k < kNK; ++k) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float wv = wl[k * kM + 4 * g + r];                      // (every lane the same address: broadcast reads)
+        va[r] = __builtin_fmaf(xa[k], wv, va[r]);
+        vb[r] = __builtin_fmaf(xb[k], wv, vb[r]);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, va[r]), ro, oa, (unsigned)(4 * g + r) * chb, 0);
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vb[r]), ro, ob, (unsigned)(4 * g + r) * chb, 0);
+    }
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void cin2_wgrad_kernel(const T2Args a) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);    // output channels 8 * wave .. + 7
+  const rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+  const rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.y_bytes, 0x00020000);
+  const int per = (a.n_pos + a.splits - 1) / a.splits;
+  const int p_lo = (int)blockIdx.x * per;
+  const int p_hi = p_lo + per < a.n_pos ? p_lo + per : a.n_pos;
+  const unsigned chb = (unsigned)(a.Ho * a.W) * 4u;
+  float acc[8][kNK], bacc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    bacc[j] = 0.f;
+#pragma unroll
+    for (int k = 0; k < kNK; ++k) acc[j][k] = 0.f;
+  }
+  for (int p = p_lo + lane; p < p_hi; p += 64) {
+    float xv[kNK], gy[8];
+    unsigned yo;
+    t2_inputs(a, rx, p, xv, yo);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      gy[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, yo, (unsigned)(8 * wave + j) * chb, 0));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      bacc[j] += gy[j];
+#pragma unroll
+      for (int k = 0; k < kNK; ++k) acc[j][k] = __builtin_fmaf(gy[j], xv[k], acc[j][k]);
+    }
+  }
+  // this block's partial: [row m][column (ci * 3 + kh) * 3 + kw], then the bias column
+  float* wpart = a.part + (size_t)blockIdx.x * a.part_stride;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int m = 8 * wave + j;
+#pragma unroll
+    for (int k = 0; k < kNK; ++k) {
+      const float s = rtg_wave_sum(acc[j][k]);
+      if (lane == 0) wpart[m * kNK + k] = s * a.gy_scale;
+    }
+    const float sb = rtg_wave_sum(bacc[j]);
+    if (lane == 0) wpart[kM * kNK + m] = sb * a.gy_scale;
+  }
+}
+
+template <class D>
+bool t2_shape_ok(const D* d) {
+  if (d->groups != 1 || d->C2 != 0 || d->h_k != kKH || d->K != kKW || d->C1 != kCr * kKH || d->Cg != d->C1 || d->Mg != kM) return false;
+  if (d->stride != 1 || d->dil != 1 || d->pad != 1 || d->h_pad != 1 || d->h_stride < 1 || d->h_stride > 2) return false;
+  if (d->h_in < 1 || d->h_n < 1 || d->B % d->h_n != 0 || d->Q != d->L_in) return false;
+  if (d->h_n != (d->h_in + 2 - kKH) / d->h_stride + 1) return false;
+  if (d->pre_mode != RTG_PRE_NONE && d->pre_mode != RTG_PRE_LRELU) return false;
+  const long long items = d->B / d->h_n;
+  if (items * kCr * d->h_in * d->L_in * 4 >= (1ll << 31) || items * kM * d->h_n * d->L_in * 4 >= (1ll << 31)) return false;
+  return true;
+}
+
+template <class D>
+void t2_fill(const D* d, T2Args* a) {
+  a->items = d->B / d->h_n; a->H = d->h_in; a->W = d->L_in; a->Ho = d->h_n; a->h_stride = d->h_stride;
+  a->pre_slope = d->pre_mode == RTG_PRE_LRELU ? d->pre_slope : 1.f;
+  a->n_pos = a->items * a->Ho * a->W;
+  a->x_bytes = a->items * kCr * a->H * a->W * 4;
+  a->y_bytes = a->items * kM * a->Ho * a->W * 4;
+}
+
+}  // namespace
+
+bool rtg_thin2d_fwd_ok(const RtgConv1dDesc* d) {
+  if (!t2_shape_ok(d) || d->h_mode != 0 || d->bf16 || d->tap_major || d->shuf_S != 1 || d->out_split != 0 || d->accumulate) return false;
+  if (d->out_C != kM || d->out_L != d->Q || d->act != RTG_ACT_NONE || d->out_scale != 1.f) return false;
+  if (d->tile_m != 32 && d->tile_m != 16) return false;
+  return !RTG_ENV_SET("RTG_THIN2D_OFF");
+}
+
+int rtg_thin2d_fwd_launch(const RtgConv1dDesc* d, const float* x, const float* wp, const float* bias, const float* mask,
+                          const float* res, float* out, hipStream_t s) {
+  if (!rtg_thin2d_fwd_ok(d) || mask || res) return RTG_EINVAL;
+  if (!x || !wp || !out) return RTG_ENULL;
+  T2Args a = {};
+  t2_fill(d, &a);
+  a.x = x; a.wp = wp; a.bias = bias; a.out = out; a.tile_m = d->tile_m;
+  RTG_KLAUNCH(cin2_fwd_kernel, dim3((unsigned)rtg_ceil_div(a.n_pos, 2 * kThreads)), dim3(kThreads), 0, s, a);
+  return rtg_launch_status();
+}
+
+bool rtg_thin2d_wgrad_ok(const RtgWgradDesc* d) {
+  if (!t2_shape_ok(d) || d->gy_mode != RTG_PRE_NONE || d->dy_L != d->Q) return false;
+  return !RTG_ENV_SET("RTG_THIN2D_OFF");
+}
+
+// one block per split; a lane should see a few dozen positions (the wave reduction at the end is ~150 values)
+int rtg_thin2d_wgrad_splits(const RtgWgradDesc* d) {
+  if (!rtg_thin2d_wgrad_ok(d)) return RTG_EINVAL;
+  const long long n_pos = (long long)d->B * d->Q;
+  long long s = n_pos / (64 * 48);
+  if (s > 512) s = 512;
+  return (int)(s < 1 ? 1 : s);
+}
+
+int rtg_thin2d_wgrad_launch(const RtgWgradDesc* d, const float* x, const float* dy, float* part, hipStream_t s) {
+  if (!rtg_thin2d_wgrad_ok(d) || d->splits != rtg_thin2d_wgrad_splits(d)) return RTG_EINVAL;
+  if (!x || !dy || !part) return RTG_ENULL;
+  T2Args a = {};
+  t2_fill(d, &a);
+  a.x = x; a.dy = dy; a.part = part; a.part_stride = d->part_stride; a.splits = d->splits; a.gy_scale = d->gy_scale;
+  RTG_KLAUNCH(cin2_wgrad_kernel, dim3((unsigned)d->splits), dim3(kThreads), 0, s, a);
+  return rtg_launch_status();
+}

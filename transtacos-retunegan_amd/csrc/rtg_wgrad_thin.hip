@@ -244,8 +244,15 @@ __global__ __launch_bounds__(RTG_THREADS) void wgrad_cout1_short_kernel(const Wt
 
 }  // namespace
 
-// 0: not served; 1: one input channel; 2: one output channel, long rows; 3: one output channel, short rows
+// rtg_thin2d.hip: the first Conv2d of StftDiscriminator (2 input channels)
+bool rtg_thin2d_wgrad_ok(const RtgWgradDesc* d);
+int rtg_thin2d_wgrad_splits(const RtgWgradDesc* d);
+int rtg_thin2d_wgrad_launch(const RtgWgradDesc* d, const float* x, const float* dy, float* part, hipStream_t s);
+
+// 0: not served; 1: one input channel; 2: one output channel, long rows; 3: one output channel, short rows;
+// 4: two input channels, 3 x 3 (rtg_thin2d.hip)
 int rtg_wgrad_thin_kind(const RtgWgradDesc* d) {
+  if (rtg_thin2d_wgrad_ok(d)) return 4;
   if (d->groups != 1 || d->C2 != 0 || d->h_k > 1 || d->h_n > 1) return 0;
   if (d->pre_mode != RTG_PRE_NONE && d->pre_mode != RTG_PRE_LRELU) return 0;
   if (d->Cg == 1 && d->C1 == 1 && d->Mg >= 2 && d->Mg <= 32 && (d->K == 5 || d->K == 7 || d->K == 15) &&
@@ -262,6 +269,7 @@ int rtg_wgrad_thin_kind(const RtgWgradDesc* d) {
 int rtg_wgrad_thin_splits(const RtgWgradDesc* d) {
   const int kind = rtg_wgrad_thin_kind(d);
   if (kind == 0) return RTG_EINVAL;
+  if (kind == 4) return rtg_thin2d_wgrad_splits(d);
   if (kind == 3) {
     const int cb = rtg_ceil_div(d->Cg, RTG_THREADS);
     int s = 512 / cb;                                  // ~512 blocks in all
@@ -276,6 +284,7 @@ int rtg_wgrad_thin_launch(const RtgWgradDesc* d, const float* x, const float* dy
                           hipStream_t s) {
   const int kind = rtg_wgrad_thin_kind(d);
   if (kind == 0) return RTG_EINVAL;
+  if (kind == 4) return rtg_thin2d_wgrad_launch(d, x, dy, part, s);
   if (d->splits != rtg_wgrad_thin_splits(d)) return RTG_EINVAL;
   if ((d->gy_mode == RTG_PRE_MUL_DLRELU || d->gy_mode == RTG_PRE_MUL_DTANH) && !aux) return RTG_ENULL;
   WtArgs a;

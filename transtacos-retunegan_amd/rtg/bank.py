@@ -99,8 +99,12 @@ class ConvLayer:
             if self.bwd_tap and self.bwd_op[3] >= min_c:
                 self.bwd_tap = 0
 
+        # (the first Conv2d of StftDiscriminator — 2 input channels, 18 products per output — is a bandwidth kernel of its
+        # own in fp32, rtg_thin2d.hip)
+        thin2d = self.kind == 'conv2d' and self.cin <= 2
+
         def ok(op, tap):
-            return bool(want_bf and not tap and op[2] > 1 and op[3] > 1)
+            return bool(want_bf and not tap and op[2] > 1 and op[3] > 1 and not thin2d)
         # the dense-layer kernel (rtg_dconv.hip, block-shape codes 8xxx) reads 16-byte operand fragments: layers it can serve
         # (>= 32 input channels, >= 64 output rows, dilation 1; 1-D: k5 at stride 1 / 3 forward, the k5 stride-1 or 2-tap
         # polyphase backward-data operator; Conv2d of the spectrogram discriminators: forward, stride-1 backward-data) carry a second image of their weights behind the standard one (RtgPackJob.frag16,
@@ -131,7 +135,7 @@ class ConvLayer:
         self.bwd16 = dense(self.bwd_op, False) if not self.bwd_tap else 0
         self.frag_bf = int(want_bf)           # the fragment images are bf16 with the layer
         self.fwd_bf = int(ok(self.fwd_op, self.fwd_tap))
-        self.wgrad_bf = int(want_bf)          # the weight-gradient kernel has one K order: every layer
+        self.wgrad_bf = int(want_bf and not thin2d)   # the weight-gradient kernel has one K order: every layer
         self.bwd_bf = int(ok(self.bwd_op, self.bwd_tap))     # (the class-pure strided 2-D backward-data included)
         # filled by the bank
         self.g_off = self.v_off = self.b_off = self.scale_off = 0
