@@ -156,9 +156,9 @@ typedef struct RtgWgradDesc {
   int shape_cfg;               /* block shape: 0 = the library's heuristic, else a code listed by
                                   rtg_wgrad_shape_candidates.  Codes 1-6 (the general kernel's block shapes) do not
                                   change the summation order (the number of splits does); 7 (one-channel layers), 8
-                                  (UNet-G residual convs), 9 (thin-group layers on the vector ALUs) and 10 .. 13 (dense
+                                  (UNet-G residual convs), 9 (thin-group layers on the vector ALUs) and 10 .. 14 (dense
                                   discriminator layers, rtg_dwgrad.hip: 1 / 2 / 4 / 8 channel chunks per block; 12 for
-                                  3-tap or bf16 layers, 13 for 3-tap bf16 layers) are kernels of their own:
+                                  3-tap or bf16 layers, 13 for 3-tap bf16 layers, 14 = 64-row blocks for 3-tap layers of 64 rows) are kernels of their own:
                                   rounding-level differences, each reproducible run to run                           */
   int bf16;                    /* 1: both operands rounded to bf16 as they are read from LDS, bf16 matrix cores, fp32
                                   accumulation and fp32 split partials (BASELINE configs[2])                         */

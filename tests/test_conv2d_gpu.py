@@ -27,7 +27,7 @@ class _Net(nn.Module):
     pass
 
 
-@pytest.mark.parametrize('force', [0, 7, 10, 11])
+@pytest.mark.parametrize('force', [0, 7, 10, 11, 14])
 @pytest.mark.parametrize('case', CASES)
 def test_conv2d_layer_forward_backward(case, force, monkeypatch):
     """force: the weight-gradient block shape the tuner would have to pick (0: the library's heuristic; 7: the bandwidth
@@ -85,8 +85,10 @@ def test_conv2d_layer_forward_backward(case, force, monkeypatch):
     close(net.c.weight_v.grad, v.grad, 'dv')
     close(net.c.weight_g.grad, g.grad, 'dg')
     close(net.c.bias.grad, bias.grad, 'dbias')
-    if force >= 10 and Cout % 128 == 0 and (Cin * k[0]) % (32 if force == 11 else 16) == 0 and out.shape[-1] >= 4:
+    if force in (10, 11) and Cout % 128 == 0 and (Cin * k[0]) % (32 if force == 11 else 16) == 0 and out.shape[-1] >= 4:
         assert used == [force], used              # the dense kernel really ran
+    if force == 14 and Cout == 64:
+        assert used == [14], used                 # the 64-row block really ran
     if force == 7 and Cin == 2:
         assert used == [7], used                  # the two-channel bandwidth kernel really ran
 

@@ -312,6 +312,7 @@ DENSE_BF16 = [
     # B, C_in, C_out, L (or H, W), K (or kh), stride (or (sh, sw))
     ('1d', 22, 512, 512, 10, 5, 1), ('1d', 3, 512, 512, 128, 5, 1), ('1d', 14, 256, 512, 44, 5, 3), ('1d', 3, 32, 128, 7, 5, 1),
     ('2d', 2, 512, 512, (8, 5), 3, (1, 1)), ('2d', 2, 64, 256, (40, 18), 5, (3, 2)), ('2d', 1, 256, 512, (22, 9), 5, (3, 2)),
+    ('2d', 2, 32, 64, (33, 35), 3, (2, 2)),          # 64 rows: the 4-wave block (code 14)
 ]
 
 

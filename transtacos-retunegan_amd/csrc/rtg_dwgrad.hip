@@ -356,7 +356,8 @@ struct DwShape {
   int wb, nch, rw;
 };
 // (the 4-chunk shape: 3-tap layers, or bf16 — half the fragment registers; the 8-chunk shape: 3-tap bf16 layers)
-constexpr DwShape kDw[] = {{8, 1, 1}, {8, 2, 1}, {8, 4, 1}, {8, 8, 1}};
+// (a 4-wave block of 64 rows for the 3-tap layers whose row count is no multiple of 128: StftDiscriminator convs.1, 32 -> 64)
+constexpr DwShape kDw[] = {{8, 1, 1}, {8, 2, 1}, {8, 4, 1}, {8, 8, 1}, {4, 2, 1}};
 constexpr int kNumDw = sizeof(kDw) / sizeof(DwShape);
 
 bool eligible(const RtgWgradDesc* d, int variant) {
@@ -376,6 +377,7 @@ bool eligible(const RtgWgradDesc* d, int variant) {
   if (d->Cg != d->C1 || d->Cg % (kCch * kDw[variant].nch) != 0 || d->Mg % kRows != 0) return false;
   if (kDw[variant].nch == 4 && d->K != 3 && !d->bf16) return false;
   if (kDw[variant].nch == 8 && (d->K != 3 || !d->bf16)) return false;
+  if (kDw[variant].wb == 4 && (d->K != 3 || d->Mg % 128 == 0)) return false;
   if (d->gy_mode != RTG_PRE_NONE || (d->pre_mode != RTG_PRE_NONE && d->pre_mode != RTG_PRE_LRELU)) return false;
   if (d->Q < 4 || d->Q > d->dy_L) return false;                               // (four consecutive reductions span <= 2 clips)
   const long long n = (long long)d->B * d->Q;
@@ -459,6 +461,7 @@ int rtg_dwgrad_launch(const RtgWgradDesc* d, int variant, const float* x, const 
     if (variant == 0) return S == 1 ? dw_launch<1, 8, 1, 1, 3, true>(a, s) : dw_launch<2, 8, 1, 1, 3, true>(a, s);
     if (variant == 1) return S == 1 ? dw_launch<1, 8, 2, 1, 3, true>(a, s) : dw_launch<2, 8, 2, 1, 3, true>(a, s);
     if (variant == 2) return S == 1 ? dw_launch<1, 8, 4, 1, 3, true>(a, s) : dw_launch<2, 8, 4, 1, 3, true>(a, s);
+    if (variant == 4) return S == 1 ? dw_launch<1, 4, 2, 1, 3, true>(a, s) : dw_launch<2, 4, 2, 1, 3, true>(a, s);
     return S == 1 ? dw_launch_bf<1, 8, 8, 1, 3, true, true>(a, s) : dw_launch_bf<2, 8, 8, 1, 3, true, true>(a, s);
   }
   if (variant == 0) return S == 1 ? dw_launch<1, 8, 1, 1, 5, false>(a, s) : dw_launch<3, 8, 1, 1, 5, false>(a, s);

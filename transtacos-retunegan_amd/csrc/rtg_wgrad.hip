@@ -57,7 +57,7 @@ constexpr int kThinShape = 7;
 constexpr int kResShape = 8;
 constexpr int kGconvShape = 9;
 constexpr int kDenseShape = 10;       // 10 .. 10 + rtg_dwgrad_variants() - 1: its block shapes
-constexpr int kDenseShapeLast = 13;
+constexpr int kDenseShapeLast = 14;
 
 struct Shape {
   int MTW, NTW, WM;
