@@ -147,41 +147,79 @@ __global__ __launch_bounds__(kWB * 64, 2) void dwgrad_kernel(const WArgs a) {
     return f;
   };
 
-  // ---- columns: the lane is reduction index n of the tile; a wave stages the K shifted copies of CPW channels
-  float sb[CPW][kK];
+  // ---- columns: the lane is reduction index n of the tile; a wave stages the K shifted copies of CPW channels.  The K taps
+  // of a reduction are K CONSECUTIVE input positions (q * S - pad + t), so a channel costs one unaligned 16-byte load (taps
+  // 0 .. 3) and, for five taps, one 4-byte load — not K loads: issuing the loads is what this kernel waits for.  Taps outside
+  // the row read the neighbouring row's elements and are zeroed by a per-lane tap mask when the image is written; an
+  // invalid lane / row loads from an out-of-range offset (zeros).  Only the very first elements of the tensor cannot be
+  // addressed that way (the 16 bytes would start before the buffer): the load starts at element 0 and the taps are taken
+  // `ssh` elements further left (first staged channel of a wave only: every other channel sits at least a row in).
+  f32x4 sbv[CPW];
+  [[maybe_unused]] float sb4[CPW];
+  constexpr int NSH = kWB >= 8 ? 1 : 2;              // channels wave + kWB * j that can be channel 0 / a kernel row of it
+  int ssh[NSH];
+  unsigned stv = 0;                                  // bit t: tap t of this lane's reduction lies inside the row
   auto b_load = [&](int tile) __attribute__((always_inline)) {
     const int n = tile * kTT + lane;
     int q;
     const int clip = divq(n, q);
     const bool valid = n < a.n_red;
+    const int p0 = q * S - a.pad;
+    unsigned tvm = 0;
+#pragma unroll
+    for (int t = 0; t < kK; ++t) tvm |= (valid && (unsigned)(p0 + t) < (unsigned)a.L_in) ? (1u << t) : 0u;
+    stv = tvm;
+    auto issue = [&](int j, int orig, bool ok) __attribute__((always_inline)) {
+      int ai = orig;
+      if (j < NSH) {
+        ai = orig < 0 ? 0 : orig;
+        ssh[j < NSH ? j : 0] = ai - orig;
+      }
+      sbv[j] = dw_load4(rx, ok ? (unsigned)ai * 4u : DW_OOB, 0);
+      if constexpr (kK == 5) sb4[j] = dw_load(rx, (ok && (tvm & 16u)) ? (unsigned)(orig + 4) * 4u : DW_OOB, 0);
+    };
     if constexpr (TWO_D) {
       // channel vc = (c, kh): input row ho * h_stride - h_pad + kh of channel c
       const int item = clip / a.h_n, ho = clip - item * a.h_n;
       const int row0 = ho * a.h_stride - a.h_pad;
       const int cin = a.Cg / a.h_k;
-      const unsigned xitem = (unsigned)item * (unsigned)cin * (unsigned)a.h_in * (unsigned)a.L_in;
+      const int xitem = item * cin * a.h_in * a.L_in + p0;
 #pragma unroll
       for (int j = 0; j < CPW; ++j) {
         const int vc = c0 + wave + kWB * j;
         const int c = vc / a.h_k, kh = vc - c * a.h_k;
         const int row = row0 + kh;
-        const bool rok = valid && (unsigned)row < (unsigned)a.h_in;
-        const unsigned rb = xitem + (unsigned)(c * a.h_in + row) * (unsigned)a.L_in;
-#pragma unroll
-        for (int t = 0; t < kK; ++t) {
-          const int pos = q * S + t - a.pad;
-          sb[j][t] = dw_load(rx, (rok && pos >= 0 && pos < a.L_in) ? (rb + (unsigned)pos) * 4u : DW_OOB, 0);
-        }
+        issue(j, xitem + (c * a.h_in + row) * a.L_in, valid && (unsigned)row < (unsigned)a.h_in);
       }
     } else {
-      const unsigned xclip = (unsigned)clip * (unsigned)a.Cg * (unsigned)a.L_in;
+      const int xclip = clip * a.Cg * a.L_in + p0;
 #pragma unroll
-      for (int t = 0; t < kK; ++t) {
-        const int pos = q * S + t - a.pad;
-        const unsigned vb = (valid && pos >= 0 && pos < a.L_in) ? (xclip + (unsigned)pos) * 4u : DW_OOB;
-#pragma unroll
-        for (int j = 0; j < CPW; ++j) sb[j][t] = dw_load(rx, vb, (unsigned)(c0 + wave + kWB * j) * rowb_x);
+      for (int j = 0; j < CPW; ++j) issue(j, xclip + (c0 + wave + kWB * j) * a.L_in, valid);
+    }
+  };
+  // tap t of staged channel j: element t (- ssh) of the 16 bytes, or the fifth load; zero outside the row
+  auto tapval = [&](const f32x4& lv, float l4, int j, int t) __attribute__((always_inline)) {
+    float v;
+    if (t == 4) {
+      v = l4;
+    } else {
+      v = lv[t];
+      if (j < NSH) {
+        const int sh = ssh[j < NSH ? j : 0];
+        const float v1 = t >= 1 ? lv[t >= 1 ? t - 1 : 0] : 0.f, v2 = t >= 2 ? lv[t >= 2 ? t - 2 : 0] : 0.f;
+        v = sh == 0 ? v : (sh == 1 ? v1 : v2);
       }
+    }
+    return (stv >> t) & 1u ? v : 0.f;
+  };
+  // (the loaded registers are consumed — and waited for — where the image is written, below the multiplications)
+  auto taken = [&](int j, f32x4& lv, float& l4) __attribute__((always_inline)) {
+    lv = sbv[j];
+    asm volatile("" : "+v"(lv));
+    l4 = 0.f;
+    if constexpr (kK == 5) {
+      l4 = sb4[j];
+      asm volatile("" : "+v"(l4));
     }
   };
   auto b_write = [&](int buf) __attribute__((always_inline)) {
@@ -193,10 +231,12 @@ __global__ __launch_bounds__(kWB * 64, 2) void dwgrad_kernel(const WArgs a) {
 #pragma unroll
       for (int j = 0; j < CPW; ++j) {
         const int c = wave + kWB * j;
+        f32x4 lv;
+        float l4;
+        taken(j, lv, l4);
 #pragma unroll
         for (int t = 0; t < kK; ++t) {
-          float v = sb[j][t];
-          asm volatile("" : "+v"(v));
+          float v = tapval(lv, l4, j, t);
           pb[((c >> 4) * kBF + ((c & 15) * kK + t) * 4) * 2] = (__bf16)(v > 0.f ? v : v * a.xslope);
         }
       }
@@ -206,10 +246,12 @@ __global__ __launch_bounds__(kWB * 64, 2) void dwgrad_kernel(const WArgs a) {
 #pragma unroll
     for (int j = 0; j < CPW; ++j) {
       const int c = wave + kWB * j;
+      f32x4 lv;
+      float l4;
+      taken(j, lv, l4);
 #pragma unroll
       for (int t = 0; t < kK; ++t) {
-        float v = sb[j][t];
-        asm volatile("" : "+v"(v));                 // keep the consumption (and its wait) here, below the multiplications
+        float v = tapval(lv, l4, j, t);
         pb[(c >> 4) * kBF + ((c & 15) * kK + t) * 4] = v > 0.f ? v : v * a.xslope;
       }
     }
