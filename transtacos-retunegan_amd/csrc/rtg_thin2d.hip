@@ -31,7 +31,11 @@ struct T2Args {
 };
 
 __device__ __forceinline__ float t2_load(rsrc_t r, unsigned off) {
+#ifdef RTG_EXP_T2_NOLOAD
+  return __builtin_bit_cast(float, off);
+#else
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+#endif
 }
 
 // the 18 inputs of output position p = (item, ho, w): x[item][ci][ho * h_stride - 1 + kh][w - 1 + kw], activation applied,
@@ -84,6 +88,9 @@ __global__ __launch_bounds__(kThreads) void cin2_fwd_kernel(const T2Args a) {
     float va[4], vb[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) va[r] = vb[r] = bl[4 * g + r];
+#ifdef RTG_EXP_T2_NOFMA
+    if (g > 0) continue;
+#endif
 #pragma unroll
     for (int k = 0; k < kNK; ++k) {
 #pragma unroll
@@ -93,6 +100,9 @@ __global__ __launch_bounds__(kThreads) void cin2_fwd_kernel(const T2Args a) {
         vb[r] = __builtin_fmaf(xb[k], wv, vb[r]);
       }
     }
+#ifdef RTG_EXP_T2_NOSTORE
+    if (va[0] + va[1] + va[2] + va[3] + vb[0] + vb[1] + vb[2] + vb[3] == 12345.678f)
+#endif
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, va[r]), ro, oa, (unsigned)(4 * g + r) * chb, 0);
