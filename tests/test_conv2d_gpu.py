@@ -38,6 +38,8 @@ def test_conv2d_layer_forward_backward(case, force, monkeypatch):
     from rtg import tune
     from rtg.lib import lib
     B, Cin, Cout, H, W, k, s, p = case
+    if (force == 7 and Cin != 2 and Cout != 1) or (force in (10, 11) and Cout % 128) or (force == 14 and Cout != 64):
+        pytest.skip('the forced kernel does not serve this layer')
     used = []
     if force:
         def forced(wd, run):

@@ -708,13 +708,17 @@ __global__ __launch_bounds__(RTG_THREADS) void cin1_flat_kernel(const ThinArgs a
 bool rtg_thin2d_fwd_ok(const RtgConv1dDesc* d);
 int rtg_thin2d_fwd_launch(const RtgConv1dDesc* d, const float* x, const float* wp, const float* bias, const float* mask,
                           const float* res, float* out, hipStream_t s);
+bool rtg_thin2d_dgrad_ok(const RtgConv1dDesc* d);
+int rtg_thin2d_dgrad_launch(const RtgConv1dDesc* d, const float* dy, const float* wp, const float* mask, const float* res,
+                            float* out, hipStream_t s);
 
 // 0: not a thin shape (use the MFMA kernel), 1: one input channel, 2: one output channel, 3: one output channel 3 x 3,
-// 4: two input channels 3 x 3 (rtg_thin2d.hip)
+// 4 / 5: two input channels 3 x 3, forward / backward-data (rtg_thin2d.hip)
 int rtg_thin_kind(const RtgConv1dDesc* d) {
   if (d->groups != 1 || d->C2 != 0 || d->shuf_S != 1 || d->out_split != 0 || d->accumulate) return 0;
   if (d->h_k > 1 || d->h_n > 1) {
     if (rtg_thin2d_fwd_ok(d)) return 4;
+    if (rtg_thin2d_dgrad_ok(d)) return 5;
     // kind 3: one output channel, 3 x 3, stride 1, "same" padding, forward addressing (cout1_k3x3_kernel)
     if (d->Mg == 1 && d->h_mode == 0 && d->h_k == 3 && d->K == 3 && d->stride == 1 && d->h_stride == 1 && d->dil == 1 &&
         d->pad == 1 && d->h_pad == 1 && d->h_n == d->h_in && d->Q == d->L_in && d->out_L == d->Q && d->h_n > 0 &&
@@ -807,6 +811,7 @@ int rtg_thin_launch(int kind, const RtgConv1dDesc* d, const float* x, const floa
   const bool legacy = RTG_ENV_SET("RTG_THIN_LEGACY");       // A/B knob: the round-1 kernels
   TileGeo g = {};
   if (kind == 4) return rtg_thin2d_fwd_launch(d, x, wp, bias, mask, res, out, s);
+  if (kind == 5) return rtg_thin2d_dgrad_launch(d, x, wp, mask, res, out, s);
   if (kind == 3) {
     const int items = d->B / d->h_n, C = d->Cg / 3;
     const long long cols = (long long)items * d->h_in * d->L_in;

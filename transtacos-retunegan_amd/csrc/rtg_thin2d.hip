@@ -9,8 +9,12 @@
 //                    8 x 18 + 8 accumulators in registers (8 coalesced dy loads, 18 cached x loads per position), one wave
 //                    reduction per block, one split partial per block in the weight bank's layout (fixed-order reduce in
 //                    rtg_weightnorm_backward).
-// Backward-data of this layer (the generator step's gradient into the STFT) stays on the general kernel.
-// Exposed as thin kind 4 of rtg_conv1d (rtg_thin_kind) and thin kind 4 of the weight-gradient shape code 7.
+//   backward-data    (the generator step's gradient into the STFT) a thread owns a pair of input rows (2g, 2g + 1) of one
+//                    column and both input channels: row 2g receives kernel row 1 of output row g, row 2g + 1 kernel rows 2
+//                    and 0 of output rows g and g + 1 — two unaligned 16-byte dy loads per output channel (the three taps
+//                    are consecutive columns), the 32 x 18 weights as broadcast LDS reads.
+// Exposed as thin kinds 4 (forward) and 5 (backward-data) of rtg_conv1d (rtg_thin_kind) and thin kind 4 of the
+// weight-gradient shape code 7.
 #include "rtg_common.h"
 
 namespace {
@@ -21,7 +25,8 @@ constexpr int kM = 32, kCr = 2, kKH = 3, kKW = 3, kNK = kCr * kKH * kKW;       /
 constexpr int kThreads = 256;
 
 struct T2Args {
-  const float *x, *wp, *bias, *dy;
+  const float *x, *wp, *bias, *dy, *mask, *res;
+  float mask_slope, out_scale;
   float *out, *part;
   long long part_stride;
   int items, H, W, Ho, h_stride, tile_m, splits;
@@ -156,6 +161,81 @@ __global__ __launch_bounds__(kThreads) void cin2_wgrad_kernel(const T2Args a) {
   }
 }
 
+// backward-data: thread = (item, row pair g, column w); dy is [items, 32, Ho, W], the result [items, 2, H, W]
+__global__ __launch_bounds__(kThreads) void cin2_dgrad_kernel(const T2Args a) {
+  __shared__ __attribute__((aligned(16))) float wl[kM * 20];          // [co][kernel row][tap][ci], padded to 20 floats
+  // weights from the packed backward image [row tile 0][chunk][tap][channel quad][kk][row]: rows = ci, channels = (kh, co),
+  // taps along the columns already flipped (tap t multiplies dy column w - 1 + t)
+  const int KK = 64 / a.tile_m;
+  for (int e = threadIdx.x; e < kM * 18; e += kThreads) {
+    const int co = e / 18, r = e - co * 18;
+    const int kh = r / 6, tap = (r - kh * 6) >> 1, ci = r & 1;
+    const int c = kh * kM + co, cc = c / RTG_CK, c16 = c - cc * RTG_CK;
+    wl[co * 20 + r] = a.wp[(cc * kKW + tap) * (RTG_CK * a.tile_m) + (c16 / KK) * 64 + (c16 % KK) * a.tile_m + ci];
+  }
+  const rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.y_bytes, 0x00020000);
+  const int G = (a.H + 1) >> 1;
+  const int n_thr = a.items * G * a.W;
+  const int p = (int)blockIdx.x * kThreads + (int)threadIdx.x;
+  const bool live = p < n_thr;
+  const int gw = G * a.W;
+  const int b = p / gw, r = p - b * gw;
+  const int g = r / a.W, w = r - g * a.W;
+  // byte offsets of dy[b][0][g][w - 1] and dy[b][0][g + 1][w - 1]; output rows past the map load from out of range
+  const int hw = a.Ho * a.W;
+  const int e0 = b * kM * hw + g * a.W + w - 1;
+  const bool r0 = live && g < a.Ho, r1 = live && g + 1 < a.Ho;
+  const bool lok = w > 0, rok = w + 1 < a.W;                            // taps 0 / 2 inside the row
+  __syncthreads();
+  float a00 = 0.f, a01 = 0.f, a10 = 0.f, a11 = 0.f;                    // [row 2g / 2g + 1][ci]
+#pragma unroll 4
+  for (int co = 0; co < kM; ++co) {
+    float u[3], v[3];                                                  // dy rows g and g + 1, columns w - 1 .. w + 1
+    const int eo = e0 + co * hw;
+    if (co == 0) {
+      // (the 16 bytes of the very first element would start before the buffer)
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        u[t] = t2_load(rd, r0 ? (unsigned)(eo + t) * 4u : kOob);
+        v[t] = t2_load(rd, r1 ? (unsigned)(eo + a.W + t) * 4u : kOob);
+      }
+      if (eo < 0) u[0] = 0.f;                                          // (element -1: the offset wrapped into range)
+    } else {
+      const f32x4 lu = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rd, r0 ? (unsigned)eo * 4u : kOob, 0, 0));
+      const f32x4 lv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rd, r1 ? (unsigned)(eo + a.W) * 4u : kOob, 0, 0));
+#pragma unroll
+      for (int t = 0; t < 3; ++t) { u[t] = lu[t]; v[t] = lv[t]; }
+    }
+    u[0] = lok ? u[0] : 0.f; v[0] = lok ? v[0] : 0.f;
+    u[2] = rok ? u[2] : 0.f; v[2] = rok ? v[2] : 0.f;
+    const float* wc = wl + co * 20;                                    // [kh][tap][ci]
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      a00 = __builtin_fmaf(wc[6 + 2 * t], u[t], a00);                  // kernel row 1, output row g -> input row 2g
+      a01 = __builtin_fmaf(wc[6 + 2 * t + 1], u[t], a01);
+      a10 = __builtin_fmaf(wc[12 + 2 * t], u[t], a10);                 // kernel row 2, output row g -> input row 2g + 1
+      a11 = __builtin_fmaf(wc[12 + 2 * t + 1], u[t], a11);
+      a10 = __builtin_fmaf(wc[2 * t], v[t], a10);                      // kernel row 0, output row g + 1 -> input row 2g + 1
+      a11 = __builtin_fmaf(wc[2 * t + 1], v[t], a11);
+    }
+  }
+  if (!live) return;
+  const float res[2][2] = {{a00, a01}, {a10, a11}};
+#pragma unroll
+  for (int rr = 0; rr < 2; ++rr) {
+    const int h = 2 * g + rr;
+    if (h >= a.H) continue;
+#pragma unroll
+    for (int ci = 0; ci < kCr; ++ci) {
+      const size_t o = ((size_t)(b * kCr + ci) * a.H + h) * a.W + w;
+      float val = res[rr][ci];
+      if (a.mask) val *= a.mask[o] > 0.f ? 1.f : a.mask_slope;
+      if (a.res) val += a.res[o];
+      a.out[o] = val * a.out_scale;
+    }
+  }
+}
+
 template <class D>
 bool t2_shape_ok(const D* d) {
   if (d->groups != 1 || d->C2 != 0 || d->h_k != kKH || d->K != kKW || d->C1 != kCr * kKH || d->Cg != d->C1 || d->Mg != kM) return false;
@@ -194,6 +274,33 @@ int rtg_thin2d_fwd_launch(const RtgConv1dDesc* d, const float* x, const float* w
   t2_fill(d, &a);
   a.x = x; a.wp = wp; a.bias = bias; a.out = out; a.tile_m = d->tile_m;
   RTG_KLAUNCH(cin2_fwd_kernel, dim3((unsigned)rtg_ceil_div(a.n_pos, 2 * kThreads)), dim3(kThreads), 0, s, a);
+  return rtg_launch_status();
+}
+
+// backward-data descriptor of the same layer (Conv2dFn.backward): clips = (item, input row), channels = (kernel row, co)
+bool rtg_thin2d_dgrad_ok(const RtgConv1dDesc* d) {
+  if (d->h_mode != 1 || d->groups != 1 || d->C2 != 0 || d->Mg != kCr || d->C1 != kM * kKH || d->Cg != d->C1) return false;
+  if (d->h_k != kKH || d->K != kKW || d->stride != 1 || d->dil != 1 || d->pad != 1 || d->h_pad != 1 || d->h_stride != 2) return false;
+  if (d->h_in < 1 || d->h_n < 1 || d->B % d->h_n != 0 || d->Q != d->L_in || d->out_L != d->Q || d->out_C != kCr) return false;
+  if (d->h_in != (d->h_n + 2 - kKH) / 2 + 1) return false;              // (h_in = output rows of the layer, h_n = its input rows)
+  if (d->bf16 || d->tap_major || d->shuf_S != 1 || d->out_split != 0 || d->accumulate || d->act != RTG_ACT_NONE) return false;
+  if (d->pre_mode != RTG_PRE_NONE || (d->tile_m != 16 && d->tile_m != 32)) return false;
+  const long long items = d->B / d->h_n;
+  if (items * kM * d->h_in * d->L_in * 4 >= (1ll << 31) || items * kCr * d->h_n * d->L_in * 4 >= (1ll << 31)) return false;
+  return !RTG_ENV_SET("RTG_THIN2D_OFF");
+}
+
+int rtg_thin2d_dgrad_launch(const RtgConv1dDesc* d, const float* dy, const float* wp, const float* mask, const float* res,
+                            float* out, hipStream_t s) {
+  if (!rtg_thin2d_dgrad_ok(d)) return RTG_EINVAL;
+  if (!dy || !wp || !out) return RTG_ENULL;
+  T2Args a = {};
+  a.items = d->B / d->h_n; a.H = d->h_n; a.W = d->L_in; a.Ho = d->h_in; a.h_stride = 2; a.tile_m = d->tile_m;
+  a.dy = dy; a.wp = wp; a.mask = mask; a.res = res; a.out = out;
+  a.mask_slope = d->mask_slope; a.out_scale = d->out_scale;
+  a.y_bytes = a.items * kM * a.Ho * a.W * 4;
+  const long long n_thr = (long long)a.items * ((a.H + 1) / 2) * a.W;
+  RTG_KLAUNCH(cin2_dgrad_kernel, dim3((unsigned)rtg_ceil_div(n_thr, kThreads)), dim3(kThreads), 0, s, a);
   return rtg_launch_status();
 }
 
