@@ -1,0 +1,11 @@
+#!/bin/bash
+# dev: fp32 polyphase / class-ordered backward-data layers over ablation libraries.  usage: abl_run_poly.sh <outdir> name ...
+out=gpurun_out/$1; shift
+mkdir -p $out
+for v in base "$@"; do
+  if [ $v = base ]; then L=""; else L="$PWD/transtacos-retunegan_amd/librtg_dev_$v.so"; fi
+  echo "== $v" >> $out/abl.log
+  RTG_DEV_LIB=$L BD_PICK=15,17 timeout -k 10 120 python tools/dbg/bench_dconv.py poly 2>&1 | grep "^poly" | cut -c1-170 >> $out/abl.log
+  RTG_DEV_LIB=$L BD_PICK=0,7 timeout -k 10 120 python tools/dbg/bench_dconv.py fwd 2>&1 | grep "^fwd" | cut -c1-170 >> $out/abl.log
+done
+cat $out/abl.log
