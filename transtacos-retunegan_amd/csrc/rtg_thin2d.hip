@@ -45,12 +45,10 @@ __device__ __forceinline__ float t2_load(rsrc_t r, unsigned off) {
 
 // the 18 inputs of output position p = (item, ho, w): x[item][ci][ho * h_stride - 1 + kh][w - 1 + kw], activation applied,
 // zeros outside the map (out-of-range buffer offsets); `yoff`: element offset of (item, channel 0, ho, w) in out / dy
-__device__ __forceinline__ void t2_inputs(const T2Args& a, rsrc_t rx, int p, float (&xv)[kNK], unsigned& yoff) {
-  const bool live = p < a.n_pos;
+__device__ __forceinline__ void t2_inputs_at(const T2Args& a, rsrc_t rx, bool live, int b, int ho, int w, float (&xv)[kNK],
+                                             unsigned& yoff) {
   const int hw = a.Ho * a.W;
-  const int b = p / hw, r = p - b * hw;
-  const int ho = r / a.W, w = r - ho * a.W;
-  yoff = live ? (unsigned)(b * kM * hw + r) * 4u : kOob;
+  yoff = live ? (unsigned)(b * kM * hw + ho * a.W + w) * 4u : kOob;
 #pragma unroll
   for (int ci = 0; ci < kCr; ++ci)
 #pragma unroll
@@ -65,6 +63,13 @@ __device__ __forceinline__ void t2_inputs(const T2Args& a, rsrc_t rx, int p, flo
         xv[(ci * kKH + kh) * kKW + kw] = v > 0.f ? v : v * a.pre_slope;
       }
     }
+}
+
+__device__ __forceinline__ void t2_inputs(const T2Args& a, rsrc_t rx, int p, float (&xv)[kNK], unsigned& yoff) {
+  const int hw = a.Ho * a.W;
+  const int b = p / hw, r = p - b * hw;
+  const int ho = r / a.W, w = r - ho * a.W;
+  t2_inputs_at(a, rx, p < a.n_pos, b, ho, w, xv, yoff);
 }
 
 __global__ __launch_bounds__(kThreads) void cin2_fwd_kernel(const T2Args a) {
@@ -132,10 +137,28 @@ __global__ __launch_bounds__(kThreads) void cin2_wgrad_kernel(const T2Args a) {
 #pragma unroll
     for (int k = 0; k < kNK; ++k) acc[j][k] = 0.f;
   }
+  // (item, row, column) of this lane's position, advanced 64 positions per iteration without divisions (W >= 5: a few
+  // conditional subtractions)
+  int pb, pho, pw;
+  {
+    const int p = p_lo + lane, hw = a.Ho * a.W;
+    pb = p / hw;
+    const int r = p - pb * hw;
+    pho = r / a.W;
+    pw = r - pho * a.W;
+  }
+  const int wq = 64 / a.W, wr = 64 - wq * a.W;                           // 64 positions = wq rows + wr columns
   for (int p = p_lo + lane; p < p_hi; p += 64) {
     float xv[kNK], gy[8];
     unsigned yo;
-    t2_inputs(a, rx, p, xv, yo);
+    t2_inputs_at(a, rx, true, pb, pho, pw, xv, yo);
+    pw += wr;
+    pho += wq + (pw >= a.W ? 1 : 0);
+    pw -= pw >= a.W ? a.W : 0;
+    while (pho >= a.Ho) {                                               // (one item at most, except on maps of a few rows)
+      pho -= a.Ho;
+      ++pb;
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j)
       gy[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, yo, (unsigned)(8 * wave + j) * chb, 0));
