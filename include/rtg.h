@@ -257,8 +257,11 @@ int rtg_weightnorm_scales(const RtgNormJob* jobs_dev, int n_jobs, int max_rows, 
                           void* stream);
 /* workgroups job *job (HOST memory; first_block / n_blocks not read) needs in rtg_weights_pack; < 0: invalid job */
 int rtg_pack_job_blocks(const RtgPackJob* job);
-/* total_blocks = sum of the jobs' n_blocks (the table is ordered by first_block) */
-int rtg_weights_pack(const RtgPackJob* jobs_dev, int n_jobs, long long total_blocks, const float* params,
+/* floats of LDS the job stages a slab of its image in (0: none); < 0: invalid job */
+int rtg_pack_job_lds(const RtgPackJob* job);
+/* total_blocks = sum of the jobs' n_blocks (the table is ordered by first_block); lds_floats = the largest rtg_pack_job_lds
+ * of the jobs (a job whose slab does not fit takes the slower gather path) */
+int rtg_weights_pack(const RtgPackJob* jobs_dev, int n_jobs, long long total_blocks, int lds_floats, const float* params,
                      const float* scales, float* packed, void* stream);
 /* grads[g_off..], grads[v_off..], grads[b_off..] += weight-norm backward of (sum of partials) */
 int rtg_weightnorm_backward(const RtgWnBwdJob* jobs_dev, int n_jobs, int max_rows, int max_inner, const float* params,

@@ -182,10 +182,10 @@ def test_pack_kernel_writes_the_fragment_image():
         assert size == ref.size
         job = (L.PackJob * 1)(L.PackJob(Cout, 0, 0, size, mode, 1, Mg, Cg, Kp, K, Cin, 3 if mode == L.PACK_DGRAD_POLY else 1,
                                        16, 1, 0, 0, 1))
-        blocks = L.assign_pack_blocks(job)
+        blocks, lds = L.assign_pack_blocks(job)
         job_d = torch.frombuffer(bytearray(bytes(memoryview(job).cast('B'))), dtype=torch.uint8).cuda()
         packed = torch.full((size,), float('nan'), device='cuda')
-        assert lib.rtg_weights_pack(_ptr(job_d), 1, blocks, _ptr(params), _ptr(scales), _ptr(packed), st) == 0
+        assert lib.rtg_weights_pack(_ptr(job_d), 1, blocks, lds, _ptr(params), _ptr(scales), _ptr(packed), st) == 0
         torch.cuda.synchronize()
         np.testing.assert_allclose(packed.cpu().numpy(), ref, rtol=1e-6, atol=1e-7)
 
@@ -312,9 +312,9 @@ def _pack_on_gpu(v, g, mode, groups, Mg, Cg, Kp, src_K, src_inner_c, S, tile_m, 
     else:
         size = lib.rtg_packed_size(groups, Mg, Cg, Kp, tile_m)
     job = L.PackJob(rows, 0, 0, size, mode, groups, Mg, Cg, Kp, src_K, src_inner_c, S, tile_m, 1, tap_major, bf16, frag16)
-    blocks = L.assign_pack_blocks([job])
+    blocks, lds = L.assign_pack_blocks([job])
     packed = torch.full((size,), float('nan'), device='cuda')
-    assert lib.rtg_weights_pack(_ptr(table(job)), 1, blocks, _ptr(params), _ptr(scales), _ptr(packed), st) == 0
+    assert lib.rtg_weights_pack(_ptr(table(job)), 1, blocks, lds, _ptr(params), _ptr(scales), _ptr(packed), st) == 0
     torch.cuda.synchronize()
     return packed.cpu().numpy()
 

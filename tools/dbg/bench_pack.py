@@ -25,29 +25,29 @@ sz = C.sizeof(L.PackJob)
 jobs = (L.PackJob * bank.n_pack).from_buffer_copy(bytes(tab.cpu().numpy().tobytes()))
 
 
-def run(ptr, n, mx, reps=10):
+def run(ptr, n, mx, lds, reps=10):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for _ in range(2):
-        lib.rtg_weights_pack(ptr, n, mx, C.c_void_p(bank.flat.data_ptr()), C.c_void_p(bank.scales.data_ptr()),
+        lib.rtg_weights_pack(ptr, n, mx, lds, C.c_void_p(bank.flat.data_ptr()), C.c_void_p(bank.scales.data_ptr()),
                              C.c_void_p(bank.packed.data_ptr()), st)
     e0.record()
     for _ in range(reps):
-        lib.rtg_weights_pack(ptr, n, mx, C.c_void_p(bank.flat.data_ptr()), C.c_void_p(bank.scales.data_ptr()),
+        lib.rtg_weights_pack(ptr, n, mx, lds, C.c_void_p(bank.flat.data_ptr()), C.c_void_p(bank.scales.data_ptr()),
                              C.c_void_p(bank.packed.data_ptr()), st)
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3
 
 
-tot = run(C.c_void_p(tab.data_ptr()), bank.n_pack, bank.pack_blocks)
+tot = run(C.c_void_p(tab.data_ptr()), bank.n_pack, bank.pack_blocks, bank.pack_lds)
 print(f'{which}: all {bank.n_pack} jobs in one launch: {tot:.1f} us, packed {bank.packed.numel() * 4 / 1e6:.1f} MB, '
       f'params {bank.n_params * 4 / 1e6:.1f} MB -> {(bank.packed.numel() + bank.n_params) * 4 / tot / 1e3:.0f} GB/s')
 s = 0.0
 for i, j in enumerate(jobs):
     one = (L.PackJob * 1).from_buffer_copy(bytes(j))
-    nblk = L.assign_pack_blocks(one)
+    nblk, lds1 = L.assign_pack_blocks(one)
     one_d = torch.frombuffer(bytearray(bytes(one)), dtype=torch.uint8).cuda()
-    us = run(C.c_void_p(one_d.data_ptr()), 1, nblk)
+    us = run(C.c_void_p(one_d.data_ptr()), 1, nblk, lds1)
     s += us
     print(f'{i:3d} mode{j.mode} g{j.groups} Mg{j.Mg} Cg{j.Cg} K{j.K} srcK{j.src_K} S{j.S} tm{j.tile_m} KH{j.KH} tap{j.tap_major} '
           f'bf{j.bf16} f16_{j.frag16}  {j.dst_size * 4 / 1e6:7.2f} MB  {us:7.1f} us  {j.dst_size * 4 / us / 1e3:7.0f} GB/s')

@@ -92,8 +92,8 @@ __host__ __device__ inline PackGeom pack_geom(const RtgPackJob& j) {
   return p;
 }
 
-__global__ __launch_bounds__(RTG_THREADS) void pack_kernel(const RtgPackJob* jobs, int n_jobs, const float* params,
-                                                           const float* scales, float* packed) {
+__global__ __launch_bounds__(RTG_THREADS) void pack_kernel(const RtgPackJob* jobs, int n_jobs, int lds_floats,
+                                                           const float* params, const float* scales, float* packed) {
   // the grid is the concatenation of the jobs' block ranges (RtgPackJob.first_block / n_blocks): the job of this block is
   // the last one that starts at or before it (every thread tests one job; a 2-D grid of (blocks of the largest job) x
   // jobs spent most of the launch dispatching blocks that had nothing to do)
@@ -168,9 +168,11 @@ __global__ __launch_bounds__(RTG_THREADS) void pack_kernel(const RtgPackJob* job
   const float inv_nco = 1.0f / (float)(n_co > 0 ? n_co : 1);
   const int RT = j.frag16 ? 16 : TM;                                         // rows of a row tile
   const int n_rt = j.frag16 ? n_mt16 : n_mt;
-  __shared__ float slab[kPackSlab];
+  // (sized by the launch to the largest slab of its jobs — rtg_pack_job_lds —: 10 KB for the 5-tap layers instead of the
+  // 31 KB of the largest slab the staging serves, three times the workgroups in flight per CU)
+  extern __shared__ float slab[];
   const PackGeom pg = pack_geom(j);
-  if (pg.staged) {
+  if (pg.staged && pg.nrow * (pg.run + 1) <= lds_floats) {
     // run length per source row and rows per slab: forward: RT rows x 16 K; stride-1 backward-data: 16 rows x RT K;
     // polyphase: 16 rows x (channels the tile's rows cover) x src_K
     const int run = pg.run, nrow = pg.nrow, pitch = run + 1;
@@ -466,13 +468,20 @@ extern "C" int rtg_pack_job_blocks(const RtgPackJob* job) {
   return (int)(n < 1 ? 1 : (n > 4096 ? 4096 : n));
 }
 
-extern "C" int rtg_weights_pack(const RtgPackJob* jobs_dev, int n_jobs, long long total_blocks, const float* params,
-                                const float* scales, float* packed, void* stream) {
+// floats of LDS job *job (HOST memory) stages a slab in (0: it takes the gather path)
+extern "C" int rtg_pack_job_lds(const RtgPackJob* job) {
+  if (!job || (job->tile_m != 16 && job->tile_m != 32)) return -1;
+  const PackGeom pg = pack_geom(*job);
+  return pg.staged ? pg.nrow * (pg.run + 1) : 0;
+}
+
+extern "C" int rtg_weights_pack(const RtgPackJob* jobs_dev, int n_jobs, long long total_blocks, int lds_floats,
+                                const float* params, const float* scales, float* packed, void* stream) {
   if (!jobs_dev || !params || !scales || !packed) return RTG_ENULL;
-  if (n_jobs < 1 || n_jobs > 65535 || total_blocks < 1) return RTG_EINVAL;
+  if (n_jobs < 1 || n_jobs > 65535 || total_blocks < 1 || lds_floats < 0 || lds_floats > kPackSlab) return RTG_EINVAL;
   if (total_blocks >= (1ll << 31)) return RTG_ERANGE;
-  RTG_KLAUNCH(pack_kernel, dim3((unsigned)total_blocks), dim3(RTG_THREADS), 0, (hipStream_t)stream, jobs_dev, n_jobs,
-              params, scales, packed);
+  RTG_KLAUNCH(pack_kernel, dim3((unsigned)total_blocks), dim3(RTG_THREADS), (size_t)lds_floats * sizeof(float),
+              (hipStream_t)stream, jobs_dev, n_jobs, lds_floats, params, scales, packed);
   return rtg_launch_status();
 }
 

@@ -281,7 +281,7 @@ class WeightBank:
                                           ly.kh, 0, ly.frag_bf, 1))
                     self.max_pack = max(self.max_pack, size)
         self.norm_table = _table(norm, self.device)
-        self.pack_blocks = L.assign_pack_blocks(pack)
+        self.pack_blocks, self.pack_lds = L.assign_pack_blocks(pack)
         self.pack_table = _table(pack, self.device)
         self.n_pack = len(pack)
 
@@ -292,7 +292,7 @@ class WeightBank:
         check(ops.timed_bw('wn_scales', 4 * self.n_params, lambda: lib.rtg_weightnorm_scales(
             _p(self.norm_table), len(self.layers), self.max_rows, _p(self.flat), _p(self.scales), st)), 'weightnorm_scales')
         check(ops.timed_bw('wn_pack', 4 * (self.n_params + self.packed.numel()), lambda: lib.rtg_weights_pack(
-            _p(self.pack_table), self.n_pack, self.pack_blocks, _p(self.flat), _p(self.scales), _p(self.packed), st)),
+            _p(self.pack_table), self.n_pack, self.pack_blocks, self.pack_lds, _p(self.flat), _p(self.scales), _p(self.packed), st)),
               'weights_pack')
 
     def prepare(self):

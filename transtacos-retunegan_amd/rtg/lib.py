@@ -117,8 +117,9 @@ PROTOTYPES = {
     'rtg_wgrad_splits': (_I, [C.POINTER(WgradDesc)]),
     'rtg_wgrad_shape_candidates': (_I, [C.POINTER(WgradDesc), C.POINTER(C.c_int), _I]),
     'rtg_weightnorm_scales': (_I, [_P, _I, _I, _P, _P, _P]),
-    'rtg_weights_pack': (_I, [_P, _I, _LL, _P, _P, _P, _P]),
+    'rtg_weights_pack': (_I, [_P, _I, _LL, _I, _P, _P, _P, _P]),
     'rtg_pack_job_blocks': (_I, [_P]),
+    'rtg_pack_job_lds': (_I, [_P]),
     'rtg_weightnorm_backward': (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P]),
     'rtg_stft_forward': (_I, [C.POINTER(StftDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'rtg_stft_backward': (_I, [C.POINTER(StftDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
@@ -197,15 +198,17 @@ _raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
 
 
 def assign_pack_blocks(jobs):
-    """fill first_block / n_blocks of a list of PackJob (rtg_pack_job_blocks per job) -> the launch's total_blocks"""
-    total = 0
+    """fill first_block / n_blocks of a list of PackJob (rtg_pack_job_blocks per job) -> (the launch's total_blocks, its
+    lds_floats = the largest slab any job stages)"""
+    total, lds = 0, 0
     for j in jobs:
+        lds = max(lds, lib.rtg_pack_job_lds(C.byref(j)))
         n = lib.rtg_pack_job_blocks(C.byref(j))
         if n < 1:
             raise RtgError(f'rtg_pack_job_blocks: invalid pack job (mode {j.mode}, {j.Mg} x {j.Cg} x {j.K})')
         j.first_block, j.n_blocks = total, n
         total += n
-    return total
+    return total, lds
 
 
 def current_stream_ptr():
