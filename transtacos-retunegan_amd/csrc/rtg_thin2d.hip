@@ -216,13 +216,13 @@ __global__ __launch_bounds__(kThreads) void cin2_dgrad_kernel(const T2Args a) {
     float u[3], v[3];                                                  // dy rows g and g + 1, columns w - 1 .. w + 1
     const int eo = e0 + co * hw;
     if (co == 0) {
-      // (the 16 bytes of the very first element would start before the buffer)
+      // (the 16 bytes of the very first element would start before the buffer: three 4-byte loads; element -1 wraps to an
+      // offset past the end and reads zero)
 #pragma unroll
       for (int t = 0; t < 3; ++t) {
         u[t] = t2_load(rd, r0 ? (unsigned)(eo + t) * 4u : kOob);
         v[t] = t2_load(rd, r1 ? (unsigned)(eo + a.W + t) * 4u : kOob);
       }
-      if (eo < 0) u[0] = 0.f;                                          // (element -1: the offset wrapped into range)
     } else {
       const f32x4 lu = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rd, r0 ? (unsigned)eo * 4u : kOob, 0, 0));
       const f32x4 lv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rd, r1 ? (unsigned)(eo + a.W) * 4u : kOob, 0, 0));

@@ -265,7 +265,6 @@ class WeightBank:
         norm, pack = [], []
         self.max_rows = max(ly.rows for ly in self.layers)
         self.max_inner = max(ly.inner for ly in self.layers)
-        self.max_pack = 0
         for ly in self.layers:
             norm.append(L.NormJob(ly.g_off, ly.v_off, ly.scale_off, ly.rows, ly.inner))
             for (mode, g, mg, cg, k, s), off, size, tm, tap, bf in (
@@ -273,14 +272,12 @@ class WeightBank:
                     (ly.bwd_op, ly.bwd_off, ly.bwd_size, ly.bwd_tm, ly.bwd_tap, ly.bwd_bf)):
                 pack.append(L.PackJob(ly.v_off, ly.scale_off, off, size, mode, g, mg, cg, k, ly.k, ly.inner_c, s, tm,
                                       ly.kh, tap, bf, 0))
-                self.max_pack = max(self.max_pack, size)
             for (mode, g, mg, cg, k, s), off, size in ((ly.fwd_op, ly.fwd_off + ly.fwd_size, ly.fwd16_size),
                                                         (ly.bwd_op, ly.bwd_off + ly.bwd_size, ly.bwd16_size)):
                 if size:
                     pack.append(L.PackJob(ly.v_off, ly.scale_off, off, size, mode, g, mg, cg, k, ly.k, ly.inner_c, s, 16,
                                           ly.kh, 0, ly.frag_bf, 1))
-                    self.max_pack = max(self.max_pack, size)
-        self.norm_table = _table(norm, self.device)
+            self.norm_table = _table(norm, self.device)
         self.pack_blocks, self.pack_lds = L.assign_pack_blocks(pack)
         self.pack_table = _table(pack, self.device)
         self.n_pack = len(pack)
