@@ -156,16 +156,20 @@ def _pmc_for(prefix, workload='config2'):
     doc = json.load(open(files[-1]))
     ks = doc['kernels']
     stale = doc.get('src_digest') != _src_digest()
-    n = b = m = 0.0
+    # HBM bytes: per launch, launch-weighted (like `achieved`); matrix-pipe occupancy: time-weighted over the instances the SQ
+    # pass has the counter for (busy cycles of the family / its SIMD cycles)
+    n = b = m = t = 0.0
     for name, e in ks.items():
         if name.startswith(prefix):
             n += e['launches']
             b += e['launches'] * (e['hbm_read_MB_per_launch'] + e['hbm_write_MB_per_launch']) * 1e6
-            m += e['launches'] * e.get('mfma_busy_frac', 0.0)
+            if 'mfma_busy_frac' in e:
+                m += e['launches'] * e['avg_us'] * e['mfma_busy_frac']
+                t += e['launches'] * e['avg_us']
     if n == 0:
         return None
-    return {'traffic': round(b / n), 'mfma_busy': round(m / n, 3), 'source': 'profiles/' + os.path.basename(files[-1]),
-            'stale': bool(stale)}
+    return {'traffic': round(b / n), 'mfma_busy': round(m / t, 3) if t else None,
+            'source': 'profiles/' + os.path.basename(files[-1]), 'stale': bool(stale)}
 
 
 def roofline(trainer, batch, bf16=False, workload='config2'):
