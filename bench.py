@@ -274,7 +274,16 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if os.environ.get('RTG_BENCH_REHEARSE') == '1':      # dev aid: all ranks on cuda:0, gradients over gloo (a one-GPU box)
         local = 0
-    if world > 1:
+    # RTG_DP_FORCE=1 with one rank: the whole data-parallel machinery (RCCL all-reduces on the communication stream, graph
+    # segments cut at the exchanges, tuner broadcast) over a 1-rank 'nccl' group — what a one-GPU box can rehearse of --gpus N
+    forced = world == 1 and os.environ.get('RTG_DP_FORCE') == '1'
+    if forced:
+        import socket
+        s_ = socket.socket(); s_.bind(('127.0.0.1', 0)); port = s_.getsockname()[1]; s_.close()
+        os.environ.setdefault('MASTER_PORT', str(port))
+        os.environ.update(RANK='0', WORLD_SIZE='1')
+    multi = world > 1 or forced
+    if multi:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         torch.cuda.set_device(local)
@@ -310,7 +319,7 @@ def main():
     # The timed step is replayed from HIP graphs (Trainer.train_step_graphed): the same kernels in the same order, issued by
     # the graph executor instead of ~770 Python-side launches per step (1.4 % faster on one GPU; with 8 ranks per host the
     # launches of all ranks compete for the host's cores).  The graphs are cut where data parallelism exchanges
-    # gradients; the all-reduces run between the segments (tests/test_dp_gpu.py::test_two_ranks_graphed_step).
+    # gradients; the all-reduces run between the segments (tests/test_zz_dp_gpu.py::test_two_ranks_graphed_step).
     # RTG_GRAPH=0: the eager step.  Capture happens here, outside warm-up and timing; if it fails the eager step is timed
     # and the record says so.
     mode = 'hip-graph replay'
@@ -320,47 +329,63 @@ def main():
     if os.environ.get('RTG_GRAPH', '1') != '0':
         # capture WITHOUT replaying, then agree on the outcome, then replay: a rank whose capture failed must not head for
         # the eager step's collectives while the others are inside a replay's (different buffers and sizes: RCCL would hang)
+        def agree(ok_, why):
+            """MIN over the ranks of `ok_`: either every rank goes on with the graphs or every rank drops them"""
+            nonlocal mode
+            if multi:
+                flag = torch.tensor([ok_], device=device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if flag.item() == 0.0 and ok_:
+                    ok_, mode = 0.0, f'eager ({why} failed on another rank)'
+            if not ok_:
+                tr._graphs = None
+            return ok_
+
         ok = 1.0
         try:
             tr.prepare_graphs(*next_batch())
         except Exception as e:  # noqa: BLE001
             ok = 0.0
             mode = f'eager (graph capture failed: {type(e).__name__}: {e})'[:200]
-            tr._graphs = None
-        if world > 1:
-            flag = torch.tensor([ok], device=device)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if flag.item() == 0.0 and ok:
-                ok, mode, tr._graphs = 0.0, 'eager (graph capture failed on another rank)', None
+        ok = agree(ok, 'graph capture')
         if ok:
-            tr.train_step_graphed(*next_batch())
-            torch.cuda.synchronize()
+            # the first replay, still outside warm-up and timing; a rank on which it raises takes every rank back to the
+            # eager step (the collectives between the segments are the eager step's: same buffers, same order)
+            try:
+                tr.train_step_graphed(*next_batch())
+                torch.cuda.synchronize()
+            except Exception as e:  # noqa: BLE001
+                ok = 0.0
+                mode = f'eager (first graph replay failed: {type(e).__name__}: {e})'[:200]
+            ok = agree(ok, 'the first graph replay')
+        if ok:
             step = tr.train_step_graphed
+        else:
+            tr.dp.pending = []
+            tr.train_step(*next_batch())             # (the eager step once more after a failed capture / replay)
+            torch.cuda.synchronize()
     else:
         mode = 'eager'
     for _ in range(a.warmup):
         step(*next_batch())
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         dl, gl = step(*next_batch())
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     per_rank = None
-    if world > 1:
-        # every rank's own time and a digest of its tuner's picks (ranks tune independently: different picks are harmless
-        # for the result, the gradients are summed, but they show as different per-rank step times)
-        import hashlib
+    if multi:
+        # every rank's own time and a digest of its tuner's picks (rank 0 tunes and broadcasts its tables,
+        # train.DataParallel.sync_tuner: the digests must be equal)
         from rtg import tune
-        picks = repr(sorted((k.hex(), v) for d_ in (tune._conv, tune._wgrad, tune._group, tune._wgroup, tune._alt)
-                            for k, v in d_.items())).encode()
-        mine = torch.tensor([elapsed / a.steps * 1e3, float(int(hashlib.sha256(picks).hexdigest()[:6], 16))],
+        mine = torch.tensor([elapsed / a.steps * 1e3, float(int(tune.digest(), 16))],
                             device=device, dtype=torch.float64)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
@@ -380,7 +405,7 @@ def main():
         # every rank runs the instrumented steps (they are train steps: under data parallelism their gradient all-reduces
         # need all ranks), rank 0 reports its own launches
         roof = roofline(tr, data, bf16=dtype == 'bf16', workload=a.workload)
-    if world > 1:
+    if multi:
         dist.barrier()
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
@@ -396,13 +421,13 @@ def main():
             'dtype': 'f32' if dtype == 'fp32' else 'bf16 operands, f32 accumulate', 'data': 'synthetic' if feeder is None else 'synthetic, fed from pinned host memory every step',
             'config': {'workload': f'{a.workload}: {desc}', 'per_gpu_batch': batch, 'clip_samples': T,
                        'global_batch': world * batch, 'd_train_times': d_times,
-                       'parallelism': f'dp{world}' if world > 1 else 'single', 'launch': mode,
+                       'parallelism': f'dp{world}' if world > 1 else ('single (1-rank RCCL group, data-parallel path forced)' if forced else 'single'), 'launch': mode,
                        **({'per_rank': per_rank} if per_rank else {})},
             'roofline': roof, 'cpu_baseline': cpu,
             'final_losses': {'gen_all': round(loss_g, 4), 'disc_all': round(loss_d, 4)},
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

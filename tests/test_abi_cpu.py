@@ -61,6 +61,24 @@ def test_struct_layouts_follow_the_header():
         assert [f[0] for f in cls._fields_] == header_struct_fields(cname), cname
 
 
+def test_integration_md_binding_stub_is_the_real_struct():
+    """INTEGRATION.md section 2 shows the ctypes stub a maintainer would copy: its RtgConv1dDesc must be the header's struct
+    field for field and type for type (round 3: the example was 4 ints short — rtg_conv1d would have read 16 bytes past it)"""
+    from rtg import lib as L
+    txt = open(os.path.join(REPO, 'INTEGRATION.md')).read()
+    block = re.search(r'```python\n(import ctypes as C, torch.*?)```', txt, flags=re.S).group(1)
+    cls_src = re.search(r'(class RtgConv1dDesc\(C\.Structure\):.*?)\n\nlib\.rtg_conv1d\.restype', block, flags=re.S).group(1)
+    ns = {'C': C}
+    exec(cls_src, ns)                                         # the documentation's own text
+    doc = ns['RtgConv1dDesc']
+    assert [(n, t) for n, t in doc._fields_] == [(n, t) for n, t in L.Conv1dDesc._fields_]
+    assert C.sizeof(doc) == C.sizeof(L.Conv1dDesc)
+    assert [f[0] for f in doc._fields_] == header_struct_fields('RtgConv1dDesc')
+    # the argument list of the stub: descriptor + 10 pointers (x1, x2, aux, wp, bias, mask, res, out, out2, stream)
+    assert 'C.POINTER(RtgConv1dDesc)] + [C.c_void_p] * 10' in block
+    assert len(L.PROTOTYPES['rtg_conv1d'][1]) == 11
+
+
 def test_abi_version_and_host_side_queries(built):
     from rtg.lib import lib, Conv1dDesc, WgradDesc
     from rtg.lib import ABI_VERSION

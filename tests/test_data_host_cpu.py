@@ -102,3 +102,106 @@ def test_trim_silence():
     y = np.concatenate([np.zeros(4000), 0.5 * np.sin(np.arange(8000) * 0.1), np.zeros(4000)]).astype(np.float32)
     t = D.trim_silence(y)
     assert 7900 <= len(t) <= 8700 and abs(t).max() > 0.49
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Round 4: what CAN be pinned of SURVEY.md 8 f1 without librosa — the transform pair against an independent implementation
+# present in the image (torch.stft / torch.istft, fp64), and the fast Griffin-Lim recursion of retunegan/audio.py:131-136
+# (n_iter 4, momentum 0.7, power 1.2, random phases from seed 114514) against a naive restatement that shares no code with
+# audio.py (explicit DFT sums, explicit frames, explicit overlap-add).  librosa itself stays unpinned (absent).
+# ---------------------------------------------------------------------------------------------------------------
+import pytest
+
+
+@pytest.mark.parametrize('n_fft,hop,win,n', [(2048, 256, 1024, 22016), (1024, 120, 600, 8192), (512, 50, 240, 8192),
+                                              (2048, 256, 1024, 8191), (64, 16, 32, 500)])
+def test_stft_pair_against_torch_fp64(n_fft, hop, win, n):
+    import audio as A
+    rng = np.random.RandomState(n_fft + n)
+    y = ((rng.rand(n) * 2 - 1) * 0.5).astype(np.float32)
+    window = torch.hann_window(win, periodic=True, dtype=torch.float64)
+    Dt = torch.stft(torch.from_numpy(y).double(), n_fft, hop, win, window, center=True, pad_mode='reflect',
+                    normalized=False, onesided=True, return_complex=True).numpy()
+    D = A.stft_np(y, n_fft, hop, win)
+    assert D.shape == Dt.shape == (n_fft // 2 + 1, 1 + n // hop) and D.dtype == np.complex64
+    # complex64 output of an fp64 computation: error = one fp32 rounding of values up to ~|D|max
+    assert np.abs(D - Dt).max() <= 2e-7 * np.abs(Dt).max() + 1e-7
+    # the inverse on an ARBITRARY (inconsistent) spectrogram, with and without a target length — torch.istft states the
+    # same operator (irfft, synthesis window, overlap-add, division by the window's squared-sum envelope, n_fft/2 trimmed)
+    Z = (rng.randn(*Dt.shape) + 1j * rng.randn(*Dt.shape))
+    Z[0].imag = 0; Z[-1].imag = 0
+    for length in (None, n, n - 37, hop * (Dt.shape[1] - 1) + 11):
+        it = torch.istft(torch.from_numpy(Z), n_fft, hop, win, window, center=True, length=length).numpy()
+        ours = A.istft_np(Z.astype(np.complex64), hop, win, length=length)
+        assert ours.shape == it.shape and ours.dtype == np.float32
+        # positions past the last frame's support are zero-filled by both; the envelope division amplifies the complex64
+        # rounding of the input near the edges where the envelope is small
+        scale = np.abs(it).max()
+        assert np.abs(ours - it).max() <= 3e-6 * scale, (length, np.abs(ours - it).max() / scale)
+    # and the round trip on a consistent spectrogram
+    np.testing.assert_allclose(A.istft_np(D, hop, win, length=n), y, atol=2e-6)
+
+
+def _naive_fast_griffin_lim(S, hop, win, n_iter, momentum, seed, length):
+    """librosa-0.8.1-style fast Griffin-Lim (Perraudin, Balazs, Sondergaard 2013: c_n = P_C1(P_C2(t_{n-1})), t_n = c_n +
+    alpha (c_n - c_{n-1}); librosa projects `rebuilt - momentum / (1 + momentum) * previous rebuilt` onto unit phases) in
+    plain fp64 loops: DFT by explicit sums, frames by explicit indexing, overlap-add by explicit accumulation."""
+    F, T = S.shape
+    N = 2 * (F - 1)
+    w = np.zeros(N)
+    lp = (N - win) // 2
+    w[lp:lp + win] = [0.5 - 0.5 * np.cos(2 * np.pi * i / win) for i in range(win)]
+    Wf = np.array([[np.exp(-2j * np.pi * k * n / N) for n in range(N)] for k in range(F)])        # rfft
+    Wi = np.array([[np.exp(2j * np.pi * k * n / N) for k in range(N)] for n in range(N)]) / N      # ifft
+
+    def istft(D):
+        full = np.concatenate([D, np.conj(D[-2:0:-1])], axis=0)                    # hermitian extension
+        y, env = np.zeros(N + hop * (T - 1)), np.zeros(N + hop * (T - 1))
+        for t in range(T):
+            fr = (Wi @ full[:, t]).real * w
+            for n in range(N):
+                y[t * hop + n] += fr[n]
+                env[t * hop + n] += w[n] ** 2
+        y = np.where(env > 1e-30, y / np.maximum(env, 1e-30), y)[N // 2:]
+        return np.concatenate([y, np.zeros(max(0, length - len(y)))])[:length]
+
+    def stft(y):
+        yp = np.concatenate([y[N // 2:0:-1], y, y[-2:-N // 2 - 2:-1]])            # reflect padding
+        return np.stack([Wf @ (w * yp[t * hop:t * hop + N]) for t in range(1 + (len(yp) - N) // hop)], axis=1)
+
+    ang = np.exp(2j * np.pi * np.random.RandomState(seed).rand(F, T))
+    prev = 0.0
+    for _ in range(n_iter):
+        reb = stft(istft(S * ang))
+        ang = reb - momentum / (1 + momentum) * prev
+        ang = ang / (np.abs(ang) + 1e-16)
+        prev = reb
+    return istft(S * ang)
+
+
+def test_fast_griffin_lim_recursion_against_naive_restatement(monkeypatch):
+    import audio as A
+    import hparam as hp
+    # a 3-frame case small enough for O(N^2) sums: n_fft 16, window 12, hop 6 -> 9 bins x 3 frames, 12 samples
+    monkeypatch.setattr(hp, 'hop_length', 6)
+    monkeypatch.setattr(hp, 'win_length', 12)
+    assert (hp.gl_iters, hp.gl_momentum, hp.gl_power, hp.randseed) == (4, 0.7, 1.2, 114514)     # audio.py:131-136 / hparam
+    rng = np.random.RandomState(7)
+    S = np.abs(rng.randn(9, 3)) + 0.1
+    for length in (12, 15):
+        got = A._griffinlim(S, wavlen=length)
+        want = _naive_fast_griffin_lim(S ** 1.2, 6, 12, 4, 0.7, 114514, length)
+        assert got.shape == want.shape == (length,)
+        np.testing.assert_allclose(got, want, atol=2e-5 * np.abs(want).max())
+    # the momentum term matters at this tolerance (a plain Griffin-Lim differs visibly): the test can tell them apart
+    plain = _naive_fast_griffin_lim(S ** 1.2, 6, 12, 4, 0.0, 114514, 12)
+    assert np.abs(plain - A._griffinlim(S, wavlen=12)).max() > 1e-3 * np.abs(plain).max()
+    # five-frame case, longer clip
+    S5 = np.abs(rng.randn(9, 5)) + 0.05
+    want = _naive_fast_griffin_lim(S5 ** 1.2, 6, 12, 4, 0.7, 114514, 24)
+    np.testing.assert_allclose(A._griffinlim(S5, wavlen=24), want, atol=2e-5 * np.abs(want).max())
+    # inv_mag on top: exp() of the log magnitude, a zero DC row for an (n_freq - 1)-bin input (audio.py:139-147)
+    monkeypatch.setattr(hp, 'n_freq', 9)
+    mag = np.log(S5[1:])
+    want = _naive_fast_griffin_lim(np.concatenate([np.zeros((1, 5)), S5[1:]]) ** 1.2, 6, 12, 4, 0.7, 114514, 24)
+    np.testing.assert_allclose(A.inv_mag(mag, wavlen=24), want, atol=2e-5 * np.abs(want).max())

@@ -70,6 +70,28 @@ def _worker(rank, world, port, out):
     dp.wait()
     assert torch.isnan(m.bank().flag()).all()
     assert torch.equal(m.bank().gflat[:1000], expect)
+    # tuner picks: rank 0 holds the timed tables, the others hold stale / partial ones; after sync_tuner every rank has
+    # rank 0's picks for rank 0's problems, the digest agrees, and rank 0's "met an unknown problem" flag reaches everybody
+    from rtg import tune
+    for name in tune._TABLES:
+        getattr(tune, name).clear()
+    if rank == 0:
+        tune._conv.update({b'\x01\x02': 3211, b'\x03': 8108})
+        tune._wgrad[b'\x09'] = 12
+        tune._alt[b'gconv\x00'] = 1
+        tune.MISSED = True
+    else:
+        tune._conv[b'\x01\x02'] = 1611          # a stale pick of its own for the same problem
+        tune.MISSED = False
+    missed = dp.sync_tuner()
+    assert missed is True
+    assert tune._conv == {b'\x01\x02': 3211, b'\x03': 8108} and tune._wgrad == {b'\x09': 12} and tune._alt == {b'gconv\x00': 1}
+    digests = [None] * world
+    dist.all_gather_object(digests, tune.digest())
+    assert len(set(digests)) == 1
+    dp.pending_probe = dp.reduce_async(m.bank().gflat)     # a collective in flight ...
+    dp.drain()                                             # ... is finished and every rank has arrived when drain returns
+    assert dp.pending == []
     if rank == 0:
         out.put('ok')
     dist.barrier()

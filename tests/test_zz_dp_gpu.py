@@ -1,7 +1,11 @@
 """Data-parallel train step end to end on the GPU box: two processes share cuda:0 and exchange gradients over gloo
 (RCCL needs one device per rank; the Trainer code path - flush hooks, side-stream all-reduce, collective NaN flag,
 averaging inside AdamW - is the same).  Two ranks with one clip each must reproduce the single-process step on both
-clips (all losses are batch means)."""
+clips (all losses are batch means).  Then RCCL itself on a one-rank 'nccl' group, and the HIP-graph capture
+under a live RCCL process group with a collective in flight (the round-3 crash, forced deterministically).
+
+The file sorts LAST on purpose (and tests/conftest.py moves it there whatever its name): these are multi-process /
+process-group tests, and under `pytest -x` they must not be able to hide a kernel-parity test."""
 import os
 import socket
 import sys
@@ -56,6 +60,7 @@ def _worker(rank, world, port, q, full=False, graphed=False):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     _setup()
     dist.init_process_group('gloo', rank=rank, world_size=world)
+    q.put(('init', rank))
     tr, O = _make_trainer(full)
     assert tr.dp.enabled and tr.dp.world == 2
     assert tr.generator.noise.rank in (None, rank)
@@ -67,7 +72,8 @@ def _worker(rank, world, port, q, full=False, graphed=False):
     else:
         dl, gl = tr.train_step(x[sl].cuda(), y_tmpl[sl].cuda(), y[sl].cuda(), noise_list=noise)
     torch.cuda.synchronize()
-    q.put((rank, _params(tr).numpy(), gl['gen_all'].item()))
+    from rtg import tune
+    q.put((rank, _params(tr).numpy(), gl['gen_all'].item(), tune.digest(), len(tune._conv)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -91,10 +97,13 @@ def test_two_ranks_match_single_process_step(full):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q, full)) for r in range(2)]
     for p in procs:
         p.start()
-    got = {r: (params, loss) for r, params, loss in _collect(q, procs, 2)}
+    res = _collect(q, procs, 2)
+    got = {r: (params, loss) for r, params, loss, _, _ in res}
     for p in procs:
         p.join(timeout=60)
     assert all(p.exitcode == 0 for p in procs)
+    # rank 0 timed the block shapes, rank 1 took its tables (train.DataParallel.sync_tuner): the same picks on both
+    assert res[0][3] == res[1][3] and res[0][4] == res[1][4] > 0, [r[3:] for r in res]
     # both ranks hold identical parameters after the step
     np.testing.assert_array_equal(got[0][0], got[1][0])
     # and they equal the single-process update on the 2-clip batch up to AdamW's sensitivity to ~0 gradients:
@@ -132,10 +141,12 @@ def test_two_ranks_graphed_step():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q, False, True)) for r in range(2)]
     for p in procs:
         p.start()
-    got = {r: (params, loss) for r, params, loss in _collect(q, procs, 2)}
+    res = _collect(q, procs, 2)
+    got = {r: (params, loss) for r, params, loss, _, _ in res}
     for p in procs:
         p.join(timeout=60)
     assert all(p.exitcode == 0 for p in procs)
+    assert res[0][3] == res[1][3] and res[0][4] == res[1][4] > 0, [r[3:] for r in res]     # identical tuner picks
     np.testing.assert_array_equal(got[0][0], got[1][0])
     assert np.isfinite(got[0][0]).all()
     move_ref, move_dp = ref - before.numpy(), got[0][0] - before.numpy()
@@ -147,16 +158,21 @@ def test_two_ranks_graphed_step():
 
 
 def _collect(q, procs, n, deadline_s=300):
-    """n results from the workers' queue; a worker that died without answering fails the test at once (instead of a queue
-    wait of many minutes that the GPU box's silence watchdog would kill the whole run for), a worker that is still alive
-    at the deadline is stopped and the test skipped: that is the environment (process-group rendezvous / RCCL start-up on
-    this box), not the arithmetic"""
+    """n results from the workers' queue.  Every worker first sends ('init', rank) once its process group stands.  A worker
+    that died without answering fails the test at once (instead of a queue wait of many minutes that the GPU box's silence
+    watchdog would kill the whole run for).  Workers still alive at the deadline are stopped and the test FAILS — a
+    collective deadlock is exactly what these tests exist to catch; only when the rendezvous itself never completed (not
+    every worker reported 'init') is the test skipped: that is the box's networking, not the code under test."""
     import queue
     import time
-    out, t0 = [], time.time()
+    out, inits, t0 = [], 0, time.time()
     while len(out) < n:
         try:
-            out.append(q.get(timeout=2))
+            m = q.get(timeout=2)
+            if isinstance(m, tuple) and len(m) == 2 and m[0] == 'init':
+                inits += 1
+            else:
+                out.append(m)
             continue
         except queue.Empty:
             pass
@@ -170,14 +186,17 @@ def _collect(q, procs, n, deadline_s=300):
             for p in procs:
                 if p.is_alive():
                     p.terminate()
-            pytest.skip(f'workers still running after {deadline_s} s (rendezvous / collective start-up on this box)')
+            if inits < len(procs):
+                pytest.skip(f'process-group rendezvous incomplete after {deadline_s} s ({inits} of {len(procs)} workers)')
+            pytest.fail(f'workers still running {deadline_s} s after the rendezvous: a collective / stream deadlock')
     return out
 
-def _rccl_worker(port, q):
+
+def _rccl_worker(port, q, body=None):
     """(errors travel back through the queue: the parent retries a failed rendezvous on a fresh port and shows anything
     else with its traceback)"""
     try:
-        _rccl_worker_body(port, q)
+        (body or _rccl_worker_body)(port, q)
     except Exception:                                  # noqa: BLE001
         import traceback
         q.put({'error': traceback.format_exc()})
@@ -193,6 +212,7 @@ def _rccl_worker_body(port, q):
     _setup()
     torch.cuda.set_device(0)
     dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    q.put(('init', 0))
     out = {}
     for full in (False, True):
         tr, O = _make_trainer(full)
@@ -246,10 +266,23 @@ def test_single_rank_rccl_forced_dp_equals_plain_step(monkeypatch):
         del tr
         torch.cuda.empty_cache()
 
+    got = _run_rccl_worker(_rccl_worker_body)
+    for full in (0, 1):
+        np.testing.assert_array_equal(got[f'eager{full}'], ref[f'eager{full}'])
+        # graphed: the forced-DP run cuts the D backward per discriminator (three backward calls instead of one over the
+        # summed loss): the same kernels on the same operands, the same bits
+        np.testing.assert_array_equal(got[f'graph{full}'], ref[f'graph{full}'])
+        assert np.isfinite(got[f'graph{full}']).all()
+        np.testing.assert_allclose(got[f'loss{full}'], ref[f'loss{full}'], rtol=1e-6)
+
+
+def _run_rccl_worker(body):
+    """run `body(port, q)` in a spawned process (a watchdog abort must not take pytest down) -> its answer; one retry on a
+    fresh port when the rendezvous itself failed (address in use / store connection), nothing else is retried"""
     ctx = mp.get_context('spawn')
     for attempt in range(2):
         q = ctx.Queue()
-        p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+        p = ctx.Process(target=_rccl_worker, args=(_free_port(), q, body))
         p.start()
         (got,) = _collect(q, [p], 1)
         p.join(timeout=60)
@@ -258,13 +291,111 @@ def test_single_rank_rccl_forced_dp_equals_plain_step(monkeypatch):
         err = got.get('error')
         if err is None:
             assert p.exitcode == 0
-            break
-        rendezvous = any(k in err for k in ('EADDRINUSE', 'Address already in use', 'TCPStore', 'timed out', 'Connection re'))
+            return got
+        rendezvous = any(k in err for k in ('EADDRINUSE', 'Address already in use', 'TCPStore', 'Connection refused',
+                                            'Connection reset'))
         assert rendezvous and attempt == 0, err          # (a taken port: once more on a fresh one; anything else is a failure)
-    for full in (0, 1):
-        np.testing.assert_array_equal(got[f'eager{full}'], ref[f'eager{full}'])
-        # graphed: the forced-DP run cuts the D backward per discriminator (three backward calls instead of one over the
-        # summed loss): the same kernels on the same operands, the same bits
-        np.testing.assert_array_equal(got[f'graph{full}'], ref[f'graph{full}'])
-        assert np.isfinite(got[f'graph{full}']).all()
-        np.testing.assert_allclose(got[f'loss{full}'], ref[f'loss{full}'], rtol=1e-6)
+
+
+RACE_REPS = 20
+
+
+def _race_worker_body(port, q):
+    """The round-3 crash forced instead of hoped for: an all-reduce nobody waits for sits behind a >= 400 ms spin kernel on a
+    side stream, so ProcessGroupNCCL's watchdog thread polls its pending event every ~100 ms; meanwhile the trainer's step
+    is captured into HIP graphs (every segment held open another 150 ms, so that polls land INSIDE captures) — straight
+    into Trainer._capture, without the drain prepare_graphs does first.  In the default 'global' capture mode the first
+    poll ends the process (hipErrorStreamCaptureUnsupported in WorkNCCL::finishedGPUExecutionInternal, GPUTEST_r03);
+    'thread_local' (train.CAPTURE_ERROR_MODE) must survive RACE_REPS repetitions and leave graphs that replay to the
+    eager step's bits."""
+    import time
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0', RTG_DP_FORCE='1',
+                      RTG_TUNE='0')
+    _setup()
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    q.put(('init', 0))
+    import train
+    tr, O = _make_trainer(False)
+    assert tr.dp.enabled
+    x, y_tmpl, y = (t.cuda() for t in O.golden_inputs(batch=2))
+    tr.train_step(x, y_tmpl, y)                                  # eager: RCCL all-reduces from the flush hooks
+    tr.train_step(x, y_tmpl, y)
+    torch.cuda.synchronize()
+    tr._tuned = True
+    # spin-kernel calibration (torch.cuda._sleep counts device clock ticks)
+    side = torch.cuda.Stream()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.cuda.stream(side):
+        torch.cuda._sleep(1000)
+        e0.record()
+        torch.cuda._sleep(20_000_000)
+        e1.record()
+    e1.synchronize()
+    ticks_per_ms = 20_000_000 / e0.elapsed_time(e1)
+    buf = torch.ones(1 << 16, device='cuda')
+    tr._capture_hook = lambda: time.sleep(0.15)
+    import threading
+    polls, capture_s = [], []
+
+    def poll(w, box):
+        """what the watchdog does, at a known time: query the collective's event from another thread 100 ms into the capture"""
+        time.sleep(0.1)
+        try:
+            box.append(('done' if w.is_completed() else 'pending', time.time()))
+        except Exception as e:          # noqa: BLE001  ('global' mode: hipErrorStreamCaptureUnsupported lands here)
+            box.append((f'{type(e).__name__}: {e}'[:200], time.time()))
+
+    for rep in range(RACE_REPS):
+        with torch.cuda.stream(side):
+            torch.cuda._sleep(int(400 * ticks_per_ms))
+            w = dist.all_reduce(buf, async_op=True)              # never waited for before the capture
+        box = []
+        th = threading.Thread(target=poll, args=(w, box))
+        t0 = time.time()
+        th.start()
+        tr._graphs = None
+        tr._capture(x, y_tmpl, y)                                # NOT prepare_graphs: no drain, the collective is in flight
+        t1 = time.time()
+        th.join()
+        capture_s.append(t1 - t0)
+        polls.append((box[0][0], t0 < box[0][1] < t1))
+        w.wait()
+        torch.cuda.synchronize()
+    tr._capture_hook = None
+    # the graphs of the last capture replay to the bits of the eager step from the same state (but for noise.w: its
+    # gradient sums the noise draws, which the replay seeds from the device step counter and the eager step from the host's)
+    gen_bank = tr.generator.bank()
+    noise_at = (tr.generator.noise.w.data_ptr() - gen_bank.flat.data_ptr()) // 4
+    state = [m.bank().flat.clone() for m in (tr.generator, *tr.discs)]
+    opt = (tr.optim_g.state_dict(), tr.optim_d.state_dict())
+    tr.train_step_graphed(x, y_tmpl, y)
+    torch.cuda.synchronize()
+    after_graph = _params(tr).numpy()
+    for m, s_ in zip((tr.generator, *tr.discs), state):
+        m.bank().flat.copy_(s_)
+    tr.optim_g.load_state_dict(opt[0]); tr.optim_d.load_state_dict(opt[1])
+    tr._graphs = None
+    hooks = [d.bank().on_flush for d in tr.discs]
+    tr.train_step(x, y_tmpl, y)
+    torch.cuda.synchronize()
+    after_eager = _params(tr).numpy()
+    moved = float(np.abs(after_graph - np.concatenate([s_.cpu().numpy() for s_ in state])).max())
+    after_graph[noise_at] = after_eager[noise_at] = 0.0
+    q.put({'reps': RACE_REPS, 'mode': train.CAPTURE_ERROR_MODE, 'capture_s': capture_s, 'polls': polls,
+           'segments': (1 + (len(tr.discs) - 1)) * tr.d_train_times + 2, 'moved': moved,
+           'max_abs_diff': float(np.abs(after_graph - after_eager).max()), 'finite': bool(np.isfinite(after_graph).all()),
+           'hooks_alive': all(h is not None for h in hooks)})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_graph_capture_with_rccl_collective_in_flight():
+    got = _run_rccl_worker(_race_worker_body)
+    assert got['reps'] == RACE_REPS and got['mode'] == 'thread_local'
+    # every capture was held open across watchdog polls (>= segments x 150 ms) ...
+    assert min(got['capture_s']) >= 0.15 * got['segments'], got['capture_s']
+    # ... and in every repetition another thread queried the collective's event INSIDE the capture and found it pending
+    assert got['polls'] == [('pending', True)] * RACE_REPS, got['polls']
+    assert got['hooks_alive'] and got['finite'] and got['moved'] > 1e-5
+    assert got['max_abs_diff'] == 0.0, got['max_abs_diff']

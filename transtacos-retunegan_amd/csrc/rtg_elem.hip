@@ -719,8 +719,10 @@ extern "C" int rtg_adamw(float* params, const float* grads, float* exp_avg, floa
 
 extern "C" int rtg_abi_version(void) { return RTG_ABI_VERSION; }
 // (a library compiled with an ablation / diagnostic define says so: rtg/lib.py refuses it as the product library)
-#if defined(RTG_EXP_NOMFMA_BF) || defined(RTG_EXP_EMPTY) || defined(RTG_EXP_SKIPLOOP) || defined(RTG_EXP_NOGENERAL) || \
-    defined(RTG_STAMPS)
+// RTG_ABLATION: set by every dev build script (tools/dev_build.sh, tools/dbg/abl.sh) whatever -DRTG_EXP_* / -DRTG_STAMPS
+// flag it compiles into whichever source — those scripts always recompile THIS file with it
+#if defined(RTG_ABLATION) || defined(RTG_EXP_NOMFMA_BF) || defined(RTG_EXP_EMPTY) || defined(RTG_EXP_SKIPLOOP) || \
+    defined(RTG_EXP_NOGENERAL) || defined(RTG_STAMPS)
 #define RTG_BUILD_KIND " ABLATION"
 #else
 #define RTG_BUILD_KIND ""

@@ -277,7 +277,7 @@ class WeightBank:
                 if size:
                     pack.append(L.PackJob(ly.v_off, ly.scale_off, off, size, mode, g, mg, cg, k, ly.k, ly.inner_c, s, 16,
                                           ly.kh, 0, ly.frag_bf, 1))
-            self.norm_table = _table(norm, self.device)
+        self.norm_table = _table(norm, self.device)
         self.pack_blocks, self.pack_lds = L.assign_pack_blocks(pack)
         self.pack_table = _table(pack, self.device)
         self.n_pack = len(pack)

@@ -862,8 +862,8 @@ def _common_group_code(descs):
     lists = []
     for d in descs:
         d.tile_cfg = 0
-        cands = (C.c_int * 32)()
-        k = lib.rtg_conv1d_tile_candidates(C.byref(d), cands, 32)
+        cands = (C.c_int * tune.MAX_CANDS)()               # the same list tune.group_cfg intersects
+        k = lib.rtg_conv1d_tile_candidates(C.byref(d), cands, tune.MAX_CANDS)
         lists.append({c for c in cands[:max(k, 0)] if 0 < c < 7000})
     return bool(set.intersection(*lists)) if lists else False
 
@@ -880,7 +880,8 @@ def mrf_group_ok(lys, x):
     # the k3 / k5 / k7 members must also share a block shape, forward and backward-data, at THIS batch and length
     # (GroupConvFn raises otherwise): any other segment length or batch falls back to the forked branches
     B, _, L_in = x.shape
-    key = (tuple(ly.lid for ly in lys), id(lys[0]), B, L_in)
+    # (keyed on the problem, not on object identity: a freed model's layer id can be reused by the next model's)
+    key = (tuple((ly.lid, ly.k, ly.dil, ly.pad, ly.fwd_bf, ly.bwd_bf) for ly in lys), c, B, L_in)
     ok = _GROUP_OK.get(key)
     if ok is None:
         ok = _common_group_code([_fwd_desc(ly, B, c, L_in, 0.15)[0] for ly in lys]) and \

@@ -21,6 +21,7 @@ ENABLED = os.environ.get('RTG_TUNE', '1') != '0'
 ACTIVE = False
 MISSED = False
 REPS = 3
+MAX_CANDS = 48            # candidate block shapes asked of rtg_conv1d_tile_candidates (general + resconv + dconv codes)
 _conv, _wgrad, _group, _wgroup, _alt = {}, {}, {}, {}, {}
 
 
@@ -64,8 +65,8 @@ def conv_cfg(d, launch):
         return cfg
     if not (ENABLED and ACTIVE):
         return _miss()
-    cands = (C.c_int * 48)()
-    n = lib.rtg_conv1d_tile_candidates(C.byref(d), cands, 48)
+    cands = (C.c_int * MAX_CANDS)()
+    n = lib.rtg_conv1d_tile_candidates(C.byref(d), cands, MAX_CANDS)
     best, best_t = 0, None
     for c in cands[:max(n, 0)]:
         d.tile_cfg = c
@@ -159,8 +160,8 @@ def group_cfg(darr, n, launch):
         return cfg
     lists = []
     for i in range(n):
-        cands = (C.c_int * 32)()
-        k = lib.rtg_conv1d_tile_candidates(C.byref(darr[i]), cands, 32)
+        cands = (C.c_int * MAX_CANDS)()
+        k = lib.rtg_conv1d_tile_candidates(C.byref(darr[i]), cands, MAX_CANDS)
         lists.append([c for c in cands[:max(k, 0)] if 0 < c < 7000])     # 7001 / 7002: rtg_resconv, not a group member
     common = [c for c in lists[0] if all(c in l for l in lists[1:])]
     if not common:
@@ -180,6 +181,30 @@ def group_cfg(darr, n, launch):
         darr[i].tile_cfg = 0
     _group[key] = best
     return best
+
+
+_TABLES = ('_conv', '_wgrad', '_group', '_wgroup', '_alt')
+
+
+def export_tables():
+    """the pick tables as one picklable object (keys: descriptor bytes — shapes, no pointers)"""
+    g = globals()
+    return {n: dict(g[n]) for n in _TABLES}
+
+
+def import_tables(tables):
+    """take another rank's picks (train.DataParallel.sync_tuner); picks of problems only this process met are kept"""
+    g = globals()
+    for n in _TABLES:
+        g[n].update(tables.get(n, {}))
+
+
+def digest():
+    """short hash of all picks (bench.py prints it per rank: equal digests = every rank runs the same kernels)"""
+    import hashlib
+    g = globals()
+    picks = repr([sorted((k.hex() if isinstance(k, bytes) else repr(k), v) for k, v in g[n].items()) for n in _TABLES])
+    return hashlib.sha256(picks.encode()).hexdigest()[:6]
 
 
 def stats():

@@ -30,6 +30,7 @@ from rtg import tune
 from rtg.lib import lib, check, RtgError, current_stream_ptr as _lib_stream_ptr
 
 device = 'cuda' if torch.cuda.is_available() else 'cpu'
+CAPTURE_ERROR_MODE = os.environ.get('RTG_CAPTURE_MODE', 'thread_local')
 
 
 def _p(t):
@@ -186,7 +187,7 @@ class DataParallel:
 
     def __init__(self, models, process_group=None):
         # RTG_DP_FORCE=1: keep the whole data-parallel machinery (flush hooks, communication stream, collectives between
-        # graph segments) on in a group of ONE rank — how tests/test_dp_gpu.py runs RCCL itself on a one-GPU box
+        # graph segments) on in a group of ONE rank — how tests/test_zz_dp_gpu.py runs RCCL itself on a one-GPU box
         self.enabled = dist.is_available() and dist.is_initialized() and (
             dist.get_world_size(process_group) > 1 or os.environ.get('RTG_DP_FORCE') == '1')
         self.group = process_group
@@ -224,6 +225,38 @@ class DataParallel:
         self.pending = []
         if self.comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
+
+    def drain(self):
+        """Quiesce the process group before a HIP-graph capture: every all-reduce this trainer issued has been waited for and
+        has FINISHED on the device, and no rank starts capturing while another still runs eager collectives.  (Round 3:
+        ProcessGroupNCCL's watchdog thread polls the events of collectives it still tracks; a capture in the default
+        'global' error mode makes that hipEventQuery fail with hipErrorStreamCaptureUnsupported and the watchdog ends the
+        process.  Trainer._capture therefore captures 'thread_local' — the fix — and drains first so that the graphs also
+        never depend on a collective in flight.)"""
+        if not self.enabled:
+            return
+        self.wait()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        dist.barrier(group=self.group)
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+
+    def sync_tuner(self, src=0):
+        """-> whether rank `src` met a problem its tables did not hold yet (every rank then tunes once more).
+        Rank `src` timed the block shapes (rtg/tune.py); every other rank takes its pick tables, so that all ranks run
+        the same kernels (the same step time: the slowest rank paces a data-parallel step) and only one tuner runs per
+        host.  The table keys are descriptor bytes (shapes only, no pointers): identical on every rank for equal
+        per-rank batches.  Collective: every rank calls it at the same point."""
+        if not self.enabled:
+            return tune.MISSED
+        mine = dist.get_rank(self.group) == src
+        box = [(tune.export_tables(), tune.MISSED) if mine else None]
+        dist.broadcast_object_list(box, src=src, group=self.group)
+        tables, missed = box[0]
+        if not mine:
+            tune.import_tables(tables)
+        return bool(missed)
 
 
 
@@ -264,6 +297,7 @@ class Trainer:
         self._tuned = False
         self._graphs = None
         self._static_in = self._static_out = None
+        self._capture_hook = None
         for m in (self.generator, *self.discs):
             m.train()
         if self.dp.enabled:
@@ -369,7 +403,10 @@ class Trainer:
         Returns (d_losses, g_losses) as device scalars — nothing here synchronises with the host."""
         # the first step (and one after any step that met a new problem shape) also times the block shapes of every
         # conv / wgrad launch and keeps the fastest (rtg/tune.py); it is an ordinary train step otherwise
-        tune.ACTIVE = tune.ENABLED and (not self._tuned or tune.MISSED)
+        tuning = tune.ENABLED and (not self._tuned or tune.MISSED)
+        # data parallel: rank 0 times, the others run this step on the library's heuristic shapes and take rank 0's picks
+        # after it (DataParallel.sync_tuner); `tuning` is the same on every rank (same shapes, same tables)
+        tune.ACTIVE = tuning and (not self.dp.enabled or dist.get_rank(self.dp.group) == 0)
         tune.MISSED = False
         try:
             with stft_cache():
@@ -381,8 +418,10 @@ class Trainer:
                     dl = self.d_step(y, y_det)
                 gl = self.g_step(y, y_g_hat)
         finally:
-            self._tuned = self._tuned or tune.ACTIVE
+            self._tuned = self._tuned or tuning
             tune.ACTIVE = False
+        if tuning and self.dp.enabled:
+            tune.MISSED = self.dp.sync_tuner()
         self.steps += 1
         return dl, gl
 
@@ -395,6 +434,7 @@ class Trainer:
             if not self._tuned or tune.MISSED:                  # block shapes are timed eagerly, never under capture
                 for _ in range(2):
                     self.train_step(x, y_tmpl, y)
+            self.dp.drain()                                     # no collective in flight on any rank while one captures
             self._capture(x, y_tmpl, y)
 
     def train_step_graphed(self, x, y_tmpl, y):
@@ -509,8 +549,14 @@ class Trainer:
             with torch.cuda.stream(cap):
                 for body, after in segs:
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, pool=pool, stream=cap):
+                    # 'thread_local': other threads of this process keep their right to call the HIP runtime while this
+                    # one captures — ProcessGroupNCCL's watchdog polls events of the collectives it tracks (in the
+                    # default 'global' mode its hipEventQuery fails, invalidates the capture and ends the process:
+                    # GPUTEST_r03); the autograd thread that launches the backward is not policed either way
+                    with torch.cuda.graph(g, pool=pool, stream=cap, capture_error_mode=CAPTURE_ERROR_MODE):
                         body()
+                        if self._capture_hook is not None:      # (tests hold a capture open: tests/test_zz_dp_gpu.py)
+                            self._capture_hook()
                     graphs.append((g, after if self.dp.enabled else None))
                     if os.environ.get('RTG_GRAPH_DEBUG'):
                         print(f'captured graph segment {len(graphs)} of {len(segs)}', flush=True)
