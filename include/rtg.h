@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define RTG_ABI_VERSION 6
+#define RTG_ABI_VERSION 7
 
 #define RTG_OK 0
 #define RTG_EINVAL (-1)   /* inconsistent descriptor               */
@@ -394,6 +394,18 @@ int rtg_resstack_forward(const RtgResStackDesc* d, const float* x, const float* 
                          float* const* outs, void* stream);
 int rtg_resstack_backward(const RtgResStackDesc* d, const float* dy, const float* y, const float* const* wpb,
                           const float* const* masks, float* const* gouts, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * HIP streams of the library's own (ABI 7).  torch.cuda.Stream() hands out streams of a pool of 32 per priority, round
+ * robin — ProcessGroupNCCL draws its collective stream from the same pool, so a stream a caller creates for HIP-graph
+ * capture (or forks inside one) can BE the RCCL stream: the process group's watchdog then polls an event whose stream is
+ * capturing and hipEventQuery fails with hipErrorCapturedEvent (the watchdog ends the process).  Streams created here are
+ * outside that pool; the host side wraps them in torch.cuda.ExternalStream (train.py, models/layers.py).  Replaces the
+ * implicit stream pool behind the reference's single-stream step (retunegan/train.py:121-193 runs on the default stream).
+ * priority: 0 normal, < 0 high (clamped to the device's range).  The stream stays alive until rtg_stream_destroy.
+ * ------------------------------------------------------------------------------------------------------------ */
+int rtg_stream_create(int priority, void** stream);
+int rtg_stream_destroy(void* stream);
 
 /* library self-description */
 int rtg_abi_version(void);

@@ -717,6 +717,22 @@ extern "C" int rtg_adamw(float* params, const float* grads, float* exp_avg, floa
   RTG_LAUNCH(adamw_bump_kernel, 1, 1, 0, stream, step_state, loss_flag);
 }
 
+extern "C" int rtg_stream_create(int priority, void** stream) {
+  if (!stream) return RTG_ENULL;
+  int lo = 0, hi = 0;                                 // (numerically: hi <= priority <= lo, hi = highest priority)
+  if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) return RTG_EINVAL;
+  int p = priority < hi ? hi : (priority > lo ? lo : priority);
+  hipStream_t s = nullptr;
+  if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, p) != hipSuccess) return RTG_EINVAL;
+  *stream = (void*)s;
+  return 0;
+}
+
+extern "C" int rtg_stream_destroy(void* stream) {
+  if (!stream) return RTG_ENULL;
+  return hipStreamDestroy((hipStream_t)stream) == hipSuccess ? 0 : RTG_EINVAL;
+}
+
 extern "C" int rtg_abi_version(void) { return RTG_ABI_VERSION; }
 // (a library compiled with an ablation / diagnostic define says so: rtg/lib.py refuses it as the product library)
 // RTG_ABLATION: set by every dev build script (tools/dev_build.sh, tools/dbg/abl.sh) whatever -DRTG_EXP_* / -DRTG_STAMPS

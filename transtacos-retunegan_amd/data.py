@@ -27,6 +27,7 @@ from torch.utils.data import Dataset as _TorchDataset
 
 import hparam as hp
 import audio as A
+from rtg.lib import new_stream
 
 assert hp.segment_size % hp.hop_length == 0            # data.py:16
 frames_per_seg = hp.segment_size // hp.hop_length
@@ -180,7 +181,7 @@ class PinnedFeeder:
 
     def __init__(self, make_batch, device, depth=2):
         self.make_batch, self.device, self.depth = make_batch, torch.device(device), depth
-        self.copy_stream = torch.cuda.Stream(device=self.device)
+        self.copy_stream = new_stream(device=self.device)
         self.free, self.ready = queue.Queue(), queue.Queue(maxsize=depth)
         self.slots = None
         self._stop = False

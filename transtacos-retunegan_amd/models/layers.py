@@ -9,7 +9,7 @@ import torch.nn as nn
 
 from rtg import ops, tune
 from rtg.bank import WeightBank
-from rtg.lib import ACT_NONE, ACT_LRELU, ACT_TANH, RtgError  # noqa: F401
+from rtg.lib import ACT_NONE, ACT_LRELU, ACT_TANH, RtgError, new_stream  # noqa: F401
 
 
 class WNConv(nn.Module):
@@ -136,7 +136,7 @@ def fork_join(fns):
     pool = _FORK_STREAMS.setdefault((main.device, path), [])
     n_str = len(fns) if _FORK_MAX <= 0 else min(len(fns), _FORK_MAX)   # RTG_FORK_MAX: branches share streams round-robin
     while len(pool) < n_str:
-        pool.append(torch.cuda.Stream(device=main.device))
+        pool.append(new_stream(device=main.device))      # (never a pooled torch stream: rtg/lib.py:new_stream)
     outs = []
     try:
         for i, f in enumerate(fns):

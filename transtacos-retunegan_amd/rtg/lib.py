@@ -90,7 +90,7 @@ CK = 16
 LOSS_L1, LOSS_L1_L1LOG, LOSS_MSE_TARGET, LOSS_MSE_REL = 0, 1, 2, 3
 MAX_LOSS_JOBS = 48
 
-ABI_VERSION = 6            # RTG_ABI_VERSION of include/rtg.h these struct layouts / prototypes were written for
+ABI_VERSION = 7            # RTG_ABI_VERSION of include/rtg.h these struct layouts / prototypes were written for
 _P = C.c_void_p
 _I, _F, _D, _LL, _ULL = C.c_int, C.c_float, C.c_double, C.c_longlong, C.c_ulonglong
 
@@ -144,6 +144,8 @@ PROTOTYPES = {
     'rtg_resstack_ok': (_I, [C.POINTER(ResStackDesc)]),
     'rtg_resstack_forward': (_I, [C.POINTER(ResStackDesc), _P, C.POINTER(PtrArray6), C.POINTER(PtrArray6), C.POINTER(PtrArray6), _P]),
     'rtg_resstack_backward': (_I, [C.POINTER(ResStackDesc), _P, _P, C.POINTER(PtrArray6), C.POINTER(PtrArray6), C.POINTER(PtrArray6), _P]),
+    'rtg_stream_create': (_I, [_I, C.POINTER(C.c_void_p)]),
+    'rtg_stream_destroy': (_I, [_P]),
     'rtg_abi_version': (_I, []),
     'rtg_build_info': (C.c_char_p, []),
 }
@@ -217,3 +219,20 @@ def current_stream_ptr():
     if _raw_stream is not None:
         return C.c_void_p(_raw_stream(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+_OWN_STREAMS = []
+
+
+def new_stream(priority=0, device=None):
+    """A HIP stream of the library's own (rtg_stream_create), wrapped for torch: NOT one of the 32 pooled streams
+    torch.cuda.Stream() hands out round robin, which ProcessGroupNCCL also draws its collective stream from — a pooled
+    stream used for HIP-graph capture can be the RCCL stream itself, and the process group's watchdog then dies polling an
+    event of a capturing stream (hipErrorCapturedEvent, round 4).  Lives as long as the process."""
+    dev = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+    with torch.cuda.device(dev):
+        h = C.c_void_p()
+        check(lib.rtg_stream_create(int(priority), C.byref(h)), 'stream_create')
+    s = torch.cuda.ExternalStream(h.value, device=dev)
+    _OWN_STREAMS.append(s)
+    return s

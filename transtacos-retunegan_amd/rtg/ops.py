@@ -111,7 +111,7 @@ class wgrad_side:
         main = torch.cuda.current_stream()
         side = _SIDE_STREAMS.get(main)
         if side is None:
-            side = _SIDE_STREAMS[main] = torch.cuda.Stream(device=main.device)
+            side = _SIDE_STREAMS[main] = L.new_stream(device=main.device)
         side.wait_stream(main)
         for t in self.tensors:
             if t is not None:

@@ -27,7 +27,7 @@ from models.layers import BankedModel, fork_join  # noqa: F401
 from models.discrminator import run_stacks
 from models.loss import stft_cache
 from rtg import tune
-from rtg.lib import lib, check, RtgError, current_stream_ptr as _lib_stream_ptr
+from rtg.lib import lib, check, RtgError, new_stream, current_stream_ptr as _lib_stream_ptr
 
 device = 'cuda' if torch.cuda.is_available() else 'cpu'
 CAPTURE_ERROR_MODE = os.environ.get('RTG_CAPTURE_MODE', 'thread_local')
@@ -211,7 +211,7 @@ class DataParallel:
             if self.comm_stream is None:
                 # high priority: its own hardware queue, so that the RCCL kernels neither wait behind nor hold up the
                 # compute kernels of a forked stream that would otherwise share a queue with it (4 queues per process)
-                self.comm_stream = torch.cuda.Stream(priority=-1)
+                self.comm_stream = new_stream(priority=-1)
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
                 w = dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
@@ -298,6 +298,7 @@ class Trainer:
         self._graphs = None
         self._static_in = self._static_out = None
         self._capture_hook = None
+        self._cap_stream = None
         for m in (self.generator, *self.discs):
             m.train()
         if self.dp.enabled:
@@ -470,7 +471,9 @@ class Trainer:
         for d, _ in hooks:
             d.bank().on_flush = None                            # collectives stay outside the graphs
         pool = torch.cuda.graph_pool_handle()
-        cap = torch.cuda.Stream()
+        if self._cap_stream is None:               # one capture stream per trainer, outside torch's stream pool (the RCCL
+            self._cap_stream = new_stream()        # stream is a pool stream: rtg/lib.py:new_stream)
+        cap = self._cap_stream
         cap.wait_stream(torch.cuda.current_stream())
         state = {}
         n_d = self.d_train_times
