@@ -32,7 +32,11 @@ enum { RTG_PRE_NONE = 0, RTG_PRE_LRELU = 1, RTG_PRE_MUL_DLRELU = 2, RTG_PRE_MUL_
 /* output activation */
 enum { RTG_ACT_NONE = 0, RTG_ACT_LRELU = 1, RTG_ACT_TANH = 2 };
 /* packed-weight layouts produced by rtg_weights_pack (see RtgPackJob.mode) */
-enum { RTG_PACK_FWD = 0, RTG_PACK_DGRAD_S1 = 1, RTG_PACK_DGRAD_POLY = 2, RTG_PACK_CONVT_POLY = 3, RTG_PACK_DGRAD_2D = 4 };
+enum { RTG_PACK_FWD = 0, RTG_PACK_DGRAD_S1 = 1, RTG_PACK_DGRAD_POLY = 2, RTG_PACK_CONVT_POLY = 3, RTG_PACK_DGRAD_2D = 4,
+       /* ABI 7: the plain layouts rtg_gconv_forward / rtg_gconv_backward_data read (what rtg_gconv_prepare[_bwd] write),
+        * produced by rtg_weights_pack with the other images of a model instead of one launch per layer and pass:
+        * [group][ci][tap][oc] resp. [group][oc][tap][ci], dst_size = groups * Mg * Cg * K floats */
+       RTG_PACK_GCONV_FWD = 5, RTG_PACK_GCONV_BWD = 6 };
 
 /* ------------------------------------------------------------------------------------------------------------
  * rtg_conv1d — implicit-GEMM 1-D convolution on the fp32 matrix cores (v_mfma_f32_32x32x2_f32 / 16x16x4_f32).

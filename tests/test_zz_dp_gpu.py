@@ -220,16 +220,22 @@ def _rccl_worker_body(port, q):
         assert all(d.bank().on_flush is not None for d in tr.discs)
         x, y_tmpl, y = (t.cuda() for t in O.golden_inputs(batch=2))
         noise = [n.cuda() for n in _noise(2)]
+        # both exchange policies: gradients all-reduced on the compute stream, one graph segment per optimizer update (the
+        # defaults) on G + MSD + MPD; the high-priority communication stream with the D backward cut per discriminator
+        # (RTG_DP_CUT=disc) on the full stack with two D updates
+        os.environ['RTG_DP_CUT'] = 'disc' if full else 'update'
         tr.train_step(x, y_tmpl, y, noise_list=noise)                     # eager: all-reduces from the flush hooks
         torch.cuda.synchronize()
-        assert tr.dp.comm_stream is not None                              # the RCCL path ran
+        assert (tr.dp.comm_stream is not None) == full                    # which RCCL path ran
         out[f'eager{int(full)}'] = _params(tr).numpy()
         dl, gl = tr.train_step_graphed(x, y_tmpl, y)                      # 2 eager tuning steps, capture, one replay
         dl, gl = tr.train_step_graphed(x, y_tmpl, y)                      # ... and a second replay of the same graphs
         torch.cuda.synchronize()
         n_seg = len(tr._graphs)
-        # D backward cut per discriminator: first | (n_disc - 1) tails, per D update, + the G-update and final segments
-        assert n_seg == (1 + (len(tr.discs) - 1)) * tr.d_train_times + 2, n_seg
+        if full:  # D backward cut per discriminator: first | (n_disc - 1) tails, per D update, + the G-update and final segments
+            assert n_seg == (1 + (len(tr.discs) - 1)) * tr.d_train_times + 2, n_seg
+        else:
+            assert n_seg == tr.d_train_times + 2, n_seg
         out[f'graph{int(full)}'] = _params(tr).numpy()
         out[f'loss{int(full)}'] = (dl['disc_all'].item(), gl['gen_all'].item())
         del tr
@@ -395,11 +401,12 @@ def _race_worker_body(port, q):
     # no stream of the capture is one of torch's 32 pooled streams (ProcessGroupNCCL's collective stream is one of those)
     from models import layers
     pooled = {torch.cuda.Stream().cuda_stream for _ in range(64)}
-    ours = [tr._cap_stream] + [s_ for pool in layers._FORK_STREAMS.values() for s_ in pool] + [tr.dp.comm_stream]
+    ours = [tr._cap_stream] + [s_ for pool in layers._FORK_STREAMS.values() for s_ in pool]
+    ours += [tr.dp.comm_stream] if tr.dp.comm_stream is not None else []
     own_streams = len(ours) >= 3 and all(s_.cuda_stream not in pooled for s_ in ours)
     after_graph[noise_at] = after_eager[noise_at] = 0.0
     q.put({'reps': len(polls), 'errors': errors, 'mode': train.CAPTURE_ERROR_MODE, 'capture_s': capture_s, 'polls': polls,
-           'segments': (1 + (len(tr.discs) - 1)) * tr.d_train_times + 2, 'moved': moved,
+           'segments': len(tr._graphs or []) or tr.d_train_times + 2, 'moved': moved,
            'max_abs_diff': float(np.abs(after_graph - after_eager).max()),
            'frac_bad': float(np.mean(np.abs(after_graph - after_eager) > 0.2 * 2e-4)), 'finite': bool(np.isfinite(after_graph).all()),
            'hooks_alive': all(h is not None for h in hooks), 'own_streams': own_streams})

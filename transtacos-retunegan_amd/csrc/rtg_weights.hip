@@ -88,7 +88,7 @@ __host__ __device__ inline PackGeom pack_geom(const RtgPackJob& j) {
   const int chs = (j.mode == RTG_PACK_DGRAD_POLY || j.mode == RTG_PACK_CONVT_POLY) ? (p.RT - 1) / S + 2 : 0;
   p.run = j.mode == RTG_PACK_FWD ? RTG_CK * j.src_K : (j.mode == RTG_PACK_DGRAD_S1 ? p.RT * j.src_K : chs * j.src_K);
   p.nrow = j.mode == RTG_PACK_FWD ? p.RT : RTG_CK;
-  p.staged = !j.bf16 && !j.tap_major && j.mode != RTG_PACK_DGRAD_2D && p.nrow * (p.run + 1) <= kPackSlab;
+  p.staged = !j.bf16 && !j.tap_major && j.mode != RTG_PACK_DGRAD_2D && j.mode < RTG_PACK_GCONV_FWD && p.nrow * (p.run + 1) <= kPackSlab;
   return p;
 }
 
@@ -108,6 +108,25 @@ __global__ __launch_bounds__(RTG_THREADS) void pack_kernel(const RtgPackJob* job
   const int n_mt = (j.Mg + TM - 1) / TM, n_cc = (j.Cg + RTG_CK - 1) / RTG_CK;
   const unsigned n_e = (unsigned)j.dst_size;
   const int lane = threadIdx.x & 63;
+  if (j.mode == RTG_PACK_GCONV_FWD || j.mode == RTG_PACK_GCONV_BWD) {
+    // the vector-ALU kernels' plain orders (rtg_gconv.hip): w'[g][ci][t][oc] = v[g * Mg + oc][ci][t] * scale[g * Mg + oc]
+    // (forward), w'[g][oc][t][ci] = the same element (backward-data); the source row of v is (ci, t)-major
+    const unsigned CK = (unsigned)(j.Cg * j.K);
+    for (unsigned e = bid * RTG_THREADS + threadIdx.x; e < n_e; e += nb * RTG_THREADS) {
+      unsigned row, sin;
+      if (j.mode == RTG_PACK_GCONV_FWD) {
+        const unsigned oc = e % (unsigned)j.Mg, r = (e / (unsigned)j.Mg) % CK, g = e / ((unsigned)j.Mg * CK);
+        row = g * (unsigned)j.Mg + oc;
+        sin = r;
+      } else {
+        const unsigned ci = e % (unsigned)j.Cg, t = (e / (unsigned)j.Cg) % (unsigned)j.K;
+        row = e / CK;
+        sin = ci * (unsigned)j.K + t;
+      }
+      packed[j.dst_off + e] = params[j.v_off + (long long)row * CK + sin] * scales[j.scale_off + row];
+    }
+    return;
+  }
   if (j.bf16 && j.frag16) {
     // the bf16 fragment image of rtg_dconv.hip: [16-row tile][32-channel chunk][tap][kgrp 4][row 16][8 bf16], channel
     // 8 * kgrp + i of the chunk in element i; one 32-bit slot = elements (2 * slot, 2 * slot + 1)
@@ -459,7 +478,7 @@ extern "C" int rtg_pack_job_blocks(const RtgPackJob* job) {
   long long n;
   if (pg.staged) {
     n = (long long)job->groups * pg.n_rt * pg.n_cc;                          // one slab per block
-  } else if (job->bf16) {
+  } else if (job->bf16 || job->mode >= RTG_PACK_GCONV_FWD) {
     n = (job->dst_size + RTG_THREADS * 4 - 1) / (RTG_THREADS * 4);
   } else {
     const long long n_steps = job->dst_size / (job->frag16 ? 256 : RTG_CK * job->tile_m);

@@ -23,6 +23,10 @@ from .lib import lib, check
 from .lib import current_stream_ptr as _lib_stream_ptr
 
 
+# RTG_GCONV=0 (rtg/ops.py): the thin-group layers never leave the matrix cores, no vector-ALU weight images either
+GCONV_IMAGES = os.environ.get('RTG_GCONV', '1') == '1'
+
+
 def _stream():
     return _lib_stream_ptr()
 
@@ -203,6 +207,16 @@ class WeightBank:
             poff += f + f16
             ly.bwd_off, ly.bwd_size, ly.bwd16_size = poff, b, b16
             poff += b + b16
+            # the thin-group k41 layers of MSD can run on the vector ALUs (rtg_gconv.hip; the tuner decides per problem):
+            # their plain weight orders are two more images of the pack launch (round 4; rounds 2-3: rtg_gconv_prepare[_bwd]
+            # per layer and pass, 72 launches of ~5 us per step)
+            ly.gconv_off = None
+            if GCONV_IMAGES and ly.kind == 'conv' and ly.groups > 1 and ly.k == 41 and ly.kh == 1:
+                n = ly.cout * (ly.cin // ly.groups) * ly.k + 128     # (+ 128: rtg_gconv_workspace — the kernels request the
+                n = (n + 3) & ~3                                     # last block of taps whole, past the image's end)
+                ly.gconv_off = (poff, poff + n)
+                ly.gconv_size = ly.cout * (ly.cin // ly.groups) * ly.k
+                poff += 2 * n
         self.packed = torch.empty(poff, device=self.device, dtype=torch.float32)
         self._bind_params()
         self._build_tables()
@@ -277,6 +291,10 @@ class WeightBank:
                 if size:
                     pack.append(L.PackJob(ly.v_off, ly.scale_off, off, size, mode, g, mg, cg, k, ly.k, ly.inner_c, s, 16,
                                           ly.kh, 0, ly.frag_bf, 1))
+            if ly.gconv_off is not None:
+                for mode, off in ((L.PACK_GCONV_FWD, ly.gconv_off[0]), (L.PACK_GCONV_BWD, ly.gconv_off[1])):
+                    pack.append(L.PackJob(ly.v_off, ly.scale_off, off, ly.gconv_size, mode, ly.groups, ly.cout // ly.groups,
+                                          ly.cin // ly.groups, ly.k, ly.k, ly.inner_c, 1, 16, 0, 0, 0, 0))
         self.norm_table = _table(norm, self.device)
         self.pack_blocks, self.pack_lds = L.assign_pack_blocks(pack)
         self.pack_table = _table(pack, self.device)
@@ -316,6 +334,12 @@ class WeightBank:
         """the layer's effective weights in the [group][ci][tap][oc] order of rtg_gconv.hip ([group][oc][tap][ci] for the
         backward-data kernel), refreshed once per forward pass (token) from the raw weight-norm parameters and the
         scales the pass's prepare() wrote"""
+        if ly.gconv_off is not None:                     # an image of this pass's pack launch
+            if lib.rtg_gconv_workspace(C.byref(gd)) != ly.gconv_size + 128:
+                raise L.RtgError(f'gconv image of {ly.name}: {ly.gconv_size} floats, the kernel expects '
+                                 f'{lib.rtg_gconv_workspace(C.byref(gd)) - 128}')
+            o = ly.gconv_off[1 if bwd else 0]
+            return self.packed[o:o + ly.gconv_size]
         key = (ly.lid, bwd)
         ent = self._gconv.get(key)
         if ent is None:

@@ -33,6 +33,19 @@ device = 'cuda' if torch.cuda.is_available() else 'cpu'
 CAPTURE_ERROR_MODE = os.environ.get('RTG_CAPTURE_MODE', 'thread_local')
 
 
+def _inline_reduce():
+    """Where the gradient all-reduces run.  Default: on the compute stream itself (async_op=False: stream-ordered after the
+    kernels that wrote the gradients and before the optimizer launch, no communication stream, no event hops) — measured on
+    one MI355X over a 1-rank RCCL group, graph replay (gpurun r04f): 28.1 ms/step against 29.9 through the high-priority
+    communication stream (27.7 with the collectives left out): the two cross-stream hops per exchange cost more than the
+    RCCL kernels.  RTG_DP_INLINE=0, or RTG_DP_CUT=disc (whose point is the overlap), keeps the communication stream."""
+    v = os.environ.get('RTG_DP_INLINE')
+    if v is None:
+        v = '0' if os.environ.get('RTG_DP_CUT') == 'disc' else '1'
+    return v == '1'
+
+
+
 def _p(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
@@ -206,6 +219,13 @@ class DataParallel:
         """all-reduce `flat_grad` on the communication stream once the kernels already queued on the current stream
         (which produce it) have finished; returns immediately."""
         if not self.enabled:
+            return
+        if os.environ.get('RTG_DP_DRY') == '1':          # dev: everything but the collective itself (cost attribution)
+            return
+        if flat_grad.is_cuda and _inline_reduce():
+            # stream-ordered on the compute stream: after the kernels that produced the gradients, before the optimizer
+            # launch that reads them; no communication stream, no event hops (nothing to overlap with: see _capture)
+            dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=self.group, async_op=False)
             return
         if flat_grad.is_cuda:
             if self.comm_stream is None:
@@ -478,14 +498,19 @@ class Trainer:
         state = {}
         n_d = self.d_train_times
 
-        # Under data parallelism the D backward is cut per discriminator, largest gradient buffer first (MTD, MPD, MSD:
-        # the stacks share no parameter and their loss terms are summed, so three backward calls give the bits of one): the
-        # all-reduce of a stack's flat gradient buffer is issued right after ITS segment and runs on the communication
-        # stream while the next stack's backward segment replays — the overlap the eager step gets from the flush hooks
-        # (BASELINE configs[3]).  One rank: one segment per D update, nothing to overlap.
-        dp = self.dp.enabled
+        # Where the graphs are cut under data parallelism (RTG_DP_CUT):
+        #   'update' (default, round 4): one segment per optimizer update, as on one GPU — the discriminators' backward passes
+        #       stay in ONE graph, forked over their streams, and every bank's all-reduce is issued after the segment.  The
+        #       exchange is not overlapped with compute: 54 MB (G + MSD + MPD) to 109 MB (full stack) per D update, ~0.3-1 ms
+        #       over xGMI, 2-4 % of the step.
+        #   'disc' (round 3): the D backward cut per discriminator, largest gradient buffer first (MTD, MPD, MSD: the stacks
+        #       share no parameter and their loss terms are summed, so three backward calls give the bits of one); a stack's
+        #       all-reduce runs on the communication stream while the next stack's backward segment replays.
+        #       Measured on one MI355X over a 1-rank RCCL group (profiles/r04_dp_capture.txt): 30.8 ms/step against 27.8
+        #       without the cuts — serialising the stacks' backward passes and five more graph launches per step cost more
+        #       than the exchange they hide, so this is the opt-in for slow links.
+        dp = self.dp.enabled and os.environ.get('RTG_DP_CUT', 'update') == 'disc'
         order = sorted(self.discs, key=lambda d: -d.bank().n_params)
-
         def d_forward_and_first():
             losses, parts = self._d_forward(sy, state['y_hat'].detach())
             state['dl'] = _detached(losses)
@@ -539,7 +564,10 @@ class Trainer:
                 return []
             return [(d_backward(d), reduce_of(d, j == len(order) - 1)) for j, d in enumerate(order) if j > 0]
 
-        first_after = reduce_of(order[0], len(order) == 1) if dp else None
+        def after_d():
+            self._d_reduce(replay=True)
+
+        first_after = reduce_of(order[0], len(order) == 1) if dp else after_d
         segs = [(seg_first, first_after)] + d_tail()
         for i in range(1, n_d + 1):
             last_d = i == n_d
