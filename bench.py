@@ -347,6 +347,8 @@ def main():
         except Exception as e:  # noqa: BLE001
             ok = 0.0
             mode = f'eager (graph capture failed: {type(e).__name__}: {e})'[:200]
+            import traceback
+            print(f'[rank {rank}] graph capture failed:\n' + traceback.format_exc(), file=sys.stderr, flush=True)
         ok = agree(ok, 'graph capture')
         if ok:
             # the first replay, still outside warm-up and timing; a rank on which it raises takes every rank back to the
@@ -357,6 +359,8 @@ def main():
             except Exception as e:  # noqa: BLE001
                 ok = 0.0
                 mode = f'eager (first graph replay failed: {type(e).__name__}: {e})'[:200]
+                import traceback
+                print(f'[rank {rank}] first graph replay failed:\n' + traceback.format_exc(), file=sys.stderr, flush=True)
             ok = agree(ok, 'the first graph replay')
         if ok:
             step = tr.train_step_graphed

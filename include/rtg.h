@@ -410,6 +410,11 @@ int rtg_resstack_backward(const RtgResStackDesc* d, const float* dy, const float
  * ------------------------------------------------------------------------------------------------------------ */
 int rtg_stream_create(int priority, void** stream);
 int rtg_stream_destroy(void* stream);
+/* End whatever capture `stream` is the origin of and drop the graph: 0 = the stream was not capturing, 1 = a capture
+ * (possibly invalidated by an illegal call) was ended.  The host side calls it when a HIP-graph capture raised, so that the
+ * process can go on with eager launches (a stream left in an invalidated capture fails every later allocation with
+ * hipErrorStreamCaptureImplicit). */
+int rtg_stream_end_capture(void* stream);
 
 /* library self-description */
 int rtg_abi_version(void);

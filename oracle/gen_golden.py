@@ -176,7 +176,16 @@ def main():
                                betas=[hp.adam_b1, hp.adam_b2])
         x, y_tmpl, y = O.golden_inputs()
         rec = []
-        for _ in range(n_steps):
+        after_first = {}
+
+        def snapshot():
+            out = {'g_stats': np.stack([stats(p) for _, p in sorted(g.named_parameters())])}
+            for tag, d, u in (('msd', msd, use_msd), ('mpd', mpd, use_mpd), ('mtd', mtd, use_mtd)):
+                if u:
+                    out[f'{tag}_stats'] = np.stack([stats(p) for _, p in sorted(d.named_parameters())])
+            return out
+
+        for step_i in range(n_steps):
             y_hat = g(x, y_tmpl)
             yd = y_hat.detach()
             for _ in range(d_times):
@@ -207,7 +216,12 @@ def main():
                 gt.backward()
             og.step()
             rec.append([tot.item(), gt.item()])
-        res = {'losses': np.array(rec),
+            if step_i == 0:
+                # (round 4) the parameters after the FIRST step: with MTD a one-step comparison can be made on the reference
+                # run's side of the frame-0 phase cut (stft<n>_frame0_phase_*), a two-step one cannot (the second step's
+                # generated wave is new) — tests/test_step_gpu.py::test_first_train_step_with_mtd_on_the_reference_branch
+                after_first = {k + '1': v for k, v in snapshot().items()}
+        res = {'losses': np.array(rec), **after_first,
                'g_stats': np.stack([stats(p) for _, p in sorted(g.named_parameters())])}
         for tag, d, u in (('msd', msd, use_msd), ('mpd', mpd, use_mpd), ('mtd', mtd, use_mtd)):
             if u:

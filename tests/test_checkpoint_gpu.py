@@ -81,3 +81,37 @@ def test_graphed_step_matches_eager(oracle):
     for (n, p), (_, q) in zip(a.generator.named_parameters(), b.generator.named_parameters()):
         d = (p.detach() - q.detach()).abs()
         assert d.mean().item() < 0.1 * 1.8e-4 and d.max().item() < 5 * 1.8e-4, (n, d.mean().item(), d.max().item())
+
+
+def test_failed_graph_capture_leaves_a_usable_trainer(oracle, monkeypatch):
+    """A capture that dies (here: a synchronous host-to-device copy inside the first segment, RTG_TEST_FAIL_CAPTURE) must
+    not leave a stream in an invalidated capture — every later allocation would fail with hipErrorStreamCaptureImplicit and
+    bench.py's eager fallback with it (round 4, the two-rank rehearsal).  Trainer._capture ends the capture itself
+    (rtg_stream_end_capture): the eager step afterwards runs and moves the parameters like the untouched trainer's, and a
+    second capture, without the fault, succeeds."""
+    from train import Trainer
+
+    def make():
+        torch.manual_seed(5)
+        tr = Trainer(use_mpd=True, use_mtd=False, d_train_times=1, dev='cuda:0')
+        with torch.no_grad():
+            tr.generator.noise.w.zero_()
+        return tr
+    x, y_tmpl, y = [t.cuda() for t in oracle.synthetic_batch(2, 8192, 3)]
+    a, b = make(), make()
+    for _ in range(2):
+        a.train_step(x, y_tmpl, y); b.train_step(x, y_tmpl, y)
+    monkeypatch.setenv('RTG_TEST_FAIL_CAPTURE', '1')
+    with pytest.raises(Exception, match='captur'):
+        b.train_step_graphed(x, y_tmpl, y)
+    assert b._graphs is None
+    monkeypatch.delenv('RTG_TEST_FAIL_CAPTURE')
+    dla, gla = a.train_step(x, y_tmpl, y)
+    dlb, glb = b.train_step(x, y_tmpl, y)                       # eager, right after the failed capture
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(gla['gen_all'].item(), glb['gen_all'].item(), rtol=1e-5)
+    dla, gla = a.train_step(x, y_tmpl, y)
+    dlb, glb = b.train_step_graphed(x, y_tmpl, y)               # and a clean capture + replay
+    torch.cuda.synchronize()
+    assert b._graphs is not None
+    np.testing.assert_allclose(gla['gen_all'].item(), glb['gen_all'].item(), rtol=1e-4)

@@ -143,11 +143,20 @@ def test_train_steps(oracle, gold, name, cfg):
     discs = [d for d in (msd, mpd, mtd) if d is not None]
     og, od = oracle.make_optimizers(g, discs)
     x, y_tmpl, y = oracle.golden_inputs()
-    rec = []
-    for _ in range(2):
+    rec, first = [], {}
+    for i in range(2):
         dl, gl = oracle.train_step(g, og, od, x, y_tmpl, y, msd, mpd, mtd, d_times)
         rec.append([sum(dl.values()).item(), gl['total'].item()])
+        if i == 0:                      # (round 4 fixture: the parameters after the first step as well)
+            first = {tag: np.stack([stats(p) for _, p in sorted(m.named_parameters())])
+                     for tag, m in (('g', g), ('msd', msd), ('mpd', mpd), ('mtd', mtd)) if m is not None}
     np.testing.assert_allclose(np.array(rec), gold[f'step_{name}_losses'], rtol=2e-4)
+    for tag, got in first.items():
+        want = gold[f'step_{name}_{tag}_stats1']
+        if not use_mtd:
+            close_stats(got, want)
+        else:
+            assert np.all(np.abs(got[:, 1] - want[:, 1]) <= 0.25 * 2e-4 * d_times)
 
     def check(mod, key):
         got = np.stack([stats(p) for _, p in sorted(mod.named_parameters())])

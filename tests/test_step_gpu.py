@@ -153,6 +153,48 @@ def test_mtd_losses_against_the_reference_fixture_on_its_branch(oracle, gold):
     assert np.all(np.abs(got[:, 0] - gold['mtd_fmap_g_stats'][:, 0]) <= 2e-4 * ne * gold['mtd_fmap_g_stats'][:, 1] + 1e-3)
 
 
+def test_first_train_step_with_mtd_on_the_reference_branch(oracle, gold, monkeypatch):
+    """The full stack (configs[3] shape at B = 2: G + MSD + MPD + MTD, d_train_times = 2) for ONE Trainer.train_step with the
+    frame-0 phases of every spectrogram on the reference run's side of the +-pi cut (the three multi_stft_loss calls of
+    the first step all see gold['y_hat']: the fixture's phases apply; the second step's generated wave is new, which is why
+    the two-step test above can only pin the parameters to 0.25 lr x updates with MTD).  On the branch the first step is as
+    tight as without MTD: losses at rtol 1e-3 (3e-3 in the two-step test), |mean| of every parameter tensor of G, MSD,
+    MPD and MTD after the step (round-4 fixture step_cfg4_*_stats1) to 5 % of lr x updates (25 % there)."""
+    import train
+    from train import Trainer
+    torch.manual_seed(3)
+    tr = Trainer(use_mpd=True, use_mtd=True, d_train_times=2, dev='cuda:0')
+    for m in (tr.generator, *tr.discs):
+        oracle.det_fill(m)
+    x, y_tmpl, y = [t.to(DEV) for t in oracle.golden_inputs()]
+    noise = _reference_noise(oracle, 1)
+    real_msl, fracs = train.multi_stft_loss, []
+
+    def on_branch(y_, yg_, ret_loss=False, ret_specs=False):
+        out = real_msl(y_, yg_, ret_loss=ret_loss, ret_specs=ret_specs)
+        if not ret_specs:
+            return out
+        loss, (S, Sg) = out if ret_loss else (None, out)
+        fix = lambda lst, tag: [_on_reference_branch(s, gold[f'stft{n}_frame0_phase_{tag}'])[0]          # noqa: E731
+                                for s, (n, _, _) in zip(lst, oracle.STFT_PARAMS)]
+        fracs.append(max(_on_reference_branch(s, gold[f'stft{n}_frame0_phase_g'])[1] for s, (n, _, _) in zip(Sg, oracle.STFT_PARAMS)))
+        S, Sg = fix(S, 'r'), fix(Sg, 'g')
+        return (loss, (S, Sg)) if ret_loss else (S, Sg)
+
+    monkeypatch.setattr(train, 'multi_stft_loss', on_branch)
+    dl, gl = tr.train_step(x, y_tmpl, y, noise_list=[n.to(DEV) for n in noise[0]])
+    torch.cuda.synchronize()
+    assert len(fracs) == 3                                   # two D updates and the G update went through the wrapper
+    np.testing.assert_allclose([dl['disc_all'].item(), gl['gen_all'].item()], gold['step_cfg4_losses'][0], rtol=1e-3)
+    lr_steps = 2e-4 * 2                                      # one step: two D updates (one G update moves less)
+    for tag, mod in (('g', tr.generator), ('msd', tr.msd), ('mpd', tr.mpd), ('mtd', tr.mtd)):
+        got, want, ne = _param_stats(mod), gold[f'step_cfg4_{tag}_stats1'], _numels(mod)
+        assert got.shape == want.shape
+        d_abs = np.abs(got[:, 1] - want[:, 1])
+        assert np.all(d_abs <= 0.05 * lr_steps + 2e-6 * want[:, 1]), (tag, d_abs.max() / lr_steps)
+        assert np.all(np.abs(got[:, 0] - want[:, 0]) <= 0.1 * lr_steps * ne + 1e-3), tag
+
+
 def test_mtd_generator_side_gradient_fixture(oracle, gold):
     """gold['grad_mtd_yhat'] (gen_golden.py): d(generator_loss + 2 feature_loss)/d y_hat through the frozen MTD, log|D|
     and angle(D) of the three STFT resolutions, down to the wave — 2-D backward-data + STFT backward kernel.  Phases of

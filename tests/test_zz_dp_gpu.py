@@ -215,16 +215,16 @@ def _rccl_worker_body(port, q):
     q.put(('init', 0))
     out = {}
     for full in (False, True):
+        # both exchange policies: gradients all-reduced on the compute stream after the backward, one graph segment per
+        # optimizer update (the defaults) on G + MSD + MPD; the high-priority communication stream fed from the banks' flush
+        # hooks, the D backward cut per discriminator under replay (RTG_DP_CUT=disc) on the full stack with two D updates
+        os.environ['RTG_DP_CUT'] = 'disc' if full else 'update'
         tr, O = _make_trainer(full)
         assert tr.dp.enabled and tr.dp.world == 1
-        assert all(d.bank().on_flush is not None for d in tr.discs)
+        assert all((d.bank().on_flush is not None) == full for d in tr.discs)
         x, y_tmpl, y = (t.cuda() for t in O.golden_inputs(batch=2))
         noise = [n.cuda() for n in _noise(2)]
-        # both exchange policies: gradients all-reduced on the compute stream, one graph segment per optimizer update (the
-        # defaults) on G + MSD + MPD; the high-priority communication stream with the D backward cut per discriminator
-        # (RTG_DP_CUT=disc) on the full stack with two D updates
-        os.environ['RTG_DP_CUT'] = 'disc' if full else 'update'
-        tr.train_step(x, y_tmpl, y, noise_list=noise)                     # eager: all-reduces from the flush hooks
+        tr.train_step(x, y_tmpl, y, noise_list=noise)                     # eager: all-reduces after / during the backward
         torch.cuda.synchronize()
         assert (tr.dp.comm_stream is not None) == full                    # which RCCL path ran
         out[f'eager{int(full)}'] = _params(tr).numpy()
@@ -320,8 +320,8 @@ def _race_worker_body(port, q):
     'thread_local' (train.CAPTURE_ERROR_MODE) all of them succeed and the captured graphs replay to the eager step's bits."""
     import time
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0', RTG_DP_FORCE='1',
-                      RTG_TUNE='0')
-    _setup()
+                      RTG_TUNE='0', RTG_DP_CUT='disc')     # (the policy with the most machinery: flush hooks, communication
+    _setup()                                                #  stream, a graph segment per discriminator)
     torch.cuda.set_device(0)
     dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
     q.put(('init', 0))
@@ -406,7 +406,7 @@ def _race_worker_body(port, q):
     own_streams = len(ours) >= 3 and all(s_.cuda_stream not in pooled for s_ in ours)
     after_graph[noise_at] = after_eager[noise_at] = 0.0
     q.put({'reps': len(polls), 'errors': errors, 'mode': train.CAPTURE_ERROR_MODE, 'capture_s': capture_s, 'polls': polls,
-           'segments': len(tr._graphs or []) or tr.d_train_times + 2, 'moved': moved,
+           'segments': (1 + (len(tr.discs) - 1)) * tr.d_train_times + 2, 'moved': moved,
            'max_abs_diff': float(np.abs(after_graph - after_eager).max()),
            'frac_bad': float(np.mean(np.abs(after_graph - after_eager) > 0.2 * 2e-4)), 'finite': bool(np.isfinite(after_graph).all()),
            'hooks_alive': all(h is not None for h in hooks), 'own_streams': own_streams})

@@ -733,6 +733,18 @@ extern "C" int rtg_stream_destroy(void* stream) {
   return hipStreamDestroy((hipStream_t)stream) == hipSuccess ? 0 : RTG_EINVAL;
 }
 
+extern "C" int rtg_stream_end_capture(void* stream) {
+  if (!stream) return RTG_ENULL;
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing((hipStream_t)stream, &st) != hipSuccess) { (void)hipGetLastError(); return RTG_EINVAL; }
+  if (st == hipStreamCaptureStatusNone) return 0;
+  hipGraph_t g = nullptr;
+  (void)hipStreamEndCapture((hipStream_t)stream, &g);          // (an invalidated capture reports an error and still ends)
+  if (g) (void)hipGraphDestroy(g);
+  (void)hipGetLastError();
+  return 1;
+}
+
 extern "C" int rtg_abi_version(void) { return RTG_ABI_VERSION; }
 // (a library compiled with an ablation / diagnostic define says so: rtg/lib.py refuses it as the product library)
 // RTG_ABLATION: set by every dev build script (tools/dev_build.sh, tools/dbg/abl.sh) whatever -DRTG_EXP_* / -DRTG_STAMPS

@@ -146,6 +146,7 @@ PROTOTYPES = {
     'rtg_resstack_backward': (_I, [C.POINTER(ResStackDesc), _P, _P, C.POINTER(PtrArray6), C.POINTER(PtrArray6), C.POINTER(PtrArray6), _P]),
     'rtg_stream_create': (_I, [_I, C.POINTER(C.c_void_p)]),
     'rtg_stream_destroy': (_I, [_P]),
+    'rtg_stream_end_capture': (_I, [_P]),
     'rtg_abi_version': (_I, []),
     'rtg_build_info': (C.c_char_p, []),
 }

@@ -319,11 +319,16 @@ class Trainer:
         self._static_in = self._static_out = None
         self._capture_hook = None
         self._cap_stream = None
+        self._settle = False
         for m in (self.generator, *self.discs):
             m.train()
-        if self.dp.enabled:
+        if self.dp.enabled and not _inline_reduce():
+            # communication-stream policy: each discriminator's all-reduce is issued from its bank's flush, as soon as ITS
+            # backward is complete, and overlaps the rest of the backward.  (Compute-stream policy, the default: no hooks —
+            # the flushes run on the forked streams of the stacks, and collectives of one communicator must not be in
+            # flight on two streams at once; _d_reduce issues them one after the other on the main stream instead.)
             for d in self.discs:
-                d.bank().on_flush = self.dp.reduce_async     # overlap each discriminator's all-reduce with backward
+                d.bank().on_flush = self.dp.reduce_async
 
     def _freeze(self, flag):
         for d in self.discs:
@@ -440,6 +445,10 @@ class Trainer:
                 gl = self.g_step(y, y_g_hat)
         finally:
             self._tuned = self._tuned or tuning
+            # a step that timed block shapes (or, data parallel, ran on the heuristic shapes while rank 0 timed) is not yet
+            # the steady state: the next step may take other split counts, i.e. other partial buffers and a rebuilt
+            # weight-norm job table (a host-to-device copy: illegal under capture) — prepare_graphs runs one more first
+            self._settle = tuning
             tune.ACTIVE = False
         if tuning and self.dp.enabled:
             tune.MISSED = self.dp.sync_tuner()
@@ -452,9 +461,12 @@ class Trainer:
         rank must know that every rank captured before the first replay — a rank whose capture failed would otherwise
         enter other collectives than the ranks already replaying (bench.py agrees on the outcome in between)."""
         if self._graphs is None:
-            if not self._tuned or tune.MISSED:                  # block shapes are timed eagerly, never under capture
-                for _ in range(2):
-                    self.train_step(x, y_tmpl, y)
+            # block shapes are timed eagerly, never under capture, and the step captured is the steady state: eager steps
+            # until one ran entirely on tuned shapes (data parallel: the same count on every rank — `tuning` is agreed)
+            for _ in range(4):
+                if self._tuned and not tune.MISSED and not self._settle:
+                    break
+                self.train_step(x, y_tmpl, y)
             self.dp.drain()                                     # no collective in flight on any rank while one captures
             self._capture(x, y_tmpl, y)
 
@@ -586,11 +598,21 @@ class Trainer:
                     # GPUTEST_r03); the autograd thread that launches the backward is not policed either way
                     with torch.cuda.graph(g, pool=pool, stream=cap, capture_error_mode=CAPTURE_ERROR_MODE):
                         body()
+                        if os.environ.get('RTG_TEST_FAIL_CAPTURE') == '1':      # (bench.py's fallback, exercised on the GPU box)
+                            torch.zeros(4).to(sx.device)                        # a synchronous copy: illegal under capture
                         if self._capture_hook is not None:      # (tests hold a capture open: tests/test_zz_dp_gpu.py)
                             self._capture_hook()
                     graphs.append((g, after if self.dp.enabled else None))
                     if os.environ.get('RTG_GRAPH_DEBUG'):
                         print(f'captured graph segment {len(graphs)} of {len(segs)}', flush=True)
+        except BaseException:
+            # leave no stream in a (possibly invalidated) capture: every later allocation would fail, the eager step too
+            lib.rtg_stream_end_capture(C.c_void_p(cap.cuda_stream))
+            try:
+                torch.cuda.synchronize()
+            except Exception:       # noqa: BLE001  (the error of the failed capture, reported once more)
+                pass
+            raise
         finally:
             for d, h in hooks:
                 d.bank().on_flush = h
