@@ -115,3 +115,43 @@ def test_failed_graph_capture_leaves_a_usable_trainer(oracle, monkeypatch):
     torch.cuda.synchronize()
     assert b._graphs is not None
     np.testing.assert_allclose(gla['gen_all'].item(), glb['gen_all'].item(), rtol=1e-4)
+
+
+def test_lean_pack_gives_the_bits_of_the_full_pack(oracle, monkeypatch):
+    """Round 4: once the block shapes have settled the Trainer drops from the pack launches the standard weight images no
+    launch read during one watched step (rtg/bank.py lean_pack: the dense layers then only keep their 16-byte-fragment
+    images).  Same seeds, same tuner tables: a trainer with the lean pack and one without end with identical parameters;
+    then a batch shape the lean trainer has never seen, with the tuner off (the library's heuristic = general block shapes
+    everywhere): the dropped images are packed again on the spot (restore_std) and the bits still agree."""
+    from train import Trainer
+    from rtg import tune
+
+    def make(lean):
+        torch.manual_seed(5)
+        tr = Trainer(use_mpd=True, use_mtd=True, d_train_times=1, dev='cuda:0')
+        tr.lean_pack_enabled = lean
+        with torch.no_grad():
+            tr.generator.noise.w.zero_()
+        return tr
+    x, y_tmpl, y = [t.cuda() for t in oracle.synthetic_batch(8, 8192, 3)]
+    a, b = make(False), make(True)
+    for _ in range(3):
+        a.train_step(x, y_tmpl, y); b.train_step(x, y_tmpl, y)
+    torch.cuda.synchronize()
+    flat = lambda tr: torch.cat([m.bank().flat for m in (tr.generator, *tr.discs)]).cpu().numpy()   # noqa: E731
+    np.testing.assert_array_equal(flat(a), flat(b))
+    off = [(ly.name, side) for m in b.discs for ly in m.bank().layers for side in (0, 1) if not ly.std_on[side]]
+    assert b.lean_dropped == len(off) and a.lean_dropped == 0
+    print('lean pack: standard images dropped', b.lean_dropped, 'pack elements', [m.bank().pack_elems for m in b.discs],
+          'vs', [m.bank().pack_elems for m in a.discs])
+    assert b.lean_dropped > 0, 'no dense layer took the fragment-image kernel for both directions at batch 8?'
+    # heuristic (general) block shapes on a new batch shape: every dropped image that is read comes back first
+    monkeypatch.setattr(tune, 'ENABLED', False)
+    for name in tune._TABLES:
+        monkeypatch.setattr(tune, name, {})
+    x2, y_tmpl2, y2 = x[:2].contiguous(), y_tmpl[:2].contiguous(), y[:2].contiguous()
+    a.train_step(x2, y_tmpl2, y2); b.train_step(x2, y_tmpl2, y2)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(flat(a), flat(b))
+    back = [(n, s) for n, s in off if dict((ly.name, ly) for m in b.discs for ly in m.bank().layers)[n].std_on[s]]
+    assert back, 'the heuristic shapes read no standard image?'

@@ -42,12 +42,36 @@ def _table(structs, device):
     return torch.frombuffer(bytearray(buf), dtype=torch.uint8).to(device)
 
 
+# packed-weight pointer -> (bank, layer, side 0 = forward / 1 = backward-data) for the layers that carry the 16-byte-fragment
+# image behind the standard one: ops._run_conv reports launches that read the STANDARD image of such a layer (a general
+# block shape), see WeightBank.lean_pack
+_WP_OWNER = {}
+
+
+def note_std_use(wp_value):
+    """a launch is about to read the standard image at `wp_value` (a general block shape on a layer that also has the
+    fragment image): remember it; if that image is currently left out of the pack launch, put it back and pack it now"""
+    ent = _WP_OWNER.get(wp_value)
+    if ent is None:
+        return
+    ref, ly, side = ent
+    bank = ref()
+    if bank is None or bank.packed.data_ptr() + 4 * (ly.bwd_off if side else ly.fwd_off) != wp_value:
+        _WP_OWNER.pop(wp_value, None)           # (a freed bank's address, reused)
+        return
+    ly.std_used[side] = True
+    if not ly.std_on[side]:
+        bank.restore_std(ly, side)
+
+
 class ConvLayer:
     """Static description + bank bookkeeping of one weight-normed convolution."""
 
     def __init__(self, name, module):
         self.name, self.module = name, module
         m = module
+        self.std_on = [True, True]        # the standard forward / backward-data image is part of the pack launch
+        self.std_used = [False, False]    # ... and was read by a launch since WeightBank.observe_std()
         self.kind, self.cin, self.cout, self.k = m.kind, m.cin, m.cout, m.k
         self.stride, self.pad, self.dil, self.groups, self.out_pad = m.stride, m.pad, m.dil, m.groups, m.out_pad
         self.kh = 1
@@ -220,6 +244,11 @@ class WeightBank:
         self.packed = torch.empty(poff, device=self.device, dtype=torch.float32)
         self._bind_params()
         self._build_tables()
+        import weakref
+        for ly in self.layers:
+            for side, (has16, off) in enumerate(((ly.fwd16_size, ly.fwd_off), (ly.bwd16_size, ly.bwd_off))):
+                if has16:
+                    _WP_OWNER[self.packed.data_ptr() + 4 * off] = (weakref.ref(self), ly, side)
         self._anchor = torch.zeros(1, device=self.device, requires_grad=True)
         self._tok_counter = 0
         self._owner = [None] * len(self.layers)
@@ -281,9 +310,11 @@ class WeightBank:
         self.max_inner = max(ly.inner for ly in self.layers)
         for ly in self.layers:
             norm.append(L.NormJob(ly.g_off, ly.v_off, ly.scale_off, ly.rows, ly.inner))
-            for (mode, g, mg, cg, k, s), off, size, tm, tap, bf in (
+            for side, ((mode, g, mg, cg, k, s), off, size, tm, tap, bf) in enumerate((
                     (ly.fwd_op, ly.fwd_off, ly.fwd_size, ly.fwd_tm, ly.fwd_tap, ly.fwd_bf),
-                    (ly.bwd_op, ly.bwd_off, ly.bwd_size, ly.bwd_tm, ly.bwd_tap, ly.bwd_bf)):
+                    (ly.bwd_op, ly.bwd_off, ly.bwd_size, ly.bwd_tm, ly.bwd_tap, ly.bwd_bf))):
+                if not ly.std_on[side]:
+                    continue                 # (lean_pack: every launch of this layer reads the fragment image)
                 pack.append(L.PackJob(ly.v_off, ly.scale_off, off, size, mode, g, mg, cg, k, ly.k, ly.inner_c, s, tm,
                                       ly.kh, tap, bf, 0))
             for (mode, g, mg, cg, k, s), off, size in ((ly.fwd_op, ly.fwd_off + ly.fwd_size, ly.fwd16_size),
@@ -298,6 +329,7 @@ class WeightBank:
         self.norm_table = _table(norm, self.device)
         self.pack_blocks, self.pack_lds = L.assign_pack_blocks(pack)
         self.pack_table = _table(pack, self.device)
+        self.pack_elems = sum(j.dst_size for j in pack)
         self.n_pack = len(pack)
 
     # ------------------------------------------------------------------ forward-side refresh
@@ -306,9 +338,48 @@ class WeightBank:
         from . import ops
         check(ops.timed_bw('wn_scales', 4 * self.n_params, lambda: lib.rtg_weightnorm_scales(
             _p(self.norm_table), len(self.layers), self.max_rows, _p(self.flat), _p(self.scales), st)), 'weightnorm_scales')
-        check(ops.timed_bw('wn_pack', 4 * (self.n_params + self.packed.numel()), lambda: lib.rtg_weights_pack(
+        check(ops.timed_bw('wn_pack', 4 * (self.n_params + self.pack_elems), lambda: lib.rtg_weights_pack(
             _p(self.pack_table), self.n_pack, self.pack_blocks, self.pack_lds, _p(self.flat), _p(self.scales), _p(self.packed), st)),
               'weights_pack')
+
+    # ------------------------------------------------------------------ lean pack (round 4)
+    # The dense layers (DiscriminatorP convs.1-4, DiscriminatorS convs.5, the Conv2d stack of StftDiscriminator) carry two
+    # images per direction: the standard one every block shape of the general kernel reads and the 16-byte-fragment one of
+    # rtg_dconv.hip.  Once the tuner has settled, a layer whose launches all take the dense kernel never reads its standard
+    # image again — half of what the pack launch writes for the discriminators.  train.Trainer watches one steady step
+    # (observe_std .. lean_pack) and drops those jobs; a later launch that does want a dropped image (another batch shape,
+    # inference) gets it packed on the spot (restore_std) and keeps it.
+    def observe_std(self):
+        for ly in self.layers:
+            ly.std_used = [False, False]
+
+    def lean_pack(self):
+        """leave the standard images nobody read since observe_std() out of the pack launch -> number of images dropped"""
+        n = 0
+        for ly in self.layers:
+            for side, has16 in enumerate((ly.fwd16_size, ly.bwd16_size)):
+                if has16 and ly.std_on[side] and not ly.std_used[side]:
+                    ly.std_on[side] = False
+                    n += 1
+        if n:
+            self._build_tables()
+        return n
+
+    def restore_std(self, ly, side):
+        if torch.cuda.is_current_stream_capturing():
+            raise L.RtgError(f'{ly.name}: a launch under HIP-graph capture reads a weight image the lean pack left out — '
+                             'capture the steady state (Trainer.prepare_graphs runs a settled eager step first)')
+        ly.std_on[side] = True
+        op, off, size, tm, tap, bf = ((ly.fwd_op, ly.fwd_off, ly.fwd_size, ly.fwd_tm, ly.fwd_tap, ly.fwd_bf),
+                                      (ly.bwd_op, ly.bwd_off, ly.bwd_size, ly.bwd_tm, ly.bwd_tap, ly.bwd_bf))[side]
+        mode, g, mg, cg, k, s = op
+        job = [L.PackJob(ly.v_off, ly.scale_off, off, size, mode, g, mg, cg, k, ly.k, ly.inner_c, s, tm, ly.kh, tap, bf, 0)]
+        blocks, lds = L.assign_pack_blocks(job)
+        tab = _table(job, self.device)
+        self._keep.append(tab)
+        check(lib.rtg_weights_pack(_p(tab), 1, blocks, lds, _p(self.flat), _p(self.scales), _p(self.packed), _stream()),
+              'weights_pack (restore)')
+        self._build_tables()
 
     def prepare(self):
         """Refresh the packed weights from the current parameters; returns the autograd token for this forward."""

@@ -7,6 +7,7 @@ import torch
 
 from . import lib as L
 from . import tune
+from . import bank as _bank
 from .lib import lib, check, current_stream_ptr as _lib_stream_ptr
 
 
@@ -66,6 +67,8 @@ def _conv_bytes(d, args):
 def _run_conv(d, args, flop, label, what):
     """rtg_conv1d with the tuned block shape (rtg/tune.py); args = everything after the descriptor"""
     d.tile_cfg = tune.conv_cfg(d, lambda: lib.rtg_conv1d(C.byref(d), *args))
+    if d.wp16 and d.tile_cfg < 8000:         # a general block shape on a layer with the fragment image: reads the standard one
+        _bank.note_std_use(args[3].value)
     check(_timed('conv1d', lib.rtg_conv1d_variant(C.byref(d)) if PROFILE is not None else 0, flop,
                  lambda: lib.rtg_conv1d(C.byref(d), *args), label, _conv_bytes(d, args) if PROFILE is not None else 0), what)
 
@@ -673,6 +676,8 @@ def _launch_group(descs, ptr_rows, flops, label, what):
         return False
     for i in range(n):
         darr[i].tile_cfg = cfg
+        if darr[i].wp16:                     # (group members run general block shapes: the standard images)
+            _bank.note_std_use(parr[i].wp)
     check(_timed('conv1d', lib.rtg_conv1d_variant(C.byref(darr[0])) if PROFILE is not None else 0, sum(flops),
                  lambda: lib.rtg_conv1d_group(n, darr, parr, st), label), what)
     return True

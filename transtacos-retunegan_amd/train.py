@@ -31,6 +31,7 @@ from rtg.lib import lib, check, RtgError, new_stream, current_stream_ptr as _lib
 
 device = 'cuda' if torch.cuda.is_available() else 'cpu'
 CAPTURE_ERROR_MODE = os.environ.get('RTG_CAPTURE_MODE', 'thread_local')
+LEAN_PACK = os.environ.get('RTG_LEAN_PACK', '1') == '1'
 
 
 def _inline_reduce():
@@ -320,6 +321,9 @@ class Trainer:
         self._capture_hook = None
         self._cap_stream = None
         self._settle = False
+        self._lean_pending = True
+        self.lean_pack_enabled = LEAN_PACK
+        self.lean_dropped = 0
         for m in (self.generator, *self.discs):
             m.train()
         if self.dp.enabled and not _inline_reduce():
@@ -434,6 +438,12 @@ class Trainer:
         # after it (DataParallel.sync_tuner); `tuning` is the same on every rank (same shapes, same tables)
         tune.ACTIVE = tuning and (not self.dp.enabled or dist.get_rank(self.dp.group) == 0)
         tune.MISSED = False
+        # the first step that runs entirely on settled block shapes is watched: standard weight images no launch of it read
+        # leave the pack launches (rtg/bank.py: lean_pack; RTG_LEAN_PACK=0 keeps everything)
+        observe = self._lean_pending and not tuning and self.lean_pack_enabled
+        if observe:
+            for m in (self.generator, *self.discs):
+                m.bank().observe_std()
         try:
             with stft_cache():
                 y_g_hat = self.generator(x, y_tmpl, noise_list) if noise_list is not None else self.generator(x, y_tmpl)
@@ -450,6 +460,11 @@ class Trainer:
             # weight-norm job table (a host-to-device copy: illegal under capture) — prepare_graphs runs one more first
             self._settle = tuning
             tune.ACTIVE = False
+        if tuning:
+            self._lean_pending = True
+        elif observe:
+            self._lean_pending = False
+            self.lean_dropped = sum(m.bank().lean_pack() for m in (self.generator, *self.discs))
         if tuning and self.dp.enabled:
             tune.MISSED = self.dp.sync_tuner()
         self.steps += 1
