@@ -228,7 +228,14 @@ def test_every_block_shape_gives_identical_bits(case):
     assert lib.rtg_conv1d_variant(C.byref(bad)) < 0
 
 
-@pytest.mark.parametrize('case', [FWD_CASES[7], FWD_CASES[8], FWD_CASES[9], FWD_CASES[15], (40, 1, 32, 911, 5, 3, 1, 2, 1, 32)])
+# (round 4) conv_post on short rows: cout1_k3_rows_kernel — rows of 4 .. 64 positions (64 / L channel rows per wave-wide
+# load, the last load of a wave partial), 8 .. 1024 channels, one clip and many
+K3_ROWS_CASES = [(704, 512, 1, 10, 3, 1, 1, 1, 1, 16), (7, 512, 1, 15, 3, 1, 1, 1, 1, 32), (5, 1024, 1, 21, 3, 1, 1, 1, 1, 16),
+                 (3, 128, 1, 64, 3, 1, 1, 1, 1, 16), (1, 512, 1, 32, 3, 1, 1, 1, 1, 16), (9, 256, 1, 4, 3, 1, 1, 1, 1, 16),
+                 (2, 512, 1, 33, 3, 1, 1, 1, 1, 16), (4, 384, 1, 63, 3, 1, 1, 1, 1, 16)]
+
+
+@pytest.mark.parametrize('case', [FWD_CASES[7], FWD_CASES[8], FWD_CASES[9], FWD_CASES[15], (40, 1, 32, 911, 5, 3, 1, 2, 1, 32)] + K3_ROWS_CASES)
 def test_thin_kernels_match_the_mfma_path(case):
     """One-input-channel / one-output-channel shapes run on the bandwidth kernels of rtg_thin.hip (variant 1 / 2) and
     agree with the MFMA kernel forced through tile_cfg, including mask and residual operands."""

@@ -472,6 +472,75 @@ __global__ __launch_bounds__(64 * kK3Waves) void cout1_k3_kernel(const ThinArgs 
   }
 }
 
+// ---- the same operator for rows of <= 64 positions (round 4): conv_post of the period discriminators (rows of 10 .. 34
+// positions, 192-704 clips) and of the lower MSD scales.  cout1_k3_kernel makes a lane a (clip, position) column: with rows
+// of 10 floats a wave-wide load touches 6 clips' 40-byte segments (256 useful bytes from six cache lines per instruction,
+// three instructions per channel for the taps): 0.5-0.9 TB/s, bound by issuing ~250 vector-memory instructions per clip.
+// A clip's [C][L] block is CONTIGUOUS, so here a wave reads it as it lies: lane = (row r < R, position q) of R = 64 / L
+// consecutive channel rows — one coalesced load instruction per R rows, every element read ONCE — and keeps the three
+// per-tap channel sums T_j[q] = sum_c w[c][j] * x[c][q] of its column (out[q] = T_0[q-1] + T_1[q] + T_2[q+1]); the 8 waves
+// of a block split the channels, the partial sums meet in LDS and are added in fixed order (wave, then row).
+__global__ __launch_bounds__(64 * kK3Waves) void cout1_k3_rows_kernel(const ThinArgs a) {
+  __shared__ float wl[3 * 1024];                      // [C][3] (C <= 1024)
+  __shared__ float part[kK3Waves][64][3];
+  __shared__ float tsum[3][64 + 2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int L = a.L_in, C = a.C;
+  for (int e = tid; e < C * 3; e += 64 * kK3Waves) {
+    const int c = e / 3, j = e - c * 3;
+    wl[e] = a.wp[packed_index(0, c, j, C, 3, a.tile_m, a.tap_major)];
+  }
+  const int R = 64 / L;                               // channel rows per wave-wide load
+  const int r = lane / L, q = lane - r * L;
+  const bool lane_ok = r < R;
+  const int clip = blockIdx.x;
+  const int cps = C / kK3Waves, c0 = wave * cps;      // this wave's channels
+  const rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.B * C * L * 4, 0x00020000);
+  const unsigned base = (unsigned)((clip * C + c0) * L) * 4u;
+  __syncthreads();
+  float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+  constexpr int U = 8;                                // loads in flight per lane
+  for (int k0 = 0; k0 < cps; k0 += U * R) {
+    float v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int cl = k0 + u * R + r;                  // channel within the wave's range
+      const unsigned off = (lane_ok && cl < cps) ? base + (unsigned)(cl * L + q) * 4u : 0x80000000u;
+      v[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, off, 0, 0));
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int cl = k0 + u * R + r;
+      if (lane_ok && cl < cps) {
+        const float* w = wl + (c0 + cl) * 3;
+        const float xv = thin_pre(v[u], a);
+        t0 = fmaf(w[0], xv, t0);
+        t1 = fmaf(w[1], xv, t1);
+        t2 = fmaf(w[2], xv, t2);
+      }
+    }
+  }
+  part[wave][lane][0] = t0; part[wave][lane][1] = t1; part[wave][lane][2] = t2;
+  __syncthreads();
+  if (tid < 3 * (L + 2)) {                             // T_j[-1 .. L]: zero outside the row
+    const int j = tid / (L + 2), p = tid - j * (L + 2) - 1;
+    float s_ = 0.f;
+    if (p >= 0 && p < L)
+      for (int w = 0; w < kK3Waves; ++w)
+        for (int rr = 0; rr < R; ++rr) s_ += part[w][rr * L + p][j];                    // fixed order
+    tsum[j][p + 1] = s_;
+  }
+  __syncthreads();
+  if (tid < L) {
+    float s_ = tsum[0][tid] + tsum[1][tid + 1] + tsum[2][tid + 2];                      // T_0[q-1] + T_1[q] + T_2[q+1]
+    if (a.bias) s_ += a.bias[0];
+    const size_t o = (size_t)clip * a.out_L + tid;
+    if (a.mask) s_ *= (a.mask[o] > 0.f ? 1.f : a.mask_slope);
+    if (a.res) s_ += a.res[o];
+    a.out[o] = thin_act(s_ * a.out_scale, a.act, a.act_slope);
+  }
+}
+
 // ---- one output channel, 3 x 3 "same" in two dimensions (conv_post of the STFT discriminators, discrminator.py:262:
 // Conv2d(512, 1, (3, 3), padding (1, 1)) on maps of 29 x 5 .. 8 x 18).  On the matrix-core path one of 16 tile rows is
 // used and a launch takes 220 us (0.2-0.4 TFLOP/s, 2.6 ms of a full-stack step).  Same scheme as cout1_k3_kernel: a lane
@@ -867,6 +936,10 @@ int rtg_thin_launch(int kind, const RtgConv1dDesc* d, const float* x, const floa
   if (kind == 2 && !legacy && !a.aux && d->K == 3 && d->stride == 1 && d->dil == 1 && d->pad == 1 && d->Q == d->L_in &&
       d->Q == d->out_L && d->Cg % (8 * 16) == 0 && d->Cg <= 1024 && (long long)d->B * d->Cg * d->L_in * 4 < (1ll << 31) &&
       !RTG_ENV_SET("RTG_THIN_NOK3")) {
+    if (d->L_in <= 64 && d->L_in >= 4 && !RTG_ENV_SET("RTG_THIN_NOK3ROWS")) {
+      RTG_KLAUNCH(cout1_k3_rows_kernel, dim3((unsigned)d->B), dim3(64 * kK3Waves), 0, s, a);
+      return rtg_launch_status();
+    }
     const int cpb = d->L_in <= 64 ? 64 / d->L_in : 1;
     const int bpc = d->L_in <= 64 ? 1 : rtg_ceil_div(d->L_in, 64);
     const long long bx = bpc == 1 ? rtg_ceil_div(d->B, cpb) : (long long)d->B * bpc;
