@@ -173,7 +173,10 @@ __global__ __launch_bounds__(WB * 64, 2) void dconv_kernel(const DArgs a) {
   // staging registers: one set (the patch of chunk v + 2 is requested during the last tap of chunk v and written during
   // chunk v + 1), or two alternating sets (BF: a chunk's matrix instructions last a few hundred cycles, less than the
   // latency of the loads: chunk v + 3 is requested at the end of chunk v)
-  constexpr int NSET = BF ? 2 : 1;
+#ifndef RTG_DC_NSET_MODE
+#define RTG_DC_NSET_MODE 0
+#endif
+  constexpr int NSET = (BF || (RTG_DC_NSET_MODE == 1 && K == 2) || (RTG_DC_NSET_MODE == 2 && (K == 2 || S == 3)) || RTG_DC_NSET_MODE == 3) ? 2 : 1;
   float st[NSET][NSI][MAXIT];
   // (unconditional: past the last chunk the loads go out of range and return zeros that nobody writes — a branch around
   // them would make the compiler's vmcnt bookkeeping pessimistic for every weight fetch after the join)
@@ -319,7 +322,7 @@ __global__ __launch_bounds__(WB * 64, 2) void dconv_kernel(const DArgs a) {
     cls_blk = c0;
     if (pure) n_v = (c0 < a.h_k ? (a.h_k - c0 + a.h_stride - 1) / a.h_stride : 0) * a.cpk;
   }
-  const int n_vp = ((K & 1) || BF) ? (n_v + 1) & ~1 : n_v;      // chunks the loop walks (an even count where it is unrolled by two)
+  const int n_vp = ((K & 1) || NSET == 2) ? (n_v + 1) & ~1 : n_v;   // chunks the loop walks (an even count where it is unrolled by two)
   // generator of the walk: virtual chunk 0, 1, 2, ... -> real chunk and (2-D backward-data) its kernel row, kept as
   // counters (no division per chunk)
   int gv = 0;
@@ -465,6 +468,9 @@ __global__ __launch_bounds__(WB * 64, 2) void dconv_kernel(const DArgs a) {
 
   // (the matrix instructions are inline asm: the compiler does not know their results are still in flight)
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#ifdef RTG_EXP_DC_NOEPI                                 // ablation: everything but the epilogue (results are not stored)
+  if (a.B > 0) return;
+#endif
   // ---- epilogue: out = act(((acc + bias) * dmask + res) * out_scale) (+ out), the arithmetic and rounding of the general
   // kernel; 32-bit element offsets through buffer descriptors, invalid rows / columns go to an out-of-range offset the
   // hardware drops.  Row m' of the GEMM is output channel m' / S_out at phase m' % S_out (polyphase backward-data).

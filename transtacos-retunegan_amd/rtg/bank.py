@@ -24,7 +24,7 @@ from .lib import current_stream_ptr as _lib_stream_ptr
 
 
 # RTG_GCONV=0 (rtg/ops.py): the thin-group layers never leave the matrix cores, no vector-ALU weight images either
-GCONV_IMAGES = os.environ.get('RTG_GCONV', '1') == '1'
+GCONV_IMAGES = os.environ.get('RTG_GCONV', '1') == '1' and os.environ.get('RTG_GCONV_PACK', '1') == '1'
 
 
 def _stream():
@@ -237,7 +237,11 @@ class WeightBank:
             ly.gconv_off = None
             if GCONV_IMAGES and ly.kind == 'conv' and ly.groups > 1 and ly.k == 41 and ly.kh == 1:
                 n = ly.cout * (ly.cin // ly.groups) * ly.k + 128     # (+ 128: rtg_gconv_workspace — the kernels request the
-                n = (n + 3) & ~3                                     # last block of taps whole, past the image's end)
+                n = (n + 63) & ~63                                   # last block of taps whole, past the image's end)
+                # 256-byte aligned like the allocations the images used to live in: the kernels fetch the weights with
+                # s_load_dwordx8, which is slower when a request straddles a 32-byte boundary (measured: the forward kernel
+                # 60 instead of 69 TFLOP/s with images at 16-byte aligned offsets)
+                poff = (poff + 63) & ~63
                 ly.gconv_off = (poff, poff + n)
                 ly.gconv_size = ly.cout * (ly.cin // ly.groups) * ly.k
                 poff += 2 * n
