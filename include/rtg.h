@@ -36,7 +36,10 @@ enum { RTG_PACK_FWD = 0, RTG_PACK_DGRAD_S1 = 1, RTG_PACK_DGRAD_POLY = 2, RTG_PAC
        /* ABI 7: the plain layouts rtg_gconv_forward / rtg_gconv_backward_data read (what rtg_gconv_prepare[_bwd] write),
         * produced by rtg_weights_pack with the other images of a model instead of one launch per layer and pass:
         * [group][ci][tap][oc] resp. [group][oc][tap][ci], dst_size = groups * Mg * Cg * K floats */
-       RTG_PACK_GCONV_FWD = 5, RTG_PACK_GCONV_BWD = 6 };
+       RTG_PACK_GCONV_FWD = 5, RTG_PACK_GCONV_BWD = 6,
+       /* [group][oc][ci][44]: the taps of a (row, channel) pair padded to 44 with zeros — what rtg_gmfma_forward reads
+        * (dst_size = groups * Mg * Cg * 44 floats) */
+       RTG_PACK_GMFMA_FWD = 7 };
 
 /* ------------------------------------------------------------------------------------------------------------
  * rtg_conv1d — implicit-GEMM 1-D convolution on the fp32 matrix cores (v_mfma_f32_32x32x2_f32 / 16x16x4_f32).
@@ -195,6 +198,13 @@ int rtg_gconv_forward(const RtgGconvDesc* d, const float* x, const float* w, con
 int rtg_gconv_prepare_bwd(const RtgGconvDesc* d, const float* v, const float* scale, float* w, void* stream);
 int rtg_gconv_backward_data(const RtgGconvDesc* d, const float* dy, const float* w, const float* mask, const float* res,
                             float* dx, void* stream);
+/* The same forward on the matrix cores with exact-fit tiles (rtg_gmfma.hip, ABI 7): a v_mfma_f32_16x16x4_f32 tile is one
+ * group (16 output channels x 16 positions x 4 input channels at one tap).  w: the image RTG_PACK_GMFMA_FWD of
+ * rtg_weights_pack ([group][oc][ci][44], 16-byte aligned; rtg_gmfma_workspace floats).  Same operator and descriptor as
+ * rtg_gconv_forward (replaces F.conv1d(..., groups=g) of discrminator.py:39-43); rows of at least 16 positions. */
+int rtg_gmfma_ok(const RtgGconvDesc* d);
+long long rtg_gmfma_workspace(const RtgGconvDesc* d);
+int rtg_gmfma_forward(const RtgGconvDesc* d, const float* x, const float* w, const float* bias, float* out, void* stream);
 
 /* n <= RTG_WGRAD_MAX_GROUP problems in ONE launch (the parallel ResBlock branches of a UNet-G decoder stage,
  * generator.py:776-778; the six convs of a ResidualStack, generator.py:33-77).  Every descriptor names the same general

@@ -103,3 +103,47 @@ def test_gconv_refuses_other_shapes():
     assert lib.rtg_gconv_ok(C.byref(GconvDesc(2, 4, 8, 16, 5, 2, 2, 100, 50, 0.15))) == 0       # k5
     assert lib.rtg_gconv_ok(C.byref(GconvDesc(2, 4, 16, 16, 41, 2, 20, 100, 50, 0.15))) == 0    # 16 channels per group
     assert lib.rtg_gconv_ok(C.byref(GconvDesc(2, 4, 8, 16, 41, 2, 20, 100, 51, 0.15))) == 0     # wrong output length
+
+
+@pytest.mark.parametrize('case', CASES + [(64, 32, 64, 4, 2, 8192, 0.15), (7, 512, 512, 64, 4, 64, 0.15), (2, 128, 512, 32, 4, 700, 0.15)])
+def test_gmfma_forward_matches_torch(case):
+    """rtg_gmfma.hip (round 4): the same forward on the matrix cores with exact-fit tiles, its weight image
+    [group][oc][ci][44] written by rtg_weights_pack (RTG_PACK_GMFMA_FWD) from the raw weight-norm parameters."""
+    from rtg import lib as L
+    from rtg.lib import lib, GconvDesc
+    B, Cin, Cout, g, s, Lin, slope = case
+    K, pad = 41, 20
+    Lo = (Lin + 2 * pad - (K - 1) - 1) // s + 1
+    d = GconvDesc(B, g, Cin // g, Cout // g, K, s, pad, Lin, Lo, slope)
+    if Lo < 16:
+        assert lib.rtg_gmfma_ok(C.byref(d)) == 0            # (rows shorter than a column tile stay with rtg_gconv)
+        return
+    assert lib.rtg_gmfma_ok(C.byref(d)) == 1
+    gen = torch.Generator().manual_seed(Cin + Lin)
+    x = torch.randn(B, Cin, Lin, generator=gen)
+    v = torch.randn(Cout, Cin // g, K, generator=gen) * 0.2
+    gg = torch.rand(Cout, generator=gen) + 0.5
+    bias = torch.randn(Cout, generator=gen)
+    scale = gg / v.flatten(1).norm(dim=1)
+    w = v * scale[:, None, None]
+    ref = F.conv1d(F.leaky_relu(x.double(), slope) if slope != 1.0 else x.double(), w.double(), bias.double(), stride=s,
+                   padding=pad, groups=g)
+    # the image through the pack launch: params = [v], scales = [scale | 1 / norm]
+    n_w = lib.rtg_gmfma_workspace(C.byref(d))
+    assert n_w == Cout * (Cin // g) * 44
+    params = v.flatten().cuda()
+    scales = torch.cat([scale, 1.0 / v.flatten(1).norm(dim=1)]).cuda()
+    packed = torch.full((n_w + 64,), float('nan'), device='cuda')
+    job = L.PackJob(0, 0, 0, n_w, L.PACK_GMFMA_FWD, g, Cout // g, Cin // g, K, K, Cin // g, 44, 16, 0, 0, 0, 0)
+    blocks, lds = L.assign_pack_blocks([job])
+    tab = torch.frombuffer(bytearray(bytes(job)), dtype=torch.uint8).cuda()
+    assert lib.rtg_weights_pack(_ptr(tab), 1, blocks, lds, _ptr(params), _ptr(scales), _ptr(packed), None) == 0
+    img = packed.cpu()[:n_w].view(Cout, Cin // g, 44)
+    assert torch.allclose(img[:, :, :41], w, rtol=1e-6, atol=0) and (img[:, :, 41:] == 0).all()
+    out = torch.full((B, Cout, Lo), float('nan'), device='cuda')
+    assert lib.rtg_gmfma_forward(C.byref(d), _ptr(x.cuda()), _ptr(packed), _ptr(bias.cuda()), _ptr(out), None) == 0
+    torch.cuda.synchronize()
+    got = out.cpu().double()
+    assert torch.isfinite(got).all()
+    err = (got - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 2e-6, err

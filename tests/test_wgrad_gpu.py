@@ -293,6 +293,25 @@ def test_gconv_wgrad_on_the_vector_alus(case):
     _check_case(case, shape_cfg=9, act='none')
 
 
+@pytest.mark.parametrize('case', GCONV_CASES)
+def test_gmfma_wgrad_on_the_matrix_cores(case):
+    """rtg_gmfma.hip backward-weight (shape code 15, round 4): exact-fit matrix-core tiles for the groups of 16 output
+    channels; listed for those layers (rows of at least 32 positions), weight, bias and weight-norm gradients through the usual
+    split partials against torch autograd."""
+    from rtg.lib import lib, WgradDesc
+    B, Cin, Cout, L, K, s, d, p, g = case
+    Lo = (L + 2 * p - d * (K - 1) - 1) // s + 1
+    probe = WgradDesc(B=B, C1=Cin, C2=0, L_in=L, groups=g, Cg=Cin // g, Mg=Cout // g, K=K, stride=s, dil=d, pad=p, Q=Lo,
+                      dy_L=Lo, pre_mode=1, pre_slope=0.15, gy_mode=0, gy_slope=1.0, gy_scale=1.0, splits=1, part_stride=0)
+    cands = (C.c_int * 12)()
+    n = lib.rtg_wgrad_shape_candidates(C.byref(probe), cands, 12)
+    if Cout // g != 16 or Lo < 32:
+        assert 15 not in list(cands[:n])                 # (8 output channels per group / short rows: rtg_gconv.hip's)
+        return
+    assert 15 in list(cands[:n])
+    _check_case(case, shape_cfg=15, act='none')
+
+
 def _partials(wd_kw, x, dy, cfg, bf16):
     """rtg_conv1d_wgrad -> the split partials summed in float64: [rows * (Cg * K + 1)]"""
     from rtg.lib import lib, WgradDesc

@@ -42,10 +42,19 @@ for sub, L0 in ((0, 8192), (1, 4096), (2, 2048)):
             tune.REPS = 20
             t0 = tune._time(lambda: lib.rtg_conv1d(C.byref(d), *args))
             t1 = tune._time(lambda: lib.rtg_gconv_forward(C.byref(gd), *gargs))
+            t2 = None
+            if lib.rtg_gmfma_ok(C.byref(gd)) == 1:
+                ref = out.clone()
+                margs = (ops._p(x), ops._p(bank.gmfma_weights(ly, gd)), bank.bias_ptr(ly), ops._p(out), None)
+                assert lib.rtg_gmfma_forward(C.byref(gd), *margs) == 0
+                torch.cuda.synchronize()
+                err = ((out - ref).abs().max() / ref.abs().max()).item()
+                t2 = tune._time(lambda: lib.rtg_gmfma_forward(C.byref(gd), *margs))
             tune.REPS = 3
             fl = 2.0 * B * Lo * ly.cout * (ly.cin // ly.groups) * ly.k
             print(f'd{sub}.convs.{li} Cg{ly.cin // ly.groups} Mg{ly.cout // ly.groups} s{ly.stride} L{L}: mfma {t0 * 1e3:7.1f} us '
-                  f'{fl / t0 / 1e9:6.1f} TF/s (cfg {d.tile_cfg})   valu {t1 * 1e3:7.1f} us {fl / t1 / 1e9:6.1f} TF/s')
+                  f'{fl / t0 / 1e9:6.1f} TF/s (cfg {d.tile_cfg})   valu {t1 * 1e3:7.1f} us {fl / t1 / 1e9:6.1f} TF/s' +
+                  (f'   gmfma {t2 * 1e3:7.1f} us {fl / t2 / 1e9:6.1f} TF/s (vs valu result: rel err {err:.1e})' if t2 else ''))
             # backward-data of the same layer
             dy = torch.randn(B, ly.cout, Lo, device='cuda')
             dx = torch.empty(B, ly.cin, L, device='cuda')

@@ -108,6 +108,16 @@ __global__ __launch_bounds__(RTG_THREADS) void pack_kernel(const RtgPackJob* job
   const int n_mt = (j.Mg + TM - 1) / TM, n_cc = (j.Cg + RTG_CK - 1) / RTG_CK;
   const unsigned n_e = (unsigned)j.dst_size;
   const int lane = threadIdx.x & 63;
+  if (j.mode == RTG_PACK_GMFMA_FWD) {
+    // [g][oc][ci][44]: row (g * Mg + oc) of v is (ci, tap)-major with 41 taps; taps 41 .. 43 of the image are zero
+    const unsigned K = (unsigned)j.K, KP = (unsigned)j.S, Cg = (unsigned)j.Cg;      // (S carries the padded tap count)
+    for (unsigned e = bid * RTG_THREADS + threadIdx.x; e < n_e; e += nb * RTG_THREADS) {
+      const unsigned t = e % KP, rc = e / KP;           // rc = row * Cg + ci
+      const unsigned row = rc / Cg;
+      packed[j.dst_off + e] = t < K ? params[j.v_off + (long long)rc * K + t] * scales[j.scale_off + row] : 0.f;
+    }
+    return;
+  }
   if (j.mode == RTG_PACK_GCONV_FWD || j.mode == RTG_PACK_GCONV_BWD) {
     // the vector-ALU kernels' plain orders (rtg_gconv.hip): w'[g][ci][t][oc] = v[g * Mg + oc][ci][t] * scale[g * Mg + oc]
     // (forward), w'[g][oc][t][ci] = the same element (backward-data); the source row of v is (ci, t)-major

@@ -45,6 +45,11 @@ int rtg_gconv_wgrad_ok(const RtgWgradDesc* d);
 int rtg_gconv_wgrad_splits(const RtgWgradDesc* d);
 int rtg_gconv_wgrad_launch(const RtgWgradDesc* d, const float* x, const float* dy, float* part, hipStream_t s);
 
+// rtg_gmfma.hip: the same layers on the matrix cores with exact-fit tiles (shape code kGmfmaShape)
+int rtg_gmfma_wgrad_ok(const RtgWgradDesc* d);
+int rtg_gmfma_wgrad_splits(const RtgWgradDesc* d);
+int rtg_gmfma_wgrad_launch(const RtgWgradDesc* d, const float* x, const float* dy, float* part, hipStream_t s);
+
 // rtg_dwgrad.hip: the dense discriminator layers with 16-byte operand fragments (shape code kDenseShape)
 int rtg_dwgrad_variants(void);
 int rtg_dwgrad_ok(const RtgWgradDesc* d, int variant);
@@ -58,6 +63,7 @@ constexpr int kResShape = 8;
 constexpr int kGconvShape = 9;
 constexpr int kDenseShape = 10;       // 10 .. 10 + rtg_dwgrad_variants() - 1: its block shapes
 constexpr int kDenseShapeLast = 14;
+constexpr int kGmfmaShape = 15;
 
 struct Shape {
   int MTW, NTW, WM;
@@ -138,7 +144,7 @@ int validate(const RtgWgradDesc* d) {
   if (d->groups > 1 && d->C2 != 0) return RTG_EINVAL;
   if (d->stride > 8) return RTG_ERANGE;
   if (d->shape_cfg < 0 || (d->shape_cfg > kNumShapes && d->shape_cfg != kThinShape && d->shape_cfg != kResShape &&
-                           d->shape_cfg != kGconvShape && !(d->shape_cfg >= kDenseShape && d->shape_cfg <= kDenseShapeLast)))
+                           d->shape_cfg != kGconvShape && d->shape_cfg != kGmfmaShape && !(d->shape_cfg >= kDenseShape && d->shape_cfg <= kDenseShapeLast)))
     return RTG_EINVAL;
   const bool two_d = d->h_k > 1 || d->h_n > 1;
   if (two_d) {
@@ -162,6 +168,7 @@ extern "C" int rtg_wgrad_splits(const RtgWgradDesc* d) {
   if (d->shape_cfg == kThinShape) return rtg_wgrad_thin_splits(d);
   if (d->shape_cfg == kResShape) return rtg_reswgrad_splits(d);
   if (d->shape_cfg == kGconvShape) return rtg_gconv_wgrad_splits(d);
+  if (d->shape_cfg == kGmfmaShape) return rtg_gmfma_wgrad_splits(d);
   if (d->shape_cfg >= kDenseShape && d->shape_cfg <= kDenseShapeLast) return rtg_dwgrad_splits(d, d->shape_cfg - kDenseShape);
   WgGeom g;
   st = geometry(d, &g);
@@ -215,6 +222,7 @@ extern "C" int rtg_wgrad_shape_candidates(const RtgWgradDesc* d, int* cfgs, int 
   if (rtg_wgrad_thin_kind(d) > 0 && cnt < max) cfgs[cnt++] = kThinShape;
   if (rtg_reswgrad_ok(d) && cnt < max) cfgs[cnt++] = kResShape;
   if (rtg_gconv_wgrad_ok(d) && cnt < max) cfgs[cnt++] = kGconvShape;
+  if (rtg_gmfma_wgrad_ok(d) && cnt < max) cfgs[cnt++] = kGmfmaShape;
   for (int v = 0; v < rtg_dwgrad_variants(); ++v)
     if (rtg_dwgrad_ok(d, v) && cnt < max) cfgs[cnt++] = kDenseShape + v;
   return cnt;
@@ -242,7 +250,7 @@ int wgrad_plan(const RtgWgradDesc* d, const float* x1, const float* x2, const fl
   if (d->splits < 1 || d->splits > 65535) return RTG_EINVAL;
   const long long need = (long long)d->groups * d->Mg * ((long long)d->Cg * d->K + 1);
   if (d->splits > 1 && d->part_stride < need) return RTG_EINVAL;
-  if (d->shape_cfg == kThinShape || d->shape_cfg == kResShape || d->shape_cfg == kGconvShape ||
+  if (d->shape_cfg == kThinShape || d->shape_cfg == kResShape || d->shape_cfg == kGconvShape || d->shape_cfg == kGmfmaShape ||
       (d->shape_cfg >= kDenseShape && d->shape_cfg <= kDenseShapeLast))
     return RTG_EINVAL;                                                               // kernels of their own
   WgGeom& g = pl->g;
@@ -292,7 +300,7 @@ int rtg_wgrad_launch_group_m1(int, const rtg_wg::WgGroupArgs&, size_t, hipStream
 extern "C" int rtg_conv1d_wgrad(const RtgWgradDesc* d, const float* x1, const float* x2, const float* dy,
                                 const float* gy_aux, float* part, void* stream) {
   if (!d || !x1 || !dy || !part) return RTG_ENULL;
-  if (d->shape_cfg == kThinShape || d->shape_cfg == kResShape || d->shape_cfg == kGconvShape ||
+  if (d->shape_cfg == kThinShape || d->shape_cfg == kResShape || d->shape_cfg == kGconvShape || d->shape_cfg == kGmfmaShape ||
       (d->shape_cfg >= kDenseShape && d->shape_cfg <= kDenseShapeLast)) {
     int st = validate(d);
     if (st) return st;
@@ -303,6 +311,7 @@ extern "C" int rtg_conv1d_wgrad(const RtgWgradDesc* d, const float* x1, const fl
     if (d->splits > 1 && d->part_stride < need) return RTG_EINVAL;
     if (d->shape_cfg == kThinShape) return rtg_wgrad_thin_launch(d, x1, dy, gy_aux, part, (hipStream_t)stream);
     if (d->shape_cfg == kGconvShape) return rtg_gconv_wgrad_launch(d, x1, dy, part, (hipStream_t)stream);
+    if (d->shape_cfg == kGmfmaShape) return rtg_gmfma_wgrad_launch(d, x1, dy, part, (hipStream_t)stream);
     if (d->shape_cfg >= kDenseShape && d->shape_cfg <= kDenseShapeLast)
       return rtg_dwgrad_launch(d, d->shape_cfg - kDenseShape, x1, dy, part, (hipStream_t)stream);
     return rtg_reswgrad_launch(d, x1, dy, part, (hipStream_t)stream);

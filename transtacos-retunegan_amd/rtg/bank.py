@@ -245,6 +245,9 @@ class WeightBank:
                 ly.gconv_off = (poff, poff + n)
                 ly.gconv_size = ly.cout * (ly.cin // ly.groups) * ly.k
                 poff += 2 * n
+                # ... and the forward image of the exact-fit matrix-core kernel (rtg_gmfma.hip): [group][oc][ci][44]
+                ly.gmfma_off, ly.gmfma_size = poff, ly.cout * (ly.cin // ly.groups) * 44
+                poff += (ly.gmfma_size + 63) & ~63
         self.packed = torch.empty(poff, device=self.device, dtype=torch.float32)
         self._bind_params()
         self._build_tables()
@@ -330,6 +333,8 @@ class WeightBank:
                 for mode, off in ((L.PACK_GCONV_FWD, ly.gconv_off[0]), (L.PACK_GCONV_BWD, ly.gconv_off[1])):
                     pack.append(L.PackJob(ly.v_off, ly.scale_off, off, ly.gconv_size, mode, ly.groups, ly.cout // ly.groups,
                                           ly.cin // ly.groups, ly.k, ly.k, ly.inner_c, 1, 16, 0, 0, 0, 0))
+                pack.append(L.PackJob(ly.v_off, ly.scale_off, ly.gmfma_off, ly.gmfma_size, L.PACK_GMFMA_FWD, ly.groups,
+                                      ly.cout // ly.groups, ly.cin // ly.groups, ly.k, ly.k, ly.inner_c, 44, 16, 0, 0, 0, 0))
         self.norm_table = _table(norm, self.device)
         self.pack_blocks, self.pack_lds = L.assign_pack_blocks(pack)
         self.pack_table = _table(pack, self.device)
@@ -426,6 +431,16 @@ class WeightBank:
                   'gconv_prepare')
             ent[1] = tok_id
         return ent[0]
+
+    def gmfma_weights(self, ly, gd):
+        """the layer's forward image for rtg_gmfma_forward ([group][oc][ci][44], part of this pass's pack launch); None: the
+        layer has none (RTG_GCONV_PACK=0)"""
+        if getattr(ly, 'gconv_off', None) is None:
+            return None
+        if lib.rtg_gmfma_workspace(C.byref(gd)) != ly.gmfma_size:
+            raise L.RtgError(f'gmfma image of {ly.name}: {ly.gmfma_size} floats, the kernel expects '
+                             f'{lib.rtg_gmfma_workspace(C.byref(gd))}')
+        return self.packed[ly.gmfma_off:ly.gmfma_off + ly.gmfma_size]
 
     def fwd_ptr(self, ly):
         return C.c_void_p(self.packed.data_ptr() + 4 * ly.fwd_off)

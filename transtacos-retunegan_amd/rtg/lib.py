@@ -85,7 +85,7 @@ class StftDesc(C.Structure):
 
 PRE_NONE, PRE_LRELU, PRE_MUL_DLRELU, PRE_MUL_DTANH = 0, 1, 2, 3
 ACT_NONE, ACT_LRELU, ACT_TANH = 0, 1, 2
-PACK_FWD, PACK_DGRAD_S1, PACK_DGRAD_POLY, PACK_CONVT_POLY, PACK_DGRAD_2D, PACK_GCONV_FWD, PACK_GCONV_BWD = 0, 1, 2, 3, 4, 5, 6
+PACK_FWD, PACK_DGRAD_S1, PACK_DGRAD_POLY, PACK_CONVT_POLY, PACK_DGRAD_2D, PACK_GCONV_FWD, PACK_GCONV_BWD, PACK_GMFMA_FWD = 0, 1, 2, 3, 4, 5, 6, 7
 CK = 16
 LOSS_L1, LOSS_L1_L1LOG, LOSS_MSE_TARGET, LOSS_MSE_REL = 0, 1, 2, 3
 MAX_LOSS_JOBS = 48
@@ -114,6 +114,9 @@ PROTOTYPES = {
     'rtg_gconv_forward': (_I, [C.POINTER(GconvDesc), _P, _P, _P, _P, _P]),
     'rtg_gconv_prepare_bwd': (_I, [C.POINTER(GconvDesc), _P, _P, _P, _P]),
     'rtg_gconv_backward_data': (_I, [C.POINTER(GconvDesc), _P, _P, _P, _P, _P, _P]),
+    'rtg_gmfma_ok': (_I, [C.POINTER(GconvDesc)]),
+    'rtg_gmfma_workspace': (C.c_longlong, [C.POINTER(GconvDesc)]),
+    'rtg_gmfma_forward': (_I, [C.POINTER(GconvDesc), _P, _P, _P, _P, _P]),
     'rtg_wgrad_splits': (_I, [C.POINTER(WgradDesc)]),
     'rtg_wgrad_shape_candidates': (_I, [C.POINTER(WgradDesc), C.POINTER(C.c_int), _I]),
     'rtg_weightnorm_scales': (_I, [_P, _I, _I, _P, _P, _P]),

@@ -240,6 +240,8 @@ def _desc(**kw):
 
 # RTG_GCONV=0: the thin-group MSD layers on the matrix cores only (A/B knob)
 GCONV = _os.environ.get('RTG_GCONV', '1') == '1'
+# RTG_GMFMA=0: without the exact-fit matrix-core forward of rtg_gmfma.hip (A/B knob)
+GMFMA = _os.environ.get('RTG_GMFMA', '1') == '1'
 
 
 def _gconv_forward(ly, bank, tok_id, d, args, x_ptr, B, L_in, out, pre_slope, flop, label):
@@ -255,10 +257,16 @@ def _gconv_forward(ly, bank, tok_id, d, args, x_ptr, B, L_in, out, pre_slope, fl
         return False
     d.tile_cfg = tune.conv_cfg(d, lambda: lib.rtg_conv1d(C.byref(d), *args))
     gargs = (x_ptr, _p(bank.gconv_weights(ly, gd, tok_id)), bank.bias_ptr(ly), _p(out), _stream())
-    if tune.alt_choice(b'gconv' + bytes(gd), [lambda: lib.rtg_conv1d(C.byref(d), *args),
-                                             lambda: lib.rtg_gconv_forward(C.byref(gd), *gargs)]) != 1:
+    ways = [lambda: lib.rtg_conv1d(C.byref(d), *args), lambda: lib.rtg_gconv_forward(C.byref(gd), *gargs)]
+    # round 4: the exact-fit matrix-core kernel (rtg_gmfma.hip) as a third way, where it serves the shape
+    wm = bank.gmfma_weights(ly, gd) if GMFMA and lib.rtg_gmfma_ok(C.byref(gd)) == 1 else None
+    if wm is not None:
+        margs = (x_ptr, _p(wm), bank.bias_ptr(ly), _p(out), _stream())
+        ways.append(lambda: lib.rtg_gmfma_forward(C.byref(gd), *margs))
+    which = tune.alt_choice((b'gconv3' if wm is not None else b'gconv') + bytes(gd), ways)
+    if which == 0:
         return False
-    check(_timed('conv1d', 7200, flop, lambda: lib.rtg_gconv_forward(C.byref(gd), *gargs), label,
+    check(_timed('conv1d', 7200 if which == 1 else 7202, flop, ways[which], label,
                  _conv_bytes(d, args) if PROFILE is not None else 0), f'gconv {label}')
     return True
 
