@@ -258,12 +258,16 @@ def test_cpu_input_is_refused(nets):
         nets[0](torch.zeros(1, 80, 32), torch.zeros(1, 1, 8192))
 
 
-def test_grouped_launch_path_matches_forked_streams(nets, oracle, gold):
+def test_grouped_launch_path_matches_forked_streams(nets, oracle, gold, monkeypatch):
     """RTG_GROUP=1 (sibling sub-discriminators layer by layer through rtg_conv1d_group) gives the same logits, feature
     maps and parameter gradients as the default forked-stream execution: the grouped launch is bit-identical per
     member, the weight-gradient split-K order is the tuner's choice in both (rounding-level differences only)."""
     import models.discrminator as D
     from models import discriminator_loss
+    from rtg import ops
+    # (the statement is about the general kernel: the thin-group layers' other kernels — rtg_gconv.hip, rtg_gmfma.hip,
+    # picked per problem by the tuner when an earlier test of this process timed these shapes — sum in another order)
+    monkeypatch.setattr(ops, 'GCONV', False)
     _, _, y = oracle.golden_inputs()
     yd = torch.from_numpy(gold['y_hat'])
     for d in (nets[1], nets[2]):
