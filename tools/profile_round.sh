@@ -1,12 +1,13 @@
 #!/bin/bash
-# One call on the GPU box: bench line, steady-state kernel stats (rocprofv3 --kernel-trace) and the PMC passes of the same
-# command, summarised there (the raw traces are too big to travel back).  usage: tools/profile_round.sh <tag> [bench args]
+# One call on the GPU box: steady-state kernel stats (rocprofv3 --kernel-trace) and the PMC passes of the bench command,
+# summarised there (the raw traces are too big to travel back), THEN the bench line — so that its roofline block reads the
+# PMC summary of these very sources (pmc_stale: false).  usage: tools/profile_round.sh <tag> [bench args]
 set -e
 TAG=$1; shift
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
-cd $GRAFT_REPO_ROOT
-timeout -k 10 300 python bench.py "$@" > $OUT/bench.json 2> $OUT/bench.err
+WL=config2
+for a in "$@"; do case $a in config[1-5]) WL=$a;; esac; done
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/prof -o r -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline "$@" > $OUT/bench_under_rocprof.json 2> $OUT/prof.err
 cd $GRAFT_REPO_ROOT
@@ -15,4 +16,6 @@ rm -rf $OUT/prof
 bash tools/pmc_pass.sh $TAG/pmc $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline "$@"
 python tools/pmc_summary.py $OUT/pmc $OUT/pmc.json > $OUT/pmc_top.txt
 rm -rf $OUT/pmc
+cp $OUT/pmc.json profiles/${TAG}_bench_${WL}_pmc.json        # (bench.py reads the newest profiles/*_bench_<workload>_pmc.json)
+timeout -k 10 300 python bench.py "$@" > $OUT/bench.json 2> $OUT/bench.err
 ls -la $OUT
