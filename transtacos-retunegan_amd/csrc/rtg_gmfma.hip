@@ -347,10 +347,10 @@ int rtg_gmfma_wgrad_splits(const RtgWgradDesc* d) {
   // a wave per (group, split): about 2048 waves (two per SIMD), at least 4 blocks of 64 positions each; every split is a
   // whole partial of the layer (written here, read back by rtg_weightnorm_backward): no more of them than that takes
   const int n_blocks = d->B * rtg_ceil_div(d->Q, 64);
-  int w = rtg_ceil_div(2048, d->groups);
+  int w = rtg_ceil_div(RTG_ENV_INT("RTG_GMFMA_WAVES", 2048), d->groups);
   const int w_max = n_blocks / 4 > 0 ? n_blocks / 4 : 1;
   if (w > w_max) w = w_max;
-  if (w > 512) w = 512;
+  if (w > RTG_ENV_INT("RTG_GMFMA_WMAX", 512)) w = RTG_ENV_INT("RTG_GMFMA_WMAX", 512);
   return w < 1 ? 1 : w;
 }
 
