@@ -232,7 +232,11 @@ def test_every_block_shape_gives_identical_bits(case):
 # load, the last load of a wave partial), 8 .. 1024 channels, one clip and many
 K3_ROWS_CASES = [(704, 512, 1, 10, 3, 1, 1, 1, 1, 16), (7, 512, 1, 15, 3, 1, 1, 1, 1, 32), (5, 1024, 1, 21, 3, 1, 1, 1, 1, 16),
                  (3, 128, 1, 64, 3, 1, 1, 1, 1, 16), (1, 512, 1, 32, 3, 1, 1, 1, 1, 16), (9, 256, 1, 4, 3, 1, 1, 1, 1, 16),
-                 (2, 512, 1, 33, 3, 1, 1, 1, 1, 16), (4, 384, 1, 63, 3, 1, 1, 1, 1, 16)]
+                 (2, 512, 1, 33, 3, 1, 1, 1, 1, 16), (4, 384, 1, 63, 3, 1, 1, 1, 1, 16),
+                 # one INPUT channel with compile-time taps / stride (cin1_flat_kernel<KT, ST>): conv_post backward-data
+                 # (1 -> 512, k3), the first layer of the period discriminators (1 -> 32, k5, stride 3), ragged rows
+                 (37, 1, 512, 10, 3, 1, 1, 1, 1, 32), (5, 1, 512, 34, 3, 1, 1, 1, 1, 32), (3, 1, 512, 127, 3, 1, 1, 1, 1, 32),
+                 (9, 1, 32, 2731, 5, 3, 1, 2, 1, 32), (4, 1, 32, 1171, 5, 3, 1, 2, 1, 32), (2, 1, 64, 50, 5, 1, 1, 2, 1, 32)]
 
 
 @pytest.mark.parametrize('case', [FWD_CASES[7], FWD_CASES[8], FWD_CASES[9], FWD_CASES[15], (40, 1, 32, 911, 5, 3, 1, 2, 1, 32)] + K3_ROWS_CASES)
