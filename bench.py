@@ -297,6 +297,7 @@ def main():
     torch.cuda.set_device(device)
 
     import hparam as hp
+    import train as train_mod
     from train import Trainer
     desc, use_mpd, use_mtd, d_times, batch, T = WORKLOADS[a.workload]
     if a.batch:
@@ -426,7 +427,11 @@ def main():
             'config': {'workload': f'{a.workload}: {desc}', 'per_gpu_batch': batch, 'clip_samples': T,
                        'global_batch': world * batch, 'd_train_times': d_times,
                        'parallelism': f'dp{world}' if world > 1 else ('single (1-rank RCCL group, data-parallel path forced)' if forced else 'single'), 'launch': mode,
-                       **({'per_rank': per_rank} if per_rank else {})},
+                       **({'per_rank': per_rank,
+                           'exchange': ('RCCL all-reduce of each model\'s flat gradient buffer '
+                                        + ('on the compute stream' if train_mod._inline_reduce() else 'on a high-priority communication stream')
+                                        + ', graphs cut per ' + ('discriminator' if os.environ.get('RTG_DP_CUT') == 'disc' else 'optimizer update')
+                                        + ('' if mode.startswith('hip-graph') else ' (eager step)'))} if per_rank else {})},
             'roofline': roof, 'cpu_baseline': cpu,
             'final_losses': {'gen_all': round(loss_g, 4), 'disc_all': round(loss_d, 4)},
         }
