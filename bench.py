@@ -201,7 +201,7 @@ def roofline(trainer, batch, bf16=False, workload='config2'):
             continue
         # one entry per kernel TEMPLATE: wgrad:<rows per MFMA> and conv1d:<instance> as before; the block shapes of the
         # dense-layer kernel (codes 8xxx: rows per wave x waves x column tiles of one template) are one kernel, dconv
-        k = ('dconv', 16) if kernel == 'conv1d' and variant > 8000 else (kernel, variant)
+        k = ('dconv', 16) if kernel == 'conv1d' and 8000 < variant < 9000 else (kernel, variant)       # (9xxx: rtg_sconv.hip)
         a = agg.setdefault(k, [0, 0.0, 0.0, 0.0])
         a[0] += 1
         a[1] += ms * 1e-3

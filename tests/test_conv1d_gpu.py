@@ -409,3 +409,86 @@ def test_resconv_kernel_matches_general_kernel_bitwise_and_torch(case, mode):
     np.testing.assert_allclose(outs[0].numpy(), ref.float().numpy(), rtol=1e-4, atol=2e-5)
     for code in codes:
         assert torch.equal(outs[code], outs[0]), (code, (outs[code] - outs[0]).abs().max().item())
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# rtg_sconv.hip (round 4): stride-1 "same" convs over few columns with split-K over the waves of a block (codes 9004 / 9008)
+# ---------------------------------------------------------------------------------------------------------------
+SCONV_CASES = [
+    # B, C1, C2, C_out, L, K, dil, out_split, extras
+    (32, 80, 128, 256, 32, 7, 1, 0, 'bias'),                  # conv_fuse forward: [mel | encoder] concatenated input
+    (32, 256, 0, 208, 32, 7, 1, 80, ''),                      # its backward-data: 208 rows split into the two inputs
+    (32, 128, 0, 128, 32, 3, 9, 0, 'pre bias res act'),       # ResidualStack conv, dilation 9 (wider than half the row)
+    (32, 128, 0, 128, 32, 3, 3, 0, 'bias mask res'),          # backward-data shaped: mask and residual gradient
+    (5, 128, 0, 144, 40, 5, 3, 0, 'bias res acc'),            # ragged: clips straddle the 64-column tiles, accumulate
+    (3, 64, 64, 128, 64, 8, 1, 0, 'pre bias'),                # 8 taps, rows of 64, two 64-channel inputs
+]
+
+
+@pytest.mark.parametrize('case', SCONV_CASES)
+def test_sconv_split_k_matches_the_general_kernel(case):
+    from rtg.lib import lib, Conv1dDesc, check
+    B, C1, C2, Cout, L, K, dil, split, extras = case
+    Cin = C1 + C2
+    pad = dil * (K - 1) // 2
+    pad_r = dil * (K - 1) - pad                                # ("same": left pad, the right one follows from Q = L)
+    gen = torch.Generator().manual_seed(C1 + K + L)
+    x = torch.randn(B, Cin, L, generator=gen)
+    w = torch.randn(Cout, Cin, K, generator=gen) / np.sqrt(Cin * K)
+    bias = torch.randn(Cout, generator=gen) if 'bias' in extras else None
+    mask = torch.randn(B, Cout, L, generator=gen) if 'mask' in extras else None
+    res = torch.randn(B, Cout, L, generator=gen) if 'res' in extras else None
+    W = packref.logical_fwd(w.numpy(), 1)
+    wp = np.concatenate([packref.pack_logical(W, 32), packref.pack_frag16(W)])
+    kw = dict(pre_mode=1, pre_slope=0.01) if 'pre' in extras else {}
+    if 'act' in extras:
+        kw.update(act=1, act_slope=0.2, out_scale=0.5)
+    if mask is not None:
+        kw.update(mask_slope=0.15)
+    desc = base_desc(B, C1, C2, L, 1, Cin, Cout, K, 1, dil, pad, L, Cout, L, 32, out_split=split, wp16=1,
+                     accumulate=int('acc' in extras), **kw)
+    cands = (C.c_int * 48)()
+    n = lib.rtg_conv1d_tile_candidates(C.byref(Conv1dDesc(**desc)), cands, 48)
+    codes = [c for c in cands[:n] if c > 9000]
+    assert codes and set(codes) <= {9004, 9008}, list(cands[:n])
+    dev = 'cuda'
+    xd = x.to(dev)
+    x1, x2 = (xd[:, :C1].contiguous(), xd[:, C1:].contiguous()) if C2 else (xd, None)
+    wpd = torch.from_numpy(wp).to(dev)
+    t = {k_: (v.to(dev) if v is not None else None) for k_, v in dict(bias=bias, mask=mask, res=res).items()}
+    init = torch.randn(B, Cout, L, generator=gen).to(dev) if 'acc' in extras else None
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def run(code):
+        d = Conv1dDesc(**dict(desc, tile_cfg=code))
+        if split:
+            o1 = torch.full((B, split, L), float('nan'), device=dev)
+            o2 = torch.full((B, Cout - split, L), float('nan'), device=dev)
+        else:
+            o1 = init.clone() if init is not None else torch.full((B, Cout, L), float('nan'), device=dev)
+            o2 = None
+        check(lib.rtg_conv1d(C.byref(d), _ptr(x1), _ptr(x2), None, _ptr(wpd), _ptr(t['bias']), _ptr(t['mask']), _ptr(t['res']),
+                             _ptr(o1), _ptr(o2), st), f'rtg_conv1d code {code}')
+        torch.cuda.synchronize()
+        return torch.cat([o1, o2], dim=1).cpu() if split else o1.cpu()
+
+    ref = run(0)                                               # the library's heuristic: a general block shape
+    assert torch.isfinite(ref).all()
+    # (independent check of the reference itself against torch, fp64)
+    xa = F.leaky_relu(x.double(), 0.01) if 'pre' in extras else x.double()
+    tr = F.conv1d(F.pad(xa, (pad, pad_r)), w.double(), bias.double() if bias is not None else None, dilation=dil)
+    if mask is not None:
+        tr = tr * torch.where(mask.double() > 0, 1.0, 0.15)
+    if res is not None:
+        tr = tr + res.double()
+    if 'act' in extras:
+        tr = F.leaky_relu(tr * 0.5, 0.2)
+    if init is not None:
+        tr = tr + init.cpu().double()
+    assert (ref.double() - tr).abs().max().item() < 2e-5 * max(1.0, tr.abs().max().item())
+    for code in codes:
+        got = run(code)
+        assert torch.isfinite(got).all(), code
+        err = (got.double() - tr).abs().max().item()
+        assert err < 2e-5 * max(1.0, tr.abs().max().item()), (code, err)
+        np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=2e-5, atol=2e-5)

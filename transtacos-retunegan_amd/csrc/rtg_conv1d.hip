@@ -174,6 +174,19 @@ int rtg_dconv_candidates(const RtgConv1dDesc* d, int* codes, int max);
 int rtg_dconv_launch(const RtgConv1dDesc* d, int code, const float* x, const float* wp, const float* bias,
                      const float* mask, const float* res, float* out, hipStream_t s);
 #define RTG_DCONV_CODE 8000
+// rtg_sconv.hip: stride-1 "same" convolutions over few columns (the bottom of the UNet) with split-K over the waves of a
+// block (block-shape codes 9000 + waves; needs RtgConv1dDesc.wp16)
+int rtg_sconv_candidates(const RtgConv1dDesc* d, int* codes, int max);
+int rtg_sconv_launch(const RtgConv1dDesc* d, int code, const float* x1, const float* x2, const float* wp, const float* bias,
+                     const float* mask, const float* res, float* out, float* out2, hipStream_t s);
+#define RTG_SCONV_CODE 9000
+static bool sconv_code_ok(const RtgConv1dDesc* d) {
+  int codes[4];
+  const int n = rtg_sconv_candidates(d, codes, 4);
+  for (int i = 0; i < n; ++i)
+    if (codes[i] == d->tile_cfg) return true;
+  return false;
+}
 static bool dconv_code_ok(const RtgConv1dDesc* d) {
   int codes[16];
   const int n = rtg_dconv_candidates(d, codes, 16);
@@ -184,6 +197,7 @@ static bool dconv_code_ok(const RtgConv1dDesc* d) {
 
 extern "C" int rtg_conv1d_variant(const RtgConv1dDesc* d) {
   if (!d) return RTG_ENULL;
+  if (d->tile_cfg > RTG_SCONV_CODE) return sconv_code_ok(d) ? d->tile_cfg : RTG_EINVAL;
   if (d->tile_cfg > RTG_DCONV_CODE) return dconv_code_ok(d) ? d->tile_cfg : RTG_EINVAL;
   if (d->tile_cfg > RTG_RESCONV_CODE && d->tile_cfg <= RTG_RESCONV_CODE + 2)
     return (rtg_resconv_variants(d) & (1 << (d->tile_cfg - RTG_RESCONV_CODE - 1))) ? d->tile_cfg : RTG_EINVAL;
@@ -225,6 +239,7 @@ extern "C" int rtg_conv1d_tile_candidates(const RtgConv1dDesc* d, int* cfgs, int
     if ((rv & (1 << (nt - 1))) && cnt < max) cfgs[cnt++] = RTG_RESCONV_CODE + nt;
   // the dense-layer kernel's best-scored shapes (all of them would double the tuning step's work on these layers)
   if (cnt < max) cnt += rtg_dconv_candidates(d, cfgs + cnt, max - cnt < 8 ? max - cnt : 8);
+  if (cnt < max) cnt += rtg_sconv_candidates(d, cfgs + cnt, max - cnt);
   return cnt;
 }
 
@@ -382,6 +397,10 @@ extern "C" int rtg_conv1d(const RtgConv1dDesc* d, const float* x1, const float* 
     if (thin > 0) {
       return rtg_thin_launch(thin, d, x1, aux, wp, bias, mask, res, out, (hipStream_t)stream);
     }
+  }
+  if (d->tile_cfg > RTG_SCONV_CODE) {
+    if (aux) return RTG_EINVAL;
+    return rtg_sconv_launch(d, d->tile_cfg, x1, x2, wp, bias, mask, res, out, out2, (hipStream_t)stream);
   }
   if (d->tile_cfg > RTG_DCONV_CODE)
     return rtg_dconv_launch(d, d->tile_cfg, x1, wp, bias, mask, res, out, (hipStream_t)stream);

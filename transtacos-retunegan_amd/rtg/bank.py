@@ -139,6 +139,13 @@ class ConvLayer:
         # RtgConv1dDesc.wp16); the tuner then times both kernels per problem.  RTG_DCONV=0: never (A/B knob).
         def dense(op, fwd):
             mode, g, mg, cg, k, s = op
+            # (round 4) the same fragment image serves rtg_sconv.hip: the stride-1 convs of >= 128 channels at the bottom of
+            # the UNet (conv_fuse, the 128-channel ResidualStack / ResBlock3 layers; any dilation, up to 8 taps), which have
+            # 1024 columns at batch 32 and want split-K over the waves of a block; fp32 only.  RTG_SCONV=0: never.
+            if os.environ.get('RTG_SCONV', '1') != '0' and not want_bf and self.kind == 'conv' and self.stride == 1 and \
+                    g == 1 and cg % L.CK == 0 and mg % 16 == 0 and cg >= 128 and mg >= 128 and k <= 8 and \
+                    mode in (L.PACK_FWD, L.PACK_DGRAD_S1):
+                return 1
             if os.environ.get('RTG_DCONV', '1') == '0' or self.dil != 1:
                 return 0
             ckc = 32 if want_bf else L.CK         # bf16: 32-channel chunks (8 bf16 per 16-byte fragment)
