@@ -492,3 +492,107 @@ def test_sconv_split_k_matches_the_general_kernel(case):
         err = (got.double() - tr).abs().max().item()
         assert err < 2e-5 * max(1.0, tr.abs().max().item()), (code, err)
         np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=2e-5, atol=2e-5)
+
+
+def _sconv_codes_and_runs(desc, ins, wp_std, wp_frag, out_shape):
+    """the general kernel (heuristic block shape) and every split-K code of rtg_sconv.hip on one problem: {code: output}"""
+    from rtg.lib import lib, Conv1dDesc
+    wp = np.concatenate([wp_std, wp_frag])
+    desc = dict(desc, wp16=1)
+    cands = (C.c_int * 48)()
+    n = lib.rtg_conv1d_tile_candidates(C.byref(Conv1dDesc(**desc)), cands, 48)
+    codes = [c for c in cands[:n] if c > 9000]
+    assert codes and set(codes) <= {9004, 9008}, list(cands[:n])
+    outs = {0: run_conv(dict(desc, tile_cfg=0), wp=wp, out_shape=out_shape, **ins)}
+    for c in codes:
+        outs[c] = run_conv(dict(desc, tile_cfg=c), wp=wp, out_shape=out_shape, **ins)
+    return outs
+
+
+SCONV_STRIDED = [
+    # B, C_in, C_out, L, K, stride, pad
+    (32, 64, 128, 256, 15, 8, 7),          # downs.2 (generator.py:700-703, hparam.py:61-62) at batch 32: 32 columns per clip
+    (3, 64, 128, 256, 15, 8, 7),           # ragged: 96 columns, three 32-column tiles
+    (5, 128, 256, 128, 8, 4, 4),           # another geometry: stride 4, 8 taps
+    (4, 64, 144, 61 * 3, 5, 3, 2),         # stride 3, rows of 61 columns (tiles straddle clips), 144 rows
+]
+
+
+@pytest.mark.parametrize('case', SCONV_STRIDED)
+def test_sconv_strided_forward_and_polyphase_backward_data(case):
+    """rtg_sconv.hip on a strided conv of the UNet bottom: the strided walk forward (with bias, leaky-relu on the input) and
+    its backward-data as the polyphase operator with the shuffle store, against fp64 torch and the general kernel"""
+    B, Cin, Cout, L, K, s, p = case
+    gen = torch.Generator().manual_seed(K + s + B)
+    x = torch.randn(B, Cin, L, generator=gen, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(Cout, Cin, K, generator=gen) / np.sqrt(Cin * K)
+    bias = torch.randn(Cout, generator=gen)
+    y = F.conv1d(F.leaky_relu(x, 0.15), w.double(), bias.double(), s, p)
+    Lo = y.shape[-1]
+    W = packref.logical_fwd(w.numpy(), 1)
+    desc = base_desc(B, Cin, 0, L, 1, Cin, Cout, K, s, 1, p, Lo, Cout, Lo, 32, pre_mode=1, pre_slope=0.15)
+    outs = _sconv_codes_and_runs(desc, dict(x1=x.detach().float(), bias=bias), packref.pack_logical(W, 32),
+                                 packref.pack_frag16(W), (B, Cout, Lo))
+    ref = y.detach()
+    for c, o in outs.items():
+        assert torch.isfinite(o).all(), c
+        err = (o.double() - ref).abs().max().item()
+        assert err < 2e-5 * max(1.0, ref.abs().max().item()), (c, err)
+    # backward-data: rows = (input channel, phase), 2 taps, shuffle store; times lrelu'(x) (the mask operand)
+    dy = torch.randn(y.shape, generator=gen)
+    y.backward(dy.double())
+    nt = -(-K // s)
+    Wd = packref.logical_dgrad_poly(w.numpy(), 1, s)
+    NQ = (L - 1 + p) // s + 1
+    desc2 = base_desc(B, Cout, 0, Lo, 1, Cout, Cin * s, nt, 1, 1, nt - 1, NQ, Cin, L, 32, shuf_S=s, shuf_P=p, mask_slope=0.15)
+    outs = _sconv_codes_and_runs(desc2, dict(x1=dy, mask=x.detach().float()), packref.pack_logical(Wd, 32),
+                                 packref.pack_frag16(Wd), (B, Cin, L))
+    ref = x.grad
+    for c, o in outs.items():
+        assert torch.isfinite(o).all(), c
+        err = (o.double() - ref).abs().max().item()
+        assert err < 2e-5 * max(1.0, ref.abs().max().item()), (c, err)
+
+
+SCONV_CONVT = [
+    # B, C_in, C_out, L, K, stride, pad, out_pad
+    (32, 256, 128, 32, 15, 8, 7, 7),       # ups.0 (generator.py:713-716, hparam.py:61-62) at batch 32
+    (3, 256, 128, 32, 15, 8, 7, 7),
+    (4, 128, 64, 40, 8, 4, 4, 3),
+]
+
+
+@pytest.mark.parametrize('case', SCONV_CONVT)
+def test_sconv_transposed_conv_forward_and_backward_data(case):
+    """rtg_sconv.hip on a transposed conv of the UNet bottom: the polyphase operator forward (bias indexed by the output
+    channel, leaky-relu on the input), the strided conv of dy backward, against fp64 torch and the general kernel"""
+    B, Cin, Cout, L, K, s, p, op = case
+    gen = torch.Generator().manual_seed(K + s + B + 1)
+    x = torch.randn(B, Cin, L, generator=gen, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(Cin, Cout, K, generator=gen) / np.sqrt(Cin * K / s)
+    bias = torch.randn(Cout, generator=gen)
+    y = F.conv_transpose1d(F.leaky_relu(x, 0.15), w.double(), bias.double(), s, p, op)
+    Lo = y.shape[-1]
+    nt = -(-K // s)
+    W = packref.logical_convT_poly(w.numpy(), s)
+    NQ = (Lo - 1 + p) // s + 1
+    desc = base_desc(B, Cin, 0, L, 1, Cin, Cout * s, nt, 1, 1, nt - 1, NQ, Cout, Lo, 32, shuf_S=s, shuf_P=p,
+                     pre_mode=1, pre_slope=0.15)
+    outs = _sconv_codes_and_runs(desc, dict(x1=x.detach().float(), bias=bias), packref.pack_logical(W, 32),
+                                 packref.pack_frag16(W), (B, Cout, Lo))
+    ref = y.detach()
+    for c, o in outs.items():
+        assert torch.isfinite(o).all(), c
+        err = (o.double() - ref).abs().max().item()
+        assert err < 2e-5 * max(1.0, ref.abs().max().item()), (c, err)
+    dy = torch.randn(y.shape, generator=gen)
+    y.backward(dy.double())
+    Wd = packref.logical_convT_dgrad(w.numpy())
+    desc2 = base_desc(B, Cout, 0, Lo, 1, Cout, Cin, K, s, 1, p, L, Cin, L, 32, mask_slope=0.15)
+    outs = _sconv_codes_and_runs(desc2, dict(x1=dy, mask=x.detach().float()), packref.pack_logical(Wd, 32),
+                                 packref.pack_frag16(Wd), (B, Cin, L))
+    ref = x.grad
+    for c, o in outs.items():
+        assert torch.isfinite(o).all(), c
+        err = (o.double() - ref).abs().max().item()
+        assert err < 2e-5 * max(1.0, ref.abs().max().item()), (c, err)

@@ -48,3 +48,36 @@ for name, C1, C2, Cout, L, K, dil, split in (('conv_fuse fwd', 80, 128, 256, 32,
         elif best is None or t < best[1]:
             best = (c, t)
     print(line + f'  | general best {best[0]}: {best[1] * 1e3:6.1f} us {fl / best[1] / 1e9:5.1f} TF', flush=True)
+
+# ---- the strided / transposed convs at the bottom (downs.2, ups.0): strided walk and polyphase operator
+wd = (np.random.RandomState(2).randn(128, 64, 15) / 30).astype(np.float32)          # downs.2 weight [C_out, C_in, K]
+wu = (np.random.RandomState(3).randn(256, 128, 15) / 30).astype(np.float32)         # ups.0 weight [C_in, C_out, K]
+CASES = (
+    # name, logical operator, C_in, rows, L_in, K, stride, pad, Q, out_C, out_L, shuf_S, shuf_P
+    ('downs.2 fwd', packref.logical_fwd(wd, 1), 64, 128, 256, 15, 8, 7, 32, 128, 32, 1, 0),
+    ('downs.2 dgrad', packref.logical_dgrad_poly(wd, 1, 8), 128, 512, 32, 2, 1, 1, 33, 64, 256, 8, 7),
+    ('ups.0 fwd', packref.logical_convT_poly(wu, 8), 256, 1024, 32, 2, 1, 1, 33, 128, 256, 8, 7),
+    ('ups.0 dgrad', packref.logical_convT_dgrad(wu), 128, 256, 256, 15, 8, 7, 32, 256, 32, 1, 0),
+)
+for name, W, Cin, Mg, L, K, S, pad, Q, out_C, out_L, sS, sP in CASES:
+    wp = torch.from_numpy(np.concatenate([packref.pack_logical(W, 32), packref.pack_frag16(W)])).cuda()
+    x1 = torch.randn(B, Cin, L, device='cuda')
+    o1 = torch.empty(B, out_C, out_L, device='cuda')
+    d = Conv1dDesc(B=B, C1=Cin, C2=0, L_in=L, groups=1, Cg=Cin, Mg=Mg, K=K, stride=S, dil=1, pad=pad, Q=Q, out_C=out_C, out_L=out_L,
+                   shuf_S=sS, shuf_P=sP, pre_mode=1, pre_slope=0.15, mask_slope=1.0, out_scale=1.0, act=0, act_slope=1.0, accumulate=0,
+                   tile_m=32, out_split=0, wp16=1)
+    cands = (C.c_int * 48)()
+    n = lib.rtg_conv1d_tile_candidates(C.byref(d), cands, 48)
+    fl = 2.0 * B * Q * Mg * Cin * K
+    line = f'{name:24s}'
+    best = None
+    for c in list(cands[:n]):
+        d.tile_cfg = c
+        t = tune._time(lambda: lib.rtg_conv1d(C.byref(d), P(x1), None, None, P(wp), None, None, None, P(o1), None, None))
+        if t is None:
+            continue
+        if c > 9000:
+            line += f'  {c}: {t * 1e3:6.1f} us {fl / t / 1e9:5.1f} TF'
+        elif best is None or t < best[1]:
+            best = (c, t)
+    print(line + f'  | general best {best[0]}: {best[1] * 1e3:6.1f} us {fl / best[1] / 1e9:5.1f} TF', flush=True)

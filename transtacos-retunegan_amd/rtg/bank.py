@@ -146,6 +146,15 @@ class ConvLayer:
                     g == 1 and cg % L.CK == 0 and mg % 16 == 0 and cg >= 128 and mg >= 128 and k <= 8 and \
                     mode in (L.PACK_FWD, L.PACK_DGRAD_S1):
                 return 1
+            # ... and the strided / transposed convs next to them (downs.2: 64 -> 128, k16, stride 8 and ups.0: 256 -> 128):
+            # the strided walk forward / backward-data of the transposed conv, the polyphase operator (2 taps, rows =
+            # (channel, phase), shuffle store) the other way.  The kernel takes rows of <= 64 columns only, so the same
+            # layers further up the UNet keep the general kernel.  RTG_SCONV_STRIDED=0: never.
+            if os.environ.get('RTG_SCONV', '1') != '0' and os.environ.get('RTG_SCONV_STRIDED', '1') != '0' and not want_bf and \
+                    self.kind in ('conv', 'convT') and 1 < self.stride <= 8 and self.dil == 1 and g == 1 and \
+                    cg % L.CK == 0 and mg % 16 == 0 and cg >= 64 and mg >= 128 and k <= 16 and \
+                    mode in (L.PACK_FWD, L.PACK_DGRAD_POLY, L.PACK_CONVT_POLY):
+                return 1
             if os.environ.get('RTG_DCONV', '1') == '0' or self.dil != 1:
                 return 0
             ckc = 32 if want_bf else L.CK         # bf16: 32-channel chunks (8 bf16 per 16-byte fragment)

@@ -314,7 +314,7 @@ class ConvFn(torch.autograd.Function):
             d = _desc(B=B, C1=C1, C2=C2, L_in=L_in, groups=1, Cg=cg, Mg=mg, K=k, stride=1, dil=1, pad=k - 1, Q=nq,
                       out_C=ly.cout, out_L=L_out, shuf_S=ly.stride, shuf_P=ly.pad, pre_mode=pre_mode,
                       pre_slope=pre_slope, out_scale=out_scale, act=act, act_slope=act_slope, tile_m=ly.fwd_tm, tap_major=ly.fwd_tap,
-                      bf16=ly.fwd_bf)
+                      bf16=ly.fwd_bf, wp16=ly.fwd16)
         lc = L_out if ly.kind == 'conv' else L_in
         args = (_p(x1), _p(x2), None, bank.fwd_ptr(ly), bank.bias_ptr(ly), None, _p(res), _p(out), None, _stream())
         plain = x2 is None and res is None and act == L.ACT_NONE and out_scale == 1.0
@@ -394,7 +394,7 @@ class ConvFn(torch.autograd.Function):
                 d = _desc(B=B, C1=ly.cout, L_in=L_out, groups=1, Cg=cg, Mg=mg, K=k, stride=ly.stride, dil=1,
                           pad=ly.pad, Q=L_in, out_C=ly.cin, out_L=L_in, pre_mode=gy_mode, pre_slope=gy_slope,
                           mask_slope=pre_slope, out_scale=out_scale, tile_m=ly.bwd_tm, out_split=split,
-                          tap_major=ly.bwd_tap, bf16=ly.bwd_bf)
+                          tap_major=ly.bwd_tap, bf16=ly.bwd_bf, wp16=ly.bwd16)
             lc = L_out if ly.kind == 'conv' else L_in
             dargs = (_p(dy), None, _p(out), bank.bwd_ptr(ly), None, _p(mask), _p(resg), _p(dx1), _p(dx2), st)
             plain = C2 == 0 and gy_mode == L.PRE_NONE and out_scale == 1.0 and dx2 is None
