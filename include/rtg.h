@@ -38,7 +38,9 @@ enum { RTG_PACK_FWD = 0, RTG_PACK_DGRAD_S1 = 1, RTG_PACK_DGRAD_POLY = 2, RTG_PAC
         * [group][ci][tap][oc] resp. [group][oc][tap][ci], dst_size = groups * Mg * Cg * K floats */
        RTG_PACK_GCONV_FWD = 5, RTG_PACK_GCONV_BWD = 6,
        /* [group][oc][ci][44]: the taps of a (row, channel) pair padded to 44 with zeros — what rtg_gmfma_forward reads
-        * (dst_size = groups * Mg * Cg * 44 floats) */
+        * (dst_size = groups * Mg * Cg * 44 floats; RtgPackJob.S = 44).  With RtgPackJob.KH = the layer's stride (the layer
+        * of 8 output channels per group): the position-pair image [group][16][ci][48], row (r, oc) = w[oc][ci][u - KH * r]
+        * (dst_size = groups * 16 * Cg * 48 floats; RtgPackJob.S = 48) */
        RTG_PACK_GMFMA_FWD = 7 };
 
 /* ------------------------------------------------------------------------------------------------------------
@@ -98,7 +100,10 @@ typedef struct RtgConv1dDesc {
   int wp16;                    /* 1 (ABI 6): `wp` carries a second image of the layer's weights right behind the standard
                                   one (at wp + rtg_packed_size(groups, Mg, Cg, K, tile_m) floats): the 16-byte-fragment
                                   image RtgPackJob.frag16 writes (rtg_packed_size_frag16 floats).  The dense-layer kernel
-                                  of rtg_dconv.hip (block-shape codes 8xxx) is only listed / accepted with it          */
+                                  of rtg_dconv.hip (block-shape codes 8xxx) is only listed / accepted with it.
+                                  2: ... and the caller also accepts the split-K kernel of rtg_sconv.hip (codes 9004 / 9008:
+                                  few columns, the reduction split over the waves of a block — a summation order of its
+                                  own, where every other block shape gives identical bits)                             */
 } RtgConv1dDesc;
 
 int rtg_conv1d(const RtgConv1dDesc* d, const float* x1, const float* x2, const float* aux, const float* wp,
@@ -201,7 +206,9 @@ int rtg_gconv_backward_data(const RtgGconvDesc* d, const float* dy, const float*
 /* The same forward on the matrix cores with exact-fit tiles (rtg_gmfma.hip, ABI 7): a v_mfma_f32_16x16x4_f32 tile is one
  * group (16 output channels x 16 positions x 4 input channels at one tap).  w: the image RTG_PACK_GMFMA_FWD of
  * rtg_weights_pack ([group][oc][ci][44], 16-byte aligned; rtg_gmfma_workspace floats).  Same operator and descriptor as
- * rtg_gconv_forward (replaces F.conv1d(..., groups=g) of discrminator.py:39-43); rows of at least 16 positions. */
+ * rtg_gconv_forward (replaces F.conv1d(..., groups=g) of discrminator.py:39-43); rows of at least 16 positions.  The layer
+ * with 8 output channels per group (discrminator.py:43) fills its tiles with PAIRS of neighbouring positions (rows =
+ * (parity, channel), a stride-8 walk of 45 taps) and reads the pair image of RTG_PACK_GMFMA_FWD. */
 int rtg_gmfma_ok(const RtgGconvDesc* d);
 long long rtg_gmfma_workspace(const RtgGconvDesc* d);
 int rtg_gmfma_forward(const RtgGconvDesc* d, const float* x, const float* w, const float* bias, float* out, void* stream);

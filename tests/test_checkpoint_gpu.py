@@ -140,7 +140,8 @@ def test_lean_pack_gives_the_bits_of_the_full_pack(oracle, monkeypatch):
     torch.cuda.synchronize()
     flat = lambda tr: torch.cat([m.bank().flat for m in (tr.generator, *tr.discs)]).cpu().numpy()   # noqa: E731
     np.testing.assert_array_equal(flat(a), flat(b))
-    off = [(ly.name, side) for m in b.discs for ly in m.bank().layers for side in (0, 1) if not ly.std_on[side]]
+    nets = (b.generator, *b.discs)       # (the generator too: its strided / transposed convs carry fragment images)
+    off = [(id(m), ly.name, side) for m in nets for ly in m.bank().layers for side in (0, 1) if not ly.std_on[side]]
     assert b.lean_dropped == len(off) and a.lean_dropped == 0
     print('lean pack: standard images dropped', b.lean_dropped, 'pack elements', [m.bank().pack_elems for m in b.discs],
           'vs', [m.bank().pack_elems for m in a.discs])
@@ -153,5 +154,5 @@ def test_lean_pack_gives_the_bits_of_the_full_pack(oracle, monkeypatch):
     a.train_step(x2, y_tmpl2, y2); b.train_step(x2, y_tmpl2, y2)
     torch.cuda.synchronize()
     np.testing.assert_array_equal(flat(a), flat(b))
-    back = [(n, s) for n, s in off if dict((ly.name, ly) for m in b.discs for ly in m.bank().layers)[n].std_on[s]]
+    back = [(n, s) for i, n, s in off if dict(((id(m), ly.name), ly) for m in nets for ly in m.bank().layers)[(i, n)].std_on[s]]
     assert back, 'the heuristic shapes read no standard image?'

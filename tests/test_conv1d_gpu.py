@@ -445,7 +445,7 @@ def test_sconv_split_k_matches_the_general_kernel(case):
         kw.update(act=1, act_slope=0.2, out_scale=0.5)
     if mask is not None:
         kw.update(mask_slope=0.15)
-    desc = base_desc(B, C1, C2, L, 1, Cin, Cout, K, 1, dil, pad, L, Cout, L, 32, out_split=split, wp16=1,
+    desc = base_desc(B, C1, C2, L, 1, Cin, Cout, K, 1, dil, pad, L, Cout, L, 32, out_split=split, wp16=2,
                      accumulate=int('acc' in extras), **kw)
     cands = (C.c_int * 48)()
     n = lib.rtg_conv1d_tile_candidates(C.byref(Conv1dDesc(**desc)), cands, 48)
@@ -498,7 +498,7 @@ def _sconv_codes_and_runs(desc, ins, wp_std, wp_frag, out_shape):
     """the general kernel (heuristic block shape) and every split-K code of rtg_sconv.hip on one problem: {code: output}"""
     from rtg.lib import lib, Conv1dDesc
     wp = np.concatenate([wp_std, wp_frag])
-    desc = dict(desc, wp16=1)
+    desc = dict(desc, wp16=2)
     cands = (C.c_int * 48)()
     n = lib.rtg_conv1d_tile_candidates(C.byref(Conv1dDesc(**desc)), cands, 48)
     codes = [c for c in cands[:n] if c > 9000]

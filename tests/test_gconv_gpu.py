@@ -105,7 +105,12 @@ def test_gconv_refuses_other_shapes():
     assert lib.rtg_gconv_ok(C.byref(GconvDesc(2, 4, 8, 16, 41, 2, 20, 100, 51, 0.15))) == 0     # wrong output length
 
 
-@pytest.mark.parametrize('case', CASES + [(64, 32, 64, 4, 2, 8192, 0.15), (7, 512, 512, 64, 4, 64, 0.15), (2, 128, 512, 32, 4, 700, 0.15)])
+@pytest.mark.parametrize('case', CASES + [(64, 32, 64, 4, 2, 8192, 0.15), (7, 512, 512, 64, 4, 64, 0.15), (2, 128, 512, 32, 4, 700, 0.15),
+                                          # the layer with 8 output channels per group (position pairs): rows of 32 / 64 / 128
+                                          # positions (MSD scales at 8192-sample clips), ragged clip counts, odd row lengths
+                                          (9, 512, 512, 64, 4, 128, 0.15), (6, 512, 512, 64, 4, 256, 0.15),
+                                          (3, 512, 512, 64, 4, 512, 1.0), (2, 512, 512, 64, 4, 1000, 0.15),
+                                          (5, 64, 64, 8, 4, 198, 0.15), (64, 512, 512, 64, 4, 128, 0.15)])
 def test_gmfma_forward_matches_torch(case):
     """rtg_gmfma.hip (round 4): the same forward on the matrix cores with exact-fit tiles, its weight image
     [group][oc][ci][44] written by rtg_weights_pack (RTG_PACK_GMFMA_FWD) from the raw weight-norm parameters."""
@@ -115,9 +120,10 @@ def test_gmfma_forward_matches_torch(case):
     K, pad = 41, 20
     Lo = (Lin + 2 * pad - (K - 1) - 1) // s + 1
     d = GconvDesc(B, g, Cin // g, Cout // g, K, s, pad, Lin, Lo, slope)
-    if Lo < 16 or Cout // g != 16:
-        assert lib.rtg_gmfma_ok(C.byref(d)) == 0            # (rows shorter than a column tile, and the layer with 8 output
-        return                                              #  channels per group — half-empty tiles —, stay with rtg_gconv)
+    pair = Cout // g == 8                                   # position-pair tiles (gmfma_pair_kernel)
+    if Lo < 16 or not (Cout // g == 16 or (pair and Cin // g == 8 and s == 4)):
+        assert lib.rtg_gmfma_ok(C.byref(d)) == 0            # (rows shorter than a column tile stay with rtg_gconv)
+        return
     assert lib.rtg_gmfma_ok(C.byref(d)) == 1
     gen = torch.Generator().manual_seed(Cin + Lin)
     x = torch.randn(B, Cin, Lin, generator=gen)
@@ -130,16 +136,25 @@ def test_gmfma_forward_matches_torch(case):
                    padding=pad, groups=g)
     # the image through the pack launch: params = [v], scales = [scale | 1 / norm]
     n_w = lib.rtg_gmfma_workspace(C.byref(d))
-    assert n_w == Cout * (Cin // g) * 44
+    kp = 48 if pair else 44
+    assert n_w == (g * 16 if pair else Cout) * (Cin // g) * kp
     params = v.flatten().cuda()
     scales = torch.cat([scale, 1.0 / v.flatten(1).norm(dim=1)]).cuda()
     packed = torch.full((n_w + 64,), float('nan'), device='cuda')
-    job = L.PackJob(0, 0, 0, n_w, L.PACK_GMFMA_FWD, g, Cout // g, Cin // g, K, K, Cin // g, 44, 16, 0, 0, 0, 0)
+    job = L.PackJob(0, 0, 0, n_w, L.PACK_GMFMA_FWD, g, Cout // g, Cin // g, K, K, Cin // g, kp, 16, s if pair else 0, 0, 0, 0)
     blocks, lds = L.assign_pack_blocks([job])
     tab = torch.frombuffer(bytearray(bytes(job)), dtype=torch.uint8).cuda()
     assert lib.rtg_weights_pack(_ptr(tab), 1, blocks, lds, _ptr(params), _ptr(scales), _ptr(packed), None) == 0
-    img = packed.cpu()[:n_w].view(Cout, Cin // g, 44)
-    assert torch.allclose(img[:, :, :41], w, rtol=1e-6, atol=0) and (img[:, :, 41:] == 0).all()
+    if pair:
+        # [group][parity r][oc][ci][48]: row (r, oc) = the taps shifted right by r * stride, zeros around them
+        img = packed.cpu()[:n_w].view(g, 2, 8, Cin // g, 48)
+        wg = w.view(g, 8, Cin // g, K)
+        for r in (0, 1):
+            assert torch.allclose(img[:, r, :, :, s * r:s * r + K], wg, rtol=1e-6, atol=0)
+            assert (img[:, r, :, :, :s * r] == 0).all() and (img[:, r, :, :, s * r + K:] == 0).all()
+    else:
+        img = packed.cpu()[:n_w].view(Cout, Cin // g, 44)
+        assert torch.allclose(img[:, :, :41], w, rtol=1e-6, atol=0) and (img[:, :, 41:] == 0).all()
     out = torch.full((B, Cout, Lo), float('nan'), device='cuda')
     assert lib.rtg_gmfma_forward(C.byref(d), _ptr(x.cuda()), _ptr(packed), _ptr(bias.cuda()), _ptr(out), None) == 0
     torch.cuda.synchronize()

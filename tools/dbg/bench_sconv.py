@@ -31,7 +31,7 @@ for name, C1, C2, Cout, L, K, dil, split in (('conv_fuse fwd', 80, 128, 256, 32,
     pad = dil * (K - 1) // 2
     d = Conv1dDesc(B=B, C1=C1, C2=C2, L_in=L, groups=1, Cg=Cin, Mg=Cout, K=K, stride=1, dil=dil, pad=pad, Q=L, out_C=Cout, out_L=L,
                    shuf_S=1, shuf_P=0, pre_mode=1, pre_slope=0.15, mask_slope=1.0, out_scale=1.0, act=0, act_slope=1.0, accumulate=0,
-                   tile_m=tm, out_split=split, wp16=1)
+                   tile_m=tm, out_split=split, wp16=2)
     cands = (C.c_int * 48)()
     n = lib.rtg_conv1d_tile_candidates(C.byref(d), cands, 48)
     fl = 2.0 * B * L * Cout * Cin * K
@@ -65,7 +65,7 @@ for name, W, Cin, Mg, L, K, S, pad, Q, out_C, out_L, sS, sP in CASES:
     o1 = torch.empty(B, out_C, out_L, device='cuda')
     d = Conv1dDesc(B=B, C1=Cin, C2=0, L_in=L, groups=1, Cg=Cin, Mg=Mg, K=K, stride=S, dil=1, pad=pad, Q=Q, out_C=out_C, out_L=out_L,
                    shuf_S=sS, shuf_P=sP, pre_mode=1, pre_slope=0.15, mask_slope=1.0, out_scale=1.0, act=0, act_slope=1.0, accumulate=0,
-                   tile_m=32, out_split=0, wp16=1)
+                   tile_m=32, out_split=0, wp16=2)
     cands = (C.c_int * 48)()
     n = lib.rtg_conv1d_tile_candidates(C.byref(d), cands, 48)
     fl = 2.0 * B * Q * Mg * Cin * K

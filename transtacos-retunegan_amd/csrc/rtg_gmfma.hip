@@ -19,6 +19,8 @@
 // LDS reads, nothing else.
 // Accumulation order per output: channel quads outermost, taps inside, one fused multiply-add chain — NOT the order of the
 // general kernel or of rtg_gconv.hip (rounding-level differences; tests/test_gconv_gpu.py holds all three to the oracle).
+#include <type_traits>
+
 #include "rtg_common.h"
 
 namespace {
@@ -160,7 +162,153 @@ __global__ __launch_bounds__(256, (CG == 8 && NT == 4) ? 2 : 3) void gmfma_fwd_k
   }
 }
 
-// instance serving the problem: 1 = (16, 8, s2), 2 = (16, 4, s4); 0 = none
+// ---------------------------------------------------------------------------------------------------------------
+// The last grouped layer, Conv1d(512, 512, 41, 4, groups=64) (discrminator.py:43): 8 input and 8 OUTPUT channels per group —
+// half of every 16-row tile would be padding.  Two neighbouring output positions fill the tile instead: row (r, oc) of the
+// tile is output channel oc at the positions of parity r, column q' the position pair (2 q', 2 q' + 1):
+//   out[oc][2 q' + r] = sum over (ci, u) of W'[(r, oc)][ci][u] * x[ci][8 q' + u - 20],   W'[(r, oc)][ci][u] = w[oc][ci][u - 4 r]
+// — a stride-8 layer of 16 rows with 45 taps (padded to 48: the image [group][16][ci][48] of RTG_PACK_GMFMA_FWD with
+// RtgPackJob.KH = 4), 41 of 48 multiply-adds real.  Rows of this layer are short (128 / 64 / 32 positions at 8192-sample
+// clips = 64 / 32 / 16 pairs): a work item is four 16-pair column tiles, one per wave, TPC of them per clip and 4 / TPC clips
+// side by side, so that no wave multiplies an empty tile.  (rtg_gconv.hip ran this layer at 14-53 TFLOP/s: ~50 us per
+// launch whatever the row length — a wave per SIMD waiting for its scalar weight loads.)
+// VEC: rows whose length is a multiple of 4 are staged with 16-byte loads and LDS writes (a window starts 20 samples left of
+// a multiple of 8 and its segments are multiples of 8 long: every quad lies inside the row or outside) — a quarter of the
+// staging instructions, which otherwise cost a wave as many issue cycles as its matrix instructions
+template <int TPC, bool VEC>
+__global__ __launch_bounds__(256, 2) void gmfma_pair_kernel(const GmArgs a) {
+  constexpr int CG = 8, MG = 8, SV = 8, KPV = 48, CPI = 4 / TPC;
+  constexpr int NCQ = CG / 4, NTG = KPV / 4;
+  constexpr int WSEG = (TPC * 16 - 1) * SV + KPV;      // input samples of one clip's TPC tiles per channel
+  constexpr int WTOT = CPI * WSEG;
+  constexpr int WINP = (WTOT + 63) & ~63;              // (rows a multiple of 256 bytes apart: see gmfma_fwd_kernel)
+  constexpr int EW = VEC ? 4 : 1;                      // samples per staged element
+  constexpr int NLD = (CG * WTOT / EW + 255) / 256;
+  static_assert(WSEG % 4 == 0 && GPAD % 4 == 0, "16-byte staging");
+  __shared__ __attribute__((aligned(16))) float xs2[2][CG * WINP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n16 = lane & 15, kgrp = lane >> 4;
+  const int c_in = a.groups * CG, c_out = a.groups * MG;
+  const rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.B * c_in * a.L_in * 4, 0x00020000);
+  const int csets = (a.B + CPI - 1) / CPI;
+  const int per_g = csets * a.n_qb;
+  const int it0 = blockIdx.x * a.per_block;
+  const int it1 = it0 + a.per_block < a.n_items ? it0 + a.per_block : a.n_items;
+  using stage_t = std::conditional_t<VEC, f32x4, float>;
+  stage_t st[NLD];
+  // element e of the item's CG x WTOT window (in units of EW samples) -> (channel, sample within the row of segments): the
+  // same for every item
+  int e_ci[NLD], e_w[NLD];
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) {
+    const int e = (tid + 256 * i) * EW;
+    e_ci[i] = e / WTOT;
+    e_w[i] = e - e_ci[i] * WTOT;
+  }
+  auto stage_issue = [&](int item) __attribute__((always_inline)) {
+    const int g = item / per_g;
+    const int rest = item - g * per_g;
+    const int cset = rest / a.n_qb, qb = rest - cset * a.n_qb;
+    const int e0 = qb * (TPC * 16) * SV - GPAD;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int seg = e_w[i] / WSEG, ws = e_w[i] - seg * WSEG;
+      const int clip = cset * CPI + seg, pos = e0 + ws;
+      const bool ok = e_ci[i] < CG && clip < a.B && pos >= 0 && pos < a.L_in;
+      const unsigned off = ok ? (unsigned)((clip * c_in + g * CG + e_ci[i]) * a.L_in + pos) * 4u : 0x80000000u;
+      if constexpr (VEC) st[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
+      else st[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, off, 0, 0));
+    }
+  };
+  auto stage_write = [&](float* xs) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      if (e_ci[i] >= CG) continue;
+      if constexpr (VEC) {
+        f32x4 v = st[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : v[k] * a.slope;
+        *reinterpret_cast<f32x4*>(xs + e_ci[i] * WINP + e_w[i]) = v;
+      } else {
+        float v = st[i];
+        xs[e_ci[i] * WINP + e_w[i]] = v > 0.f ? v : v * a.slope;
+      }
+    }
+  };
+  f32x4 af[NCQ][NTG];
+  int g_cur = -1, cur = 0;
+  if (it0 < it1) {
+    stage_issue(it0);
+    stage_write(xs2[0]);
+  }
+  __syncthreads();
+  const int seg = wave / TPC, tl = wave - seg * TPC;   // this wave's clip of the set and its column tile within the clip
+  for (int item = it0; item < it1; ++item) {
+    const int g = item / per_g;
+    const int rest = item - g * per_g;
+    const int cset = rest / a.n_qb, qb = rest - cset * a.n_qb;
+    if (g != g_cur) {
+      g_cur = g;
+      // A fragments: row n16 = (parity, oc) of the group's pair image, channel 4 c' + kgrp, shifted taps 4 tg .. + 3
+#pragma unroll
+      for (int cq = 0; cq < NCQ; ++cq)
+#pragma unroll
+        for (int tg = 0; tg < NTG; ++tg)
+          af[cq][tg] = *reinterpret_cast<const f32x4*>(a.w + ((size_t)((g * 16 + n16) * CG + 4 * cq + kgrp)) * KPV + 4 * tg);
+    }
+    if (item + 1 < it1) stage_issue(item + 1);
+    const float* xb = xs2[cur] + kgrp * WINP + seg * WSEG + (tl * 16 + n16) * SV;
+    // one accumulator per channel quad: two independent chains of 48 matrix instructions
+    f32x4 acc[NCQ];
+#pragma unroll
+    for (int cq = 0; cq < NCQ; ++cq) acc[cq] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tg = 0; tg < NTG; ++tg) {
+      f32x4 b[NCQ];
+#pragma unroll
+      for (int cq = 0; cq < NCQ; ++cq) b[cq] = *reinterpret_cast<const f32x4*>(xb + (4 * cq) * WINP + 4 * tg);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int cq = 0; cq < NCQ; ++cq)
+          acc[cq] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cq][tg][j], b[cq][j], acc[cq], 0, 0, 0);
+    }
+    // ---- store: lane (kgrp, n16) holds rows 4 kgrp .. + 3 = (parity kgrp / 2, oc 4 (kgrp % 2) + r) of pair n16
+    const int clip = cset * CPI + seg;
+    const int q = 2 * ((qb * TPC + tl) * 16 + n16) + (kgrp >> 1);
+    if (clip < a.B && q < a.L_out) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int oc = 4 * (kgrp & 1) + r;
+        float v = acc[0][r];
+#pragma unroll
+        for (int cq = 1; cq < NCQ; ++cq) v += acc[cq][r];
+        a.out[((size_t)clip * c_out + g * MG + oc) * a.L_out + q] = v + (a.bias ? a.bias[g * MG + oc] : 0.f);
+      }
+    }
+    if (item + 1 < it1) stage_write(xs2[cur ^ 1]);
+    __syncthreads();
+    cur ^= 1;
+  }
+}
+
+template <int TPC>
+int launch_pair(const RtgGconvDesc* d, GmArgs a, hipStream_t s) {
+  const bool vec = d->L_in % 4 == 0 && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0;
+  const int lv = (d->L_out + 1) / 2;                   // position pairs per row
+  a.n_qb = rtg_ceil_div(lv, TPC * 16);
+  const long long items = (long long)d->groups * rtg_ceil_div(d->B, 4 / TPC) * a.n_qb;
+  if (items > (1ll << 30)) return RTG_ERANGE;
+  a.n_items = (int)items;
+  long long blocks = items < 1024 ? items : 1024;
+  a.per_block = (int)((items + blocks - 1) / blocks);
+  blocks = (items + a.per_block - 1) / a.per_block;
+  if (vec) RTG_KLAUNCH((gmfma_pair_kernel<TPC, true>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+  else RTG_KLAUNCH((gmfma_pair_kernel<TPC, false>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+  return rtg_launch_status();
+}
+
+// instance serving the problem: 1 = (16, 8, s2), 2 = (16, 4, s4), 3 = (8, 8, s4: position pairs); 0 = none
 int gmfma_kind(const RtgGconvDesc* d) {
   if (!d || d->K != GK || d->B < 1 || d->groups < 1 || d->L_in < 1 || d->L_out < 16 || d->pad != GPAD) return 0;
   if ((long long)d->B * d->groups * (d->Cg > d->Mg ? d->Cg : d->Mg) * (d->L_in > d->L_out ? d->L_in : d->L_out) * 4 >=
@@ -169,7 +317,8 @@ int gmfma_kind(const RtgGconvDesc* d) {
   if (d->L_out != (d->L_in + 2 * d->pad - (GK - 1) - 1) / d->stride + 1) return 0;
   if (d->Mg == 16 && d->Cg == 8 && d->stride == 2) return 1;
   if (d->Mg == 16 && d->Cg == 4 && d->stride == 4) return 2;
-  return 0;          // (Mg = 8, the last grouped layer: half of every tile would be padding — rtg_gconv.hip keeps it)
+  if (d->Mg == 8 && d->Cg == 8 && d->stride == 4) return 3;       // (the last grouped layer: gmfma_pair_kernel)
+  return 0;
 }
 
 template <int MG, int CG, int S, int NT>
@@ -212,7 +361,8 @@ struct GwmArgs {
   const float *x, *dy;
   float* part;
   int B, groups, L_in, L_out;
-  int W, bpc, n_blocks, per;                // splits, position blocks per clip, blocks in all, blocks per split
+  int W, bpc, n_blocks, per;                // waves per group, position blocks per clip, blocks in all, blocks per wave
+  int red;                                  // 1: the four waves of a block add their tiles in LDS and write ONE partial
   long long part_stride;
   float slope, gy_scale;
 };
@@ -307,8 +457,40 @@ __global__ __launch_bounds__(256, 2) void gmfma_wgrad_kernel(const GwmArgs a) {
       }
     }
   }
-  // ---- this wave's split partial: rows g * 16 .. + 15 of [rows][N] (+ the bias vector behind the matrix)
-  float* wpart = a.part + (size_t)split * a.part_stride;
+  // ---- the four waves of a block are four slices of ONE group's reduction (W a multiple of 4): they meet in LDS, TCH tiles a
+  // round, and wave 0 adds them in fixed order (its own, then wave 1, 2, 3) — a quarter of the split partials leave the
+  // chip (written here, read back by rtg_weightnorm_backward: at 2048 waves the partials of the four grouped layers of one
+  // MSD scale were 130 MB)
+  if (a.red) {
+    constexpr int TCH = 7;
+    static_assert(3 * TCH * 256 <= 4 * (ZEROS + ROWW), "the reduction rounds fit in the staging rows");
+    float* red = &xs[0][0];
+#pragma unroll
+    for (int c0 = 0; c0 < NCT; c0 += TCH) {
+      __syncthreads();                                // (the rows' last readers / the previous round's are done)
+      if (wave > 0) {
+#pragma unroll
+        for (int ct = c0; ct < c0 + TCH && ct < NCT; ++ct)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) red[((wave - 1) * TCH + (ct - c0)) * 256 + r * 64 + lane] = acc[ct][r];
+      }
+      __syncthreads();
+      if (wave == 0) {
+#pragma unroll
+        for (int ct = c0; ct < c0 + TCH && ct < NCT; ++ct)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float v = acc[ct][r];
+#pragma unroll
+            for (int w = 0; w < 3; ++w) v += red[(w * TCH + (ct - c0)) * 256 + r * 64 + lane];
+            acc[ct][r] = v;
+          }
+      }
+    }
+    if (wave != 0) return;
+  }
+  // ---- this wave's (block's) split partial: rows g * 16 .. + 15 of [rows][N] (+ the bias vector behind the matrix)
+  float* wpart = a.part + (size_t)(a.red ? split >> 2 : split) * a.part_stride;
   float* bpart = wpart + (size_t)c_out * N;
 #pragma unroll
   for (int ct = 0; ct < NCT; ++ct) {
@@ -342,16 +524,25 @@ int rtg_gmfma_wgrad_ok(const RtgWgradDesc* d) {
   return gmfma_wgrad_kind(d) > 0 ? 1 : 0;
 }
 
-int rtg_gmfma_wgrad_splits(const RtgWgradDesc* d) {
-  if (!gmfma_wgrad_kind(d)) return RTG_EINVAL;
-  // a wave per (group, split): about 2048 waves (two per SIMD), at least 4 blocks of 64 positions each; every split is a
-  // whole partial of the layer (written here, read back by rtg_weightnorm_backward): no more of them than that takes
+// waves per group: about 2048 waves in all (two per SIMD), at least 4 blocks of 64 positions each; a multiple of 4 where
+// there are four or more (the waves of a block then share a group and reduce in LDS)
+static int gmfma_wgrad_waves(const RtgWgradDesc* d) {
   const int n_blocks = d->B * rtg_ceil_div(d->Q, 64);
   int w = rtg_ceil_div(RTG_ENV_INT("RTG_GMFMA_WAVES", 2048), d->groups);
   const int w_max = n_blocks / 4 > 0 ? n_blocks / 4 : 1;
   if (w > w_max) w = w_max;
   if (w > RTG_ENV_INT("RTG_GMFMA_WMAX", 512)) w = RTG_ENV_INT("RTG_GMFMA_WMAX", 512);
-  return w < 1 ? 1 : w;
+  if (w < 1) w = 1;
+  if (w >= 4 && RTG_ENV_INT("RTG_GMFMA_RED", 1)) w &= ~3;
+  return w;
+}
+
+// split partials the launch writes (every one a whole partial of the layer, read back by rtg_weightnorm_backward): one per
+// block of four waves, or one per wave where a group has fewer than four
+int rtg_gmfma_wgrad_splits(const RtgWgradDesc* d) {
+  if (!gmfma_wgrad_kind(d)) return RTG_EINVAL;
+  const int w = gmfma_wgrad_waves(d);
+  return (w % 4 == 0 && RTG_ENV_INT("RTG_GMFMA_RED", 1)) ? w / 4 : w;
 }
 
 int rtg_gmfma_wgrad_launch(const RtgWgradDesc* d, const float* x, const float* dy, float* part, hipStream_t s) {
@@ -361,7 +552,8 @@ int rtg_gmfma_wgrad_launch(const RtgWgradDesc* d, const float* x, const float* d
   GwmArgs a;
   a.x = x; a.dy = dy; a.part = part;
   a.B = d->B; a.groups = d->groups; a.L_in = d->L_in; a.L_out = d->Q;
-  a.W = d->splits;
+  a.W = gmfma_wgrad_waves(d);
+  a.red = a.W != d->splits ? 1 : 0;                  // (splits = W / 4: checked above)
   a.bpc = rtg_ceil_div(d->Q, 64);
   a.n_blocks = d->B * a.bpc;
   a.per = rtg_ceil_div(a.n_blocks, a.W);
@@ -376,9 +568,11 @@ int rtg_gmfma_wgrad_launch(const RtgWgradDesc* d, const float* x, const float* d
 
 extern "C" int rtg_gmfma_ok(const RtgGconvDesc* d) { return gmfma_kind(d) > 0 ? 1 : 0; }
 
-// floats of the weight image [group][oc][ci][44] (RTG_PACK_GMFMA_FWD)
+// floats of the weight image [group][oc][ci][44] (RTG_PACK_GMFMA_FWD); the pair image [group][16][ci][48] (KH = stride)
 extern "C" long long rtg_gmfma_workspace(const RtgGconvDesc* d) {
-  return gmfma_kind(d) ? (long long)d->groups * d->Mg * d->Cg * GKP : 0;
+  const int kind = gmfma_kind(d);
+  if (kind == 3) return (long long)d->groups * 16 * d->Cg * 48;
+  return kind ? (long long)d->groups * d->Mg * d->Cg * GKP : 0;
 }
 
 extern "C" int rtg_gmfma_forward(const RtgGconvDesc* d, const float* x, const float* w, const float* bias, float* out,
@@ -394,5 +588,9 @@ extern "C" int rtg_gmfma_forward(const RtgGconvDesc* d, const float* x, const fl
   a.n_qb = 0; a.n_items = 0; a.per_block = 0;
   hipStream_t s = (hipStream_t)stream;
   if (kind == 1) return launch_kind<16, 8, 2>(d, a, s);
+  if (kind == 3) {
+    const int lv = (d->L_out + 1) / 2;
+    return lv <= 16 ? launch_pair<1>(d, a, s) : lv <= 32 ? launch_pair<2>(d, a, s) : launch_pair<4>(d, a, s);
+  }
   return launch_kind<16, 4, 4>(d, a, s);
 }

@@ -175,7 +175,8 @@ __global__ __launch_bounds__(KS * 64) void sconv_kernel(const SArgs a) {
 
 // the instance (NT, MAXIT) that serves the descriptor: 1 = <4 tiles, 6>, 2 = <2 tiles, 9>; 0 = none
 int sconv_kind(const RtgConv1dDesc* d) {
-  if (!d->wp16 || d->groups != 1 || d->tap_major || d->bf16 || d->stride < 1 || d->stride > 8) return 0;
+  // (wp16 == 2: the layer's owner allows this kernel's summation order next to the bit-identical block shapes, rtg/bank.py)
+  if (d->wp16 != 2 || d->groups != 1 || d->tap_major || d->bf16 || d->stride < 1 || d->stride > 8) return 0;
   if (d->h_k > 1 || d->h_n > 1 || d->dil < 1 || d->K < 1 || d->K > 16 || d->shuf_S < 1 || d->shuf_S > 8) return 0;
   if (d->pre_mode != RTG_PRE_NONE && d->pre_mode != RTG_PRE_LRELU) return 0;
   if (d->C1 % 16 != 0 || d->C2 % 16 != 0 || d->C1 + d->C2 != d->Cg || d->Mg % 16 != 0 || d->Mg != d->out_C * d->shuf_S) return 0;

@@ -111,6 +111,21 @@ __global__ __launch_bounds__(RTG_THREADS) void pack_kernel(const RtgPackJob* job
   if (j.mode == RTG_PACK_GMFMA_FWD) {
     // [g][oc][ci][44]: row (g * Mg + oc) of v is (ci, tap)-major with 41 taps; taps 41 .. 43 of the image are zero
     const unsigned K = (unsigned)j.K, KP = (unsigned)j.S, Cg = (unsigned)j.Cg;      // (S carries the padded tap count)
+    if (j.KH > 0) {
+      // the pair image of the layer with 8 output channels per group (rtg_gmfma.hip, gmfma_pair_kernel): [g][16][ci][KP],
+      // row (r, oc) holds w[g * 8 + oc][ci][u - KH * r] (KH = the layer's stride), zero outside the 41 taps
+      const unsigned Mg = (unsigned)j.Mg;               // 8
+      for (unsigned e = bid * RTG_THREADS + threadIdx.x; e < n_e; e += nb * RTG_THREADS) {
+        const unsigned u = e % KP, rc = e / KP;         // rc = (g * 2 * Mg + r * Mg + oc) * Cg + ci
+        const unsigned ci = rc % Cg, vrow = rc / Cg;
+        const unsigned g = vrow / (2 * Mg), m = vrow % (2 * Mg), r = m / Mg, oc = m % Mg;
+        const unsigned row = g * Mg + oc;
+        const int t = (int)u - (int)r * j.KH;
+        packed[j.dst_off + e] =
+            (t >= 0 && t < (int)K) ? params[j.v_off + ((long long)row * Cg + ci) * K + t] * scales[j.scale_off + row] : 0.f;
+      }
+      return;
+    }
     for (unsigned e = bid * RTG_THREADS + threadIdx.x; e < n_e; e += nb * RTG_THREADS) {
       const unsigned t = e % KP, rc = e / KP;           // rc = row * Cg + ci
       const unsigned row = rc / Cg;

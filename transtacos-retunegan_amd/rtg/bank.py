@@ -138,43 +138,44 @@ class ConvLayer:
         # polyphase backward-data operator; Conv2d of the spectrogram discriminators: forward, stride-1 backward-data) carry a second image of their weights behind the standard one (RtgPackJob.frag16,
         # RtgConv1dDesc.wp16); the tuner then times both kernels per problem.  RTG_DCONV=0: never (A/B knob).
         def dense(op, fwd):
+            """0: no fragment image; 1: the image, for the dense kernel (rtg_dconv.hip); 2: the image, for the dense kernel AND
+            the split-K kernel (rtg_sconv.hip: another summation order, so only layers the dense-kernel rules do not name —
+            the generator's — offer it; RtgConv1dDesc.wp16 carries the value)"""
             mode, g, mg, cg, k, s = op
+            ckc = 32 if want_bf else L.CK         # bf16: 32-channel chunks (8 bf16 per 16-byte fragment)
+            if os.environ.get('RTG_DCONV', '1') != '0' and self.dil == 1 and g == 1 and cg % ckc == 0 and cg >= 32 and mg >= 64:
+                if self.kind == 'conv2d':
+                    # StftDiscriminator (3 taps along the last axis): forward and backward-data
+                    if fwd:
+                        return int(k == 3 and self.stride in (1, 2))
+                    if mode != L.PACK_DGRAD_2D:
+                        return 0
+                    if s == 1 and self.sh == 1:
+                        return int(k == 3)
+                    # row-strided layers: class-ordered clips, 2 taps of the polyphase walk, whole chunks per kernel row
+                    return int(k == 2 and s == 2 and 2 <= self.sh <= 4 and self.cout % ckc == 0)
+                if self.kind == 'conv':
+                    if fwd and k == 5 and self.stride in (1, 3):
+                        return 1
+                    if not fwd and ((mode == L.PACK_DGRAD_S1 and k == 5) or (mode == L.PACK_DGRAD_POLY and k == 2 and s == 3)):
+                        return 1
+            if self.kind == 'conv2d' or want_bf or os.environ.get('RTG_SCONV', '1') == '0':
+                return 0
             # (round 4) the same fragment image serves rtg_sconv.hip: the stride-1 convs of >= 128 channels at the bottom of
             # the UNet (conv_fuse, the 128-channel ResidualStack / ResBlock3 layers; any dilation, up to 8 taps), which have
             # 1024 columns at batch 32 and want split-K over the waves of a block; fp32 only.  RTG_SCONV=0: never.
-            if os.environ.get('RTG_SCONV', '1') != '0' and not want_bf and self.kind == 'conv' and self.stride == 1 and \
-                    g == 1 and cg % L.CK == 0 and mg % 16 == 0 and cg >= 128 and mg >= 128 and k <= 8 and \
-                    mode in (L.PACK_FWD, L.PACK_DGRAD_S1):
-                return 1
-            # ... and the strided / transposed convs next to them (downs.2: 64 -> 128, k16, stride 8 and ups.0: 256 -> 128):
+            if self.kind == 'conv' and self.stride == 1 and g == 1 and cg % L.CK == 0 and mg % 16 == 0 and cg >= 128 and \
+                    mg >= 128 and k <= 8 and mode in (L.PACK_FWD, L.PACK_DGRAD_S1):
+                return 2
+            # ... and the strided / transposed convs next to them (downs.2: 64 -> 128, k15, stride 8 and ups.0: 256 -> 128):
             # the strided walk forward / backward-data of the transposed conv, the polyphase operator (2 taps, rows =
-            # (channel, phase), shuffle store) the other way.  The kernel takes rows of <= 64 columns only, so the same
-            # layers further up the UNet keep the general kernel.  RTG_SCONV_STRIDED=0: never.
-            if os.environ.get('RTG_SCONV', '1') != '0' and os.environ.get('RTG_SCONV_STRIDED', '1') != '0' and not want_bf and \
-                    self.kind in ('conv', 'convT') and 1 < self.stride <= 8 and self.dil == 1 and g == 1 and \
-                    cg % L.CK == 0 and mg % 16 == 0 and cg >= 64 and mg >= 128 and k <= 16 and \
+            # (channel, phase), shuffle store) the other way.  The split-K kernel takes rows of <= 64 columns only; further up
+            # the UNet the dense kernel's 2-tap instance serves the polyphase operators.  RTG_SCONV_STRIDED=0: never.
+            if os.environ.get('RTG_SCONV_STRIDED', '1') != '0' and self.kind in ('conv', 'convT') and 1 < self.stride <= 8 and \
+                    self.dil == 1 and g == 1 and cg % L.CK == 0 and mg % 16 == 0 and cg >= 64 and mg >= 128 and k <= 16 and \
                     mode in (L.PACK_FWD, L.PACK_DGRAD_POLY, L.PACK_CONVT_POLY):
-                return 1
-            if os.environ.get('RTG_DCONV', '1') == '0' or self.dil != 1:
-                return 0
-            ckc = 32 if want_bf else L.CK         # bf16: 32-channel chunks (8 bf16 per 16-byte fragment)
-            if g != 1 or cg % ckc != 0 or cg < 32 or mg < 64:
-                return 0
-            if self.kind == 'conv2d':
-                # StftDiscriminator (3 taps along the last axis): forward and backward-data
-                if fwd:
-                    return int(k == 3 and self.stride in (1, 2))
-                if mode != L.PACK_DGRAD_2D:
-                    return 0
-                if s == 1 and self.sh == 1:
-                    return int(k == 3)
-                # row-strided layers: class-ordered clips, 2 taps of the polyphase walk, whole chunks per kernel row
-                return int(k == 2 and s == 2 and 2 <= self.sh <= 4 and self.cout % ckc == 0)
-            if self.kind != 'conv':
-                return 0
-            if fwd:
-                return int(k == 5 and self.stride in (1, 3))
-            return int((mode == L.PACK_DGRAD_S1 and k == 5) or (mode == L.PACK_DGRAD_POLY and k == 2 and s == 3))
+                return 2
+            return 0
         self.fwd16 = dense(self.fwd_op, True) if not self.fwd_tap else 0
         self.bwd16 = dense(self.bwd_op, False) if not self.bwd_tap else 0
         self.frag_bf = int(want_bf)           # the fragment images are bf16 with the layer
@@ -261,8 +262,12 @@ class WeightBank:
                 ly.gconv_off = (poff, poff + n)
                 ly.gconv_size = ly.cout * (ly.cin // ly.groups) * ly.k
                 poff += 2 * n
-                # ... and the forward image of the exact-fit matrix-core kernel (rtg_gmfma.hip): [group][oc][ci][44]
-                ly.gmfma_off, ly.gmfma_size = poff, ly.cout * (ly.cin // ly.groups) * 44
+                # ... and the forward image of the exact-fit matrix-core kernel (rtg_gmfma.hip): [group][oc][ci][44]; the layer
+                # with 8 output channels per group: the position-pair image [group][16][ci][48] (gmfma_pair_kernel)
+                ly.gmfma_pair = ly.stride if ly.cout // ly.groups == 8 else 0
+                ly.gmfma_kp = 48 if ly.gmfma_pair else 44
+                ly.gmfma_off = poff
+                ly.gmfma_size = (ly.groups * 16 if ly.gmfma_pair else ly.cout) * (ly.cin // ly.groups) * ly.gmfma_kp
                 poff += (ly.gmfma_size + 63) & ~63
         self.packed = torch.empty(poff, device=self.device, dtype=torch.float32)
         self._bind_params()
@@ -350,7 +355,8 @@ class WeightBank:
                     pack.append(L.PackJob(ly.v_off, ly.scale_off, off, ly.gconv_size, mode, ly.groups, ly.cout // ly.groups,
                                           ly.cin // ly.groups, ly.k, ly.k, ly.inner_c, 1, 16, 0, 0, 0, 0))
                 pack.append(L.PackJob(ly.v_off, ly.scale_off, ly.gmfma_off, ly.gmfma_size, L.PACK_GMFMA_FWD, ly.groups,
-                                      ly.cout // ly.groups, ly.cin // ly.groups, ly.k, ly.k, ly.inner_c, 44, 16, 0, 0, 0, 0))
+                                      ly.cout // ly.groups, ly.cin // ly.groups, ly.k, ly.k, ly.inner_c, ly.gmfma_kp, 16,
+                                      ly.gmfma_pair, 0, 0, 0))
         self.norm_table = _table(norm, self.device)
         self.pack_blocks, self.pack_lds = L.assign_pack_blocks(pack)
         self.pack_table = _table(pack, self.device)

@@ -490,6 +490,9 @@ class ResStackFn(torch.autograd.Function):
         if fused:
             d = _stack_desc(lys, B, Lx, pre_slope, final_act_slope)
             wp = L.PtrArray6(*[bank.fwd_ptr(ly).value for ly in lys])
+            for ly in lys:                                        # (the fused kernel reads the STANDARD images: a layer that
+                if ly.fwd16:                                      # also carries the fragment image must keep it in the pack)
+                    _bank.note_std_use(bank.fwd_ptr(ly).value)
             bias = L.PtrArray6(*[bank.bias_ptr(ly).value for ly in lys])
             op = L.PtrArray6(*[o.data_ptr() for o in outs])
             flop = sum(_conv_flop(ly, B, Lx) for ly in lys)
@@ -529,6 +532,9 @@ class ResStackFn(torch.autograd.Function):
         if fused:
             d = _stack_desc(lys, B, Lx, pre_slope, final_act_slope, reverse=True)
             wpb = L.PtrArray6(*[bank.bwd_ptr(ly).value for ly in reversed(lys)])
+            for ly in lys:
+                if ly.bwd16:
+                    _bank.note_std_use(bank.bwd_ptr(ly).value)
             masks = L.PtrArray6(*[t.data_ptr() for t in masks_t])
             gp = L.PtrArray6(*[g.data_ptr() for g in gouts])
             flop = sum(_conv_flop(ly, B, Lx) for ly in lys)
