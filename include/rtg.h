@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define RTG_ABI_VERSION 7
+#define RTG_ABI_VERSION 8
 
 #define RTG_OK 0
 #define RTG_EINVAL (-1)   /* inconsistent descriptor               */
@@ -324,6 +324,13 @@ int rtg_noise_lrelu_fwd(const float* x, const float* w, const float* u_in, float
 int rtg_noise_lrelu_bwd(const float* x, const float* w, const float* u_in, const float* dy, float* dx,
                         float* dw_part, int n_blocks, long long n, float slope, unsigned long long seed,
                         const float* salt_dev, void* stream);
+/* (ABI 8) the same, and the launch finishes the reduction itself: the block that arrives last (`ticket`: a device word,
+ * zero before the first launch, reset by the kernel) adds the n_blocks partials in a fixed order and does *dw_acc += sum —
+ * the gradient slot of the shared scalar `w` of GaussianNoise (generator.py:19-30); replaces part.sum() + grad accumulation.
+ * Launches that share a ticket must be ordered on one stream. */
+int rtg_noise_lrelu_bwd_acc(const float* x, const float* w, const float* u_in, const float* dy, float* dx,
+                            float* dw_part, int n_blocks, long long n, float slope, unsigned long long seed,
+                            const float* salt_dev, float* dw_acc, unsigned* ticket, void* stream);
 
 /* out[c] += sum_{b,t} x[b,c,t]   (bias gradient of ConvTranspose1d layers; x is [B, C, L]); ws: 32 * C floats of scratch
  * (two fixed-order stages: partial sums over every 32nd clip, then their sum) */
@@ -434,6 +441,18 @@ int rtg_stream_destroy(void* stream);
 int rtg_stream_end_capture(void* stream);
 
 /* library self-description */
+/* (ABI 8) out[0] = sum_i w[i] * *p[i] over n <= RTG_MAX_SCALAR_TERMS device scalars, in list order (the loss totals of
+ * retunegan/train.py:137-158,170-189), and the backward of that sum: out[i] = w[i] * g[0].  The term table is read on the
+ * host and travels by value (legal under stream capture). */
+#define RTG_MAX_SCALAR_TERMS 16
+typedef struct RtgScalarTerms {
+  const float* p[RTG_MAX_SCALAR_TERMS];
+  float w[RTG_MAX_SCALAR_TERMS];
+  int n;
+} RtgScalarTerms;
+int rtg_scalar_wsum(const RtgScalarTerms* terms, float* out, void* stream);
+int rtg_scalar_fanout(const RtgScalarTerms* terms, const float* g, float* out, void* stream);
+
 int rtg_abi_version(void);
 const char* rtg_build_info(void);
 

@@ -67,8 +67,10 @@ __global__ __launch_bounds__(RTG_THREADS) void noise_bwd_kernel(const float* __r
                                                                 const float* __restrict__ u_in,
                                                                 const float* __restrict__ dy, float* __restrict__ dx,
                                                                 float* __restrict__ dw_part, long long n, float slope,
-                                                                unsigned long long seed, const float* salt) {
+                                                                unsigned long long seed, const float* salt,
+                                                                float* __restrict__ dw_acc, unsigned* __restrict__ ticket) {
   __shared__ float red[4];
+  __shared__ unsigned last;
   const float wv = *w;
   const unsigned long long sd = mix_salt(seed, salt);
   float acc = 0.f;
@@ -100,6 +102,25 @@ __global__ __launch_bounds__(RTG_THREADS) void noise_bwd_kernel(const float* __r
   }
   acc = rtg_block_sum(acc, red);
   if (threadIdx.x == 0) dw_part[blockIdx.x] = acc;
+  if (!dw_acc) return;
+  // ---- the block that arrives last adds the partials — element t, t + 256, ... per thread, then the block tree: the same
+  // order whichever block it is — and accumulates into the parameter's gradient slot (no second launch, no ATen sum / add)
+  if (threadIdx.x == 0) {
+    __threadfence();                                   // (this block's partial is visible before its ticket)
+    last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  const volatile float* vp = dw_part;                  // (past the vector cache: other CUs wrote these)
+  float t = 0.f;
+  for (unsigned i = threadIdx.x; i < gridDim.x; i += RTG_THREADS) t += vp[i];
+  __syncthreads();                                     // (red is reused)
+  t = rtg_block_sum(t, red);
+  if (threadIdx.x == 0) {
+    *dw_acc += t;
+    *ticket = 0u;                                      // (ready for the next launch on this stream)
+  }
 }
 
 template <int VEC>
@@ -475,9 +496,24 @@ extern "C" int rtg_noise_lrelu_bwd(const float* x, const float* w, const float* 
   RTG_REQ(x && w && dy && dx && dw_part);
   if (n < 1 || n_blocks < 1 || n_blocks > MAX_GRID) return RTG_EINVAL;
   if (vec4_ok(n, x, dy, dx, u_in)) {
-    RTG_LAUNCH(noise_bwd_kernel<4>, n_blocks, RTG_THREADS, 0, stream, x, w, u_in, dy, dx, dw_part, n, slope, seed, salt_dev);
+    RTG_LAUNCH(noise_bwd_kernel<4>, n_blocks, RTG_THREADS, 0, stream, x, w, u_in, dy, dx, dw_part, n, slope, seed, salt_dev,
+               (float*)nullptr, (unsigned*)nullptr);
   }
-  RTG_LAUNCH(noise_bwd_kernel<1>, n_blocks, RTG_THREADS, 0, stream, x, w, u_in, dy, dx, dw_part, n, slope, seed, salt_dev);
+  RTG_LAUNCH(noise_bwd_kernel<1>, n_blocks, RTG_THREADS, 0, stream, x, w, u_in, dy, dx, dw_part, n, slope, seed, salt_dev,
+             (float*)nullptr, (unsigned*)nullptr);
+}
+
+extern "C" int rtg_noise_lrelu_bwd_acc(const float* x, const float* w, const float* u_in, const float* dy, float* dx,
+                                       float* dw_part, int n_blocks, long long n, float slope, unsigned long long seed,
+                                       const float* salt_dev, float* dw_acc, unsigned* ticket, void* stream) {
+  RTG_REQ(x && w && dy && dx && dw_part && dw_acc && ticket);
+  if (n < 1 || n_blocks < 1 || n_blocks > MAX_GRID) return RTG_EINVAL;
+  if (vec4_ok(n, x, dy, dx, u_in)) {
+    RTG_LAUNCH(noise_bwd_kernel<4>, n_blocks, RTG_THREADS, 0, stream, x, w, u_in, dy, dx, dw_part, n, slope, seed, salt_dev,
+               dw_acc, ticket);
+  }
+  RTG_LAUNCH(noise_bwd_kernel<1>, n_blocks, RTG_THREADS, 0, stream, x, w, u_in, dy, dx, dw_part, n, slope, seed, salt_dev,
+             dw_acc, ticket);
 }
 
 extern "C" int rtg_axpby(const float* a, const float* b, float* out, long long n, float alpha, float beta,
@@ -743,6 +779,33 @@ extern "C" int rtg_stream_end_capture(void* stream) {
   if (g) (void)hipGraphDestroy(g);
   (void)hipGetLastError();
   return 1;
+}
+
+// ---- weighted sum of device scalars (the step's loss total) and its backward fan-out: one launch each instead of an ATen
+// mul / add per term (train.py:137-158, 170-189 of the reference add the terms one by one)
+__global__ void scalar_wsum_kernel(const RtgScalarTerms t, float* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float s = 0.f;
+  for (int i = 0; i < t.n; ++i) s += t.w[i] * *t.p[i];          // terms in list order, one rounding per product and sum
+  out[0] = s;
+}
+__global__ void scalar_fanout_kernel(const RtgScalarTerms t, const float* __restrict__ g, float* __restrict__ out) {
+  const int i = threadIdx.x;
+  if (blockIdx.x == 0 && i < t.n) out[i] = t.w[i] * g[0];
+}
+
+extern "C" int rtg_scalar_wsum(const RtgScalarTerms* terms, float* out, void* stream) {
+  RTG_REQ(terms && out);
+  if (terms->n < 1 || terms->n > RTG_MAX_SCALAR_TERMS) return RTG_EINVAL;
+  for (int i = 0; i < terms->n; ++i)
+    if (!terms->p[i]) return RTG_ENULL;
+  RTG_LAUNCH(scalar_wsum_kernel, 1, 64, 0, stream, *terms, out);
+}
+
+extern "C" int rtg_scalar_fanout(const RtgScalarTerms* terms, const float* g, float* out, void* stream) {
+  RTG_REQ(terms && g && out);
+  if (terms->n < 1 || terms->n > RTG_MAX_SCALAR_TERMS) return RTG_EINVAL;
+  RTG_LAUNCH(scalar_fanout_kernel, 1, 64, 0, stream, *terms, g, out);
 }
 
 extern "C" int rtg_abi_version(void) { return RTG_ABI_VERSION; }

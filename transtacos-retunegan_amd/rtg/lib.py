@@ -60,6 +60,13 @@ class PackJob(C.Structure):
                                        'frag16', 'first_block', 'n_blocks')]
 
 
+MAX_SCALAR_TERMS = 16
+
+
+class ScalarTerms(C.Structure):
+    _fields_ = [('p', C.c_void_p * MAX_SCALAR_TERMS), ('w', C.c_float * MAX_SCALAR_TERMS), ('n', C.c_int)]
+
+
 class WnBwdJob(C.Structure):
     _fields_ = [('g_off', C.c_longlong), ('v_off', C.c_longlong), ('b_off', C.c_longlong), ('scale_off', C.c_longlong),
                 ('part_off', C.c_longlong), ('part_stride', C.c_longlong), ('splits', C.c_int), ('rows', C.c_int),
@@ -90,7 +97,7 @@ CK = 16
 LOSS_L1, LOSS_L1_L1LOG, LOSS_MSE_TARGET, LOSS_MSE_REL = 0, 1, 2, 3
 MAX_LOSS_JOBS = 48
 
-ABI_VERSION = 7            # RTG_ABI_VERSION of include/rtg.h these struct layouts / prototypes were written for
+ABI_VERSION = 8            # RTG_ABI_VERSION of include/rtg.h these struct layouts / prototypes were written for
 _P = C.c_void_p
 _I, _F, _D, _LL, _ULL = C.c_int, C.c_float, C.c_double, C.c_longlong, C.c_ulonglong
 
@@ -128,6 +135,7 @@ PROTOTYPES = {
     'rtg_stft_backward': (_I, [C.POINTER(StftDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'rtg_noise_lrelu_fwd': (_I, [_P, _P, _P, _P, _LL, _F, _ULL, _P, _P]),
     'rtg_noise_lrelu_bwd': (_I, [_P, _P, _P, _P, _P, _P, _I, _LL, _F, _ULL, _P, _P]),
+    'rtg_noise_lrelu_bwd_acc': (_I, [_P, _P, _P, _P, _P, _P, _I, _LL, _F, _ULL, _P, _P, _P, _P]),
     'rtg_channel_sum': (_I, [_P, _P, _I, _I, _I, _P, _P]),
     'rtg_axpby': (_I, [_P, _P, _P, _LL, _F, _F, _I, _P]),
     'rtg_lrelu_bwd': (_I, [_P, _P, _P, _LL, _F, _P]),
@@ -150,6 +158,8 @@ PROTOTYPES = {
     'rtg_stream_create': (_I, [_I, C.POINTER(C.c_void_p)]),
     'rtg_stream_destroy': (_I, [_P]),
     'rtg_stream_end_capture': (_I, [_P]),
+    'rtg_scalar_wsum': (_I, [C.POINTER(ScalarTerms), _P, _P]),
+    'rtg_scalar_fanout': (_I, [C.POINTER(ScalarTerms), _P, _P, _P]),
     'rtg_abi_version': (_I, []),
     'rtg_build_info': (C.c_char_p, []),
 }

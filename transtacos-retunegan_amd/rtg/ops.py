@@ -912,6 +912,20 @@ def mrf_group_ok(lys, x):
 # ---------------------------------------------------------------------------------------------------------------
 # GaussianNoise
 # ---------------------------------------------------------------------------------------------------------------
+NOISE_ACC = _os.environ.get('RTG_NOISE_ACC', '1') == '1'      # A/B knob: 0 = part.sum() and autograd's accumulation
+_NOISE_TICKETS = {}
+
+
+def _noise_ticket(device):
+    """the device word the self-finishing noise backward counts its blocks in: one per (device, stream) — launches that share
+    one must be ordered on a stream; zero before its first use, reset by every launch"""
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+    t = _NOISE_TICKETS.get(key)
+    if t is None:
+        t = _NOISE_TICKETS[key] = torch.zeros(1, device=device, dtype=torch.int32)
+    return t
+
+
 class NoiseFn(torch.autograd.Function):
     N_BLOCKS = 2048         # (256: one block per CU streamed 1.2 TB/s; the kernel is a pure 12-byte-per-element stream)
 
@@ -933,6 +947,15 @@ class NoiseFn(torch.autograd.Function):
         dy = _c(dy)
         dx = torch.empty_like(x)
         part = torch.empty(NoiseFn.N_BLOCKS, device=x.device)
+        # the shared scalar's gradient: where w.grad is a live buffer (the weight bank's flat gradient view) the launch adds
+        # its sum there itself (the last block reduces the partials in fixed order) and autograd gets no gradient to
+        # accumulate: six part.sum() + five grad add_ launches per generator backward are gone
+        g = w.grad if ctx.needs_input_grad[1] and NOISE_ACC and not torch.is_grad_enabled() else None
+        if g is not None and g.is_cuda and g.dtype == torch.float32 and g.numel() == 1:
+            check(lib.rtg_noise_lrelu_bwd_acc(_p(x), _p(w), _p(u_in), _p(dy), _p(dx), _p(part), NoiseFn.N_BLOCKS, x.numel(),
+                                              slope, C.c_ulonglong(seed), _p(salt), _p(g), _p(_noise_ticket(x.device)),
+                                              _stream()), 'noise bwd')
+            return dx, None, None, None, None, None
         check(lib.rtg_noise_lrelu_bwd(_p(x), _p(w), _p(u_in), _p(dy), _p(dx), _p(part), NoiseFn.N_BLOCKS, x.numel(),
                                       slope, C.c_ulonglong(seed), _p(salt), _stream()), 'noise bwd')
         dw = part.sum().reshape(w.shape) if ctx.needs_input_grad[1] else None
@@ -1089,6 +1112,50 @@ class PairLossFn(torch.autograd.Function):
 
 def pair_loss(parents, relative=False):
     return PairLossFn.apply(bool(relative), *parents)
+
+
+class WSumFn(torch.autograd.Function):
+    """total = sum_i w_i * term_i over device scalars, in list order: one launch forward, one backward (the fan-out of the
+    incoming gradient), instead of an ATen mul / add / fill per term of the loss totals (train.py:137-158, 170-189)."""
+
+    @staticmethod
+    def forward(ctx, weights, *terms):
+        _need_cuda(*terms)
+        ts = [_c(t).reshape(1) for t in terms]
+        tab = L.ScalarTerms()
+        tab.n = len(ts)
+        for i, (t, w) in enumerate(zip(ts, weights)):
+            tab.p[i] = t.data_ptr()
+            tab.w[i] = w
+        out = torch.empty(1, device=ts[0].device)
+        check(lib.rtg_scalar_wsum(C.byref(tab), _p(out), _stream()), 'scalar wsum')
+        ctx.weights = weights
+        return out.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        n = len(ctx.weights)
+        tab = L.ScalarTerms()
+        tab.n = n
+        for i, w in enumerate(ctx.weights):
+            tab.w[i] = w
+        g = _c(g).reshape(1)
+        out = torch.empty(n, device=g.device)
+        check(lib.rtg_scalar_fanout(C.byref(tab), _p(g), _p(out), _stream()), 'scalar fan-out')
+        return (None, *[out[i].reshape(()) if ctx.needs_input_grad[1 + i] else None for i in range(n)])
+
+
+def weighted_sum(terms, weights=None):
+    """sum_i weights[i] * terms[i] of device scalars (the loss totals of the train step) as one autograd node"""
+    terms = list(terms)
+    weights = [1.0] * len(terms) if weights is None else [float(w) for w in weights]
+    assert len(terms) == len(weights) and len(terms) >= 1
+    if len(terms) > L.MAX_SCALAR_TERMS or not all(t.is_cuda and t.dtype == torch.float32 and t.numel() == 1 for t in terms):
+        total = terms[0] * weights[0]
+        for t, w in zip(terms[1:], weights[1:]):
+            total = total + t * w
+        return total
+    return WSumFn.apply(weights, *terms)
 
 
 def multi_loss(kind, a_list, b_list=None, weights=None, target=0.0):

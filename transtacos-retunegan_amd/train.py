@@ -26,7 +26,7 @@ from models import (multi_stft_loss, dynamic_loss, discriminator_loss, generator
 from models.layers import BankedModel, fork_join  # noqa: F401
 from models.discrminator import run_stacks
 from models.loss import stft_cache
-from rtg import tune
+from rtg import ops, tune
 from rtg.lib import lib, check, RtgError, new_stream, current_stream_ptr as _lib_stream_ptr
 
 device = 'cuda' if torch.cuda.is_available() else 'cpu'
@@ -354,7 +354,7 @@ class Trainer:
             jobs.append(('disc_t', (self.mtd, S, S_g)))
         for (tag, _), (r, g, _, _) in zip(jobs, run_stacks([j for _, j in jobs])):
             losses[tag] = discriminator_loss(r, g)
-        total = sum(losses.values())
+        total = ops.weighted_sum(list(losses.values()))        # (one launch; the reference adds the terms one by one)
         losses['disc_all'] = total
         for d in self.discs:                 # before the backward: the flush hooks all-reduce the buffers, flag included
             d.bank().set_flag(total)
@@ -394,10 +394,10 @@ class Trainer:
         losses['env'] = envelope_loss(y, y_g_hat) if hp.envelope_loss else None          # train.py:166-168
         losses['dyn'] = dynamic_loss(y, y_g_hat) if hp.dynamic_loss else None
         losses['sm'] = strip_mirror_loss(y_g_hat) if hp.strip_mirror_loss else None
-        total = losses['mstft'] * hp.w_loss_mstft
+        terms, weights = [losses['mstft']], [hp.w_loss_mstft]  # the total is ONE weighted sum over the terms, in this order
         for key, w in (('env', hp.w_loss_env), ('dyn', hp.w_loss_dyn), ('sm', hp.w_loss_sm)):
             if losses[key] is not None:
-                total = total + losses[key] * w
+                terms.append(losses[key]); weights.append(w)
         self._freeze(True)       # the reference lets D weight gradients accumulate and discards them at the next
         try:                     # optim_d.zero_grad() (train.py:133): skipping them changes no result
             jobs = [('s', (self.msd, y, y_g_hat))]
@@ -408,7 +408,8 @@ class Trainer:
             for (tag, _), (r, g, fr, fg) in zip(jobs, run_stacks([j for _, j in jobs])):
                 losses['gen_' + tag] = generator_loss(g, r)
                 losses['fm_' + tag] = feature_loss(fr, fg)
-                total = total + losses['gen_' + tag] + losses['fm_' + tag] * hp.w_loss_fm
+                terms += [losses['gen_' + tag], losses['fm_' + tag]]; weights += [1.0, hp.w_loss_fm]
+            total = ops.weighted_sum(terms, weights)
             losses['gen_all'] = total
             self.generator.bank().set_flag(total)
             total.backward()
