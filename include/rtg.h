@@ -324,13 +324,12 @@ int rtg_noise_lrelu_fwd(const float* x, const float* w, const float* u_in, float
 int rtg_noise_lrelu_bwd(const float* x, const float* w, const float* u_in, const float* dy, float* dx,
                         float* dw_part, int n_blocks, long long n, float slope, unsigned long long seed,
                         const float* salt_dev, void* stream);
-/* (ABI 8) the same, and the launch finishes the reduction itself: the block that arrives last (`ticket`: a device word,
- * zero before the first launch, reset by the kernel) adds the n_blocks partials in a fixed order and does *dw_acc += sum —
- * the gradient slot of the shared scalar `w` of GaussianNoise (generator.py:19-30); replaces part.sum() + grad accumulation.
- * Launches that share a ticket must be ordered on one stream. */
+/* (ABI 8) the same, followed by a one-block launch that adds the n_blocks partials in a fixed order and does
+ * *dw_acc += sum — the gradient slot of the shared scalar `w` of GaussianNoise (generator.py:19-30); replaces part.sum()
+ * and the gradient accumulation of the autograd engine */
 int rtg_noise_lrelu_bwd_acc(const float* x, const float* w, const float* u_in, const float* dy, float* dx,
                             float* dw_part, int n_blocks, long long n, float slope, unsigned long long seed,
-                            const float* salt_dev, float* dw_acc, unsigned* ticket, void* stream);
+                            const float* salt_dev, float* dw_acc, void* stream);
 
 /* out[c] += sum_{b,t} x[b,c,t]   (bias gradient of ConvTranspose1d layers; x is [B, C, L]); ws: 32 * C floats of scratch
  * (two fixed-order stages: partial sums over every 32nd clip, then their sum) */

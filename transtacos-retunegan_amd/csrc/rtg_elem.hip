@@ -67,10 +67,8 @@ __global__ __launch_bounds__(RTG_THREADS) void noise_bwd_kernel(const float* __r
                                                                 const float* __restrict__ u_in,
                                                                 const float* __restrict__ dy, float* __restrict__ dx,
                                                                 float* __restrict__ dw_part, long long n, float slope,
-                                                                unsigned long long seed, const float* salt,
-                                                                float* __restrict__ dw_acc, unsigned* __restrict__ ticket) {
+                                                                unsigned long long seed, const float* salt) {
   __shared__ float red[4];
-  __shared__ unsigned last;
   const float wv = *w;
   const unsigned long long sd = mix_salt(seed, salt);
   float acc = 0.f;
@@ -102,25 +100,18 @@ __global__ __launch_bounds__(RTG_THREADS) void noise_bwd_kernel(const float* __r
   }
   acc = rtg_block_sum(acc, red);
   if (threadIdx.x == 0) dw_part[blockIdx.x] = acc;
-  if (!dw_acc) return;
-  // ---- the block that arrives last adds the partials — element t, t + 256, ... per thread, then the block tree: the same
-  // order whichever block it is — and accumulates into the parameter's gradient slot (no second launch, no ATen sum / add)
-  if (threadIdx.x == 0) {
-    __threadfence();                                   // (this block's partial is visible before its ticket)
-    last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
-  }
-  __syncthreads();
-  if (!last) return;
-  __threadfence();
-  const volatile float* vp = dw_part;                  // (past the vector cache: other CUs wrote these)
+}
+
+// *acc += sum of part[0 .. n): element t, t + 256, ... per thread, then the block tree — a fixed order.  One block: the
+// second launch of rtg_noise_lrelu_bwd_acc (a reduction INSIDE the first launch — the block that arrives last adds the
+// partials — needs a device-scope release per block, i.e. a write-back of the XCD's L2 while the kernel streams its 33 MB
+// of output through it: measured 15 -> 93 us per launch)
+__global__ __launch_bounds__(RTG_THREADS) void reduce_acc_kernel(const float* __restrict__ part, int n, float* __restrict__ acc) {
+  __shared__ float red[4];
   float t = 0.f;
-  for (unsigned i = threadIdx.x; i < gridDim.x; i += RTG_THREADS) t += vp[i];
-  __syncthreads();                                     // (red is reused)
+  for (int i = threadIdx.x; i < n; i += RTG_THREADS) t += part[i];
   t = rtg_block_sum(t, red);
-  if (threadIdx.x == 0) {
-    *dw_acc += t;
-    *ticket = 0u;                                      // (ready for the next launch on this stream)
-  }
+  if (threadIdx.x == 0) *acc += t;
 }
 
 template <int VEC>
@@ -496,24 +487,18 @@ extern "C" int rtg_noise_lrelu_bwd(const float* x, const float* w, const float* 
   RTG_REQ(x && w && dy && dx && dw_part);
   if (n < 1 || n_blocks < 1 || n_blocks > MAX_GRID) return RTG_EINVAL;
   if (vec4_ok(n, x, dy, dx, u_in)) {
-    RTG_LAUNCH(noise_bwd_kernel<4>, n_blocks, RTG_THREADS, 0, stream, x, w, u_in, dy, dx, dw_part, n, slope, seed, salt_dev,
-               (float*)nullptr, (unsigned*)nullptr);
+    RTG_LAUNCH(noise_bwd_kernel<4>, n_blocks, RTG_THREADS, 0, stream, x, w, u_in, dy, dx, dw_part, n, slope, seed, salt_dev);
   }
-  RTG_LAUNCH(noise_bwd_kernel<1>, n_blocks, RTG_THREADS, 0, stream, x, w, u_in, dy, dx, dw_part, n, slope, seed, salt_dev,
-             (float*)nullptr, (unsigned*)nullptr);
+  RTG_LAUNCH(noise_bwd_kernel<1>, n_blocks, RTG_THREADS, 0, stream, x, w, u_in, dy, dx, dw_part, n, slope, seed, salt_dev);
 }
 
 extern "C" int rtg_noise_lrelu_bwd_acc(const float* x, const float* w, const float* u_in, const float* dy, float* dx,
                                        float* dw_part, int n_blocks, long long n, float slope, unsigned long long seed,
-                                       const float* salt_dev, float* dw_acc, unsigned* ticket, void* stream) {
-  RTG_REQ(x && w && dy && dx && dw_part && dw_acc && ticket);
-  if (n < 1 || n_blocks < 1 || n_blocks > MAX_GRID) return RTG_EINVAL;
-  if (vec4_ok(n, x, dy, dx, u_in)) {
-    RTG_LAUNCH(noise_bwd_kernel<4>, n_blocks, RTG_THREADS, 0, stream, x, w, u_in, dy, dx, dw_part, n, slope, seed, salt_dev,
-               dw_acc, ticket);
-  }
-  RTG_LAUNCH(noise_bwd_kernel<1>, n_blocks, RTG_THREADS, 0, stream, x, w, u_in, dy, dx, dw_part, n, slope, seed, salt_dev,
-             dw_acc, ticket);
+                                       const float* salt_dev, float* dw_acc, void* stream) {
+  RTG_REQ(dw_acc);
+  const int rc = rtg_noise_lrelu_bwd(x, w, u_in, dy, dx, dw_part, n_blocks, n, slope, seed, salt_dev, stream);
+  if (rc != RTG_OK) return rc;
+  RTG_LAUNCH(reduce_acc_kernel, 1, RTG_THREADS, 0, stream, (const float*)dw_part, n_blocks, dw_acc);
 }
 
 extern "C" int rtg_axpby(const float* a, const float* b, float* out, long long n, float alpha, float beta,

@@ -135,7 +135,7 @@ PROTOTYPES = {
     'rtg_stft_backward': (_I, [C.POINTER(StftDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'rtg_noise_lrelu_fwd': (_I, [_P, _P, _P, _P, _LL, _F, _ULL, _P, _P]),
     'rtg_noise_lrelu_bwd': (_I, [_P, _P, _P, _P, _P, _P, _I, _LL, _F, _ULL, _P, _P]),
-    'rtg_noise_lrelu_bwd_acc': (_I, [_P, _P, _P, _P, _P, _P, _I, _LL, _F, _ULL, _P, _P, _P, _P]),
+    'rtg_noise_lrelu_bwd_acc': (_I, [_P, _P, _P, _P, _P, _P, _I, _LL, _F, _ULL, _P, _P, _P]),
     'rtg_channel_sum': (_I, [_P, _P, _I, _I, _I, _P, _P]),
     'rtg_axpby': (_I, [_P, _P, _P, _LL, _F, _F, _I, _P]),
     'rtg_lrelu_bwd': (_I, [_P, _P, _P, _LL, _F, _P]),

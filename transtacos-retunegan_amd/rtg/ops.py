@@ -913,17 +913,6 @@ def mrf_group_ok(lys, x):
 # GaussianNoise
 # ---------------------------------------------------------------------------------------------------------------
 NOISE_ACC = _os.environ.get('RTG_NOISE_ACC', '1') == '1'      # A/B knob: 0 = part.sum() and autograd's accumulation
-_NOISE_TICKETS = {}
-
-
-def _noise_ticket(device):
-    """the device word the self-finishing noise backward counts its blocks in: one per (device, stream) — launches that share
-    one must be ordered on a stream; zero before its first use, reset by every launch"""
-    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
-    t = _NOISE_TICKETS.get(key)
-    if t is None:
-        t = _NOISE_TICKETS[key] = torch.zeros(1, device=device, dtype=torch.int32)
-    return t
 
 
 class NoiseFn(torch.autograd.Function):
@@ -947,14 +936,13 @@ class NoiseFn(torch.autograd.Function):
         dy = _c(dy)
         dx = torch.empty_like(x)
         part = torch.empty(NoiseFn.N_BLOCKS, device=x.device)
-        # the shared scalar's gradient: where w.grad is a live buffer (the weight bank's flat gradient view) the launch adds
-        # its sum there itself (the last block reduces the partials in fixed order) and autograd gets no gradient to
-        # accumulate: six part.sum() + five grad add_ launches per generator backward are gone
+        # the shared scalar's gradient: where w.grad is a live buffer (the weight bank's flat gradient view) a one-block
+        # launch adds the partials into it in fixed order and autograd gets no gradient to accumulate (six ATen sum + five
+        # grad add_ launches per generator backward -> six launches of ours)
         g = w.grad if ctx.needs_input_grad[1] and NOISE_ACC and not torch.is_grad_enabled() else None
         if g is not None and g.is_cuda and g.dtype == torch.float32 and g.numel() == 1:
             check(lib.rtg_noise_lrelu_bwd_acc(_p(x), _p(w), _p(u_in), _p(dy), _p(dx), _p(part), NoiseFn.N_BLOCKS, x.numel(),
-                                              slope, C.c_ulonglong(seed), _p(salt), _p(g), _p(_noise_ticket(x.device)),
-                                              _stream()), 'noise bwd')
+                                              slope, C.c_ulonglong(seed), _p(salt), _p(g), _stream()), 'noise bwd')
             return dx, None, None, None, None, None
         check(lib.rtg_noise_lrelu_bwd(_p(x), _p(w), _p(u_in), _p(dy), _p(dx), _p(part), NoiseFn.N_BLOCKS, x.numel(),
                                       slope, C.c_ulonglong(seed), _p(salt), _stream()), 'noise bwd')
