@@ -24,19 +24,23 @@ __device__ __forceinline__ cpx* fft_stockham(cpx* a, cpx* b, int n, const float*
   const int half = n >> 1;
   cpx *src = a, *dst = b;
   for (int s = 1; s < n; s <<= 1) {          // s = stride, current sub-length = n / s
-    const int m = (n / s) >> 1;
+    // butterfly idx = q + s * p (q < s) takes src[idx] and src[idx + n / 2] to dst[q + 2 s p] and dst[q + 2 s p + s] with
+    // the twiddle exp(-2 pi i p / (n / s)) = table[s p]: s p = idx with its low log2(s) bits cleared — masks, no division
+    // (measured: the same 23 us per launch as with the divisions, and as with the twiddle table staged in LDS — the passes'
+    // barriers and LDS round trips set the time, not their arithmetic)
+    const int hi = ~(s - 1);
+#pragma unroll 4
     for (int idx = threadIdx.x; idx < half; idx += RTG_THREADS) {
-      const int p = idx / s, q = idx - p * s;
-      const cpx u = src[q + s * p], v = src[q + s * (p + m)];
-      const int k = p * s;                    // twiddle exp(-2*pi*i*p/(n/s)) = table[p*s]
+      const int k = idx & hi;
+      const cpx u = src[idx], v = src[idx + half];
       const float c = tw_cos[k], sn = tw_sin[k];
       const float dx = u.x - v.x, dy = u.y - v.y;
       cpx o0, o1;
       o0.x = u.x + v.x; o0.y = u.y + v.y;
       o1.x = dx * c + dy * sn;                // (dx + i dy) * (c - i sn)
       o1.y = dy * c - dx * sn;
-      dst[q + s * (2 * p)] = o0;
-      dst[q + s * (2 * p + 1)] = o1;
+      dst[idx + k] = o0;
+      dst[idx + k + s] = o1;
     }
     __syncthreads();
     cpx* t = src; src = dst; dst = t;
