@@ -631,11 +631,14 @@ __device__ __forceinline__ void cin1_stage(const ThinArgs& a, int b, int g0, int
   }
 }
 
-// ---- one input channel, long rows (out_L % 4 == 0): block = (clip, 1024 positions) x RB output rows; a thread keeps the
-// 4 x K input values of its four consecutive positions in registers and walks the rows: K broadcast weight reads, 4K
-// multiply-adds and ONE 16-byte store per row.
+// ---- one input channel, long rows: block = (clip, 1024 positions) x RB output rows; a thread keeps the 4 x K input values
+// of its four positions in registers and walks the rows: K broadcast weight reads, 4K multiply-adds per row.
+// VEC (out_L % 4 == 0, 16-byte aligned tensors): the four positions are consecutive, ONE 16-byte store per row.
+// !VEC (rows of any length and alignment — the first layer of the period discriminators: rows of 2731 / 1639 / 1171 / 745,
+// discrminator.py:100): the four positions are 256 apart, four 4-byte stores per row, each coalesced over the wave.  These
+// rows used to take cin1_flat_kernel, whose blocks stage the clip's WHOLE input row (8193 samples) for 8192 outputs.
 constexpr int kRowTile = 4 * RTG_THREADS;
-template <int KT>
+template <int KT, bool VEC>
 __global__ __launch_bounds__(RTG_THREADS) void cin1_rows_kernel(const ThinArgs a, const TileGeo g) {
   const int K = KT > 0 ? KT : a.K;
   constexpr int KR = KT > 0 ? KT : kMaxTaps;         // taps kept in registers
@@ -655,13 +658,15 @@ __global__ __launch_bounds__(RTG_THREADS) void cin1_rows_kernel(const ThinArgs a
   for (int r = tid; r < rows; r += RTG_THREADS) bl[r] = a.bias ? a.bias[m0 + r] : 0.f;
   cin1_stage(a, b, t0 * a.stride - a.pad, g.W, xs);
   __syncthreads();
-  const int t = t0 + 4 * tid;
+  // position i of this thread within the tile: 4 tid + i (VEC) or tid + 256 i
+  constexpr int PS = VEC ? 1 : RTG_THREADS, PB = VEC ? 4 : 1;
+  const int t = t0 + PB * tid;
   if (t >= a.Q) return;
   float xv[4][KR];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < KR; ++j) xv[i][j] = j < K ? xs[(4 * tid + i) * a.stride + j * a.dil] : 0.f;
+    for (int j = 0; j < KR; ++j) xv[i][j] = j < K ? xs[(PB * tid + PS * i) * a.stride + j * a.dil] : 0.f;
   const float mslope = a.mask_slope;
   for (int r = 0; r < rows; ++r) {
     const f32x4* w4 = reinterpret_cast<const f32x4*>(wl + r * kMaxTaps);
@@ -681,7 +686,7 @@ __global__ __launch_bounds__(RTG_THREADS) void cin1_rows_kernel(const ThinArgs a
       acc[i] = s_;
     }
     const size_t o = ((size_t)b * a.M + m0 + r) * a.out_L + t;
-    if (t + 3 < a.Q) {
+    if (VEC && t + 3 < a.Q) {
       f32x4 v{acc[0], acc[1], acc[2], acc[3]};
       if (a.mask) {
         const f32x4 mk = *reinterpret_cast<const f32x4*>(a.mask + o);
@@ -696,11 +701,13 @@ __global__ __launch_bounds__(RTG_THREADS) void cin1_rows_kernel(const ThinArgs a
       v.z = thin_act(v.z * a.out_scale, a.act, a.act_slope); v.w = thin_act(v.w * a.out_scale, a.act, a.act_slope);
       *reinterpret_cast<f32x4*>(a.out + o) = v;
     } else {
-      for (int i = 0; i < 4 && t + i < a.Q; ++i) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (t + PS * i >= a.Q) break;
         float v = acc[i];
-        if (a.mask) v *= (a.mask[o + i] > 0.f ? 1.f : mslope);
-        if (a.res) v += a.res[o + i];
-        a.out[o + i] = thin_act(v * a.out_scale, a.act, a.act_slope);
+        if (a.mask) v *= (a.mask[o + PS * i] > 0.f ? 1.f : mslope);
+        if (a.res) v += a.res[o + PS * i];
+        a.out[o + PS * i] = thin_act(v * a.out_scale, a.act, a.act_slope);
       }
     }
   }
@@ -890,7 +897,8 @@ int rtg_thin_launch(int kind, const RtgConv1dDesc* d, const float* x, const floa
   if (kind == 1 && !legacy && d->Q == d->out_L) {
     const long long wq = (long long)(d->Q - 1) * d->stride + (long long)(d->K - 1) * d->dil + 1;
     const bool vec_io = d->out_L % 4 == 0 && aligned16(out) && (!mask || aligned16(mask)) && (!res || aligned16(res));
-    if (vec_io && d->Q >= 256) {
+    // (unaligned rows from 192 positions: a quarter-filled tile still beats cin1_flat_kernel's whole-row staging — period 11)
+    if ((vec_io && d->Q >= 256) || (!vec_io && d->Q >= 192 && RTG_ENV_INT("RTG_THIN_ROWS1", 1))) {
       g.tiles = rtg_ceil_div(d->Q, kRowTile);
       g.W = (kRowTile - 1) * d->stride + (d->K - 1) * d->dil + 1;
       const long long bx = (long long)d->B * g.tiles;
@@ -905,7 +913,9 @@ int rtg_thin_launch(int kind, const RtgConv1dDesc* d, const float* x, const floa
       const size_t lds = ((size_t)rb * (kMaxTaps + 1) + g.W) * sizeof(float);
       const int gy = rtg_ceil_div(d->Mg, rb);
       if (bx <= 0x7fffffffLL && gy <= 65535 && lds <= 48 * 1024) {
-#define RTG_C1R(KT) RTG_KLAUNCH((cin1_rows_kernel<KT>), dim3((unsigned)bx, gy), dim3(RTG_THREADS), lds, s, a, g)
+#define RTG_C1R(KT)                                                                                             \
+  if (vec_io) RTG_KLAUNCH((cin1_rows_kernel<KT, true>), dim3((unsigned)bx, gy), dim3(RTG_THREADS), lds, s, a, g); \
+  else RTG_KLAUNCH((cin1_rows_kernel<KT, false>), dim3((unsigned)bx, gy), dim3(RTG_THREADS), lds, s, a, g)
         switch (d->K) {
           case 3: RTG_C1R(3); break;
           case 5: RTG_C1R(5); break;
