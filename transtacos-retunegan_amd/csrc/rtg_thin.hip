@@ -714,10 +714,12 @@ __global__ __launch_bounds__(RTG_THREADS) void cin1_rows_kernel(const ThinArgs a
 }
 
 // ---- one input channel, any row length: the [M, Q] outputs of a clip are one contiguous run; block = (clip, chunk of
-// kFlatChunk flat outputs), thread = 4 consecutive flat outputs per pass (16-byte stores when the run allows it), each
+// PASSES x 1024 flat outputs), thread = 4 consecutive flat outputs per pass (16-byte stores when the run allows it), each
 // output looks up its row's taps and its K inputs in LDS (the clip's whole input row is staged once per block).
-constexpr int kFlatChunk = 32 * RTG_THREADS;
+// PASSES: passes of a block (a chunk = PASSES * 1024 outputs)
+template <int PASSES>
 __global__ __launch_bounds__(RTG_THREADS) void cin1_flat_kernel(const ThinArgs a, const TileGeo g) {
+  constexpr int kFlatChunk = PASSES * 4 * RTG_THREADS;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* wl = sm;                                     // [rows of this chunk][K]
   float* bl = wl + g.RB * a.K;                        // [rows of this chunk]
@@ -928,6 +930,11 @@ int rtg_thin_launch(int kind, const RtgConv1dDesc* d, const float* x, const floa
       }
     }
     const long long n_out = (long long)d->Mg * d->Q;
+    // two passes per block (2048 outputs): conv_post backward-data (512 rows of 10-128 positions per clip) is a chain of
+    // dependent mask loads and stores per thread — 4 x more blocks hide it better than 8 passes in one (measured in the
+    // step, 14 launches: 0.44 -> 0.27 ms; one pass: the same)
+    const int passes = RTG_ENV_INT("RTG_FLAT_PASSES", 2);
+    const int kFlatChunk = passes * 4 * RTG_THREADS;
     int rows_max = kFlatChunk / d->Q + 2;              // output rows a chunk can touch
     if (rows_max > d->Mg) rows_max = d->Mg;
     const size_t lds = ((size_t)rows_max * (d->K + 1) + wq) * sizeof(float);
@@ -938,7 +945,11 @@ int rtg_thin_launch(int kind, const RtgConv1dDesc* d, const float* x, const floa
       g.vec = (n_out % 4 == 0 && aligned16(out) && (!mask || aligned16(mask)) && (!res || aligned16(res))) ? 1 : 0;
       const long long bx = (long long)d->B * g.chunks;
       if (bx <= 0x7fffffffLL) {
-        RTG_KLAUNCH(cin1_flat_kernel, dim3((unsigned)bx), dim3(RTG_THREADS), lds, s, a, g);
+        if (passes == 8) RTG_KLAUNCH(cin1_flat_kernel<8>, dim3((unsigned)bx), dim3(RTG_THREADS), lds, s, a, g);
+        else if (passes == 4) RTG_KLAUNCH(cin1_flat_kernel<4>, dim3((unsigned)bx), dim3(RTG_THREADS), lds, s, a, g);
+        else if (passes == 2) RTG_KLAUNCH(cin1_flat_kernel<2>, dim3((unsigned)bx), dim3(RTG_THREADS), lds, s, a, g);
+        else if (passes == 1) RTG_KLAUNCH(cin1_flat_kernel<1>, dim3((unsigned)bx), dim3(RTG_THREADS), lds, s, a, g);
+        else return RTG_EINVAL;
         return rtg_launch_status();
       }
     }
