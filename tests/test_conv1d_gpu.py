@@ -596,3 +596,21 @@ def test_sconv_transposed_conv_forward_and_backward_data(case):
         assert torch.isfinite(o).all(), c
         err = (o.double() - ref).abs().max().item()
         assert err < 2e-5 * max(1.0, ref.abs().max().item()), (c, err)
+
+
+def test_sconv_is_offered_only_where_the_owner_allows_its_summation_order():
+    """RtgConv1dDesc.wp16 == 1 promises that every listed block shape gives the general kernel's bits (the discriminators'
+    grouped-launch / per-clip tests rely on it): the split-K codes 9004 / 9008 are listed and accepted with wp16 == 2 only."""
+    from rtg.lib import lib, Conv1dDesc
+    B, C_, L, K = 4, 128, 32, 3
+    base = base_desc(B, C_, 0, L, 1, C_, C_, K, 1, 1, 1, L, C_, L, 32)
+    cands = (C.c_int * 48)()
+    for wp16, expect in ((0, False), (1, False), (2, True)):
+        n = lib.rtg_conv1d_tile_candidates(C.byref(Conv1dDesc(**dict(base, wp16=wp16))), cands, 48)
+        assert any(c > 9000 for c in cands[:n]) == expect, (wp16, list(cands[:n]))
+    W = packref.logical_fwd(np.zeros((C_, C_, K), dtype=np.float32), 1)
+    wp = torch.from_numpy(np.concatenate([packref.pack_logical(W, 32), packref.pack_frag16(W)])).cuda()
+    x, out = torch.zeros(B, C_, L, device='cuda'), torch.zeros(B, C_, L, device='cuda')
+    d = Conv1dDesc(**dict(base, wp16=1, tile_cfg=9008))
+    rc = lib.rtg_conv1d(C.byref(d), _ptr(x), None, None, _ptr(wp), None, None, None, _ptr(out), None, None)
+    assert rc != 0

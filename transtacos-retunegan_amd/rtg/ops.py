@@ -1118,6 +1118,7 @@ class WSumFn(torch.autograd.Function):
         out = torch.empty(1, device=ts[0].device)
         check(lib.rtg_scalar_wsum(C.byref(tab), _p(out), _stream()), 'scalar wsum')
         ctx.weights = weights
+        ctx.shapes = [t.shape for t in terms]
         return out.reshape(())
 
     @staticmethod
@@ -1130,7 +1131,7 @@ class WSumFn(torch.autograd.Function):
         g = _c(g).reshape(1)
         out = torch.empty(n, device=g.device)
         check(lib.rtg_scalar_fanout(C.byref(tab), _p(g), _p(out), _stream()), 'scalar fan-out')
-        return (None, *[out[i].reshape(()) if ctx.needs_input_grad[1 + i] else None for i in range(n)])
+        return (None, *[out[i].reshape(ctx.shapes[i]) if ctx.needs_input_grad[1 + i] else None for i in range(n)])
 
 
 def weighted_sum(terms, weights=None):
