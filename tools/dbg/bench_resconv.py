@@ -9,7 +9,7 @@ from rtg.ops import _desc
 p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
 dev = 'cuda'
 for B, Cc, L in ((32, 32, 8192), (32, 64, 2048)):
-    for K, dil in ((3, 9), (7, 9)):
+    for K, dil in ((3, 9), (3, 1), (5, 3), (7, 9)):
         gen = torch.Generator().manual_seed(1)
         x = torch.randn(B, Cc, L, generator=gen).to(dev)
         w = torch.randn(Cc, Cc, K, generator=gen) / np.sqrt(Cc * K)
