@@ -76,7 +76,12 @@ def _run_conv(d, args, flop, label, what):
 def _run_wgrad(wd, ptrs, st, bank, ly, tok_id, flop, label, what):
     """rtg_conv1d_wgrad into the bank's partial slot with the tuned block shape; ptrs = (x1, x2, dy, gy_aux)"""
     wd.bf16 = int(getattr(ly, 'wgrad_bf', 0))
-    wd.shape_cfg = tune.wgrad_cfg(wd, lambda part: lib.rtg_conv1d_wgrad(C.byref(wd), *ptrs, _p(part), st))
+    run = lambda part: lib.rtg_conv1d_wgrad(C.byref(wd), *ptrs, _p(part), st)  # noqa: E731
+    if wd.bf16 and BF16_FP32_THIN and ly.kind == 'conv' and ly.groups > 1 and ly.k == 41:
+        # (a thin-group layer under bf16 operands: its fp32 shapes — exact-fit matrix-core tiles, vector ALUs — compete)
+        wd.bf16, wd.shape_cfg = tune.wgrad_cfg_any(wd, run)
+    else:
+        wd.shape_cfg = tune.wgrad_cfg(wd, run)
     splits = lib.rtg_wgrad_splits(C.byref(wd))
     if splits < 1:
         raise L.RtgError(f'wgrad geometry refused for {ly.name}: {splits}')
@@ -242,6 +247,10 @@ def _desc(**kw):
 GCONV = _os.environ.get('RTG_GCONV', '1') == '1'
 # RTG_GMFMA=0: without the exact-fit matrix-core forward of rtg_gmfma.hip (A/B knob)
 GMFMA = _os.environ.get('RTG_GMFMA', '1') == '1'
+# bf16 operands (hparam.compute_dtype, BASELINE configs[2]): the thin-group layers' fp32 kernels (vector ALUs, exact-fit
+# matrix-core tiles) stay candidates next to the bf16 general kernel, whose tiles are mostly padding for 8 channels per
+# group — fp32 arithmetic where it is FASTER than bf16 is no loss of precision.  0: bf16 layers take the bf16 kernel only
+BF16_FP32_THIN = _os.environ.get('RTG_BF16_FP32_THIN', '1') == '1'
 
 
 def _gconv_forward(ly, bank, tok_id, d, args, x_ptr, B, L_in, out, pre_slope, flop, label):
@@ -249,7 +258,7 @@ def _gconv_forward(ly, bank, tok_id, d, args, x_ptr, B, L_in, out, pre_slope, fl
     padding) or the vector ALUs (rtg_gconv.hip), whichever the tuner measured faster for this problem.  d / args: the
     rtg_conv1d launch of the same plain forward (out = conv(lrelu(x)) + bias) on B clips at x_ptr.  True: ran on the
     vector ALUs."""
-    if not (GCONV and ly.kind == 'conv' and ly.groups > 1 and ly.k == 41 and not ly.fwd_bf):
+    if not (GCONV and ly.kind == 'conv' and ly.groups > 1 and ly.k == 41 and (not ly.fwd_bf or BF16_FP32_THIN)):
         return False
     gd = L.GconvDesc(B, ly.groups, ly.cin // ly.groups, ly.cout // ly.groups, ly.k, ly.stride, ly.pad, L_in, out.shape[-1],
                      pre_slope)
@@ -273,7 +282,7 @@ def _gconv_forward(ly, bank, tok_id, d, args, x_ptr, B, L_in, out, pre_slope, fl
 
 def _gconv_dgrad(ly, bank, tok_id, d, args, dy_ptr, mask_ptr, res_ptr, B, L_in, L_out, dx, pre_slope, flop, label):
     """backward-data of the same layers: dx = res + lrelu'(x) * conv_transpose(dy); d / args: the rtg_conv1d launch of it"""
-    if not (GCONV and ly.kind == 'conv' and ly.groups > 1 and ly.k == 41 and not ly.bwd_bf):
+    if not (GCONV and ly.kind == 'conv' and ly.groups > 1 and ly.k == 41 and (not ly.bwd_bf or BF16_FP32_THIN)):
         return False
     gd = L.GconvDesc(B, ly.groups, ly.cin // ly.groups, ly.cout // ly.groups, ly.k, ly.stride, ly.pad, L_in, L_out, pre_slope)
     if lib.rtg_gconv_ok(C.byref(gd)) != 1:

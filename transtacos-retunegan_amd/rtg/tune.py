@@ -106,6 +106,38 @@ def wgrad_cfg(wd, run):
     return best
 
 
+def wgrad_cfg_any(wd, run):
+    """(bf16, shape_cfg) for a bf16 weight-gradient descriptor whose layer may just as well run its fp32 shapes (the
+    thin-group layers: exact-fit fp32 tiles against bf16 tiles that are mostly padding): every candidate of either
+    arithmetic is timed.  Stored in the weight-gradient table as shape_cfg (+ 1000 for an fp32 pick)."""
+    wd.bf16, wd.shape_cfg, wd.splits, wd.part_stride = 1, 0, 1, 0
+    key = b'any' + bytes(wd)
+    code = _wgrad.get(key)
+    if code is None:
+        if not (ENABLED and ACTIVE):
+            _miss()
+            return 1, 0
+        need = wd.groups * wd.Mg * (wd.Cg * wd.K + 1)
+        best, best_t = 0, None
+        for bf in (1, 0):
+            wd.bf16 = bf
+            cands = (C.c_int * 12)()
+            n = lib.rtg_wgrad_shape_candidates(C.byref(wd), cands, 12)
+            for c in cands[:max(n, 0)]:
+                wd.shape_cfg, wd.splits, wd.part_stride = c, 1, 0
+                splits = lib.rtg_wgrad_splits(C.byref(wd))
+                if splits < 1:
+                    continue
+                part = torch.empty(splits * need, device='cuda')
+                wd.splits, wd.part_stride = splits, need
+                t = _time(lambda: run(part))
+                if t is not None and (best_t is None or t < best_t):
+                    best, best_t = c + (0 if bf else 1000), t
+        code = _wgrad[key] = best
+    wd.bf16, wd.shape_cfg, wd.splits, wd.part_stride = (0 if code >= 1000 else 1), 0, 1, 0
+    return wd.bf16, code % 1000
+
+
 def wgrad_group_cfg(wds, run_group, run_singles):
     """How to run the weight gradients of n layers that may share one launch (rtg_conv1d_wgrad_group).  -> 0: one by
     one (each with its own tuned shape), else shape_cfg + 16 * d with the members' split counts divided by n (d = 1) or
