@@ -5,6 +5,10 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
+`--gpus N` with N > 1 outside a launcher (WORLD_SIZE unset) starts the N ranks itself — one child process per GPU, before
+anything in this process touches a GPU — relays rank 0's JSON line and exits non-zero if a rank fails or the node has fewer
+than N devices; under a launcher `--gpus` must equal WORLD_SIZE.  It never silently times fewer GPUs than it was asked for.
+
 One "step" = one iteration of retunegan/train.py:121-193 (1 G forward, d_train_times D updates, 1 G update) on a batch
 of synthetic clips already resident in HBM.  Default workload = BASELINE.json configs[1]: UNet-G + MSD + MPD,
 per-GPU batch 32, 8192-sample clips, multi-STFT loss, fp32.  Rank 0 prints ONE JSON line.
@@ -267,11 +271,65 @@ def roofline(trainer, batch, bf16=False, workload='config2'):
     return out
 
 
+def self_launch(a):
+    """`--gpus N` (N > 1) outside a launcher: start the N ranks as child processes of this script — nothing in this process
+    has touched a GPU yet (torch.cuda.device_count() does not initialise the runtime on this image), no exec — relay rank
+    0's stdout (the JSON line), and fail loudly: fewer than N devices, or any rank exiting non-zero (the others are killed:
+    they would wait in a collective forever), ends this process with a non-zero code and a message on stderr."""
+    import signal
+    import socket
+    import subprocess
+    rehearse = os.environ.get('RTG_BENCH_REHEARSE') == '1'
+    n_dev = torch.cuda.device_count()
+    if n_dev < 1 or (n_dev < a.gpus and not rehearse):
+        raise SystemExit(f'bench.py --gpus {a.gpus}: this node exposes {n_dev} GPU(s); refusing to time fewer ranks than asked '
+                         f'(RTG_BENCH_REHEARSE=1 rehearses {a.gpus} gloo ranks on one GPU)')
+    s_ = socket.socket(); s_.bind(('127.0.0.1', 0)); port = s_.getsockname()[1]; s_.close()
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        # rank 0's stdout is this process's (the JSON line); the other ranks' goes to stderr.  Own sessions: a failed job is
+        # killed group by group, never by name
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
+                                      stdout=None if r == 0 else sys.stderr, start_new_session=True))
+
+    def kill_all():
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)
+                except ProcessLookupError:
+                    pass
+        for p in procs:
+            p.wait()
+
+    try:
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                kill_all()
+                raise SystemExit(f'bench.py --gpus {a.gpus}: rank {bad[0][0]} exited with code {bad[0][1]}; the other ranks were stopped')
+            if all(c == 0 for c in codes):
+                return
+            time.sleep(0.2)
+    except BaseException:
+        kill_all()
+        raise
+
+
 def main():
     a = parse()
+    if a.gpus < 1:
+        raise SystemExit('bench.py: --gpus must be >= 1')
+    if 'WORLD_SIZE' not in os.environ and a.gpus > 1:
+        return self_launch(a)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != a.gpus:
+        raise SystemExit(f'bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks')
     if os.environ.get('RTG_BENCH_REHEARSE') == '1':      # dev aid: all ranks on cuda:0, gradients over gloo (a one-GPU box)
         local = 0
     # RTG_DP_FORCE=1 with one rank: the whole data-parallel machinery (RCCL all-reduces on the communication stream, graph
@@ -283,14 +341,20 @@ def main():
         os.environ.setdefault('MASTER_PORT', str(port))
         os.environ.update(RANK='0', WORLD_SIZE='1')
     multi = world > 1 or forced
+    backend_desc = None
     if multi:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         torch.cuda.set_device(local)
         if os.environ.get('RTG_BENCH_REHEARSE') == '1':
             dist.init_process_group('gloo')
+            backend_desc = 'gloo (rehearsal: all ranks on one GPU)'
         else:
             dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+            try:
+                backend_desc = 'nccl = RCCL ' + '.'.join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:  # noqa: BLE001
+                backend_desc = 'nccl = RCCL (version unavailable)'
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the hot path has no CPU fallback')
     device = torch.device('cuda', local)
@@ -323,13 +387,20 @@ def main():
     # gradients; the all-reduces run between the segments (tests/test_zz_dp_gpu.py::test_two_ranks_graphed_step).
     # RTG_GRAPH=0: the eager step.  Capture happens here, outside warm-up and timing; if it fails the eager step is timed
     # and the record says so.
-    mode = 'hip-graph replay'
     tr.train_step(*next_batch())
     torch.cuda.synchronize()
-    step = tr.train_step
-    if os.environ.get('RTG_GRAPH', '1') != '0':
+
+    def setup_step(policy):
+        """-> (step function, launch mode) under the exchange policy `policy`: graphs captured and replayed once, or the
+        eager step if that failed on any rank (or RTG_GRAPH=0)"""
+        mode = 'hip-graph replay'
+        if multi:
+            tr.set_exchange(policy)                       # (drops the graphs of another policy: they are cut elsewhere)
+        if os.environ.get('RTG_GRAPH', '1') == '0':
+            return tr.train_step, 'eager'
         # capture WITHOUT replaying, then agree on the outcome, then replay: a rank whose capture failed must not head for
         # the eager step's collectives while the others are inside a replay's (different buffers and sizes: RCCL would hang)
+
         def agree(ok_, why):
             """MIN over the ranks of `ok_`: either every rank goes on with the graphs or every rank drops them"""
             nonlocal mode
@@ -364,41 +435,64 @@ def main():
                 print(f'[rank {rank}] first graph replay failed:\n' + traceback.format_exc(), file=sys.stderr, flush=True)
             ok = agree(ok, 'the first graph replay')
         if ok:
-            step = tr.train_step_graphed
-        else:
-            tr.dp.pending = []
-            tr.train_step(*next_batch())             # (the eager step once more after a failed capture / replay)
-            torch.cuda.synchronize()
+            return tr.train_step_graphed, mode
+        tr.dp.pending = []
+        tr.train_step(*next_batch())             # (the eager step once more after a failed capture / replay)
+        torch.cuda.synchronize()
+        return tr.train_step, mode
+
+    def timed(step_fn, k):
+        """seconds for k steps, barrier + synchronize on both sides, MAX over the ranks"""
+        torch.cuda.synchronize()
+        if multi:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0_ = time.perf_counter()
+        out_ = None
+        for _ in range(k):
+            out_ = step_fn(*next_batch())
+        torch.cuda.synchronize()
+        if multi:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el_ = time.perf_counter() - t0_
+        mine_ = el_
+        if multi:
+            t_ = torch.tensor([el_], device=device, dtype=torch.float64)
+            dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+            el_ = t_.item()
+        return el_, mine_, out_
+
+    # Exchange policy (data parallel only): both are set up and timed over 5 steps HERE, on the job's own ranks and links
+    # — round 4 picked 'update' from a 1-rank RCCL group, where an all-reduce moves no bytes — and the faster one (MAX over
+    # ranks, so every rank picks the same) runs the warm-up and the timed steps.  RTG_DP_CUT set: that policy, no trial.
+    exchange_trials = None
+    if multi and 'RTG_DP_CUT' not in os.environ:
+        exchange_trials = {}
+        for pol in train_mod.EXCHANGE_POLICIES:
+            step, mode = setup_step(pol)
+            step(*next_batch())
+            exchange_trials[pol] = round(timed(step, 5)[0] / 5 * 1e3, 3)
+        best = min(train_mod.EXCHANGE_POLICIES, key=lambda p_: exchange_trials[p_])
+        if best != tr.dp.exchange:
+            step, mode = setup_step(best)
     else:
-        mode = 'eager'
+        step, mode = setup_step(tr.dp.exchange)
     for _ in range(a.warmup):
         step(*next_batch())
-    torch.cuda.synchronize()
-    if multi:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        dl, gl = step(*next_batch())
-    torch.cuda.synchronize()
-    if multi:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    # EXACTLY a.steps steps between barrier + synchronize pairs; `elapsed` is the MAX over the ranks
+    elapsed, my_elapsed, (dl, gl) = timed(step, a.steps)
     per_rank = None
     if multi:
         # every rank's own time and a digest of its tuner's picks (rank 0 tunes and broadcasts its tables,
         # train.DataParallel.sync_tuner: the digests must be equal)
         from rtg import tune
-        mine = torch.tensor([elapsed / a.steps * 1e3, float(int(tune.digest(), 16))],
+        mine = torch.tensor([my_elapsed / a.steps * 1e3, float(int(tune.digest(), 16))],
                             device=device, dtype=torch.float64)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         per_rank = {'ms_per_step': [round(t[0].item(), 3) for t in allr],
                     'tuner_picks_digest': [f'{int(t[1].item()):06x}' for t in allr]}
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
     loss_g = gl['gen_all'].item()
     loss_d = dl['disc_all'].item()
 
@@ -421,17 +515,20 @@ def main():
         value = world * batch * T / SAMPLE_RATE / (elapsed / a.steps)
         out = {
             'metric': 'G+D train-step audio-seconds/sec', 'value': round(value, 2), 'unit': 'audio-s/s',
-            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(ms, 3),
+            'n_gpus': dist.get_world_size() if multi else 1, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(ms, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32' if dtype == 'fp32' else 'bf16 operands, f32 accumulate', 'data': 'synthetic' if feeder is None else 'synthetic, fed from pinned host memory every step',
             'config': {'workload': f'{a.workload}: {desc}', 'per_gpu_batch': batch, 'clip_samples': T,
                        'global_batch': world * batch, 'd_train_times': d_times,
                        'parallelism': f'dp{world}' if world > 1 else ('single (1-rank RCCL group, data-parallel path forced)' if forced else 'single'), 'launch': mode,
-                       **({'per_rank': per_rank,
-                           'exchange': ('RCCL all-reduce of each model\'s flat gradient buffer '
-                                        + ('on the compute stream' if train_mod._inline_reduce() else 'on a high-priority communication stream')
-                                        + ', graphs cut per ' + ('discriminator' if os.environ.get('RTG_DP_CUT') == 'disc' else 'optimizer update')
-                                        + ('' if mode.startswith('hip-graph') else ' (eager step)'))} if per_rank else {})},
+                       **({'per_rank': per_rank, 'world_size': dist.get_world_size(), 'backend': backend_desc,
+                           'exchange': {'policy': tr.dp.exchange,
+                                        'what': ('RCCL all-reduce of each model\'s flat gradient buffer '
+                                                 + ('on the compute stream, graphs cut per optimizer update' if tr.dp.exchange == 'update'
+                                                    else 'on a high-priority communication stream from the banks\' flush hooks, graphs cut per discriminator')
+                                                 + ('' if mode.startswith('hip-graph') else ' (eager step)')),
+                                        'chosen_by': ('RTG_DP_CUT' if exchange_trials is None else '5 timed steps per policy in set-up (MAX over ranks)'),
+                                        'trial_ms_per_step': exchange_trials}} if per_rank else {})},
             'roofline': roof, 'cpu_baseline': cpu,
             'final_losses': {'gen_all': round(loss_g, 4), 'disc_all': round(loss_d, 4)},
         }

@@ -156,3 +156,33 @@ def test_lean_pack_gives_the_bits_of_the_full_pack(oracle, monkeypatch):
     np.testing.assert_array_equal(flat(a), flat(b))
     back = [(n, s) for i, n, s in off if dict(((id(m), ly.name), ly) for m in nets for ly in m.bank().layers)[(i, n)].std_on[s]]
     assert back, 'the heuristic shapes read no standard image?'
+
+
+def test_lean_pack_at_a_clip_length_with_the_unfused_residual_stack(oracle):
+    """Round-4 advisor finding: at any clip length but 8192 the generator's 128-channel ResidualStack runs as six launches of
+    the general kernel, which read the STANDARD weight images of layers that also carry a fragment image; that path did not
+    report its reads, the lean pack dropped the images and every later step convolved with the weights of the drop step.
+    T = 5632 (22 frames: the stack sees 22 positions, not 32): a trainer with the lean pack and one without stay bit-identical
+    over the steps after the drop (dropped images are NaN-filled under test, tests/conftest.py: a missed report is loud)."""
+    from train import Trainer
+    from rtg import bank as bank_mod
+
+    assert bank_mod.LEAN_POISON
+
+    def make(lean):
+        torch.manual_seed(7)
+        tr = Trainer(use_mpd=True, use_mtd=False, d_train_times=1, dev='cuda:0')
+        tr.lean_pack_enabled = lean
+        with torch.no_grad():
+            tr.generator.noise.w.zero_()
+        return tr
+    x, y_tmpl, y = [t.cuda() for t in oracle.synthetic_batch(4, 5632, 11)]
+    a, b = make(False), make(True)
+    for _ in range(5):
+        a.train_step(x, y_tmpl, y); b.train_step(x, y_tmpl, y)
+    torch.cuda.synchronize()
+    flat = lambda tr: torch.cat([m.bank().flat for m in (tr.generator, *tr.discs)]).cpu().numpy()   # noqa: E731
+    fa, fb = flat(a), flat(b)
+    assert np.isfinite(fb).all()
+    np.testing.assert_array_equal(fa, fb)
+    assert not b._lean_pending and b.lean_dropped > 0

@@ -38,10 +38,12 @@ def test_weighted_sum_is_one_node_with_torch_values_and_gradients():
 
 
 @pytest.mark.parametrize('shape', [(3, 32, 1000), (2, 16, 4096)])
-def test_noise_backward_accumulates_the_scalar_gradient_in_place(shape, monkeypatch):
-    """NoiseFn.backward (generator.py:19-30): with a live w.grad buffer the launch pair rtg_noise_lrelu_bwd_acc adds
-    sum(dy * lrelu' * u) to it and autograd receives no gradient for w; the result equals the part.sum() + accumulation path
-    (RTG_NOISE_ACC = 0) and the closed form on a replayed noise field, and two calls accumulate."""
+def test_noise_backward_accumulates_the_scalar_gradient_in_place(shape):
+    """NoiseFn.backward (generator.py:19-30): inside ops.noise_grad_accumulate() (train.Trainer.g_step's backward) with a
+    live w.grad buffer the launch pair rtg_noise_lrelu_bwd_acc adds sum(dy * lrelu' * u) to it and autograd receives no
+    gradient for w; the result equals the part.sum() + accumulation path (any other backward) and the closed form on a
+    replayed noise field, and two calls accumulate.  torch.autograd.grad outside the context returns dw and leaves w.grad
+    alone (round-4 advisor finding)."""
     from rtg import ops
     gen = torch.Generator().manual_seed(5)
     x = torch.randn(*shape, generator=gen).cuda()
@@ -50,14 +52,15 @@ def test_noise_backward_accumulates_the_scalar_gradient_in_place(shape, monkeypa
     w0 = 0.3
 
     def run(acc, calls):
-        monkeypatch.setattr(ops, 'NOISE_ACC', acc)
+        import contextlib
         w = torch.nn.Parameter(torch.tensor([w0], device='cuda'))
         w.grad = torch.full((1,), 0.25, device='cuda')            # a live buffer with a value to accumulate onto
         xs = []
         for _ in range(calls):
             xi = x.clone().requires_grad_(True)
             out = ops.NoiseFn.apply(xi, w, u, 0.15, 1234, None)
-            out.backward(dy)
+            with (ops.noise_grad_accumulate() if acc else contextlib.nullcontext()):
+                out.backward(dy)
             xs.append(xi.grad)
         torch.cuda.synchronize()
         return w.grad.item(), xs
@@ -70,3 +73,13 @@ def test_noise_backward_accumulates_the_scalar_gradient_in_place(shape, monkeypa
     for a, b in zip(xa, xb):
         assert torch.equal(a, b)
         np.testing.assert_allclose(a.cpu().numpy(), d.float().cpu().numpy(), rtol=1e-6, atol=1e-7)
+    # torch.autograd.grad with a live w.grad: dw comes back, w.grad is not touched
+    w = torch.nn.Parameter(torch.tensor([w0], device='cuda'))
+    w.grad = torch.full((1,), 0.25, device='cuda')
+    xi = x.clone().requires_grad_(True)
+    out = ops.NoiseFn.apply(xi, w, u, 0.15, 1234, None)
+    dx, dw = torch.autograd.grad(out, (xi, w), dy)
+    assert w.grad.item() == 0.25
+    assert dw.item() == pytest.approx((d * u.double()).sum().item(), rel=2e-5)
+    (dx_only,) = torch.autograd.grad(ops.NoiseFn.apply(xi, w, u, 0.15, 1234, None), (xi,), dy)
+    assert w.grad.item() == 0.25 and torch.equal(dx_only, dx)

@@ -1,8 +1,13 @@
 """Host-side logic that needs no GPU: reference-shaped construction API, state-dict keys, loud failure on CPU tensors,
 mel filterbank / STFT plans, optimizer state-dict format."""
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_models_star_import_surface():
@@ -170,3 +175,23 @@ def test_loss_switches_refuse_cpu():
         envelope_loss(torch.zeros(1, 1, 320), torch.zeros(1, 1, 320))
     with pytest.raises(RtgError):
         strip_mirror_loss(torch.zeros(1, 1, 320))
+
+
+def _run_bench(args, env_extra=None, timeout=120):
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'RTG_BENCH_REHEARSE')}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), *args], env=env, capture_output=True, text=True,
+                          timeout=timeout)
+
+
+def test_bench_refuses_to_time_fewer_gpus_than_asked():
+    """Round-4 verdict: `bench.py --gpus N` silently timed ONE GPU.  Outside a launcher it now starts N ranks itself and
+    refuses when the node has fewer than N devices (this container has none); under a launcher --gpus must equal WORLD_SIZE.
+    Both exits are non-zero with a message that names the numbers, and no JSON line is printed."""
+    r = _run_bench(['--gpus', '2'])
+    assert r.returncode != 0 and '--gpus 2' in r.stderr and 'GPU(s)' in r.stderr, (r.returncode, r.stderr[-400:])
+    assert '"metric"' not in r.stdout
+    r = _run_bench(['--gpus', '2'], {'WORLD_SIZE': '4', 'RANK': '0', 'LOCAL_RANK': '0'})
+    assert r.returncode != 0 and 'WORLD_SIZE=4' in r.stderr, (r.returncode, r.stderr[-400:])
+    assert '"metric"' not in r.stdout

@@ -426,3 +426,37 @@ def test_graph_capture_with_rccl_collective_in_flight():
     # same kernels on the same operands; AdamW turns a rounding-level gradient difference at a near-zero gradient into an
     # lr-sized one, so the comparison is on the parameter move like the two-rank tests above (bit-identical when measured: 0.0)
     assert got['frac_bad'] < 2e-3, (got['frac_bad'], got['max_abs_diff'])
+
+
+def _bench(args, env_extra=None, timeout=900):
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'RTG_BENCH_REHEARSE',
+                                                            'RTG_DP_FORCE', 'RTG_DP_CUT', 'RTG_TUNE')}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), *args], env=env, capture_output=True, text=True,
+                          timeout=timeout)
+
+
+def test_bench_gpus_2_launches_two_ranks_itself_or_refuses():
+    """Round-4 verdict item 1.  `RTG_BENCH_REHEARSE=1 python bench.py --gpus 2` (no launcher) starts two ranks as child
+    processes (gloo, both on the box's one GPU), times BOTH exchange policies in set-up, keeps the faster and prints ONE JSON
+    line with n_gpus = 2, the world size, equal tuner digests on both ranks and the trial numbers; plain
+    `python bench.py --gpus 2` on a one-GPU box exits non-zero with a message instead of timing one GPU."""
+    import json
+    if torch.cuda.device_count() < 2:
+        r = _bench(['--gpus', '2', '--steps', '2', '--warmup', '0', '--workload', 'config1', '--no-roofline', '--no-cpu-baseline'])
+        assert r.returncode != 0 and '"metric"' not in r.stdout, (r.returncode, r.stdout[-300:])
+        assert 'refusing to time fewer ranks' in r.stderr, r.stderr[-600:]
+    r = _bench(['--gpus', '2', '--steps', '3', '--warmup', '1', '--workload', 'config1', '--no-roofline', '--no-cpu-baseline'],
+               {'RTG_BENCH_REHEARSE': '1'})
+    assert r.returncode == 0, (r.returncode, r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    c = d['config']
+    assert d['n_gpus'] == 2 and c['world_size'] == 2 and c['global_batch'] == 2 * c['per_gpu_batch']
+    assert len(c['per_rank']['ms_per_step']) == 2 and len(set(c['per_rank']['tuner_picks_digest'])) == 1
+    ex = c['exchange']
+    assert ex['policy'] in ('update', 'disc') and set(ex['trial_ms_per_step']) == {'update', 'disc'}
+    assert ex['policy'] == min(ex['trial_ms_per_step'], key=ex['trial_ms_per_step'].get)
+    assert d['value'] > 0 and np.isfinite(d['final_losses']['gen_all'])

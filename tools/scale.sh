@@ -13,16 +13,13 @@ NGPU=$(python3 -c 'import torch; print(torch.cuda.device_count())')
 base=""
 for N in 1 2 4 8; do
   if [ "$N" -gt "$NGPU" ]; then echo "N=$N: only $NGPU GPU(s) visible, skipped"; continue; fi
-  if [ "$N" -eq 1 ]; then
-    out=$(python3 bench.py --gpus 1 --steps $STEPS --warmup $WARM --workload $WL --no-cpu-baseline --no-roofline)
-  else
-    out=$(python3 -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port $((29500 + N)) \
-          bench.py --gpus $N --steps $STEPS --warmup $WARM --workload $WL --no-cpu-baseline --no-roofline | tail -1)
-  fi
+  # (bench.py --gpus N starts its N ranks itself, one process per GPU; under torchrun it checks --gpus against WORLD_SIZE)
+  out=$(python3 bench.py --gpus $N --steps $STEPS --warmup $WARM --workload $WL --no-cpu-baseline --no-roofline | tail -1)
   val=$(echo "$out" | python3 -c 'import sys, json; d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d["value"], d["ms_per_step"])')
   v=${val% *}; ms=${val#* }
-  # per-rank step times and tuner-pick digests (ranks tune their block shapes independently)
-  echo "$out" | python3 -c 'import sys, json; d = json.loads(sys.stdin.read().strip().splitlines()[-1]); pr = d["config"].get("per_rank"); print("      per rank ms/step", pr["ms_per_step"], "tuner picks", pr["tuner_picks_digest"]) if pr else None'
+  # per-rank step times, tuner-pick digests (rank 0 tunes the block shapes and broadcasts its tables: the digests are equal)
+  # and the exchange policy bench.py picked after timing both
+  echo "$out" | python3 -c 'import sys, json; d = json.loads(sys.stdin.read().strip().splitlines()[-1]); c = d["config"]; pr = c.get("per_rank"); print("      per rank ms/step", pr["ms_per_step"], "tuner picks", pr["tuner_picks_digest"], "exchange", c["exchange"]["policy"], c["exchange"]["trial_ms_per_step"]) if pr else None'
   [ -z "$base" ] && base=$v
   eff=$(python3 -c "print(round($v / ($N * $base), 3))")
   echo "N=$N  $v audio-s/s  $ms ms/step  efficiency $eff"

@@ -32,6 +32,21 @@ static inline int rtg_launch_status() {
 #define RTG_ENV_INT(name, dflt) \
   ([]() -> int { static const int v = []() -> int { const char* e = getenv(name); return e ? atoi(e) : (dflt); }(); return v; }())
 
+// The > 64 KB dynamic-LDS opt-in of a kernel.  hipFuncSetAttribute applies to the CURRENT device, so it is tracked per
+// device (a bit per ordinal) in an atomic the call site owns — one `static std::atomic<unsigned>` per kernel instance; safe
+// from several host threads (the forked autograd threads launch concurrently: setting the attribute twice is harmless).
+#include <atomic>
+static inline int rtg_lds_optin(const void* kernel, std::atomic<unsigned>& done) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return RTG_ERANGE;
+  const unsigned bit = 1u << (dev & 31);
+  if (!(done.load(std::memory_order_acquire) & bit)) {
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return RTG_ERANGE;
+    done.fetch_or(bit, std::memory_order_release);
+  }
+  return RTG_OK;
+}
+
 static inline int rtg_ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 __device__ __forceinline__ float rtg_lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }

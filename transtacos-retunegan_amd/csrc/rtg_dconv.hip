@@ -595,14 +595,8 @@ bool dconv_eligible(const RtgConv1dDesc* d) {
 template <int RW16, int WB, int NT16, int S, int K, bool TWO_D, bool CLS, bool BF, bool HB = CLS>
 int launch(const DArgs& a, unsigned blocks, size_t lds_bytes, hipStream_t s) {
   auto k = dconv_kernel<RW16, WB, NT16, S, K, TWO_D, CLS, BF, HB>;
-  if (lds_bytes > 64 * 1024) {
-    static bool attr_set = false;                      // (> 64 KB of dynamic LDS needs the opt-in once per kernel)
-    if (!attr_set) {
-      if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-        return RTG_ERANGE;
-      attr_set = true;
-    }
-  }
+  static std::atomic<unsigned> optin{0};              // (> 64 KB of dynamic LDS: opt-in per kernel and device)
+  if (lds_bytes > 64 * 1024 && rtg_lds_optin((const void*)k, optin) != RTG_OK) return RTG_ERANGE;
   RTG_KLAUNCH(k, dim3(blocks), dim3(WB * 64), lds_bytes, s, a);
   return rtg_launch_status();
 }

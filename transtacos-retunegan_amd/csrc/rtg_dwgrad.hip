@@ -460,11 +460,8 @@ static int dw_launch_bf(const WArgs& a, hipStream_t s) {
   auto k = dwgrad_kernel<S, WB, NCH, RW, K, TWO_D, BF>;
   constexpr int kPS = (kCch * K * 4 + 63) / 64 * 64, kGS = 4 * kPS + 8;     // (the kernel's plane / group strides)
   const size_t lds_bytes = (size_t)2 * NCH * ((BF ? 2 : kNG) * kGS) * sizeof(float);
-  static bool attr_set = false;
-  if (lds_bytes > 64 * 1024 && !attr_set) {
-    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return RTG_ERANGE;
-    attr_set = true;
-  }
+  static std::atomic<unsigned> optin{0};              // (> 64 KB of dynamic LDS: opt-in per kernel and device)
+  if (lds_bytes > 64 * 1024 && rtg_lds_optin((const void*)k, optin) != RTG_OK) return RTG_ERANGE;
   RTG_KLAUNCH(k, dim3((unsigned)(8 * a.per_xcd)), dim3(WB * 64), lds_bytes, s, a);
   return rtg_launch_status();
 }

@@ -189,13 +189,8 @@ int launch(ResArgs a, int n_mt, size_t lds_bytes, hipStream_t s) {
   if (RTG_ENV_SET("RTG_RC_GX")) gx = RTG_ENV_INT("RTG_RC_GX", 0) / n_mt;
   if (gx > a.total) gx = a.total;
   gx = rtg_ceil_div(a.total, rtg_ceil_div(a.total, gx));
-  static bool attr_set = false;                        // (> 64 KB of dynamic LDS needs the opt-in once per kernel)
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&resconv_kernel<CIN, KT, NT>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-      return RTG_ERANGE;
-    attr_set = true;
-  }
+  static std::atomic<unsigned> optin{0};              // (> 64 KB of dynamic LDS: opt-in per kernel and device)
+  if (rtg_lds_optin(reinterpret_cast<const void*>(&resconv_kernel<CIN, KT, NT>), optin) != RTG_OK) return RTG_ERANGE;
   RTG_KLAUNCH((resconv_kernel<CIN, KT, NT>), dim3((unsigned)gx, n_mt), dim3(RTG_THREADS), lds_bytes, s, a);
   return rtg_launch_status();
 }

@@ -183,13 +183,8 @@ int launch(StackArgs a, int L, hipStream_t s) {
   constexpr int LP = R + 2 * kHalo + 2;
   constexpr int NKS = kStackWaves / ((C / 32) * (R / 32));
   const size_t lds_bytes = ((size_t)2 * C * LP + (NKS == 2 ? 4 * 1024 : 0)) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&resstack_kernel<C, R, CEN>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-      return RTG_ERANGE;
-    attr_set = true;
-  }
+  static std::atomic<unsigned> optin{0};              // (> 64 KB of dynamic LDS: opt-in per kernel and device)
+  if (rtg_lds_optin(reinterpret_cast<const void*>(&resstack_kernel<C, R, CEN>), optin) != RTG_OK) return RTG_ERANGE;
   a.L = L;
   a.n_t = (L + CEN - 1) / CEN;
   RTG_KLAUNCH((resstack_kernel<C, R, CEN>), dim3((unsigned)(a.B * a.n_t)), dim3(64 * kStackWaves), lds_bytes, s, a);

@@ -155,13 +155,8 @@ __global__ __launch_bounds__(RTG_THREADS, 1) void reswgrad_kernel(const RwArgs a
 
 template <int CIN, int KT>
 int launch(const RwArgs& a, int splits, size_t lds_bytes, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&reswgrad_kernel<CIN, KT>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-      return RTG_ERANGE;
-    attr_set = true;
-  }
+  static std::atomic<unsigned> optin{0};              // (> 64 KB of dynamic LDS: opt-in per kernel and device)
+  if (rtg_lds_optin(reinterpret_cast<const void*>(&reswgrad_kernel<CIN, KT>), optin) != RTG_OK) return RTG_ERANGE;
   RTG_KLAUNCH((reswgrad_kernel<CIN, KT>), dim3(splits), dim3(RTG_THREADS), lds_bytes, s, a);
   return rtg_launch_status();
 }

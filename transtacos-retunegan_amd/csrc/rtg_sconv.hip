@@ -227,11 +227,8 @@ int rtg_sconv_candidates(const RtgConv1dDesc* d, int* codes, int max) {
 template <int KS, int NT, int MAXIT>
 static int sconv_go(const SArgs& a, unsigned blocks, size_t lds_bytes, hipStream_t s) {
   auto k = sconv_kernel<KS, NT, MAXIT>;
-  static bool attr_set = false;                        // (> 64 KB of dynamic LDS needs the opt-in once per kernel)
-  if (lds_bytes > 64 * 1024 && !attr_set) {
-    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return RTG_ERANGE;
-    attr_set = true;
-  }
+  static std::atomic<unsigned> optin{0};              // (> 64 KB of dynamic LDS: opt-in per kernel and device)
+  if (lds_bytes > 64 * 1024 && rtg_lds_optin((const void*)k, optin) != RTG_OK) return RTG_ERANGE;
   RTG_KLAUNCH(k, dim3(blocks), dim3(KS * 64), lds_bytes, s, a);
   return rtg_launch_status();
 }

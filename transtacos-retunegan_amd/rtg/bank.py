@@ -25,6 +25,9 @@ from .lib import current_stream_ptr as _lib_stream_ptr
 
 # RTG_GCONV=0 (rtg/ops.py): the thin-group layers never leave the matrix cores, no vector-ALU weight images either
 GCONV_IMAGES = os.environ.get('RTG_GCONV', '1') == '1' and os.environ.get('RTG_GCONV_PACK', '1') == '1'
+# debug aid (tests/conftest.py turns it on): WeightBank.lean_pack() fills every image it drops with NaN, so a launch that
+# still reads one without reporting it (note_std_use) fails loudly instead of training on the weights of an earlier step
+LEAN_POISON = False
 
 
 def _stream():
@@ -270,6 +273,7 @@ class WeightBank:
                 ly.gmfma_size = (ly.groups * 16 if ly.gmfma_pair else ly.cout) * (ly.cin // ly.groups) * ly.gmfma_kp
                 poff += (ly.gmfma_size + 63) & ~63
         self.packed = torch.empty(poff, device=self.device, dtype=torch.float32)
+        self._old_tables = []
         self._bind_params()
         self._build_tables()
         import weakref
@@ -357,6 +361,11 @@ class WeightBank:
                 pack.append(L.PackJob(ly.v_off, ly.scale_off, ly.gmfma_off, ly.gmfma_size, L.PACK_GMFMA_FWD, ly.groups,
                                       ly.cout // ly.groups, ly.cin // ly.groups, ly.k, ly.k, ly.inner_c, ly.gmfma_kp, 16,
                                       ly.gmfma_pair, 0, 0, 0))
+        # superseded tables stay alive: a captured HIP graph holds their device pointers (and its job count) baked into the
+        # rtg_weights_pack / rtg_weightnorm_scales launches; table_gen tells train.Trainer to capture again
+        if getattr(self, 'pack_table', None) is not None:
+            self._old_tables += [self.norm_table, self.pack_table]
+        self.table_gen = getattr(self, 'table_gen', -1) + 1
         self.norm_table = _table(norm, self.device)
         self.pack_blocks, self.pack_lds = L.assign_pack_blocks(pack)
         self.pack_table = _table(pack, self.device)
@@ -392,6 +401,9 @@ class WeightBank:
                 if has16 and ly.std_on[side] and not ly.std_used[side]:
                     ly.std_on[side] = False
                     n += 1
+                    if LEAN_POISON:
+                        off, size = (ly.bwd_off, ly.bwd_size) if side else (ly.fwd_off, ly.fwd_size)
+                        self.packed[off:off + size].fill_(float('nan'))
         if n:
             self._build_tables()
         return n

@@ -67,7 +67,10 @@ def _conv_bytes(d, args):
 def _run_conv(d, args, flop, label, what):
     """rtg_conv1d with the tuned block shape (rtg/tune.py); args = everything after the descriptor"""
     d.tile_cfg = tune.conv_cfg(d, lambda: lib.rtg_conv1d(C.byref(d), *args))
-    if d.wp16 and d.tile_cfg < 8000:         # a general block shape on a layer with the fragment image: reads the standard one
+    if d.tile_cfg < 8000:
+        # a general block shape reads the STANDARD image: report it, keyed on the image's address (a dictionary miss for
+        # layers without a fragment image) rather than on d.wp16 — a caller that forgot wp16 in its descriptor must not
+        # make the lean pack drop an image that is still read (round 4: the unfused ResidualStack forward)
         _bank.note_std_use(args[3].value)
     check(_timed('conv1d', lib.rtg_conv1d_variant(C.byref(d)) if PROFILE is not None else 0, flop,
                  lambda: lib.rtg_conv1d(C.byref(d), *args), label, _conv_bytes(d, args) if PROFILE is not None else 0), what)
@@ -516,7 +519,7 @@ class ResStackFn(torch.autograd.Function):
                 d = _desc(B=B, C1=Cc, C2=0, L_in=Lx, groups=g, Cg=cg, Mg=mg, K=k, stride=1, dil=ly.dil, pad=ly.pad, Q=Lx,
                           out_C=Cc, out_L=Lx, pre_mode=L.PRE_LRELU, pre_slope=pre_slope,
                           act=L.ACT_LRELU if last else L.ACT_NONE, act_slope=final_act_slope if last else 1.0,
-                          tile_m=ly.fwd_tm, tap_major=ly.fwd_tap, bf16=ly.fwd_bf)
+                          tile_m=ly.fwd_tm, tap_major=ly.fwd_tap, bf16=ly.fwd_bf, wp16=ly.fwd16)
                 res = ins[i - 1] if i % 2 else None           # x_{j+1} = x_j + conv3(lrelu(r_{j+1}))
                 _run_conv(d, (_p(ins[i]), None, None, bank.fwd_ptr(ly), bank.bias_ptr(ly), None, _p(res), _p(outs[i]), None,
                               st), _conv_flop(ly, B, Lx), f'fwd {ly.name} B{B} L{Lx}', f'conv1d fwd {ly.name}')
@@ -699,8 +702,7 @@ def _launch_group(descs, ptr_rows, flops, label, what):
         return False
     for i in range(n):
         darr[i].tile_cfg = cfg
-        if darr[i].wp16:                     # (group members run general block shapes: the standard images)
-            _bank.note_std_use(parr[i].wp)
+        _bank.note_std_use(parr[i].wp)       # (group members run general block shapes: the standard images)
     check(_timed('conv1d', lib.rtg_conv1d_variant(C.byref(darr[0])) if PROFILE is not None else 0, sum(flops),
                  lambda: lib.rtg_conv1d_group(n, darr, parr, st), label), what)
     return True
@@ -921,7 +923,26 @@ def mrf_group_ok(lys, x):
 # ---------------------------------------------------------------------------------------------------------------
 # GaussianNoise
 # ---------------------------------------------------------------------------------------------------------------
-NOISE_ACC = _os.environ.get('RTG_NOISE_ACC', '1') == '1'      # A/B knob: 0 = part.sum() and autograd's accumulation
+# The shared scalar's gradient is added straight into the bank's gradient slot by a launch of ours — but only inside a
+# backward that asked for it (train.Trainer.g_step wraps total.backward() in noise_grad_accumulate()): any other
+# differentiation (torch.autograd.grad(...), a user's own backward) gets dw returned like every other gradient and
+# w.grad stays untouched.
+_NOISE_ACC_DEPTH = 0
+
+
+class noise_grad_accumulate:
+    """context: GaussianNoise backward passes inside accumulate d noise.w into noise.w.grad in place (one launch of ours
+    instead of an ATen sum + add_ per noise call) and return no gradient for it"""
+
+    def __enter__(self):
+        global _NOISE_ACC_DEPTH
+        _NOISE_ACC_DEPTH += 1
+        return self
+
+    def __exit__(self, *exc):
+        global _NOISE_ACC_DEPTH
+        _NOISE_ACC_DEPTH -= 1
+        return False
 
 
 class NoiseFn(torch.autograd.Function):
@@ -948,7 +969,7 @@ class NoiseFn(torch.autograd.Function):
         # the shared scalar's gradient: where w.grad is a live buffer (the weight bank's flat gradient view) a one-block
         # launch adds the partials into it in fixed order and autograd gets no gradient to accumulate (six ATen sum + five
         # grad add_ launches per generator backward -> six launches of ours)
-        g = w.grad if ctx.needs_input_grad[1] and NOISE_ACC and not torch.is_grad_enabled() else None
+        g = w.grad if ctx.needs_input_grad[1] and _NOISE_ACC_DEPTH > 0 and not torch.is_grad_enabled() else None
         if g is not None and g.is_cuda and g.dtype == torch.float32 and g.numel() == 1:
             check(lib.rtg_noise_lrelu_bwd_acc(_p(x), _p(w), _p(u_in), _p(dy), _p(dx), _p(part), NoiseFn.N_BLOCKS, x.numel(),
                                               slope, C.c_ulonglong(seed), _p(salt), _p(g), _stream()), 'noise bwd')

@@ -7,8 +7,11 @@ the D x d_train_times -> G update order with its detach semantics and loss weigh
 
 What is new (absent from the reference): one flat fused AdamW launch per optimizer, device-side NaN guard (no host
 sync inside a step), the real wave's spectra computed once per step, and plain data parallelism over clips: one process
-per GPU, gradients of each model's flat buffer all-reduced with RCCL (torch.distributed backend "nccl") on a side stream
-as soon as that model's backward has been flushed, overlapping the rest of the backward.
+per GPU, gradients of each model's flat buffer all-reduced with RCCL (torch.distributed backend "nccl").  Two exchange
+policies (DataParallel.exchange, Trainer.set_exchange): 'update' — the all-reduces run on the compute stream between the
+backward and the optimizer launch, one HIP-graph segment per optimizer update; 'disc' — each discriminator's all-reduce
+is issued from its bank's flush on a high-priority communication stream and overlaps the next discriminator's backward
+(graphs cut per discriminator).  bench.py times both on the job's actual links when it runs on more than one rank.
 """
 import ctypes as C
 import itertools  # noqa: F401
@@ -34,16 +37,21 @@ CAPTURE_ERROR_MODE = os.environ.get('RTG_CAPTURE_MODE', 'thread_local')
 LEAN_PACK = os.environ.get('RTG_LEAN_PACK', '1') == '1'
 
 
-def _inline_reduce():
-    """Where the gradient all-reduces run.  Default: on the compute stream itself (async_op=False: stream-ordered after the
-    kernels that wrote the gradients and before the optimizer launch, no communication stream, no event hops) — measured on
-    one MI355X over a 1-rank RCCL group, graph replay (gpurun r04f): 28.1 ms/step against 29.9 through the high-priority
-    communication stream (27.7 with the collectives left out): the two cross-stream hops per exchange cost more than the
-    RCCL kernels.  RTG_DP_INLINE=0, or RTG_DP_CUT=disc (whose point is the overlap), keeps the communication stream."""
-    v = os.environ.get('RTG_DP_INLINE')
-    if v is None:
-        v = '0' if os.environ.get('RTG_DP_CUT') == 'disc' else '1'
-    return v == '1'
+EXCHANGE_POLICIES = ('update', 'disc')
+
+
+def default_exchange():
+    """The exchange policy a Trainer starts with (RTG_DP_CUT: 'update' | 'disc'; Trainer.set_exchange changes it).
+    'update': all-reduces on the compute stream itself (async_op=False: stream-ordered after the kernels that wrote the
+    gradients and before the optimizer launch, no communication stream, no event hops).  Measured on one MI355X over a
+    1-RANK RCCL group (round 4): 28.1 ms/step against 29.9-30.8 for 'disc' (27.7 with the collectives left out) — the
+    cross-stream hops and the serialised discriminator backward passes cost more than they hide when the exchange moves no
+    bytes over xGMI.  A 1-rank measurement cannot decide the N > 1 case: bench.py times both policies on the job's ranks
+    and keeps the faster (config.exchange in its record)."""
+    v = os.environ.get('RTG_DP_CUT', 'update')
+    if v not in EXCHANGE_POLICIES:
+        raise RtgError(f'RTG_DP_CUT={v!r}: expected one of {EXCHANGE_POLICIES}')
+    return v
 
 
 
@@ -209,6 +217,7 @@ class DataParallel:
         self.models = [m for m in models if m is not None]
         self.pending = []
         self.comm_stream = None
+        self.exchange = default_exchange()
 
     def broadcast_parameters(self):
         if not self.enabled:
@@ -223,7 +232,7 @@ class DataParallel:
             return
         if os.environ.get('RTG_DP_DRY') == '1':          # dev: everything but the collective itself (cost attribution)
             return
-        if flat_grad.is_cuda and _inline_reduce():
+        if flat_grad.is_cuda and self.exchange == 'update':
             # stream-ordered on the compute stream: after the kernels that produced the gradients, before the optimizer
             # launch that reads them; no communication stream, no event hops (nothing to overlap with: see _capture)
             dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=self.group, async_op=False)
@@ -317,6 +326,7 @@ class Trainer:
         self.steps = 0
         self._tuned = False
         self._graphs = None
+        self._graph_gen = None
         self._static_in = self._static_out = None
         self._capture_hook = None
         self._cap_stream = None
@@ -326,13 +336,24 @@ class Trainer:
         self.lean_dropped = 0
         for m in (self.generator, *self.discs):
             m.train()
-        if self.dp.enabled and not _inline_reduce():
-            # communication-stream policy: each discriminator's all-reduce is issued from its bank's flush, as soon as ITS
-            # backward is complete, and overlaps the rest of the backward.  (Compute-stream policy, the default: no hooks —
-            # the flushes run on the forked streams of the stacks, and collectives of one communicator must not be in
-            # flight on two streams at once; _d_reduce issues them one after the other on the main stream instead.)
-            for d in self.discs:
-                d.bank().on_flush = self.dp.reduce_async
+        self.set_exchange(self.dp.exchange)
+
+    def set_exchange(self, policy):
+        """'update' | 'disc' (module docstring).  Drops captured graphs: the policy decides where they are cut."""
+        if policy not in EXCHANGE_POLICIES:
+            raise RtgError(f'exchange policy {policy!r}: expected one of {EXCHANGE_POLICIES}')
+        self.dp.wait()
+        self.dp.exchange = policy
+        self._graphs = None
+        # 'disc': each discriminator's all-reduce is issued from its bank's flush, as soon as ITS backward is complete, and
+        # overlaps the rest of the backward.  'update': no hooks — the flushes run on the forked streams of the stacks, and
+        # collectives of one communicator must not be in flight on two streams at once; _d_reduce issues them one after the
+        # other on the main stream instead.
+        for d in self.discs:
+            d.bank().on_flush = self.dp.reduce_async if (self.dp.enabled and policy == 'disc') else None
+
+    def _table_gen(self):
+        return sum(m.bank().table_gen for m in (self.generator, *self.discs))
 
     def _freeze(self, flag):
         for d in self.discs:
@@ -412,7 +433,8 @@ class Trainer:
             total = ops.weighted_sum(terms, weights)
             losses['gen_all'] = total
             self.generator.bank().set_flag(total)
-            total.backward()
+            with ops.noise_grad_accumulate():
+                total.backward()
         finally:
             self._freeze(False)
         losses = _detached(losses)
@@ -497,6 +519,11 @@ class Trainer:
         all-reduces run eagerly between the segments, so one code path serves 1 and N GPUs.  Inputs are copied into
         static buffers; the returned loss dicts hold static device scalars overwritten by every replay.  The learning
         rate is a launch argument: end_epoch() drops the graphs and the next step captures them again."""
+        if self._graphs is not None and self._graph_gen != self._table_gen():
+            # a bank rebuilt its device job tables since the capture (an eager launch at another shape restored a weight
+            # image the lean pack had dropped, rtg/bank.py:restore_std): the captured pack launches still name the old
+            # tables (kept alive, so the replay is memory-safe) — capture the step again on the new ones
+            self._graphs = None
         self.prepare_graphs(x, y_tmpl, y)
         sx, sy_tmpl, sy = self._static_in
         for dst, src in ((sx, x), (sy_tmpl, y_tmpl), (sy, y)):
@@ -537,7 +564,7 @@ class Trainer:
         #       Measured on one MI355X over a 1-rank RCCL group (profiles/r04_dp_capture.txt): 30.8 ms/step against 27.8
         #       without the cuts — serialising the stacks' backward passes and five more graph launches per step cost more
         #       than the exchange they hide, so this is the opt-in for slow links.
-        dp = self.dp.enabled and os.environ.get('RTG_DP_CUT', 'update') == 'disc'
+        dp = self.dp.enabled and self.dp.exchange == 'disc'
         order = sorted(self.discs, key=lambda d: -d.bank().n_params)
         def d_forward_and_first():
             losses, parts = self._d_forward(sy, state['y_hat'].detach())
@@ -634,6 +661,7 @@ class Trainer:
                 d.bank().on_flush = h
         torch.cuda.current_stream().wait_stream(cap)
         self._graphs = graphs
+        self._graph_gen = self._table_gen()
         self._static_out = (state['dl'], state['gl'])
 
     def end_epoch(self):
