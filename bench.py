@@ -363,6 +363,12 @@ def main():
     import hparam as hp
     import train as train_mod
     from train import Trainer
+    t_start = time.perf_counter()
+
+    def note(msg):
+        """progress on stderr (a multi-rank set-up takes minutes: tuner, two captures, the policy trial)"""
+        if multi or os.environ.get('RTG_BENCH_VERBOSE') == '1':
+            print(f'[bench rank {rank} +{time.perf_counter() - t_start:6.1f}s] {msg}', file=sys.stderr, flush=True)
     desc, use_mpd, use_mtd, d_times, batch, T = WORKLOADS[a.workload]
     if a.batch:
         batch = a.batch
@@ -387,8 +393,10 @@ def main():
     # gradients; the all-reduces run between the segments (tests/test_zz_dp_gpu.py::test_two_ranks_graphed_step).
     # RTG_GRAPH=0: the eager step.  Capture happens here, outside warm-up and timing; if it fails the eager step is timed
     # and the record says so.
+    note('trainer built; first step (block shapes are timed here)')
     tr.train_step(*next_batch())
     torch.cuda.synchronize()
+    note('first step done')
 
     def setup_step(policy):
         """-> (step function, launch mode) under the exchange policy `policy`: graphs captured and replayed once, or the
@@ -414,6 +422,7 @@ def main():
             return ok_
 
         ok = 1.0
+        note(f'exchange {policy!r}: capturing')
         try:
             tr.prepare_graphs(*next_batch())
         except Exception as e:  # noqa: BLE001
@@ -422,6 +431,7 @@ def main():
             import traceback
             print(f'[rank {rank}] graph capture failed:\n' + traceback.format_exc(), file=sys.stderr, flush=True)
         ok = agree(ok, 'graph capture')
+        note(f'exchange {policy!r}: captured ok={ok}; first replay')
         if ok:
             # the first replay, still outside warm-up and timing; a rank on which it raises takes every rank back to the
             # eager step (the collectives between the segments are the eager step's: same buffers, same order)
@@ -473,11 +483,13 @@ def main():
             step, mode = setup_step(pol)
             step(*next_batch())
             exchange_trials[pol] = round(timed(step, 5)[0] / 5 * 1e3, 3)
+            note(f'exchange {pol!r}: {exchange_trials[pol]} ms/step over 5 steps ({mode})')
         best = min(train_mod.EXCHANGE_POLICIES, key=lambda p_: exchange_trials[p_])
         if best != tr.dp.exchange:
             step, mode = setup_step(best)
     else:
         step, mode = setup_step(tr.dp.exchange)
+    note(f'set-up done: exchange {tr.dp.exchange!r}, {mode}; warm-up and timing')
     for _ in range(a.warmup):
         step(*next_batch())
     # EXACTLY a.steps steps between barrier + synchronize pairs; `elapsed` is the MAX over the ranks

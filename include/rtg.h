@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define RTG_ABI_VERSION 8
+#define RTG_ABI_VERSION 9
 
 #define RTG_OK 0
 #define RTG_EINVAL (-1)   /* inconsistent descriptor               */
@@ -104,7 +104,21 @@ typedef struct RtgConv1dDesc {
                                   2: ... and the caller also accepts the split-K kernel of rtg_sconv.hip (codes 9004 / 9008:
                                   few columns, the reduction split over the waves of a block — a summation order of its
                                   own, where every other block shape gives identical bits)                             */
+  int io_bf16;                 /* ABI 9: bf16 feature maps in HBM (BASELINE configs[2]) — a bit mask of RTG_IO_*: which of
+                                  the tensor arguments are bf16 NCW instead of fp32 (the pointer parameters stay `float*`).
+                                  RTG_IO_X_BF16: x1 holds bf16 values that are ALREADY activated — what a producer with
+                                  RTG_IO_OUT_BF16 stored, or a gradient; the kernel applies no pre-activation to it
+                                  (pre_mode / pre_slope then describe the tensor, not work to do).
+                                  RTG_IO_OUT_BF16: out = bf16(leaky_relu(result, enc_slope)), rounded to nearest even — the
+                                  consumer's leaky-relu applied once by the producer (enc_slope = 1: a plain bf16 store,
+                                  used for gradients); the sign, all a leaky-relu backward needs, survives.
+                                  RTG_IO_MASK_BF16 / RTG_IO_RES_BF16: `mask` / `res` are bf16.
+                                  Needs bf16 = 1 and a block shape of the dense-layer kernel (codes 8xxx):
+                                  rtg_conv1d_tile_candidates lists only those for such a descriptor, possibly none —
+                                  the caller then converts (rtg_bf16_decode / rtg_bf16_encode) around an fp32 launch.   */
+  float enc_slope;
 } RtgConv1dDesc;
+enum { RTG_IO_X_BF16 = 1, RTG_IO_OUT_BF16 = 2, RTG_IO_MASK_BF16 = 4, RTG_IO_RES_BF16 = 8 };
 
 int rtg_conv1d(const RtgConv1dDesc* d, const float* x1, const float* x2, const float* aux, const float* wp,
                const float* bias, const float* mask, const float* res, float* out, float* out2, void* stream);
@@ -174,6 +188,10 @@ typedef struct RtgWgradDesc {
                                   rounding-level differences, each reproducible run to run                           */
   int bf16;                    /* 1: both operands rounded to bf16 as they are read from LDS, bf16 matrix cores, fp32
                                   accumulation and fp32 split partials (BASELINE configs[2])                         */
+  int io_bf16;                 /* ABI 9: bf16 feature maps in HBM — bit 0 (RTG_IO_X_BF16): x1 is bf16 and already activated
+                                  (no pre-activation is applied); bit 1 (RTG_IO_OUT_BF16): dy is bf16.  Needs bf16 = 1 and
+                                  a shape of the dense-layer kernel (codes 10 .. 14): rtg_wgrad_shape_candidates lists only
+                                  those for such a descriptor, possibly none (the caller then converts).  Partials stay fp32 */
 } RtgWgradDesc;
 
 int rtg_conv1d_wgrad(const RtgWgradDesc* d, const float* x1, const float* x2, const float* dy, const float* gy_aux,
@@ -339,6 +357,12 @@ int rtg_axpby(const float* a, const float* b, float* out, long long n, float alp
               void* stream);
 /* dx = dy * (ref > 0 ? 1 : slope) */
 int rtg_lrelu_bwd(const float* dy, const float* ref, float* dx, long long n, float slope, void* stream);
+/* (ABI 9) bf16 feature maps in HBM, the conversions at the edge of the kernels that read / write them natively
+ * (RtgConv1dDesc.io_bf16):  rtg_bf16_encode: dst[i] = bf16(leaky_relu(src[i], slope)) rounded to nearest even (slope 1: a
+ * plain conversion, gradients);  rtg_bf16_decode: dst[i] = v > 0 ? v : v / slope for v = float(src[i]).  `dst` / `src` of
+ * the bf16 side are arrays of 2-byte elements */
+int rtg_bf16_encode(const float* src, void* dst_bf16, long long n, float slope, void* stream);
+int rtg_bf16_decode(const void* src_bf16, float* dst, long long n, float slope, void* stream);
 
 /* nn.AvgPool1d(4, 2, 1) (discrminator.py:113) forward / backward on [rows, L] -> [rows, L/2] */
 int rtg_avgpool4s2_fwd(const float* x, float* out, int rows, int L, void* stream);
@@ -355,10 +379,14 @@ int rtg_period_fold_bwd(const float* dout, float* dy, int B, int T, int p, int H
  *   RTG_LOSS_MSE_TARGET (target - a)^2                  LSGAN terms, equal-length rows (loss.py:121-122,142)
  *   RTG_LOSS_MSE_REL    (target - (a - b))^2            relative LSGAN terms, b detached: no gradient to b
  *                                                        (loss.py:116,136: hparam.relative_gan_loss)
+ *   RTG_LOSS_L1_ENC     |dec(a) - dec(b)|               (ABI 9) F.l1_loss over bf16 feature maps as RTG_IO_OUT_BF16 stores
+ *                                                        them: a, b are bf16 arrays of leaky_relu(x, s) values, dec(v) =
+ *                                                        v > 0 ? v : v / s with s = the job's `target` field; da, db are
+ *                                                        written as bf16 (gradients w.r.t. the decoded values)
  * Partials are summed in fixed order (ws needs 64 * n_jobs floats).  The backward writes (not accumulates)
  * d loss / d a into da and / or d loss / d b into db, scaled by w_j / n_j and by the device scalar *gscale (NULL = 1). */
 #define RTG_MAX_LOSS_JOBS 48
-enum { RTG_LOSS_L1 = 0, RTG_LOSS_L1_L1LOG = 1, RTG_LOSS_MSE_TARGET = 2, RTG_LOSS_MSE_REL = 3 };
+enum { RTG_LOSS_L1 = 0, RTG_LOSS_L1_L1LOG = 1, RTG_LOSS_MSE_TARGET = 2, RTG_LOSS_MSE_REL = 3, RTG_LOSS_L1_ENC = 4 };
 typedef struct RtgLossJob {
   const float* a; const float* b; float* da; float* db;
   long long n; float w; float target;

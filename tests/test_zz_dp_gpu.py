@@ -428,13 +428,19 @@ def test_graph_capture_with_rccl_collective_in_flight():
     assert got['frac_bad'] < 2e-3, (got['frac_bad'], got['max_abs_diff'])
 
 
-def _bench(args, env_extra=None, timeout=900):
+def _bench(args, env_extra=None, timeout=400):
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'RTG_BENCH_REHEARSE',
                                                             'RTG_DP_FORCE', 'RTG_DP_CUT', 'RTG_TUNE')}
     env.update(env_extra or {})
-    return subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), *args], env=env, capture_output=True, text=True,
-                          timeout=timeout)
+    # stderr (the ranks' progress lines) goes to a file the GPU box's silence watchdog can see grow
+    os.makedirs(os.path.join(REPO, 'gpurun_out'), exist_ok=True)
+    log = os.path.join(REPO, 'gpurun_out', 'bench_selflaunch.err')
+    with open(log, 'a') as err:
+        r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), *args], env=env, stdout=subprocess.PIPE, stderr=err,
+                           text=True, timeout=timeout)
+    r.stderr = open(log).read()
+    return r
 
 
 def test_bench_gpus_2_launches_two_ranks_itself_or_refuses():

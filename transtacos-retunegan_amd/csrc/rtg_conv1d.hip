@@ -197,6 +197,11 @@ static bool dconv_code_ok(const RtgConv1dDesc* d) {
 
 extern "C" int rtg_conv1d_variant(const RtgConv1dDesc* d) {
   if (!d) return RTG_ENULL;
+  if (d->io_bf16 != 0) {
+    int code = d->tile_cfg;
+    if (code == 0 && rtg_dconv_candidates(d, &code, 1) < 1) return RTG_ERANGE;
+    return (code > RTG_DCONV_CODE && code < RTG_SCONV_CODE) ? code : RTG_EINVAL;
+  }
   if (d->tile_cfg > RTG_SCONV_CODE) return sconv_code_ok(d) ? d->tile_cfg : RTG_EINVAL;
   if (d->tile_cfg > RTG_DCONV_CODE) return dconv_code_ok(d) ? d->tile_cfg : RTG_EINVAL;
   if (d->tile_cfg > RTG_RESCONV_CODE && d->tile_cfg <= RTG_RESCONV_CODE + 2)
@@ -217,6 +222,10 @@ extern "C" int rtg_conv1d_tile_candidates(const RtgConv1dDesc* d, int* cfgs, int
   if ((d->tile_m != 32 && d->tile_m != 16) || d->Mg < 1 || d->Q < 1 || d->B < 1 || d->groups < 1 || d->stride < 1 ||
       d->K < 1 || d->dil < 1 || max < 1)
     return RTG_EINVAL;
+  if (d->io_bf16 != 0) {
+    // bf16 tensors (ABI 9): only the dense-layer kernel reads / writes them — its shapes or nothing (the caller converts)
+    return rtg_dconv_candidates(d, cfgs, max < 8 ? max : 8);
+  }
   if (rtg_thin_kind(d)) {       // served by a bandwidth kernel: nothing to choose (0 = the library's default)
     cfgs[0] = 0;
     return 1;
@@ -285,6 +294,7 @@ struct ConvPlan {
 static int conv_plan(const RtgConv1dDesc* d, const float* x1, const float* x2, const float* aux, const float* wp,
                      const float* bias, const float* mask, const float* res, float* out, float* out2, ConvPlan* pl) {
   if (!d || !x1 || !wp) return RTG_ENULL;
+  if (d->io_bf16 != 0) return RTG_EINVAL;                  // (bf16 tensors: the dense-layer kernel only, rtg_conv1d routes them)
   if (d->out_split == 0 ? !out : (!out && !out2)) return RTG_ENULL;
   if (d->out_split < 0 || d->out_split >= d->out_C) return RTG_EINVAL;
   if (d->out_split > 0 && (mask || res)) return RTG_EINVAL;
@@ -392,6 +402,13 @@ extern "C" int rtg_conv1d(const RtgConv1dDesc* d, const float* x1, const float* 
                           const float* bias, const float* mask, const float* res, float* out, float* out2,
                           void* stream) {
   if (!d) return RTG_ENULL;
+  if (d->io_bf16 != 0) {
+    // bf16 tensors: the dense-layer kernel or nothing.  tile_cfg 0 (the library's heuristic) = its best-scored shape
+    int code = d->tile_cfg;
+    if (code == 0 && rtg_dconv_candidates(d, &code, 1) < 1) return RTG_ERANGE;
+    if (code <= RTG_DCONV_CODE || code > RTG_SCONV_CODE || x2 || aux || out2) return RTG_EINVAL;
+    return rtg_dconv_launch(d, code, x1, wp, bias, mask, res, out, (hipStream_t)stream);
+  }
   if (d->tile_cfg == 0 && x1 && wp) {
     const int thin = rtg_thin_kind(d);
     if (thin > 0) {

@@ -44,7 +44,7 @@ struct WArgs {
   // second dimension (RtgWgradDesc.h_*; forward geometry): a clip is an (item, output row) pair, a channel a (channel,
   // kernel row) pair; x is [items, Cg / h_k, h_in, L_in], dy [items, Mg, h_n, dy_L]
   int h_in, h_k, h_stride, h_pad, h_n;
-  int bf;                       // (host side: which instance)
+  int bf, io;                   // (host side: which instance)
 };
 
 __device__ __forceinline__ float dw_load(rsrc_t r, unsigned voff, unsigned soff) {
@@ -61,9 +61,18 @@ __device__ __forceinline__ f32x4 dw_load4(rsrc_t r, unsigned voff, unsigned soff
 // reductions — two of the 4-element gy groups, converted when the fragment is built; the column image holds bf16 (a tile is
 // two 32-reduction groups of four planes [kgrp][column][8 bf16], the staging writes are 2-byte), the activation is applied
 // in fp32 and rounded to nearest even at the LDS write.  Same loads, same loop; an eighth of the matrix instructions.
+//
+// IO (RtgWgradDesc.io_bf16, round 5: bf16 feature maps in HBM; BF only).  Bit 0, x is bf16 and already activated (what a
+// producer with RTG_IO_OUT_BF16 stored): the K taps of a reduction are one 16-byte load (8 positions; fp32: 16 + 4 bytes) and
+// go to the column image as they are — no activation, no conversion, a 2-byte LDS write each.  Bit 1, dy is bf16: a lane's
+// fragment of 8 consecutive reductions is ONE 16-byte load (a second one behind a clip boundary, merged by bit selects;
+// fp32: four loads and eight conversions); rows of at least 8 positions.
 using bf16x8 = __bf16 __attribute__((ext_vector_type(8)));
-template <int S, int kWB, int NCH, int RW, int kK, bool TWO_D, bool BF>
+template <int S, int kWB, int NCH, int RW, int kK, bool TWO_D, bool BF, int IO = 0>
 __global__ __launch_bounds__(kWB * 64, 2) void dwgrad_kernel(const WArgs a) {
+  static_assert(IO == 0 || BF, "bf16 tensors go with bf16 operands");
+  constexpr bool XB = (IO & 1) != 0, YB = (IO & 2) != 0;
+  constexpr unsigned XES = XB ? 2u : 4u, YES = YB ? 2u : 4u;           // element sizes of x and dy
   constexpr int NSTEP = BF ? 2 : kNG;                                 // matrix k-groups per 64-reduction tile
   constexpr int kCols = kCch * kK, kNCT = kCols / 16;                 // columns / column tiles of one chunk
   // The column image of one chunk and 16-reduction group: four planes [kgrp][column][4 reductions] (element (column, r) at
@@ -92,7 +101,6 @@ __global__ __launch_bounds__(kWB * 64, 2) void dwgrad_kernel(const WArgs a) {
 
   const rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
   const rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.dy_bytes, 0x00020000);
-  const unsigned rowb_x = (unsigned)a.L_in * 4u;
   const int r16 = lane & 15, kgrp = lane >> 4;
 
   auto divq = [&](int n, int& q) __attribute__((always_inline)) {      // n / Q (n < 2^23) through the float reciprocal
@@ -104,38 +112,55 @@ __global__ __launch_bounds__(kWB * 64, 2) void dwgrad_kernel(const WArgs a) {
   };
 
   // ---- rows: this lane's four consecutive reductions of row (wave's tile, r16) for each 16-reduction group of a tile
-  f32x4 l1[RW][kNG], l2[RW][kNG];
-  int arem[kNG], aval[kNG];                    // elements before the clip boundary; valid elements (n < n_red)
-  const unsigned arow = (unsigned)(m0 + wave * RW * 16 + r16) * (unsigned)(a.h_n * a.dy_L) * 4u;     // (h_n == 1 in 1-D)
-  const unsigned atile = 16u * (unsigned)(a.h_n * a.dy_L) * 4u;  // bytes between the wave's row tiles
+  constexpr int NAG = YB ? NSTEP : kNG;        // row-operand loads per tile: 4-element groups (fp32 dy) or 8-element fragments
+  constexpr int AEL = YB ? 8 : 4;
+  f32x4 l1[RW][NAG], l2[RW][NAG];              // (bf16 dy: the 16 bytes are 8 elements)
+  int arem[NAG], aval[NAG];                    // elements before the clip boundary; valid elements (n < n_red)
+  const unsigned arow = (unsigned)(m0 + wave * RW * 16 + r16) * (unsigned)(a.h_n * a.dy_L) * YES;     // (h_n == 1 in 1-D)
+  const unsigned atile = 16u * (unsigned)(a.h_n * a.dy_L) * YES;  // bytes between the wave's row tiles
   // byte offset of (clip, row 0, position 0) in dy: clip = item (1-D) or (item, output row)
   auto dy_clip = [&](int clip) __attribute__((always_inline)) {
     if constexpr (TWO_D) {
       const int item = clip / a.h_n, ho = clip - item * a.h_n;
-      return ((unsigned)item * (unsigned)a.Mg * (unsigned)a.h_n + (unsigned)ho) * (unsigned)a.dy_L * 4u;
+      return ((unsigned)item * (unsigned)a.Mg * (unsigned)a.h_n + (unsigned)ho) * (unsigned)a.dy_L * YES;
     } else {
-      return (unsigned)clip * (unsigned)a.Mg * (unsigned)a.dy_L * 4u;
+      return (unsigned)clip * (unsigned)a.Mg * (unsigned)a.dy_L * YES;
     }
   };
   auto a_load = [&](int tile) __attribute__((always_inline)) {
 #pragma unroll
-    for (int g = 0; g < kNG; ++g) {
-      // this lane's four consecutive reductions of group g (bf16: halves g & 1 of the 8 reductions of k-group g >> 1)
-      const int n0 = tile * kTT + (BF ? (g >> 1) * 32 + kgrp * 8 + (g & 1) * 4 : g * 16 + kgrp * 4);
+    for (int g = 0; g < NAG; ++g) {
+      // this lane's four consecutive reductions of group g (bf16: halves g & 1 of the 8 reductions of k-group g >> 1); bf16
+      // dy: the 8 reductions of k-group g
+      const int n0 = tile * kTT + (YB ? g * 32 + kgrp * 8 : (BF ? (g >> 1) * 32 + kgrp * 8 + (g & 1) * 4 : g * 16 + kgrp * 4));
       int q0;
       const int clip = divq(n0, q0);
       const int left = a.n_red - n0;
       aval[g] = left < 0 ? 0 : left;
       arem[g] = a.Q - q0;
-      const unsigned o1 = left > 0 ? dy_clip(clip) + arow + (unsigned)q0 * 4u : DW_OOB;
-      // the part behind a clip boundary: row r of the NEXT clip, element e at position e - arem
-      const unsigned o2 = (left > arem[g] && arem[g] < 4) ? dy_clip(clip + 1) + arow - (unsigned)arem[g] * 4u : DW_OOB;
+      const unsigned o1 = left > 0 ? dy_clip(clip) + arow + (unsigned)q0 * YES : DW_OOB;
+      // the part behind a clip boundary: row r of the NEXT clip, element e at position e - arem.  (The very first bytes of
+      // the tensor cannot be addressed from before its start: clip + 1 >= 1 keeps this offset positive.)
+      const unsigned o2 = (left > arem[g] && arem[g] < AEL) ? dy_clip(clip + 1) + arow - (unsigned)arem[g] * YES : DW_OOB;
 #pragma unroll
       for (int i = 0; i < RW; ++i) {
         l1[i][g] = dw_load4(rd, o1, i * atile);
         l2[i][g] = dw_load4(rd, o2, i * atile);
       }
     }
+  };
+  // bf16 dy: the fragment of k-group g — elements before the clip boundary from the first load, the rest from the second,
+  // nothing past the end of the reduction; as bit selects on the packed pairs
+  auto a_frag_b = [&](int i, int g) __attribute__((always_inline)) {
+    const u32x4 v1 = __builtin_bit_cast(u32x4, l1[i][g]), v2 = __builtin_bit_cast(u32x4, l2[i][g]);
+    u32x4 f;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const unsigned m1 = (2 * d < arem[g] ? 0xffffu : 0u) | (2 * d + 1 < arem[g] ? 0xffff0000u : 0u);
+      const unsigned mv = (2 * d < aval[g] ? 0xffffu : 0u) | (2 * d + 1 < aval[g] ? 0xffff0000u : 0u);
+      f[d] = ((v1[d] & m1) | (v2[d] & ~m1)) & mv;
+    }
+    return __builtin_bit_cast(bf16x8, f);
   };
   auto a_frag = [&](int i, int g) __attribute__((always_inline)) {
     f32x4 f;
@@ -175,8 +200,8 @@ __global__ __launch_bounds__(kWB * 64, 2) void dwgrad_kernel(const WArgs a) {
         ai = orig < 0 ? 0 : orig;
         ssh[j < NSH ? j : 0] = ai - orig;
       }
-      sbv[j] = dw_load4(rx, ok ? (unsigned)ai * 4u : DW_OOB, 0);
-      if constexpr (kK == 5) sb4[j] = dw_load(rx, (ok && (tvm & 16u)) ? (unsigned)(orig + 4) * 4u : DW_OOB, 0);
+      sbv[j] = dw_load4(rx, ok ? (unsigned)ai * XES : DW_OOB, 0);       // (bf16 x: the 16 bytes are 8 positions, all taps)
+      if constexpr (kK == 5 && !XB) sb4[j] = dw_load(rx, (ok && (tvm & 16u)) ? (unsigned)(orig + 4) * 4u : DW_OOB, 0);
     };
     if constexpr (TWO_D) {
       // channel vc = (c, kh): input row ho * h_stride - h_pad + kh of channel c
@@ -217,10 +242,23 @@ __global__ __launch_bounds__(kWB * 64, 2) void dwgrad_kernel(const WArgs a) {
     lv = sbv[j];
     asm volatile("" : "+v"(lv));
     l4 = 0.f;
-    if constexpr (kK == 5) {
+    if constexpr (kK == 5 && !XB) {
       l4 = sb4[j];
       asm volatile("" : "+v"(l4));
     }
+  };
+  // bf16 x: tap t of staged channel j as the 16 bits the column image takes — element t (- ssh) of the 8 loaded, zero outside
+  // the row; the tensor holds activated values (no leaky-relu here)
+  auto tapbits = [&](const u32x4& lv, int j, int t) __attribute__((always_inline)) {
+    auto half = [&](int e) __attribute__((always_inline)) {
+      return e < 0 ? 0u : ((e & 1) ? lv[e >> 1] >> 16 : lv[e >> 1] & 0xffffu);
+    };
+    unsigned v = half(t);
+    if (j < NSH) {
+      const int sh = ssh[j < NSH ? j : 0];
+      v = sh == 0 ? v : (sh == 1 ? half(t - 1) : half(t - 2));
+    }
+    return (unsigned short)((stv >> t) & 1u ? v : 0u);
   };
   auto b_write = [&](int buf) __attribute__((always_inline)) {
     // channel c = wave + kWB * j of the block's NCH * 16: chunk c / 16, column (c % 16) * K + t
@@ -236,8 +274,13 @@ __global__ __launch_bounds__(kWB * 64, 2) void dwgrad_kernel(const WArgs a) {
         taken(j, lv, l4);
 #pragma unroll
         for (int t = 0; t < kK; ++t) {
-          float v = tapval(lv, l4, j, t);
-          pb[((c >> 4) * kBF + ((c & 15) * kK + t) * 4) * 2] = (__bf16)(v > 0.f ? v : v * a.xslope);
+          if constexpr (XB) {
+            reinterpret_cast<unsigned short*>(pb)[((c >> 4) * kBF + ((c & 15) * kK + t) * 4) * 2] =
+                tapbits(__builtin_bit_cast(u32x4, lv), j, t);
+          } else {
+            float v = tapval(lv, l4, j, t);
+            pb[((c >> 4) * kBF + ((c & 15) * kK + t) * 4) * 2] = (__bf16)(v > 0.f ? v : v * a.xslope);
+          }
         }
       }
     } else {
@@ -287,11 +330,18 @@ __global__ __launch_bounds__(kWB * 64, 2) void dwgrad_kernel(const WArgs a) {
       const int nxt = tile + a.splits < a.n_tiles ? tile + a.splits : (1 << 24);
       // this tile's row fragments (requested a tile ago), then the requests of the next tile: past the last tile every
       // offset is out of range and the loads return zeros nobody uses (no branch: the compiler's wait counts stay exact)
-      f32x4 fa[RW][kNG];
+      [[maybe_unused]] f32x4 fa[RW][YB ? 1 : kNG];
+      [[maybe_unused]] bf16x8 fab[RW][YB ? NSTEP : 1];
 #pragma unroll
-      for (int i = 0; i < RW; ++i)
+      for (int i = 0; i < RW; ++i) {
+        if constexpr (YB) {
 #pragma unroll
-        for (int g = 0; g < kNG; ++g) fa[i][g] = a_frag(i, g);
+          for (int g = 0; g < NSTEP; ++g) fab[i][g] = a_frag_b(i, g);
+        } else {
+#pragma unroll
+          for (int g = 0; g < kNG; ++g) fa[i][g] = a_frag(i, g);
+        }
+      }
       a_load(nxt);
       b_load(nxt);
       const float* pb = lds + cur * (NCH * kBF) + boff;
@@ -307,10 +357,14 @@ __global__ __launch_bounds__(kWB * 64, 2) void dwgrad_kernel(const WArgs a) {
 #pragma unroll
           for (int i = 0; i < RW; ++i) {
             bf16x8 av;
+            if constexpr (YB) {
+              av = fab[i][g];
+            } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              av[e] = (__bf16)fa[i][2 * g][e];
-              av[4 + e] = (__bf16)fa[i][2 * g + 1][e];
+              for (int e = 0; e < 4; ++e) {
+                av[e] = (__bf16)fa[i][2 * g][e];
+                av[4 + e] = (__bf16)fa[i][2 * g + 1][e];
+              }
             }
 #pragma unroll
             for (int h = 0; h < NCH; ++h)
@@ -323,19 +377,19 @@ __global__ __launch_bounds__(kWB * 64, 2) void dwgrad_kernel(const WArgs a) {
               accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, ones, accb[i], 0, 0, 0);
             }
           }
-          return;
+        } else {
+#pragma unroll
+          for (int kq = 0; kq < 4; ++kq)
+#pragma unroll
+            for (int i = 0; i < RW; ++i) {
+#pragma unroll
+              for (int h = 0; h < NCH; ++h)
+#pragma unroll
+                for (int j = 0; j < kNCT; ++j)
+                  acc[i][h][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][g][kq], f.b[h][j][kq], acc[i][h][j], 0, 0, 0);
+              if constexpr (BIAS) accb[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][g][kq], 1.0f, accb[i], 0, 0, 0);
+            }
         }
-#pragma unroll
-        for (int kq = 0; kq < 4; ++kq)
-#pragma unroll
-          for (int i = 0; i < RW; ++i) {
-#pragma unroll
-            for (int h = 0; h < NCH; ++h)
-#pragma unroll
-              for (int j = 0; j < kNCT; ++j)
-                acc[i][h][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][g][kq], f.b[h][j][kq], acc[i][h][j], 0, 0, 0);
-            if constexpr (BIAS) accb[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][g][kq], 1.0f, accb[i], 0, 0, 0);
-          }
       };
       // the column fragments of 16-reduction group g + 1 are requested before group g is multiplied (two register sets;
       // one set where twelve fragments are already 48 registers: the 4-chunk shape)
@@ -422,6 +476,10 @@ bool eligible(const RtgWgradDesc* d, int variant) {
   if (kDw[variant].wb == 4 && (d->K != 3 || d->Mg % 128 == 0)) return false;
   if (d->gy_mode != RTG_PRE_NONE || (d->pre_mode != RTG_PRE_NONE && d->pre_mode != RTG_PRE_LRELU)) return false;
   if (d->Q < 4 || d->Q > d->dy_L) return false;                               // (four consecutive reductions span <= 2 clips)
+  // bf16 tensors (RtgWgradDesc.io_bf16): with bf16 operands; a bf16 dy fragment is 8 consecutive reductions
+  if (d->io_bf16 < 0 || d->io_bf16 > 3 || (d->io_bf16 != 0 && !d->bf16)) return false;
+  if ((d->io_bf16 & 2) && d->Q < 8) return false;
+  if ((d->io_bf16 & 1) && d->pre_mode != RTG_PRE_NONE && d->pre_mode != RTG_PRE_LRELU) return false;
   const long long n = (long long)d->B * d->Q;
   if (n >= (1ll << 23)) return false;                                         // float-reciprocal division of n by Q
   if ((long long)d->B * d->Mg * d->dy_L * 4 >= (1ll << 31)) return false;
@@ -455,15 +513,26 @@ int rtg_dwgrad_splits(const RtgWgradDesc* d, int variant) {
   return (int)best_s;
 }
 
-template <int S, int WB, int NCH, int RW, int K, bool TWO_D, bool BF>
-static int dw_launch_bf(const WArgs& a, hipStream_t s) {
-  auto k = dwgrad_kernel<S, WB, NCH, RW, K, TWO_D, BF>;
+template <int S, int WB, int NCH, int RW, int K, bool TWO_D, bool BF, int IO = 0>
+static int dw_launch_io(const WArgs& a, hipStream_t s) {
+  auto k = dwgrad_kernel<S, WB, NCH, RW, K, TWO_D, BF, IO>;
   constexpr int kPS = (kCch * K * 4 + 63) / 64 * 64, kGS = 4 * kPS + 8;     // (the kernel's plane / group strides)
   const size_t lds_bytes = (size_t)2 * NCH * ((BF ? 2 : kNG) * kGS) * sizeof(float);
   static std::atomic<unsigned> optin{0};              // (> 64 KB of dynamic LDS: opt-in per kernel and device)
   if (lds_bytes > 64 * 1024 && rtg_lds_optin((const void*)k, optin) != RTG_OK) return RTG_ERANGE;
   RTG_KLAUNCH(k, dim3((unsigned)(8 * a.per_xcd)), dim3(WB * 64), lds_bytes, s, a);
   return rtg_launch_status();
+}
+// bf16 operands: on fp32 tensors, or with bf16 dy (io 2: the first dense layer of a stack, whose input is fp32) or bf16 x and
+// dy (io 3).  (x bf16 with fp32 dy does not occur: a layer's output gradient is bf16 whenever its input is.)
+template <int S, int WB, int NCH, int RW, int K, bool TWO_D, bool BF>
+static int dw_launch_bf(const WArgs& a, hipStream_t s) {
+  if constexpr (BF) {
+    if (a.io == 2) return dw_launch_io<S, WB, NCH, RW, K, TWO_D, true, 2>(a, s);
+    if (a.io == 3) return dw_launch_io<S, WB, NCH, RW, K, TWO_D, true, 3>(a, s);
+    if (a.io != 0) return RTG_EINVAL;
+  }
+  return dw_launch_io<S, WB, NCH, RW, K, TWO_D, BF, 0>(a, s);
 }
 template <int S, int WB, int NCH, int RW, int K, bool TWO_D>
 static int dw_launch(const WArgs& a, hipStream_t s) {
@@ -473,10 +542,10 @@ static int dw_launch(const WArgs& a, hipStream_t s) {
 int rtg_dwgrad_launch(const RtgWgradDesc* d, int variant, const float* x, const float* dy, float* part, hipStream_t s) {
   if (!eligible(d, variant)) return RTG_EINVAL;
   if (!x || !dy || !part) return RTG_ENULL;
-  if ((reinterpret_cast<uintptr_t>(dy) & 3) != 0) return RTG_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(dy) & ((d->io_bf16 & 2) ? 1 : 3)) != 0) return RTG_EINVAL;
   const DwShape sh = kDw[variant];
   WArgs a;
-  a.x = x; a.dy = dy; a.part = part; a.bf = d->bf16;
+  a.x = x; a.dy = dy; a.part = part; a.bf = d->bf16; a.io = d->io_bf16;
   a.B = d->B; a.Cg = d->Cg; a.L_in = d->L_in; a.Mg = d->Mg; a.Q = d->Q; a.dy_L = d->dy_L; a.pad = d->pad;
   a.xslope = d->pre_mode == RTG_PRE_LRELU ? d->pre_slope : 1.f;
   a.gy_scale = d->gy_scale;
@@ -493,8 +562,8 @@ int rtg_dwgrad_launch(const RtgWgradDesc* d, int variant, const float* x, const 
   const bool two_d = d->h_k > 1 || d->h_n > 1;
   a.h_in = two_d ? d->h_in : 1; a.h_k = two_d ? d->h_k : 1; a.h_stride = two_d ? d->h_stride : 1;
   a.h_pad = two_d ? d->h_pad : 0; a.h_n = two_d ? d->h_n : 1;
-  a.x_bytes = (d->B / a.h_n) * (d->C1 / a.h_k) * a.h_in * d->L_in * 4;
-  a.dy_bytes = d->B * d->Mg * d->dy_L * 4;                            // (B = items * h_n)
+  a.x_bytes = (d->B / a.h_n) * (d->C1 / a.h_k) * a.h_in * d->L_in * ((d->io_bf16 & 1) ? 2 : 4);
+  a.dy_bytes = d->B * d->Mg * d->dy_L * ((d->io_bf16 & 2) ? 2 : 4);  // (B = items * h_n)
   const int S = d->stride;
   if (two_d) {
     if (variant == 0) return S == 1 ? dw_launch<1, 8, 1, 1, 3, true>(a, s) : dw_launch<2, 8, 1, 1, 3, true>(a, s);

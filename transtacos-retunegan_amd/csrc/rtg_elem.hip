@@ -183,6 +183,48 @@ __global__ __launch_bounds__(RTG_THREADS) void lrelu_bwd_kernel(const float* __r
   }
 }
 
+// bf16 feature maps in HBM: the conversions at the edge of the kernels that read / write them natively (8 elements per thread
+// and pass where the pointers allow 16-byte accesses on the bf16 side)
+typedef unsigned rtg_u32x4e __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(RTG_THREADS) void bf16_encode_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst,
+                                                                  long long n, float slope, int vec) {
+  auto enc = [&](float v) __attribute__((always_inline)) {
+    return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)(v > 0.f ? v : v * slope));
+  };
+  long long done = 0;
+  if (vec) {
+    const long long n8 = n >> 3;
+    for (long long i = (long long)blockIdx.x * RTG_THREADS + threadIdx.x; i < n8; i += (long long)gridDim.x * RTG_THREADS) {
+      const f32x4 a = reinterpret_cast<const f32x4*>(src)[2 * i], b = reinterpret_cast<const f32x4*>(src)[2 * i + 1];
+      reinterpret_cast<rtg_u32x4e*>(dst)[i] = rtg_u32x4e{enc(a.x) | (enc(a.y) << 16), enc(a.z) | (enc(a.w) << 16),
+                                                         enc(b.x) | (enc(b.y) << 16), enc(b.z) | (enc(b.w) << 16)};
+    }
+    done = n8 << 3;
+  }
+  for (long long i = done + (long long)blockIdx.x * RTG_THREADS + threadIdx.x; i < n; i += (long long)gridDim.x * RTG_THREADS)
+    dst[i] = (unsigned short)enc(src[i]);
+}
+
+__global__ __launch_bounds__(RTG_THREADS) void bf16_decode_kernel(const unsigned short* __restrict__ src, float* __restrict__ dst,
+                                                                  long long n, float inv_slope, int vec) {
+  auto dec = [&](unsigned h) __attribute__((always_inline)) {
+    const float v = __builtin_bit_cast(float, h << 16);
+    return v > 0.f ? v : v * inv_slope;
+  };
+  long long done = 0;
+  if (vec) {
+    const long long n8 = n >> 3;
+    for (long long i = (long long)blockIdx.x * RTG_THREADS + threadIdx.x; i < n8; i += (long long)gridDim.x * RTG_THREADS) {
+      const rtg_u32x4e v = reinterpret_cast<const rtg_u32x4e*>(src)[i];
+      reinterpret_cast<f32x4*>(dst)[2 * i] = f32x4{dec(v.x & 0xffffu), dec(v.x >> 16), dec(v.y & 0xffffu), dec(v.y >> 16)};
+      reinterpret_cast<f32x4*>(dst)[2 * i + 1] = f32x4{dec(v.z & 0xffffu), dec(v.z >> 16), dec(v.w & 0xffffu), dec(v.w >> 16)};
+    }
+    done = n8 << 3;
+  }
+  for (long long i = done + (long long)blockIdx.x * RTG_THREADS + threadIdx.x; i < n; i += (long long)gridDim.x * RTG_THREADS)
+    dst[i] = dec(src[i]);
+}
+
 __global__ __launch_bounds__(RTG_THREADS) void avgpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ out,
                                                                   int rows, int L) {
   const int Lo = L / 2;
@@ -244,6 +286,7 @@ __global__ __launch_bounds__(RTG_THREADS) void fold_bwd_kernel(const float* __re
 // ---------------------------------------------------------------------------------------------------------------
 // multi-tensor scalar losses
 // ---------------------------------------------------------------------------------------------------------------
+typedef unsigned rtg_u32x4 __attribute__((ext_vector_type(4)));
 struct LossJobs {
   int n_jobs;
   RtgLossJob job[RTG_MAX_LOSS_JOBS];
@@ -265,7 +308,29 @@ __global__ __launch_bounds__(RTG_THREADS) void loss_fwd_kernel(int kind, const L
   // loads a thread had one request in flight per iteration, 1.8 TB/s); the order of the additions is fixed either way
   const bool vec = ((reinterpret_cast<uintptr_t>(j.a) | reinterpret_cast<uintptr_t>(j.b)) & 15) == 0;
   long long done = 0;
-  if (vec) {
+  if (kind == RTG_LOSS_L1_ENC) {
+    // bf16 feature maps (leaky-relu encoded, slope = j.target): 8 elements per 16-byte load
+    const float inv = 1.f / j.target;
+    const unsigned short* pa = reinterpret_cast<const unsigned short*>(j.a);
+    const unsigned short* pb = reinterpret_cast<const unsigned short*>(j.b);
+    auto dec = [&](unsigned h) __attribute__((always_inline)) {
+      const float v = __builtin_bit_cast(float, h << 16);
+      return v > 0.f ? v : v * inv;
+    };
+    if (vec) {
+      const long long n8 = j.n >> 3;
+      for (long long i = (long long)blockIdx.x * RTG_THREADS + threadIdx.x; i < n8; i += (long long)LOSS_GX * RTG_THREADS) {
+        const rtg_u32x4 va = reinterpret_cast<const rtg_u32x4*>(pa)[i], vb = reinterpret_cast<const rtg_u32x4*>(pb)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          acc += fabsf(dec(va[e] & 0xffffu) - dec(vb[e] & 0xffffu)) + fabsf(dec(va[e] >> 16) - dec(vb[e] >> 16));
+      }
+      done = n8 << 3;
+    }
+    for (long long i = done + (long long)blockIdx.x * RTG_THREADS + threadIdx.x; i < j.n; i += (long long)LOSS_GX * RTG_THREADS)
+      acc += fabsf(dec(pa[i]) - dec(pb[i]));
+    done = j.n;
+  } else if (vec) {
     const long long n4 = j.n >> 2;
     const f32x4* a4 = reinterpret_cast<const f32x4*>(j.a);
     const f32x4* b4 = reinterpret_cast<const f32x4*>(j.b);
@@ -311,6 +376,46 @@ __global__ __launch_bounds__(RTG_THREADS) void loss_bwd_kernel(int kind, const L
     }
   };
   long long done = 0;
+  if (kind == RTG_LOSS_L1_ENC) {
+    // d |dec(a) - dec(b)| / d dec(a) = sign; gradients stored as bf16 (+-k or 0: exact up to the rounding of k)
+    const float inv = 1.f / j.target;
+    const unsigned short* pa = reinterpret_cast<const unsigned short*>(j.a);
+    const unsigned short* pb = reinterpret_cast<const unsigned short*>(j.b);
+    unsigned short* da = reinterpret_cast<unsigned short*>(j.da);
+    unsigned short* db = reinterpret_cast<unsigned short*>(j.db);
+    const unsigned kp = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)k), kn = kp ^ 0x8000u;
+    auto dec = [&](unsigned h) __attribute__((always_inline)) {
+      const float v = __builtin_bit_cast(float, h << 16);
+      return v > 0.f ? v : v * inv;
+    };
+    auto sg = [&](unsigned ha, unsigned hb) __attribute__((always_inline)) {       // bf16 bits of k * sign(dec(a) - dec(b))
+      const float a = dec(ha), b = dec(hb);
+      return a > b ? kp : (a < b ? kn : 0u);
+    };
+    if (((reinterpret_cast<uintptr_t>(j.a) | reinterpret_cast<uintptr_t>(j.b) | reinterpret_cast<uintptr_t>(j.da) |
+          reinterpret_cast<uintptr_t>(j.db)) & 15) == 0) {
+      const long long n8 = j.n >> 3;
+      for (long long i = (long long)blockIdx.x * RTG_THREADS + threadIdx.x; i < n8; i += (long long)gridDim.x * RTG_THREADS) {
+        const rtg_u32x4 va = reinterpret_cast<const rtg_u32x4*>(pa)[i], vb = reinterpret_cast<const rtg_u32x4*>(pb)[i];
+        rtg_u32x4 oa, ob;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const unsigned lo = sg(va[e] & 0xffffu, vb[e] & 0xffffu), hi = sg(va[e] >> 16, vb[e] >> 16);
+          oa[e] = lo | (hi << 16);
+          ob[e] = (lo ? lo ^ 0x8000u : 0u) | ((hi ? hi ^ 0x8000u : 0u) << 16);
+        }
+        if (da) reinterpret_cast<rtg_u32x4*>(da)[i] = oa;
+        if (db) reinterpret_cast<rtg_u32x4*>(db)[i] = ob;
+      }
+      done = n8 << 3;
+    }
+    for (long long i = done + (long long)blockIdx.x * RTG_THREADS + threadIdx.x; i < j.n; i += (long long)gridDim.x * RTG_THREADS) {
+      const unsigned g = sg(pa[i], pb[i]);
+      if (da) da[i] = (unsigned short)g;
+      if (db) db[i] = (unsigned short)(g ? g ^ 0x8000u : 0u);
+    }
+    return;
+  }
   if (((reinterpret_cast<uintptr_t>(j.a) | reinterpret_cast<uintptr_t>(j.b) | reinterpret_cast<uintptr_t>(j.da) |
         reinterpret_cast<uintptr_t>(j.db)) & 15) == 0) {
     const long long n4 = j.n >> 2;
@@ -535,6 +640,21 @@ extern "C" int rtg_avgpool4s2_fwd(const float* x, float* out, int rows, int L, v
   RTG_LAUNCH(avgpool_fwd_kernel, grid_for((long long)rows * (L / 2)), RTG_THREADS, 0, stream, x, out, rows, L);
 }
 
+extern "C" int rtg_bf16_encode(const float* src, void* dst_bf16, long long n, float slope, void* stream) {
+  RTG_REQ(src && dst_bf16);
+  if (n < 1 || !(slope > 0.f)) return RTG_EINVAL;
+  const int vec = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst_bf16)) & 15) == 0 ? 1 : 0;
+  RTG_LAUNCH(bf16_encode_kernel, grid_for(n / 8 + 1, 2), RTG_THREADS, 0, stream, src, (unsigned short*)dst_bf16, n, slope, vec);
+}
+
+extern "C" int rtg_bf16_decode(const void* src_bf16, float* dst, long long n, float slope, void* stream) {
+  RTG_REQ(src_bf16 && dst);
+  if (n < 1 || !(slope > 0.f)) return RTG_EINVAL;
+  const int vec = ((reinterpret_cast<uintptr_t>(src_bf16) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0 ? 1 : 0;
+  RTG_LAUNCH(bf16_decode_kernel, grid_for(n / 8 + 1, 2), RTG_THREADS, 0, stream, (const unsigned short*)src_bf16, dst, n,
+             1.f / slope, vec);
+}
+
 extern "C" int rtg_avgpool4s2_bwd(const float* dy, float* dx, int rows, int L, void* stream) {
   RTG_REQ(dy && dx);
   if (rows < 1 || L < 4 || (L & 1)) return RTG_EINVAL;
@@ -556,7 +676,8 @@ extern "C" int rtg_period_fold_bwd(const float* dout, float* dy, int B, int T, i
 static int fill_jobs(LossJobs* lj, int kind, const RtgLossJob* jobs, int n_jobs, bool bwd) {
   if (!jobs) return RTG_ENULL;
   if (n_jobs < 1 || n_jobs > RTG_MAX_LOSS_JOBS) return RTG_EINVAL;
-  if (kind != RTG_LOSS_L1 && kind != RTG_LOSS_L1_L1LOG && kind != RTG_LOSS_MSE_TARGET && kind != RTG_LOSS_MSE_REL)
+  if (kind != RTG_LOSS_L1 && kind != RTG_LOSS_L1_L1LOG && kind != RTG_LOSS_MSE_TARGET && kind != RTG_LOSS_MSE_REL &&
+      kind != RTG_LOSS_L1_ENC)
     return RTG_EINVAL;
   lj->n_jobs = n_jobs;
   for (int i = 0; i < n_jobs; ++i) {

@@ -206,12 +206,18 @@ extern "C" int rtg_wgrad_shape_candidates(const RtgWgradDesc* d, int* cfgs, int 
   if (max < 1) return RTG_EINVAL;
   int st = validate(d);
   if (st) return st;
+  int cnt = 0;
+  if (d->io_bf16 != 0) {
+    // bf16 tensors (ABI 9): the dense-layer kernel's shapes or nothing (the caller then converts around an fp32 launch)
+    for (int v = 0; v < rtg_dwgrad_variants(); ++v)
+      if (rtg_dwgrad_ok(d, v) && cnt < max) cfgs[cnt++] = kDenseShape + v;
+    return cnt;
+  }
   RtgWgradDesc t = *d;
   WgGeom g;
   t.shape_cfg = 0;
   st = geometry(&t, &g);
   if (st) return st;
-  int cnt = 0;
   cfgs[cnt++] = g.shape + 1;                                    // the heuristic's choice first
   for (int s = 0; s < kNumShapes && cnt < max; ++s) {
     if (s == g.shape) continue;
@@ -248,6 +254,7 @@ int wgrad_plan(const RtgWgradDesc* d, const float* x1, const float* x2, const fl
   if ((d->gy_mode == RTG_PRE_MUL_DLRELU || d->gy_mode == RTG_PRE_MUL_DTANH) && !gy_aux) return RTG_ENULL;
   if (d->pre_mode != RTG_PRE_NONE && d->pre_mode != RTG_PRE_LRELU) return RTG_EINVAL;
   if (d->splits < 1 || d->splits > 65535) return RTG_EINVAL;
+  if (d->io_bf16 != 0) return RTG_EINVAL;                  // (bf16 tensors: the dense-layer kernel only)
   const long long need = (long long)d->groups * d->Mg * ((long long)d->Cg * d->K + 1);
   if (d->splits > 1 && d->part_stride < need) return RTG_EINVAL;
   if (d->shape_cfg == kThinShape || d->shape_cfg == kResShape || d->shape_cfg == kGconvShape || d->shape_cfg == kGmfmaShape ||
@@ -309,6 +316,7 @@ extern "C" int rtg_conv1d_wgrad(const RtgWgradDesc* d, const float* x1, const fl
     if (d->splits < 1 || d->splits > 65535) return RTG_EINVAL;
     const long long need = (long long)d->groups * d->Mg * ((long long)d->Cg * d->K + 1);
     if (d->splits > 1 && d->part_stride < need) return RTG_EINVAL;
+    if (d->io_bf16 != 0 && !(d->shape_cfg >= kDenseShape && d->shape_cfg <= kDenseShapeLast)) return RTG_EINVAL;
     if (d->shape_cfg == kThinShape) return rtg_wgrad_thin_launch(d, x1, dy, gy_aux, part, (hipStream_t)stream);
     if (d->shape_cfg == kGconvShape) return rtg_gconv_wgrad_launch(d, x1, dy, part, (hipStream_t)stream);
     if (d->shape_cfg == kGmfmaShape) return rtg_gmfma_wgrad_launch(d, x1, dy, part, (hipStream_t)stream);

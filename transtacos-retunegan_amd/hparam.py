@@ -94,6 +94,11 @@ valid_limit = batch_size * 4
 # cores (BASELINE configs[1]); 'bf16' = operands rounded to bf16 on the bf16 matrix cores, fp32 accumulation, fp32 tensors,
 # fp32 losses and optimizer (BASELINE configs[2]); read when a model's weight bank is built.
 compute_dtype = 'fp32'
+# with compute_dtype 'bf16': the feature maps between the dense discriminator layers (and their gradients) live in HBM as
+# bf16, stored activated — bf16(leaky_relu(x, 0.15)), what every consumer inside the stacks applies to them anyway; fp32
+# accumulators, losses, weight norm and optimizer.  The fmaps the discriminators return are then such bf16 tensors
+# (feature_loss reads them; rtg.ops.decode gives the fp32 feature map).  False: fp32 tensors in HBM, bf16 operands only.
+bf16_maps = True
 # resume schedule: False = the installed torch's ExponentialLR (2.x: the constructor leaves the loaded lr untouched);
 # True = torch 1.8's (the reference's README.md:15): one more factor of lr_decay per resume.  See train.ExponentialLR.
 legacy_resume_lr = False

@@ -10,7 +10,7 @@ import hparam as hp
 from audio import get_stft_torch, stft_mel_spec  # noqa: F401
 from utils import PI  # noqa: F401
 from rtg import ops
-from rtg.lib import LOSS_L1, LOSS_L1_L1LOG, LOSS_MSE_TARGET, LOSS_MSE_REL, MAX_LOSS_JOBS, RtgError  # noqa: F401
+from rtg.lib import LOSS_L1, LOSS_L1_L1LOG, LOSS_L1_ENC, LOSS_MSE_TARGET, LOSS_MSE_REL, MAX_LOSS_JOBS, RtgError  # noqa: F401
 
 _real_cache = {}
 
@@ -119,4 +119,15 @@ def feature_loss(fmap_r, fmap_g):
     kernel-side layout of MPD maps is used directly)."""
     rs = [_base(r) for dr in fmap_r for r in dr]
     gs = [_base(g) for dg in fmap_g for g in dg]
-    return ops.multi_loss(LOSS_L1, rs, gs)
+    # bf16 feature maps (hparam.bf16_maps) are stored leaky-relu encoded: their pairs go through the decoding loss kind
+    enc = [i for i, (r, g) in enumerate(zip(rs, gs)) if r.dtype == torch.bfloat16 and g.dtype == torch.bfloat16]
+    if not enc:
+        return ops.multi_loss(LOSS_L1, rs, gs)
+    if any((r.dtype == torch.bfloat16) != (g.dtype == torch.bfloat16) for r, g in zip(rs, gs)):
+        rs, gs = [ops.decode(r) for r in rs], [ops.decode(g) for g in gs]
+        return ops.multi_loss(LOSS_L1, rs, gs)
+    plain = [i for i in range(len(rs)) if i not in set(enc)]
+    terms = [ops.multi_loss(LOSS_L1_ENC, [rs[i] for i in enc], [gs[i] for i in enc], target=ops.ENC_SLOPE)]
+    if plain:
+        terms.append(ops.multi_loss(LOSS_L1, [rs[i] for i in plain], [gs[i] for i in plain]))
+    return ops.weighted_sum(terms)

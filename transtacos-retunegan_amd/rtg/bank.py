@@ -181,6 +181,10 @@ class ConvLayer:
             return 0
         self.fwd16 = dense(self.fwd_op, True) if not self.fwd_tap else 0
         self.bwd16 = dense(self.bwd_op, False) if not self.bwd_tap else 0
+        # bf16 feature maps in HBM (hparam.bf16_maps with compute_dtype 'bf16'): a layer whose forward the dense kernel serves
+        # stores bf16(leaky_relu(out, LRELU_SLOPE)) and reads such tensors natively (rtg/ops.py); only the discriminators'
+        # dense layers qualify (fwd16 == 1: k5 1-D / 3-tap 2-D, dilation 1, >= 32 input and >= 64 output channels)
+        self.maps_bf = bool(want_bf and getattr(hp, 'bf16_maps', True) and self.fwd16 == 1 and self.kind in ('conv', 'conv2d'))
         self.frag_bf = int(want_bf)           # the fragment images are bf16 with the layer
         self.fwd_bf = int(ok(self.fwd_op, self.fwd_tap))
         self.wgrad_bf = int(want_bf and not thin2d)   # the weight-gradient kernel has one K order: every layer

@@ -20,7 +20,7 @@ class Conv1dDesc(C.Structure):
                [('pre_slope', C.c_float), ('mask_slope', C.c_float), ('out_scale', C.c_float), ('act', C.c_int),
                 ('act_slope', C.c_float), ('accumulate', C.c_int), ('tile_m', C.c_int), ('out_split', C.c_int)] + \
                [(n, C.c_int) for n in ('h_in', 'h_k', 'h_stride', 'h_pad', 'h_n', 'h_mode', 'tap_major', 'tile_cfg', 'bf16',
-                                       'wp16')]
+                                       'wp16', 'io_bf16')] + [('enc_slope', C.c_float)]
 
 
 class ConvPtrs(C.Structure):
@@ -36,7 +36,8 @@ class WgradDesc(C.Structure):
                                        'dy_L', 'pre_mode')] + \
                [('pre_slope', C.c_float), ('gy_mode', C.c_int), ('gy_slope', C.c_float), ('gy_scale', C.c_float),
                 ('splits', C.c_int),
-                ('part_stride', C.c_longlong)] + [(n, C.c_int) for n in ('h_in', 'h_k', 'h_stride', 'h_pad', 'h_n', 'shape_cfg', 'bf16')]
+                ('part_stride', C.c_longlong)] + [(n, C.c_int) for n in ('h_in', 'h_k', 'h_stride', 'h_pad', 'h_n', 'shape_cfg', 'bf16',
+                                                                         'io_bf16')]
 
 
 class GconvDesc(C.Structure):
@@ -93,11 +94,12 @@ class StftDesc(C.Structure):
 PRE_NONE, PRE_LRELU, PRE_MUL_DLRELU, PRE_MUL_DTANH = 0, 1, 2, 3
 ACT_NONE, ACT_LRELU, ACT_TANH = 0, 1, 2
 PACK_FWD, PACK_DGRAD_S1, PACK_DGRAD_POLY, PACK_CONVT_POLY, PACK_DGRAD_2D, PACK_GCONV_FWD, PACK_GCONV_BWD, PACK_GMFMA_FWD = 0, 1, 2, 3, 4, 5, 6, 7
+IO_X_BF16, IO_OUT_BF16, IO_MASK_BF16, IO_RES_BF16 = 1, 2, 4, 8
 CK = 16
-LOSS_L1, LOSS_L1_L1LOG, LOSS_MSE_TARGET, LOSS_MSE_REL = 0, 1, 2, 3
+LOSS_L1, LOSS_L1_L1LOG, LOSS_MSE_TARGET, LOSS_MSE_REL, LOSS_L1_ENC = 0, 1, 2, 3, 4
 MAX_LOSS_JOBS = 48
 
-ABI_VERSION = 8            # RTG_ABI_VERSION of include/rtg.h these struct layouts / prototypes were written for
+ABI_VERSION = 9            # RTG_ABI_VERSION of include/rtg.h these struct layouts / prototypes were written for
 _P = C.c_void_p
 _I, _F, _D, _LL, _ULL = C.c_int, C.c_float, C.c_double, C.c_longlong, C.c_ulonglong
 
@@ -139,6 +141,8 @@ PROTOTYPES = {
     'rtg_channel_sum': (_I, [_P, _P, _I, _I, _I, _P, _P]),
     'rtg_axpby': (_I, [_P, _P, _P, _LL, _F, _F, _I, _P]),
     'rtg_lrelu_bwd': (_I, [_P, _P, _P, _LL, _F, _P]),
+    'rtg_bf16_encode': (_I, [_P, _P, _LL, _F, _P]),
+    'rtg_bf16_decode': (_I, [_P, _P, _LL, _F, _P]),
     'rtg_avgpool4s2_fwd': (_I, [_P, _P, _I, _I, _P]),
     'rtg_avgpool4s2_bwd': (_I, [_P, _P, _I, _I, _P]),
     'rtg_period_fold_fwd': (_I, [_P, _P, _I, _I, _I, _I, _P]),

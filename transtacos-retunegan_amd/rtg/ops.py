@@ -57,11 +57,135 @@ def _conv_bytes(d, args):
     two_d = d.h_k > 1 or d.h_n > 1
     x = (d.B // max(d.h_n, 1)) * (d.C1 // max(d.h_k, 1)) * d.h_in * d.L_in if two_d else d.B * (d.C1 + d.C2) * d.L_in
     out = d.B * d.out_C * d.out_L
-    n = x + out + d.groups * d.Mg * d.Cg * d.K // (2 if d.bf16 else 1)
+    io = d.io_bf16
     aux, mask, res = args[2], args[5], args[6]
-    n += x if aux else 0
-    n += out * ((1 if mask else 0) + (1 if res else 0))
-    return 4 * n
+    n = x * (2 if io & 1 else 4) + out * (2 if io & 2 else 4) + 4 * (d.groups * d.Mg * d.Cg * d.K // (2 if d.bf16 else 1))
+    n += 4 * x if aux else 0
+    n += out * ((2 if io & 4 else 4) if mask else 0) + out * ((2 if io & 8 else 4) if res else 0)
+    return n
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# bf16 feature maps in HBM (hparam.compute_dtype = 'bf16' with hparam.bf16_maps; BASELINE configs[2])
+# ---------------------------------------------------------------------------------------------------------------
+# A bf16 ACTIVATION tensor of this package holds bf16(leaky_relu(x, ENC_SLOPE)) of the feature map x it stands for: the
+# dense layers of the discriminators store their outputs that way (the consumer's activation applied once by the producer,
+# RtgConv1dDesc.io_bf16), every consumer inside the stacks applies leaky_relu(., LRELU_SLOPE) to it anyway
+# (retunegan/models/discrminator.py:90-98,212-218,300-304) and the sign — all a leaky-relu backward needs — survives; the
+# feature-matching loss decodes (RTG_LOSS_L1_ENC).  A bf16 GRADIENT tensor is a plain rounding.  Kernels without a native
+# bf16 path are served through rtg_bf16_decode / rtg_bf16_encode around their fp32 launch (correct for every shape; the
+# hot shapes take the native path).
+ENC_SLOPE = 0.15
+_BF = torch.bfloat16
+
+
+def _is_bf(t):
+    return t is not None and t.dtype == _BF
+
+
+def bf16_encode(x, slope):
+    """fp32 -> bf16(leaky_relu(x, slope)); slope 1: a plain rounding (gradients)"""
+    x = _c(x)
+    out = torch.empty(x.shape, device=x.device, dtype=_BF)
+    check(timed_bw('bf16_cvt', 6 * x.numel(), lambda: lib.rtg_bf16_encode(_p(x), _p(out), x.numel(), float(slope), _stream())),
+          'bf16_encode')
+    return out
+
+
+def bf16_decode(x, slope):
+    """bf16(leaky_relu(x, slope)) -> fp32 x (slope 1: a plain widening)"""
+    x = _c(x)
+    out = torch.empty(x.shape, device=x.device, dtype=torch.float32)
+    check(timed_bw('bf16_cvt', 6 * x.numel(), lambda: lib.rtg_bf16_decode(_p(x), _p(out), x.numel(), float(slope), _stream())),
+          'bf16_decode')
+    return out
+
+
+class DecodeFn(torch.autograd.Function):
+    """bf16 activation tensor -> the fp32 feature map it stands for (for layers / kernels that read fp32); the gradient goes
+    back as a bf16 tensor"""
+
+    @staticmethod
+    def forward(ctx, x):
+        _need_cuda(x)
+        return bf16_decode(x, ENC_SLOPE)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return bf16_encode(dy, 1.0) if dy is not None else None
+
+
+class PairDecodeFn(torch.autograd.Function):
+    """DecodeFn for the two halves (constant, differentiable) of one 2B-clip buffer: -> the halves of ONE fp32 buffer"""
+
+    @staticmethod
+    def forward(ctx, x_c, x_g):
+        _need_cuda(x_c, x_g)
+        assert _adjacent(x_c, x_g)
+        B = x_c.shape[0]
+        whole = torch.as_strided(x_c, (2 * B,) + tuple(x_c.shape[1:]), x_c.stride())
+        buf = bf16_decode(whole, ENC_SLOPE)
+        o_c, o_g = buf[:B], buf[B:]
+        ctx.mark_non_differentiable(o_c)
+        ctx.set_materialize_grads(False)
+        return o_c, o_g
+
+    @staticmethod
+    def backward(ctx, d_c, d_g):
+        return None, (bf16_encode(d_g, 1.0) if d_g is not None else None)
+
+
+def decode(x):
+    return DecodeFn.apply(x) if _is_bf(x) else x
+
+
+_NATIVE = {}
+
+
+def _conv_native(d):
+    """does a kernel read / write the bf16 tensors of descriptor `d` (io_bf16 set) natively at this shape?"""
+    d.tile_cfg = 0
+    key = bytes(d)
+    ok = _NATIVE.get(key)
+    if ok is None:
+        cands = (C.c_int * 8)()
+        ok = _NATIVE[key] = lib.rtg_conv1d_tile_candidates(C.byref(d), cands, 8) > 0
+    return ok
+
+
+def _wgrad_native(wd):
+    wd.shape_cfg, wd.splits, wd.part_stride = 0, 1, 0
+    key = b'w' + bytes(wd)
+    ok = _NATIVE.get(key)
+    if ok is None:
+        cands = (C.c_int * 12)()
+        ok = _NATIVE[key] = lib.rtg_wgrad_shape_candidates(C.byref(wd), cands, 12) > 0
+    return ok
+
+
+def _run_conv_t(d, x1, wp, bias, mask, res, out, flop, label, what, x_slope=1.0, out_slope=1.0):
+    """rtg_conv1d on tensors of either type (single-input layers: no x2 / aux / out2).  x1 bf16: activations encoded with
+    x_slope (= the layer's pre_slope) or, x_slope 1, a gradient; out bf16: stored as bf16(leaky_relu(., out_slope)).  Native
+    where the dense-layer kernel serves the shape, else through fp32 copies."""
+    io = (L.IO_X_BF16 if _is_bf(x1) else 0) | (L.IO_OUT_BF16 if _is_bf(out) else 0) | \
+         (L.IO_MASK_BF16 if _is_bf(mask) else 0) | (L.IO_RES_BF16 if _is_bf(res) else 0)
+    if io:
+        if _is_bf(x1) and d.pre_mode == L.PRE_LRELU and abs(d.pre_slope - x_slope) > 1e-6:
+            raise L.RtgError(f'{label}: a bf16 activation tensor encoded with slope {x_slope} feeds a layer with pre-activation '
+                             f'slope {d.pre_slope}')
+        d.io_bf16, d.enc_slope = io, float(out_slope)
+        if not _conv_native(d):
+            # no native kernel at this shape: fp32 copies around the fp32 launch
+            d.io_bf16, d.enc_slope = 0, 1.0
+            x32 = bf16_decode(x1, x_slope if d.pre_mode == L.PRE_LRELU else 1.0) if _is_bf(x1) else x1
+            m32 = bf16_decode(mask, 1.0) if _is_bf(mask) else mask
+            r32 = bf16_decode(res, 1.0) if _is_bf(res) else res
+            o32 = torch.empty(out.shape, device=out.device, dtype=torch.float32) if _is_bf(out) else out
+            _run_conv(d, (_p(x32), None, None, wp, bias, _p(m32), _p(r32), _p(o32), None, _stream()), flop, label, what)
+            if _is_bf(out):
+                check(lib.rtg_bf16_encode(_p(o32), _p(out), out.numel(), float(out_slope), _stream()), 'bf16_encode')
+            return
+    _run_conv(d, (_p(x1), None, None, wp, bias, _p(mask), _p(res), _p(out), None, _stream()), flop, label, what)
 
 
 def _run_conv(d, args, flop, label, what):
@@ -74,6 +198,22 @@ def _run_conv(d, args, flop, label, what):
         _bank.note_std_use(args[3].value)
     check(_timed('conv1d', lib.rtg_conv1d_variant(C.byref(d)) if PROFILE is not None else 0, flop,
                  lambda: lib.rtg_conv1d(C.byref(d), *args), label, _conv_bytes(d, args) if PROFILE is not None else 0), what)
+
+
+def _wgrad_io(wd, ly, a1, gyt):
+    """bf16 operands of a weight gradient (x = a bf16 activation tensor and / or dy = a bf16 gradient): native where the
+    dense-layer kernel serves the shape (RtgWgradDesc.io_bf16), else fp32 copies.  -> (x, dy) to launch on"""
+    io = (L.IO_X_BF16 if _is_bf(a1) else 0) | (L.IO_OUT_BF16 if _is_bf(gyt) else 0)
+    wd.io_bf16 = 0
+    if io:
+        wd.bf16, wd.io_bf16 = int(getattr(ly, 'wgrad_bf', 0)), io
+        if not (wd.bf16 and _wgrad_native(wd)):
+            wd.io_bf16 = 0
+            if _is_bf(a1):
+                a1 = bf16_decode(a1, ENC_SLOPE if wd.pre_mode == L.PRE_LRELU else 1.0)
+            if _is_bf(gyt):
+                gyt = bf16_decode(gyt, 1.0)
+    return a1, gyt
 
 
 def _run_wgrad(wd, ptrs, st, bank, ly, tok_id, flop, label, what):
@@ -313,7 +453,12 @@ class ConvFn(torch.autograd.Function):
         C2 = x2.shape[1] if x2 is not None else 0
         assert C1 + C2 == ly.cin, (ly.name, C1, C2, ly.cin)
         L_out = _conv_out_len(ly, L_in)
-        out = torch.empty(B, ly.cout, L_out, device=x1.device, dtype=torch.float32)
+        plain = x2 is None and res is None and act == L.ACT_NONE and out_scale == 1.0
+        # bf16 feature maps: a dense discriminator layer stores bf16(leaky_relu(out, ENC_SLOPE)) (what its consumer stages)
+        out_bf = bool(ly.maps_bf and plain and ly.kind == 'conv')
+        if _is_bf(x1) and not (plain and ly.kind == 'conv'):
+            raise L.RtgError(f'{ly.name}: a bf16 feature map feeds a layer form without a bf16 path (ops.conv decodes first)')
+        out = torch.empty(B, ly.cout, L_out, device=x1.device, dtype=_BF if out_bf else torch.float32)
         mode, g, mg, cg, k, s = ly.fwd_op
         pre_mode = L.PRE_LRELU if pre_slope != 1.0 else L.PRE_NONE
         if ly.kind == 'conv':
@@ -328,11 +473,14 @@ class ConvFn(torch.autograd.Function):
                       pre_slope=pre_slope, out_scale=out_scale, act=act, act_slope=act_slope, tile_m=ly.fwd_tm, tap_major=ly.fwd_tap,
                       bf16=ly.fwd_bf, wp16=ly.fwd16)
         lc = L_out if ly.kind == 'conv' else L_in
-        args = (_p(x1), _p(x2), None, bank.fwd_ptr(ly), bank.bias_ptr(ly), None, _p(res), _p(out), None, _stream())
-        plain = x2 is None and res is None and act == L.ACT_NONE and out_scale == 1.0
-        if not (plain and _gconv_forward(ly, bank, token._rtg_id, d, args, _p(x1), B, L_in, out, pre_slope, _conv_flop(ly, B, lc),
-                                         f'fwd {ly.name} B{B} L{L_in}')):
-            _run_conv(d, args, _conv_flop(ly, B, lc), f'fwd {ly.name} B{B} L{L_in}', f'conv1d fwd {ly.name}')
+        if out_bf or _is_bf(x1):
+            _run_conv_t(d, x1, bank.fwd_ptr(ly), bank.bias_ptr(ly), None, None, out, _conv_flop(ly, B, lc),
+                        f'fwd {ly.name} B{B} L{L_in}', f'conv1d fwd {ly.name}', x_slope=ENC_SLOPE, out_slope=ENC_SLOPE)
+        else:
+            args = (_p(x1), _p(x2), None, bank.fwd_ptr(ly), bank.bias_ptr(ly), None, _p(res), _p(out), None, _stream())
+            if not (plain and _gconv_forward(ly, bank, token._rtg_id, d, args, _p(x1), B, L_in, out, pre_slope, _conv_flop(ly, B, lc),
+                                             f'fwd {ly.name} B{B} L{L_in}')):
+                _run_conv(d, args, _conv_flop(ly, B, lc), f'fwd {ly.name} B{B} L{L_in}', f'conv1d fwd {ly.name}')
         ctx.ly, ctx.bank, ctx.tok_id = ly, bank, token._rtg_id
         ctx.cfg = (pre_slope, act, act_slope, out_scale, res_is_input, res is not None)
         ctx.save_for_backward(x1, x2, out if act != L.ACT_NONE else None)
@@ -408,11 +556,18 @@ class ConvFn(torch.autograd.Function):
                           mask_slope=pre_slope, out_scale=out_scale, tile_m=ly.bwd_tm, out_split=split,
                           tap_major=ly.bwd_tap, bf16=ly.bwd_bf, wp16=ly.bwd16)
             lc = L_out if ly.kind == 'conv' else L_in
-            dargs = (_p(dy), None, _p(out), bank.bwd_ptr(ly), None, _p(mask), _p(resg), _p(dx1), _p(dx2), st)
             plain = C2 == 0 and gy_mode == L.PRE_NONE and out_scale == 1.0 and dx2 is None
-            if not (plain and _gconv_dgrad(ly, bank, ctx.tok_id, d, dargs, _p(dy), _p(x1), _p(resg), B, L_in, L_out, dx1, pre_slope,
-                                           _conv_flop(ly, B, lc), f'dgrad {ly.name} B{B} L{L_in}')):
-                _run_conv(d, dargs, _conv_flop(ly, B, lc), f'dgrad {ly.name} B{B} L{L_in}', f'conv1d bwd-data {ly.name}')
+            if _is_bf(dy) or _is_bf(x1):
+                # bf16 feature maps: dy is a bf16 gradient, the mask a bf16 (encoded: same sign) or fp32 feature map, dx takes
+                # the type of the tensor it is the gradient of
+                assert plain and ly.kind == 'conv' and out is None
+                _run_conv_t(d, dy, bank.bwd_ptr(ly), None, mask, resg, dx1, _conv_flop(ly, B, lc),
+                            f'dgrad {ly.name} B{B} L{L_in}', f'conv1d bwd-data {ly.name}')
+            else:
+                dargs = (_p(dy), None, _p(out), bank.bwd_ptr(ly), None, _p(mask), _p(resg), _p(dx1), _p(dx2), st)
+                if not (plain and _gconv_dgrad(ly, bank, ctx.tok_id, d, dargs, _p(dy), _p(x1), _p(resg), B, L_in, L_out, dx1, pre_slope,
+                                               _conv_flop(ly, B, lc), f'dgrad {ly.name} B{B} L{L_in}')):
+                    _run_conv(d, dargs, _conv_flop(ly, B, lc), f'dgrad {ly.name} B{B} L{L_in}', f'conv1d bwd-data {ly.name}')
             if not need_x1:
                 dx1 = None
 
@@ -436,6 +591,7 @@ class ConvFn(torch.autograd.Function):
             lc = L_out if ly.kind == 'conv' else L_in
             with wgrad_side(bank, (a1, a2, gyt, aux, dy)):
                 st = _stream()
+                a1, gyt = _wgrad_io(wd, ly, a1, gyt)
                 part, splits, immediate = _run_wgrad(wd, (_p(a1), _p(a2), _p(gyt), _p(aux)), st, bank, ly, ctx.tok_id,
                                                      _conv_flop(ly, B, lc), f'wgrad {ly.name} B{B} L{L_in}',
                                                      f'conv1d wgrad {ly.name}')
@@ -593,6 +749,8 @@ def resstack(token, lys, x, pre_slope, final_act_slope=None):
 
 
 def conv(token, ly, x1, x2=None, res=None, pre_slope=1.0, act=L.ACT_NONE, act_slope=1.0, out_scale=1.0):
+    if _is_bf(x1) and not ly.maps_bf:
+        x1 = decode(x1)                  # (a layer without a bf16 input path, e.g. conv_post: the fp32 feature map)
     if ly.kind == 'conv2d':
         assert x2 is None and res is None and act == L.ACT_NONE and out_scale == 1.0
         return Conv2dFn.apply(token, x1, ly, float(pre_slope))
@@ -614,14 +772,14 @@ class Conv2dFn(torch.autograd.Function):
         assert Cin == ly.cin
         Ho = (H + 2 * ly.ph - ly.kh) // ly.sh + 1
         Wo = (W + 2 * ly.pad - ly.k) // ly.stride + 1
-        out = torch.empty(B, ly.cout, Ho, Wo, device=x.device, dtype=torch.float32)
+        out = torch.empty(B, ly.cout, Ho, Wo, device=x.device, dtype=_BF if ly.maps_bf else torch.float32)
         pre_mode = L.PRE_LRELU if pre_slope != 1.0 else L.PRE_NONE
         d = _desc(B=B * Ho, C1=Cin * ly.kh, L_in=W, groups=1, Cg=Cin * ly.kh, Mg=ly.cout, K=ly.k, stride=ly.stride,
                   pad=ly.pad, Q=Wo, out_C=ly.cout, out_L=Wo, pre_mode=pre_mode, pre_slope=pre_slope, tile_m=ly.fwd_tm,
                   h_in=H, h_k=ly.kh, h_stride=ly.sh, h_pad=ly.ph, h_n=Ho, h_mode=0, bf16=ly.fwd_bf, wp16=ly.fwd16)
         flop = 2.0 * B * Ho * Wo * ly.cout * Cin * ly.kh * ly.k
-        _run_conv(d, (_p(x), None, None, bank.fwd_ptr(ly), bank.bias_ptr(ly), None, None, _p(out), None, _stream()),
-                  flop, f'fwd2d {ly.name} B{B} {H}x{W}', f'conv2d fwd {ly.name}')
+        _run_conv_t(d, x, bank.fwd_ptr(ly), bank.bias_ptr(ly), None, None, out, flop, f'fwd2d {ly.name} B{B} {H}x{W}',
+                    f'conv2d fwd {ly.name}', x_slope=ENC_SLOPE, out_slope=ENC_SLOPE)
         ctx.ly, ctx.bank, ctx.tok_id, ctx.pre_slope = ly, bank, token._rtg_id, pre_slope
         ctx.save_for_backward(x)
         ctx.set_materialize_grads(False)
@@ -651,15 +809,16 @@ class Conv2dFn(torch.autograd.Function):
             else:
                 d = _desc(stride=1, pad=k - 1, Q=(W - 1 + ly.pad) // ly.stride + 1, shuf_S=ly.stride, shuf_P=ly.pad,
                           **common)
-            _run_conv(d, (_p(dy), None, None, bank.bwd_ptr(ly), None, _p(mask), None, _p(dx), None, st),
-                      flop, f'dgrad2d {ly.name} B{B} {H}x{W}', f'conv2d bwd-data {ly.name}')
+            _run_conv_t(d, dy, bank.bwd_ptr(ly), None, mask, None, dx, flop, f'dgrad2d {ly.name} B{B} {H}x{W}',
+                        f'conv2d bwd-data {ly.name}')
         if ctx.needs_input_grad[0]:
             pre_mode = L.PRE_LRELU if pre_slope != 1.0 else L.PRE_NONE
             wd = L.WgradDesc(B=B * Ho, C1=Cin * ly.kh, C2=0, L_in=W, groups=1, Cg=Cin * ly.kh, Mg=ly.cout, K=ly.k,
                              stride=ly.stride, dil=1, pad=ly.pad, Q=Wo, dy_L=Wo, pre_mode=pre_mode, pre_slope=pre_slope,
                              gy_mode=L.PRE_NONE, gy_slope=1.0, gy_scale=1.0, splits=1, part_stride=0, h_in=H,
                              h_k=ly.kh, h_stride=ly.sh, h_pad=ly.ph, h_n=Ho)
-            part, splits, immediate = _run_wgrad(wd, (_p(x), None, _p(dy), None), st, bank, ly, ctx.tok_id, flop,
+            xw, dyw = _wgrad_io(wd, ly, x, dy)
+            part, splits, immediate = _run_wgrad(wd, (_p(xw), None, _p(dyw), None), st, bank, ly, ctx.tok_id, flop,
                                                  f'wgrad2d {ly.name} B{B} {H}x{W}', f'conv2d wgrad {ly.name}')
             if immediate:
                 bank.flush_one(ly, part, splits)
@@ -751,11 +910,16 @@ class PairConvFn(torch.autograd.Function):
         B, C1, L_in = x_c.shape
         assert C1 == ly.cin
         d, L_out = _fwd_desc(ly, 2 * B, C1, L_in, pre_slope)
-        out = torch.empty(2 * B, ly.cout, L_out, device=x_c.device, dtype=torch.float32)
-        args = (_p(x_c), None, None, bank.fwd_ptr(ly), bank.bias_ptr(ly), None, None, _p(out), None, _stream())
-        if not _gconv_forward(ly, bank, token._rtg_id, d, args, _p(x_c), 2 * B, L_in, out, pre_slope, _conv_flop(ly, 2 * B, L_out),
-                              f'fwd {ly.name} B{2 * B} L{L_in}'):
-            _run_conv(d, args, _conv_flop(ly, 2 * B, L_out), f'fwd {ly.name} B{2 * B} L{L_in}', f'conv1d fwd {ly.name}')
+        out = torch.empty(2 * B, ly.cout, L_out, device=x_c.device, dtype=_BF if ly.maps_bf else torch.float32)
+        if ly.maps_bf or _is_bf(x_c):
+            whole = torch.as_strided(x_c, (2 * B, C1, L_in), x_c.stride())
+            _run_conv_t(d, whole, bank.fwd_ptr(ly), bank.bias_ptr(ly), None, None, out, _conv_flop(ly, 2 * B, L_out),
+                        f'fwd {ly.name} B{2 * B} L{L_in}', f'conv1d fwd {ly.name}', x_slope=ENC_SLOPE, out_slope=ENC_SLOPE)
+        else:
+            args = (_p(x_c), None, None, bank.fwd_ptr(ly), bank.bias_ptr(ly), None, None, _p(out), None, _stream())
+            if not _gconv_forward(ly, bank, token._rtg_id, d, args, _p(x_c), 2 * B, L_in, out, pre_slope, _conv_flop(ly, 2 * B, L_out),
+                                  f'fwd {ly.name} B{2 * B} L{L_in}'):
+                _run_conv(d, args, _conv_flop(ly, 2 * B, L_out), f'fwd {ly.name} B{2 * B} L{L_in}', f'conv1d fwd {ly.name}')
         o_c, o_g = out[:B], out[B:]
         ctx.ly, ctx.bank, ctx.pre_slope, ctx.tok_id = ly, bank, pre_slope, token._rtg_id
         ctx.save_for_backward(x_g)
@@ -784,6 +948,10 @@ class PairConvFn(torch.autograd.Function):
         dx = torch.empty_like(x_g)
         d = _dgrad_desc(ly, B, L_in, L_out, pre_slope)
         res = _c(d_tap) if d_tap is not None else None            # dx = lrelu'(x) * convT(d_g) + d_tap
+        if _is_bf(d_g) or _is_bf(x_g):
+            _run_conv_t(d, d_g, bank.bwd_ptr(ly), None, x_g if pre_slope != 1.0 else None, res, dx, _conv_flop(ly, B, L_out),
+                        f'dgrad {ly.name} B{B} L{L_in}', f'conv1d bwd-data {ly.name}')
+            return None, None, None, None, None, dx
         dargs = (_p(d_g), None, None, bank.bwd_ptr(ly), None, _p(x_g) if pre_slope != 1.0 else None, _p(res), _p(dx), None,
                  _stream())
         if not _gconv_dgrad(ly, bank, ctx.tok_id, d, dargs, _p(d_g), _p(x_g), _p(res), B, L_in, L_out, dx, pre_slope,
@@ -798,6 +966,8 @@ def pair_entry(x_const, x_grad):
 
 def pair_conv(token, ly, x_c, x_g, pre_slope=1.0, tap=False):
     """-> (out_const, out_grad) and, with tap, the input x_g passed through as a third output (see PairConvFn.forward)"""
+    if _is_bf(x_g) and not ly.maps_bf:
+        x_c, x_g = PairDecodeFn.apply(x_c, x_g)      # (a layer without a bf16 input path, e.g. conv_post)
     return PairConvFn.apply(token, ly, float(pre_slope), bool(tap), x_c, x_g)
 
 
@@ -1073,6 +1243,7 @@ class MultiLossFn(torch.autograd.Function):
             b_list.append(rest.pop(0) if hb else None)
         g = _c(g).reshape(1)
         st = _stream()
+        # (RTG_LOSS_L1_ENC: bf16 feature maps in, bf16 gradients out — empty_like keeps the type)
         da = [torch.empty_like(a) if ctx.needs_input_grad[4 + i] else None for i, a in enumerate(a_list)]
         db = [torch.empty_like(b) if (b is not None and ctx.needs_input_grad[4 + n + i]) else None
               for i, b in enumerate(b_list)]
