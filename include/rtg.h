@@ -113,6 +113,9 @@ typedef struct RtgConv1dDesc {
                                   consumer's leaky-relu applied once by the producer (enc_slope = 1: a plain bf16 store,
                                   used for gradients); the sign, all a leaky-relu backward needs, survives.
                                   RTG_IO_MASK_BF16 / RTG_IO_RES_BF16: `mask` / `res` are bf16.
+                                  A bf16 x1 (and the bf16 x / dy of rtg_conv1d_wgrad) must be followed by 16 READABLE
+                                  bytes: the rows are read with 16-byte loads at 2-byte granularity, a load that starts
+                                  at the tensor's last elements runs past its end (what it reads there is discarded).
                                   Needs bf16 = 1 and a block shape of the dense-layer kernel (codes 8xxx):
                                   rtg_conv1d_tile_candidates lists only those for such a descriptor, possibly none —
                                   the caller then converts (rtg_bf16_decode / rtg_bf16_encode) around an fp32 launch.   */

@@ -80,15 +80,25 @@ class WNConv(nn.Module):
     bf16 = False        # set per instance by the bf16 tests: operands rounded to bf16, products and sums in fp32
                         # (what the bf16 matrix cores compute; BASELINE configs[2])
 
+    store_bf16 = False  # set per instance by the bf16 tests: the product keeps this layer's output in HBM as
+                        # bf16(leaky_relu(out, LRELU_SLOPE)) (hparam.bf16_maps: the dense discriminator layers) — every reader
+                        # sees the value that decodes from it (straight-through for the gradient: the product's gradients
+                        # are rounded to bf16 too, which a stock autograd graph does not model)
+
     def forward(self, x):
         w = self.weight()
         if self.bf16:
             x, w = x.bfloat16().float(), w.bfloat16().float()
         if self.kind == 'conv1d':
-            return F.conv1d(x, w, self.bias, self.stride, self.padding, self.dilation, self.groups)
-        if self.kind == 'convT1d':
-            return F.conv_transpose1d(x, w, self.bias, self.stride, self.padding, self.output_padding, self.groups)
-        return F.conv2d(x, w, self.bias, self.stride, self.padding, self.dilation, self.groups)
+            out = F.conv1d(x, w, self.bias, self.stride, self.padding, self.dilation, self.groups)
+        elif self.kind == 'convT1d':
+            out = F.conv_transpose1d(x, w, self.bias, self.stride, self.padding, self.output_padding, self.groups)
+        else:
+            out = F.conv2d(x, w, self.bias, self.stride, self.padding, self.dilation, self.groups)
+        if self.store_bf16:
+            a = F.leaky_relu(out.detach(), LRELU_SLOPE).bfloat16().float()
+            out = out + (torch.where(a > 0, a, a / LRELU_SLOPE) - out.detach())
+        return out
 
 
 class _Seq(nn.Module):

@@ -22,13 +22,23 @@ def bf16_mode():
 
 def _mirror_flags(model, omodel):
     """switch on bf16 rounding in the oracle for the layers whose FORWARD the product runs in bf16"""
-    flags = {ly.name: ly.fwd_bf for ly in model.bank().layers}
+    flags = {ly.name: (ly.fwd_bf, ly.maps_bf) for ly in model.bank().layers}
     n = 0
     for name, m in omodel.named_modules():
         if name in flags:
-            m.bf16 = bool(flags[name])
+            m.bf16 = bool(flags[name][0])
+            m.store_bf16 = bool(flags[name][1])      # (hparam.bf16_maps: the layer's output lives in HBM as encoded bf16)
             n += m.bf16
     return n, len(flags)
+
+
+def _fmap(t):
+    """a feature map as the product returns it -> fp32 values (bf16 maps are stored leaky-relu encoded, hparam.bf16_maps)"""
+    t = t.detach().cpu()
+    if t.dtype == torch.bfloat16:
+        t = t.float()
+        t = torch.where(t > 0, t, t / 0.15)
+    return t
 
 
 def test_generator_forward_bf16(oracle, bf16_mode):
@@ -73,8 +83,11 @@ def test_discriminator_forward_bf16(oracle, gold, bf16_mode, which):
         return ((a.cpu() - b).norm() / (b.norm() + 1e-20)).item()
     for a, b in zip(lr + lg, olr + olg):
         assert rel(a, b) < 5e-3
+    n_bf = 0
     for a, b in zip([f for fl in fr + fg for f in fl], [f for fl in ofr + ofg for f in fl]):
-        assert rel(a, b) < 5e-3
+        n_bf += a.dtype == torch.bfloat16
+        assert ((_fmap(a) - b).norm() / (b.norm() + 1e-20)).item() < 5e-3
+    assert n_bf > 0, 'no feature map of the stack lives in HBM as bf16?'
 
 
 def test_train_step_bf16_close_to_fp32(oracle, bf16_mode):

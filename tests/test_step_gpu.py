@@ -485,10 +485,11 @@ def test_bf16_two_steps_against_the_bf16_rounding_oracle(oracle):
             for m in ms:
                 oracle.det_fill(m)
         for prod, om in zip((tr.generator, tr.msd, tr.mpd), nets['bf16']):
-            flags = {ly.name: ly.fwd_bf for ly in prod.bank().layers}
+            flags = {ly.name: (ly.fwd_bf, ly.maps_bf) for ly in prod.bank().layers}
             for name, mod in om.named_modules():
                 if name in flags:
-                    mod.bf16 = bool(flags[name])
+                    mod.bf16 = bool(flags[name][0])
+                    mod.store_bf16 = bool(flags[name][1])     # the oracle rounds the stored maps where the product does
         x, y_tmpl, y = oracle.golden_inputs()
         rec = {k: [] for k in ('hip', 'bf16', 'fp32')}
         opts = {k: oracle.make_optimizers(ms[0], list(ms[1:])) for k, ms in nets.items()}

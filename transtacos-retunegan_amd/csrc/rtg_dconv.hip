@@ -170,7 +170,9 @@ int rtg_dconv_launch(const RtgConv1dDesc* d, int code, const float* x, const flo
   a.total = (int)total;
   a.per_xcd = rtg_ceil_div(total, 8);
   a.PW = window_positions(a.n_cols < BN ? a.n_cols : BN, d->Q, d->stride, d->K);
-  a.x_bytes = (d->B / a.h_n) * a.C * a.h_in * d->L_in * (xb ? 2 : 4);       // 1-D: h_n = h_in = 1
+  // (bf16 x: + the 16 readable bytes the caller guarantees behind the tensor — a 16-byte load that starts at its last elements
+  // runs past the end, and the range check drops whole dwords: clipped at the end it would lose the last element)
+  a.x_bytes = (d->B / a.h_n) * a.C * a.h_in * d->L_in * (xb ? 2 : 4) + (xb ? 16 : 0);       // 1-D: h_n = h_in = 1
   const int out_elems = d->B * d->out_C * d->out_L;               // (B = items * h_n)
   a.out_bytes = out_elems * (ob ? 2 : 4);
   a.mask_bytes = out_elems * (a.mask_b16 ? 2 : 4); a.res_bytes = out_elems * (a.res_b16 ? 2 : 4);

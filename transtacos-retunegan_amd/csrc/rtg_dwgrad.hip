@@ -562,8 +562,9 @@ int rtg_dwgrad_launch(const RtgWgradDesc* d, int variant, const float* x, const 
   const bool two_d = d->h_k > 1 || d->h_n > 1;
   a.h_in = two_d ? d->h_in : 1; a.h_k = two_d ? d->h_k : 1; a.h_stride = two_d ? d->h_stride : 1;
   a.h_pad = two_d ? d->h_pad : 0; a.h_n = two_d ? d->h_n : 1;
-  a.x_bytes = (d->B / a.h_n) * (d->C1 / a.h_k) * a.h_in * d->L_in * ((d->io_bf16 & 1) ? 2 : 4);
-  a.dy_bytes = d->B * d->Mg * d->dy_L * ((d->io_bf16 & 2) ? 2 : 4);  // (B = items * h_n)
+  // (bf16 tensors: + the 16 readable bytes the caller guarantees behind them, see RtgConv1dDesc.io_bf16)
+  a.x_bytes = (d->B / a.h_n) * (d->C1 / a.h_k) * a.h_in * d->L_in * ((d->io_bf16 & 1) ? 2 : 4) + ((d->io_bf16 & 1) ? 16 : 0);
+  a.dy_bytes = d->B * d->Mg * d->dy_L * ((d->io_bf16 & 2) ? 2 : 4) + ((d->io_bf16 & 2) ? 16 : 0);  // (B = items * h_n)
   const int S = d->stride;
   if (two_d) {
     if (variant == 0) return S == 1 ? dw_launch<1, 8, 1, 1, 3, true>(a, s) : dw_launch<2, 8, 1, 1, 3, true>(a, s);

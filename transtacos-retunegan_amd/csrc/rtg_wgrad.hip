@@ -161,10 +161,24 @@ int validate(const RtgWgradDesc* d) {
 
 }  // namespace
 
-extern "C" int rtg_wgrad_splits(const RtgWgradDesc* d) {
-  if (!d) return RTG_ENULL;
+// bf16 tensors (RtgWgradDesc.io_bf16) with shape_cfg 0: the library's pick among the dense-layer kernel's shapes — the one
+// with the most channel chunks per block that serves the problem (fewest operand loads per matrix instruction); 0: none
+static int dense_default_shape(const RtgWgradDesc* d) {
+  for (int v = 3; v >= 0; --v)
+    if (rtg_dwgrad_ok(d, v)) return kDenseShape + v;
+  for (int v = 4; v < rtg_dwgrad_variants(); ++v)
+    if (rtg_dwgrad_ok(d, v)) return kDenseShape + v;
+  return 0;
+}
+
+extern "C" int rtg_wgrad_splits(const RtgWgradDesc* d_in) {
+  if (!d_in) return RTG_ENULL;
+  RtgWgradDesc dd = *d_in;
+  if (dd.io_bf16 != 0 && dd.shape_cfg == 0) dd.shape_cfg = dense_default_shape(&dd);
+  const RtgWgradDesc* d = &dd;
   int st = validate(d);
   if (st) return st;
+  if (d->io_bf16 != 0 && !(d->shape_cfg >= kDenseShape && d->shape_cfg <= kDenseShapeLast)) return RTG_ERANGE;
   if (d->shape_cfg == kThinShape) return rtg_wgrad_thin_splits(d);
   if (d->shape_cfg == kResShape) return rtg_reswgrad_splits(d);
   if (d->shape_cfg == kGconvShape) return rtg_gconv_wgrad_splits(d);
@@ -304,9 +318,12 @@ int wgrad_plan(const RtgWgradDesc* d, const float* x1, const float* x2, const fl
 int rtg_wgrad_launch_group_m0(int, const rtg_wg::WgGroupArgs&, size_t, hipStream_t);
 int rtg_wgrad_launch_group_m1(int, const rtg_wg::WgGroupArgs&, size_t, hipStream_t);
 
-extern "C" int rtg_conv1d_wgrad(const RtgWgradDesc* d, const float* x1, const float* x2, const float* dy,
+extern "C" int rtg_conv1d_wgrad(const RtgWgradDesc* d_in, const float* x1, const float* x2, const float* dy,
                                 const float* gy_aux, float* part, void* stream) {
-  if (!d || !x1 || !dy || !part) return RTG_ENULL;
+  if (!d_in || !x1 || !dy || !part) return RTG_ENULL;
+  RtgWgradDesc dd = *d_in;
+  if (dd.io_bf16 != 0 && dd.shape_cfg == 0) dd.shape_cfg = dense_default_shape(&dd);      // (as rtg_wgrad_splits picked)
+  const RtgWgradDesc* d = &dd;
   if (d->shape_cfg == kThinShape || d->shape_cfg == kResShape || d->shape_cfg == kGconvShape || d->shape_cfg == kGmfmaShape ||
       (d->shape_cfg >= kDenseShape && d->shape_cfg <= kDenseShapeLast)) {
     int st = validate(d);

@@ -83,10 +83,38 @@ def _is_bf(t):
     return t is not None and t.dtype == _BF
 
 
+_SLACK = 16        # readable bytes a bf16 tensor must have behind its last element (include/rtg.h, RtgConv1dDesc.io_bf16)
+
+
+def empty_bf(shape, device):
+    """an uninitialised bf16 tensor with _SLACK readable bytes behind it: the kernels read bf16 rows with 16-byte loads at
+    2-byte granularity, and a load that starts at the last elements of the tensor runs past its end (the hardware's range
+    check works on whole dwords: clipping the load at the tensor's end would drop the last element with it)"""
+    n = 1
+    for s in shape:
+        n *= int(s)
+    return torch.empty(n + _SLACK // 2, device=device, dtype=_BF)[:n].view(tuple(shape))
+
+
+def _slacked(t):
+    """`t` (bf16, contiguous) with the slack its kernels need: itself when its storage extends far enough behind it (every
+    tensor this package allocates, and every clip-range slice of one), else a copy (tensors made by ATen, e.g. the sum
+    autograd forms of two gradients)"""
+    if t is None or t.dtype != _BF:
+        return t
+    t = _c(t)
+    end = (t.storage_offset() + t.numel()) * 2
+    if t.untyped_storage().nbytes() - end >= _SLACK:
+        return t
+    out = empty_bf(t.shape, t.device)
+    out.copy_(t)
+    return out
+
+
 def bf16_encode(x, slope):
     """fp32 -> bf16(leaky_relu(x, slope)); slope 1: a plain rounding (gradients)"""
     x = _c(x)
-    out = torch.empty(x.shape, device=x.device, dtype=_BF)
+    out = empty_bf(x.shape, x.device)
     check(timed_bw('bf16_cvt', 6 * x.numel(), lambda: lib.rtg_bf16_encode(_p(x), _p(out), x.numel(), float(slope), _stream())),
           'bf16_encode')
     return out
@@ -170,6 +198,7 @@ def _run_conv_t(d, x1, wp, bias, mask, res, out, flop, label, what, x_slope=1.0,
     io = (L.IO_X_BF16 if _is_bf(x1) else 0) | (L.IO_OUT_BF16 if _is_bf(out) else 0) | \
          (L.IO_MASK_BF16 if _is_bf(mask) else 0) | (L.IO_RES_BF16 if _is_bf(res) else 0)
     if io:
+        x1 = _slacked(x1)
         if _is_bf(x1) and d.pre_mode == L.PRE_LRELU and abs(d.pre_slope - x_slope) > 1e-6:
             raise L.RtgError(f'{label}: a bf16 activation tensor encoded with slope {x_slope} feeds a layer with pre-activation '
                              f'slope {d.pre_slope}')
@@ -206,6 +235,7 @@ def _wgrad_io(wd, ly, a1, gyt):
     io = (L.IO_X_BF16 if _is_bf(a1) else 0) | (L.IO_OUT_BF16 if _is_bf(gyt) else 0)
     wd.io_bf16 = 0
     if io:
+        a1, gyt = _slacked(a1), _slacked(gyt)
         wd.bf16, wd.io_bf16 = int(getattr(ly, 'wgrad_bf', 0)), io
         if not (wd.bf16 and _wgrad_native(wd)):
             wd.io_bf16 = 0
@@ -458,7 +488,7 @@ class ConvFn(torch.autograd.Function):
         out_bf = bool(ly.maps_bf and plain and ly.kind == 'conv')
         if _is_bf(x1) and not (plain and ly.kind == 'conv'):
             raise L.RtgError(f'{ly.name}: a bf16 feature map feeds a layer form without a bf16 path (ops.conv decodes first)')
-        out = torch.empty(B, ly.cout, L_out, device=x1.device, dtype=_BF if out_bf else torch.float32)
+        out = empty_bf((B, ly.cout, L_out), x1.device) if out_bf else torch.empty(B, ly.cout, L_out, device=x1.device)
         mode, g, mg, cg, k, s = ly.fwd_op
         pre_mode = L.PRE_LRELU if pre_slope != 1.0 else L.PRE_NONE
         if ly.kind == 'conv':
@@ -533,7 +563,7 @@ class ConvFn(torch.autograd.Function):
             if C2 > 0:
                 assert pre_slope == 1.0, 'input activation on a concatenated pair is not used by the path'
             if need_x1 or C2 == 0:
-                dx1 = torch.empty_like(x1)
+                dx1 = empty_bf(x1.shape, x1.device) if _is_bf(x1) else torch.empty_like(x1)
             if C2 > 0 and need_x2:
                 dx2 = torch.empty_like(x2)
             mask = x1 if pre_slope != 1.0 else None
@@ -772,7 +802,7 @@ class Conv2dFn(torch.autograd.Function):
         assert Cin == ly.cin
         Ho = (H + 2 * ly.ph - ly.kh) // ly.sh + 1
         Wo = (W + 2 * ly.pad - ly.k) // ly.stride + 1
-        out = torch.empty(B, ly.cout, Ho, Wo, device=x.device, dtype=_BF if ly.maps_bf else torch.float32)
+        out = empty_bf((B, ly.cout, Ho, Wo), x.device) if ly.maps_bf else torch.empty(B, ly.cout, Ho, Wo, device=x.device)
         pre_mode = L.PRE_LRELU if pre_slope != 1.0 else L.PRE_NONE
         d = _desc(B=B * Ho, C1=Cin * ly.kh, L_in=W, groups=1, Cg=Cin * ly.kh, Mg=ly.cout, K=ly.k, stride=ly.stride,
                   pad=ly.pad, Q=Wo, out_C=ly.cout, out_L=Wo, pre_mode=pre_mode, pre_slope=pre_slope, tile_m=ly.fwd_tm,
@@ -798,7 +828,7 @@ class Conv2dFn(torch.autograd.Function):
         flop = 2.0 * B * Ho * Wo * ly.cout * Cin * ly.kh * ly.k
         dx = None
         if ctx.needs_input_grad[1]:
-            dx = torch.empty_like(x)
+            dx = empty_bf(x.shape, x.device) if _is_bf(x) else torch.empty_like(x)
             mode, g, mg, cg, k, s = ly.bwd_op
             mask = x if pre_slope != 1.0 else None
             common = dict(B=B * H, C1=ly.cout * ly.kh, L_in=Wo, groups=1, Cg=cg, Mg=mg, K=k, out_C=Cin, out_L=W,
@@ -910,7 +940,7 @@ class PairConvFn(torch.autograd.Function):
         B, C1, L_in = x_c.shape
         assert C1 == ly.cin
         d, L_out = _fwd_desc(ly, 2 * B, C1, L_in, pre_slope)
-        out = torch.empty(2 * B, ly.cout, L_out, device=x_c.device, dtype=_BF if ly.maps_bf else torch.float32)
+        out = empty_bf((2 * B, ly.cout, L_out), x_c.device) if ly.maps_bf else torch.empty(2 * B, ly.cout, L_out, device=x_c.device)
         if ly.maps_bf or _is_bf(x_c):
             whole = torch.as_strided(x_c, (2 * B, C1, L_in), x_c.stride())
             _run_conv_t(d, whole, bank.fwd_ptr(ly), bank.bias_ptr(ly), None, None, out, _conv_flop(ly, 2 * B, L_out),
@@ -945,7 +975,7 @@ class PairConvFn(torch.autograd.Function):
         d_g = _c(d_g)
         B, C1, L_in = x_g.shape
         L_out = d_g.shape[-1]
-        dx = torch.empty_like(x_g)
+        dx = empty_bf(x_g.shape, x_g.device) if _is_bf(x_g) else torch.empty_like(x_g)
         d = _dgrad_desc(ly, B, L_in, L_out, pre_slope)
         res = _c(d_tap) if d_tap is not None else None            # dx = lrelu'(x) * convT(d_g) + d_tap
         if _is_bf(d_g) or _is_bf(x_g):
@@ -1243,10 +1273,10 @@ class MultiLossFn(torch.autograd.Function):
             b_list.append(rest.pop(0) if hb else None)
         g = _c(g).reshape(1)
         st = _stream()
-        # (RTG_LOSS_L1_ENC: bf16 feature maps in, bf16 gradients out — empty_like keeps the type)
-        da = [torch.empty_like(a) if ctx.needs_input_grad[4 + i] else None for i, a in enumerate(a_list)]
-        db = [torch.empty_like(b) if (b is not None and ctx.needs_input_grad[4 + n + i]) else None
-              for i, b in enumerate(b_list)]
+        # (RTG_LOSS_L1_ENC: bf16 feature maps in, bf16 gradients out)
+        like = lambda t: empty_bf(t.shape, t.device) if _is_bf(t) else torch.empty_like(t)      # noqa: E731
+        da = [like(a) if ctx.needs_input_grad[4 + i] else None for i, a in enumerate(a_list)]
+        db = [like(b) if (b is not None and ctx.needs_input_grad[4 + n + i]) else None for i, b in enumerate(b_list)]
         idx = [i for i in range(n) if da[i] is not None or db[i] is not None]
         for s in range(0, len(idx), L.MAX_LOSS_JOBS):
             ent = [(a_list[i], b_list[i], da[i], db[i], weights[i], target) for i in idx[s:s + L.MAX_LOSS_JOBS]]
