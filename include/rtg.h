@@ -284,6 +284,10 @@ typedef struct RtgPackJob {      /* one per packed layout of a layer            
                                     (dst_size = rtg_packed_size_frag16_bf16 floats)                                       */
   int first_block, n_blocks;     /* (ABI 6) the job's range of workgroups in the launch: n_blocks = rtg_pack_job_blocks(job),
                                     first_block = sum of n_blocks of the jobs before it in the table                     */
+  int src_T;                     /* (ABI 9) 1: the layer runs on its input with the last two axes swapped (StftDiscriminator
+                                    along the frequency axis): the operator's kernel rows are the source tensor's LAST kernel
+                                    axis and its taps the one before — the source [C_out][C_in][src_K][KH] is read where the
+                                    operator means [C_out][C_in][KH][src_K]                                              */
 } RtgPackJob;
 
 typedef struct RtgWnBwdJob {     /* one per weight-normed tensor                                               */
@@ -293,6 +297,9 @@ typedef struct RtgWnBwdJob {     /* one per weight-normed tensor                
   long long part_stride;
   int splits;
   int rows, inner;
+  int t_rows, t_taps;            /* (ABI 9) both 0, or the kernel rows / taps of a layer packed with RtgPackJob.src_T: its
+                                    partials are in the operator's order [C_in][t_rows][t_taps], the gradient is written in
+                                    the tensor's [C_in][t_taps][t_rows]                                                  */
 } RtgWnBwdJob;
 
 int rtg_weightnorm_scales(const RtgNormJob* jobs_dev, int n_jobs, int max_rows, const float* params, float* scales,
@@ -321,6 +328,9 @@ int rtg_weightnorm_backward(const RtgWnBwdJob* jobs_dev, int n_jobs, int max_row
  * ------------------------------------------------------------------------------------------------------------ */
 typedef struct RtgStftDesc {
   int B, T, n_fft, win, hop, frames, n_mel;
+  int spec_T;                    /* (ABI 9) 0: spec / dspec are [B][2][F][frames] (the reference's stack, loss.py:36-44);
+                                    1: [B][2][frames][F] — frequency contiguous: coalesced stores, and the layout the
+                                    spectrogram discriminators walk (callers hand out the transposed view)          */
 } RtgStftDesc;
 
 int rtg_stft_forward(const RtgStftDesc* d, const float* y, const float* window, const float* twiddle,

@@ -82,8 +82,7 @@ class WNConv(nn.Module):
 
     store_bf16 = False  # set per instance by the bf16 tests: the product keeps this layer's output in HBM as
                         # bf16(leaky_relu(out, LRELU_SLOPE)) (hparam.bf16_maps: the dense discriminator layers) — every reader
-                        # sees the value that decodes from it (straight-through for the gradient: the product's gradients
-                        # are rounded to bf16 too, which a stock autograd graph does not model)
+                        # sees the value that decodes from it, and the gradient of such a map is stored as bf16 as well
 
     def forward(self, x):
         w = self.weight()
@@ -96,9 +95,22 @@ class WNConv(nn.Module):
         else:
             out = F.conv2d(x, w, self.bias, self.stride, self.padding, self.dilation, self.groups)
         if self.store_bf16:
-            a = F.leaky_relu(out.detach(), LRELU_SLOPE).bfloat16().float()
-            out = out + (torch.where(a > 0, a, a / LRELU_SLOPE) - out.detach())
+            out = _StoreBf16.apply(out)
         return out
+
+
+class _StoreBf16(torch.autograd.Function):
+    """a feature map as the product keeps it in HBM under hparam.bf16_maps: forward, the value that decodes from
+    bf16(leaky_relu(x, LRELU_SLOPE)); backward, the map's (summed) gradient rounded to bf16 — the product stores it so"""
+
+    @staticmethod
+    def forward(ctx, x):
+        a = F.leaky_relu(x, LRELU_SLOPE).bfloat16().float()
+        return torch.where(a > 0, a, a / LRELU_SLOPE)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.bfloat16().float()
 
 
 class _Seq(nn.Module):

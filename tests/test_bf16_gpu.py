@@ -82,7 +82,9 @@ def test_discriminator_forward_bf16(oracle, gold, bf16_mode, which):
     def rel(a, b):
         return ((a.cpu() - b).norm() / (b.norm() + 1e-20)).item()
     for a, b in zip(lr + lg, olr + olg):
-        assert rel(a, b) < 5e-3
+        # (with the feature maps stored as bf16 two evaluations also differ by the rounding decisions of the stored maps:
+        # one more 2^-9 per dense layer in front of the 512 -> 1 conv_post sum)
+        assert rel(a, b) < 1e-2
     n_bf = 0
     for a, b in zip([f for fl in fr + fg for f in fl], [f for fl in ofr + ofg for f in fl]):
         n_bf += a.dtype == torch.bfloat16
@@ -112,10 +114,13 @@ def test_train_step_bf16_close_to_fp32(oracle, bf16_mode):
 
 @pytest.mark.parametrize('cin,cout,k,stride,dil,L', [(64, 96, 5, 1, 1, 300), (128, 256, 5, 3, 1, 304), (48, 16, 7, 1, 3, 2048),
                                                      (256, 64, 3, 1, 9, 700)])
-def test_single_layer_bf16_is_exact_on_rounded_operands(bf16_mode, cin, cout, k, stride, dil, L):
+def test_single_layer_bf16_is_exact_on_rounded_operands(bf16_mode, monkeypatch, cin, cout, k, stride, dil, L):
     """one conv layer, forward and backward-data, against torch on the SAME bf16-rounded operands: products of bf16
-    numbers are exact in fp32, so only the summation order differs (tile_m 32 and 16, stride 1 / 3, dilation)"""
+    numbers are exact in fp32, so only the summation order differs (tile_m 32 and 16, stride 1 / 3, dilation).  fp32 tensors
+    in HBM (hparam.bf16_maps off: the bf16-tensor forms of the k5 layers have tests/test_bf16_maps_gpu.py)"""
     import torch.nn.functional as F
+    import hparam as hp
+    monkeypatch.setattr(hp, 'bf16_maps', False)
     from models.layers import WNConv, BankedModel, conv
 
     class One(BankedModel):

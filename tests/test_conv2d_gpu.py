@@ -33,11 +33,14 @@ def _serves(case, force):
     return not ((force == 7 and Cin != 2 and Cout != 1) or (force in (10, 11) and Cout % 128) or (force == 14 and Cout != 64))
 
 
+@pytest.mark.parametrize('wt', [False, True])
 @pytest.mark.parametrize('case,force', [(c, f) for c in CASES for f in (0, 7, 10, 11, 14) if _serves(c, f)])
-def test_conv2d_layer_forward_backward(case, force, monkeypatch):
+def test_conv2d_layer_forward_backward(case, force, wt, monkeypatch):
     """force: the weight-gradient block shape the tuner would have to pick (0: the library's heuristic; 7: the bandwidth
     kernels of rtg_wgrad_thin.hip / rtg_thin2d.hip; 10, 11: the dense kernel of rtg_dwgrad.hip in its 2-D mode, where it
-    serves the layer)"""
+    serves the layer).  wt: the layer built with WNConv(wt=True) — run on the input with its last two axes swapped (how the
+    spectrogram discriminators run along the frequency axis), same parameters: its output / input gradient are the
+    transposes, its parameter gradients the very same tensors."""
     import ctypes as C
     from models.layers import WNConv, BankedModel, conv
     from rtg import tune
@@ -57,11 +60,12 @@ def test_conv2d_layer_forward_backward(case, force, monkeypatch):
     class Net(BankedModel):
         def __init__(self):
             super().__init__()
-            self.c = WNConv('conv2d', Cin, Cout, k, stride=s, pad=p)
+            self.c = WNConv('conv2d', Cin, Cout, k, stride=s, pad=p, wt=wt)
 
         def forward(self, x):
             return conv(self.token(), self.c, x, pre_slope=0.15)
 
+    tr = (lambda t: t.transpose(2, 3).contiguous()) if wt else (lambda t: t)      # noqa: E731
     torch.manual_seed(3)
     net = Net()
     x = torch.randn(B, Cin, H, W)
@@ -76,21 +80,21 @@ def test_conv2d_layer_forward_backward(case, force, monkeypatch):
     dy = torch.randn(y.shape, generator=dy_seed)
     y.backward(dy.double())
     net.to(DEV)
-    xg = x.to(DEV).requires_grad_(True)
+    xg = tr(x).to(DEV).requires_grad_(True)
     out = net(xg)
-    out.backward(dy.to(DEV))
+    out.backward(tr(dy).to(DEV))
     torch.cuda.synchronize()
 
     def close(a, b, name):
         err = (a.detach().cpu().double() - b).abs().max().item()
         assert err <= 2e-4 * b.abs().max().item() + 1e-5, (name, err, b.abs().max().item())
 
-    close(out, y.detach(), 'out')
-    close(xg.grad, xr.grad, 'dx')
+    close(tr(out), y.detach(), 'out')
+    close(tr(xg.grad), xr.grad, 'dx')
     close(net.c.weight_v.grad, v.grad, 'dv')
     close(net.c.weight_g.grad, g.grad, 'dg')
     close(net.c.bias.grad, bias.grad, 'dbias')
-    if force in (10, 11) and Cout % 128 == 0 and (Cin * k[0]) % (32 if force == 11 else 16) == 0 and out.shape[-1] >= 4:
+    if force in (10, 11) and Cout % 128 == 0 and (Cin * (k[1] if wt else k[0])) % (32 if force == 11 else 16) == 0 and out.shape[-1] >= 4:
         assert used == [force], used              # the dense kernel really ran
     if force == 14 and Cout == 64:
         assert used == [14], used                 # the 64-row block really ran

@@ -95,7 +95,10 @@ def get_plan(n_fft, win_length, hop_length):
 
 def stft_mel_spec(y, n_fft, win_length, hop_length, want_spec=False):
     """y [B,T] -> (mel [B,80,frames], spec [B,2,F,frames] = stack(log|D+1e-9|, angle(D)/PI) or None)."""
-    return ops.StftFn.apply(y, get_plan(n_fft, win_length, hop_length), want_spec)
+    mel, spec = ops.StftFn.apply(y, get_plan(n_fft, win_length, hop_length), want_spec)
+    if spec is not None and ops.SPEC_FREQ_MAJOR:
+        spec = spec.transpose(2, 3)          # stored [B, 2, frames, F] (frequency contiguous); the map is its transposed view
+    return mel, spec
 
 
 def get_stft_torch(y, n_fft, win_length, hop_length):

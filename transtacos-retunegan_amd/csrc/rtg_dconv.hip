@@ -53,7 +53,8 @@ bool dconv_eligible(const RtgConv1dDesc* d) {
     if (d->h_mode == 1 && d->h_stride > 1) {
       if (d->K != 2 || d->stride != 1 || d->h_stride > 4) return false;
     } else {
-      if (d->K != 3 || (d->stride != 1 && d->stride != 2) || d->shuf_S != 1) return false;
+      const bool k3 = d->K == 3 && (d->stride == 1 || d->stride == 2), k5 = d->K == 5 && d->stride == 3 && d->h_mode == 0;
+      if (!(k3 || k5) || d->shuf_S != 1) return false;
       if (d->h_mode == 1 && d->stride != 1) return false;
     }
     if ((long long)(d->B / d->h_n) * (d->C1 / d->h_k) * d->h_in * d->L_in * 4 >= (1ll << 31)) return false;
@@ -102,7 +103,8 @@ int rtg_dconv_candidates(const RtgConv1dDesc* d, int* codes, int max) {
            (kShapes[si].wb == 4 && (kNT[ni] == 7 || (kNT[ni] == 6 && d->stride > 1)))))
         continue;
       const int pw = window_positions((int)(n_cols < BN ? n_cols : BN), d->Q, d->stride, d->K);
-      if (lds_bytes_for(pw, d->stride, kShapes[si].wb, (d->io_bf16 & RTG_IO_X_BF16) != 0) > 158 * 1024) continue;
+      const int xbt = (d->io_bf16 & RTG_IO_X_BF16) ? xb_max_tasks(BN, min_q(d->K, two_d), d->stride, d->K, kShapes[si].wb) : 0;
+      if (lds_bytes_for(pw, d->stride, kShapes[si].wb, xbt) > 158 * 1024) continue;
       const long long blocks = (long long)n_mb * ((n_cols + BN - 1) / BN);
       // rounds of the chip at one block per CU (two for the 4-wave shapes): the tail round's idle CUs are the loss
       const double slots = 256.0 * (kShapes[si].wb == 4 ? 2 : 1);
@@ -181,7 +183,7 @@ int rtg_dconv_launch(const RtgConv1dDesc* d, int code, const float* x, const flo
   if (a.xb_Lv < 1) a.xb_Lv = 1;
   a.xb_ups = (a.xb_Lv + 7) / 8;
   a.xb_j0 = a.xb_n0 = a.xb_units = 0;                             // (per block: computed in the kernel)
-  const size_t lds_bytes = lds_bytes_for(a.PW, d->stride, wb, xb);
+  const size_t lds_bytes = lds_bytes_for(a.PW, d->stride, wb, xb ? xb_max_tasks(BN, min_q(d->K, two_d), d->stride, d->K, wb) : 0);
   if (lds_bytes > 158 * 1024) return RTG_ERANGE;
   const unsigned blocks = (unsigned)(8 * a.per_xcd);
   if (d->io_bf16 & 3) {

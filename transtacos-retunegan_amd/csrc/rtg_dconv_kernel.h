@@ -302,8 +302,11 @@ __global__ __launch_bounds__(WB * 64, 2) void dconv_kernel(const DArgs a) {
   [[maybe_unused]] int xl_cls[CLS ? MAXT : 1];
   [[maybe_unused]] int xc[(TWO_D && !HB) ? MAXT : 1], xr[(TWO_D && !HB) ? MAXT : 1];   // 2-D forward: this lane's (channel, kernel row)
   [[maybe_unused]] int xs_off[MAXT];                 // store side: float offset of this lane's position in a buffer; < 0: none
-  [[maybe_unused]] float* const xscr = lds + 2 * bufF + wave * kXbScrF;
-  [[maybe_unused]] float* const xdump = lds + 2 * bufF + WB * kXbScrF + tid * 4;
+  // (a scratch per wave AND task slot: the tasks of a chunk go through write -> transposing read -> write side by side, one
+  // LDS round trip for all of them; with one scratch per wave they queued up behind each other's latency)
+  [[maybe_unused]] float* const xscr = lds + 2 * bufF + wave * MAXT * kXbScrF;
+  [[maybe_unused]] float* const xdump = lds + 2 * bufF + WB * MAXT * kXbScrF + tid * 4;
+  [[maybe_unused]] int xb_cnt = 0;                    // task slots of this wave that hold units (wave-uniform)
   [[maybe_unused]] const unsigned chb2 = (unsigned)a.L_in * 2u;
   // scratch addresses: the load side parks 16 bytes at [channel lane & 7][unit slot lane >> 3]; the transposing read of lane
   // 16 g + 4 q + p names row q, columns 16 g + 4 p .. + 3 and hands lane 16 g + i column 16 g + i (rows q = 0..3 as 4 x bf16)
@@ -323,6 +326,11 @@ __global__ __launch_bounds__(WB * 64, 2) void dconv_kernel(const DArgs a) {
     int n0u = (nseg == 1 ? jhi_last : a.xb_ups) - j0;
     n0u = n0u > 0 ? n0u : 0;
     const int total_u = nseg == 1 ? n0u : n0u + (nseg - 2) * a.xb_ups + jhi_last;
+    {
+      const int n_tasks = 4 * ((total_u + 7) >> 3);   // (plane x block of 8 units), dealt to the waves round robin
+      const int c = (n_tasks - wave + WB - 1) / WB;
+      xb_cnt = c < 0 ? 0 : (c > MAXT ? MAXT : c);
+    }
     [[maybe_unused]] int m0q_b = 0, m0rem_b = 0;
 #pragma unroll
     for (int it = 0; it < MAXT; ++it) {
@@ -401,19 +409,33 @@ __global__ __launch_bounds__(WB * 64, 2) void dconv_kernel(const DArgs a) {
   };
   auto stage_write_b = [&](float* buf, auto set_tag) __attribute__((always_inline)) {
     constexpr int SET = decltype(set_tag)::value;
+    // three passes over the wave's task slots — park, read back transposed, write the positions — so that the LDS latencies
+    // of the slots overlap; slots past the wave's share hold nothing (uniform skip: LDS traffic only, the loads were issued
+    // whatever they fetch so that the vector-memory wait counts stay exact)
 #pragma unroll
     for (int it = 0; it < MAXT; ++it) {
       u32x4 v = xst[SET][it];
       asm volatile("" : "+v"(v));                      // the wait for this load sits here, below the multiplications
-      *reinterpret_cast<u32x4*>(xscr_w) = v;
-      asm volatile("" ::: "memory");                   // (same wave, LDS executes in order: no wait between the write and the reads)
-      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(xscr_r));
-      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(xscr_r + 4 * 72));
-      asm volatile("" ::: "memory");
-      const unsigned long long l64 = __builtin_bit_cast(unsigned long long, lo), h64 = __builtin_bit_cast(unsigned long long, hi);
-      const u32x4 o4 = {(unsigned)l64, (unsigned)(l64 >> 32), (unsigned)h64, (unsigned)(h64 >> 32)};
-      float* dst = xs_off[it] >= 0 ? buf + xs_off[it] : xdump;
-      *reinterpret_cast<u32x4*>(dst) = o4;
+      if (it < xb_cnt) *reinterpret_cast<u32x4*>(xscr_w + it * kXbScrF) = v;
+    }
+    asm volatile("" ::: "memory");                     // (same wave, LDS executes in order: no wait between the writes and the reads)
+    s16x4 lo[MAXT], hi[MAXT];
+#pragma unroll
+    for (int it = 0; it < MAXT; ++it) {
+      if (it < xb_cnt) {
+        lo[it] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(xscr_r + it * (kXbScrF * 2)));
+        hi[it] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(xscr_r + it * (kXbScrF * 2) + 4 * 72));
+      }
+    }
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int it = 0; it < MAXT; ++it) {
+      if (it < xb_cnt) {
+        const unsigned long long l64 = __builtin_bit_cast(unsigned long long, lo[it]), h64 = __builtin_bit_cast(unsigned long long, hi[it]);
+        const u32x4 o4 = {(unsigned)l64, (unsigned)(l64 >> 32), (unsigned)h64, (unsigned)(h64 >> 32)};
+        float* dst = xs_off[it] >= 0 ? buf + xs_off[it] : xdump;
+        *reinterpret_cast<u32x4*>(dst) = o4;
+      }
     }
   };
   auto stage_issue = [&](const Walk& w, auto set_tag) __attribute__((always_inline)) {
@@ -718,8 +740,9 @@ constexpr DShape kShapes[] = {{2, 4}, {1, 8}, {1, 4}, {2, 8}};       // code dig
 constexpr int kNT[] = {4, 6, 7, 8};
 
 // dynamic LDS of an instance: two patch buffers; bf16 input: + a transposition scratch per wave and a dump slot per lane
-inline size_t lds_bytes_for(int PW, int S, int WB, bool xb) {
-  return (size_t)2 * 4 * plane_floats(PW, S) * sizeof(float) + (xb ? (size_t)WB * kXbScrF * 4 + (size_t)WB * 64 * 16 : 0);
+inline size_t lds_bytes_for(int PW, int S, int WB, int xb_tasks) {
+  return (size_t)2 * 4 * plane_floats(PW, S) * sizeof(float) +
+         (xb_tasks ? (size_t)WB * xb_tasks * kXbScrF * 4 + (size_t)WB * 64 * 16 : 0);
 }
 
 template <int RW16, int WB, int NT16, int S, int K, bool TWO_D, bool CLS, bool BF, bool HB = CLS, int IO = 0>
@@ -743,6 +766,8 @@ int launch_sk(const DArgs& a, int S, int K, bool two_d, unsigned blocks, size_t 
     if (S == 1 && K == 3 && a.h_mode == 1) return launch<RW16, WB, NT16, 1, 3, true, false, BF, true, IO>(a, blocks, lds_bytes, s);
     if (S == 1 && K == 3) return launch<RW16, WB, NT16, 1, 3, true, false, BF, false, IO>(a, blocks, lds_bytes, s);
     if (S == 2 && K == 3 && a.h_mode == 0) return launch<RW16, WB, NT16, 2, 3, true, false, BF, false, IO>(a, blocks, lds_bytes, s);
+    // (round 5: StftDiscriminator along the frequency axis — its (5, 3) kernels with stride (3, 2) walk 5 taps at stride 3)
+    if (S == 3 && K == 5 && a.h_mode == 0) return launch<RW16, WB, NT16, 3, 5, true, false, BF, false, IO>(a, blocks, lds_bytes, s);
     return RTG_EINVAL;
   }
   if (S == 1 && K == 5) return launch<RW16, WB, NT16, 1, 5, false, false, BF, false, IO>(a, blocks, lds_bytes, s);

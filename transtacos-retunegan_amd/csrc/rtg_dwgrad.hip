@@ -462,7 +462,8 @@ bool eligible(const RtgWgradDesc* d, int variant) {
   if (d->groups != 1 || d->C2 != 0 || (d->bf16 != 0 && d->bf16 != 1) || d->dil != 1) return false;
   const bool two_d = d->h_k > 1 || d->h_n > 1;
   if (two_d) {
-    if (d->K != 3 || (d->stride != 1 && d->stride != 2)) return false;
+    // 3 taps at stride 1 / 2, or (round 5: StftDiscriminator along the frequency axis) 5 taps at stride 3
+    if (!((d->K == 3 && (d->stride == 1 || d->stride == 2)) || (d->K == 5 && d->stride == 3))) return false;
     if (d->h_in < 1 || d->h_k < 1 || d->h_stride < 1 || d->h_pad < 0 || d->h_n < 1 || d->C1 % d->h_k != 0 || d->B % d->h_n != 0)
       return false;
     if ((long long)(d->B / d->h_n) * (d->C1 / d->h_k) * d->h_in * d->L_in * 4 >= (1ll << 31)) return false;
@@ -566,6 +567,12 @@ int rtg_dwgrad_launch(const RtgWgradDesc* d, int variant, const float* x, const 
   a.x_bytes = (d->B / a.h_n) * (d->C1 / a.h_k) * a.h_in * d->L_in * ((d->io_bf16 & 1) ? 2 : 4) + ((d->io_bf16 & 1) ? 16 : 0);
   a.dy_bytes = d->B * d->Mg * d->dy_L * ((d->io_bf16 & 2) ? 2 : 4) + ((d->io_bf16 & 2) ? 16 : 0);  // (B = items * h_n)
   const int S = d->stride;
+  if (two_d && d->K == 5) {
+    if (variant == 0) return dw_launch<3, 8, 1, 1, 5, true>(a, s);
+    if (variant == 1) return dw_launch<3, 8, 2, 1, 5, true>(a, s);
+    if (variant == 2 && a.bf) return dw_launch_bf<3, 8, 4, 1, 5, true, true>(a, s);
+    return RTG_EINVAL;
+  }
   if (two_d) {
     if (variant == 0) return S == 1 ? dw_launch<1, 8, 1, 1, 3, true>(a, s) : dw_launch<2, 8, 1, 1, 3, true>(a, s);
     if (variant == 1) return S == 1 ? dw_launch<1, 8, 2, 1, 3, true>(a, s) : dw_launch<2, 8, 2, 1, 3, true>(a, s);

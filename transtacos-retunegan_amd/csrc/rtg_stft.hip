@@ -93,7 +93,9 @@ __global__ __launch_bounds__(RTG_THREADS) void stft_fwd_kernel(RtgStftDesc d, co
       im_out[fo + f] = im;
     }
     if (spec) {
-      const size_t so = (((size_t)b * 2) * F + f) * d.frames + frame;
+      // [B][2][F][frames] (the reference's stack, loss.py:36-44: lanes 4 bytes x `frames` apart) or, spec_T, [B][2][frames][F]:
+      // a frame's bins are consecutive — coalesced stores, and the layout the spectrogram discriminators walk (round 5)
+      const size_t so = d.spec_T ? (((size_t)b * 2) * d.frames + frame) * F + f : (((size_t)b * 2) * F + f) * d.frames + frame;
       spec[so] = logf(mag);
       spec[so + (size_t)F * d.frames] = atan2f(im, re) / RTG_PI_REF;
     }
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(RTG_THREADS) void stft_bwd_frame_kernel(RtgStftDesc
       }
       float dP = 0.f;
       if (dspec) {
-        const size_t so = (((size_t)b * 2) * F + f) * d.frames + frame;
+        const size_t so = d.spec_T ? (((size_t)b * 2) * d.frames + frame) * F + f : (((size_t)b * 2) * F + f) * d.frames + frame;
         dS += dspec[so] / mag;                            // d log S
         dP = dspec[so + (size_t)F * d.frames] / RTG_PI_REF;
       }

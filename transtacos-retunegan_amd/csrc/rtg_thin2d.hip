@@ -30,8 +30,10 @@ struct T2Args {
   float *out, *part;
   long long part_stride;
   int items, H, W, Ho, h_stride, tile_m, splits;
+  int Wo, w_stride;            // output columns and column stride (forward / weight gradient; round 5: the layer along the
+                               // frequency axis has stride (1, 2) where the reference layout has (2, 1))
   float pre_slope, gy_scale;
-  int n_pos;                   // items * Ho * W
+  int n_pos;                   // items * Ho * Wo
   int x_bytes, y_bytes;        // bytes of x and of the [items, 32, Ho, W] tensor (out / dy)
 };
 
@@ -43,12 +45,12 @@ __device__ __forceinline__ float t2_load(rsrc_t r, unsigned off) {
 #endif
 }
 
-// the 18 inputs of output position p = (item, ho, w): x[item][ci][ho * h_stride - 1 + kh][w - 1 + kw], activation applied,
+// the 18 inputs of output position p = (item, ho, w): x[item][ci][ho * h_stride - 1 + kh][w * w_stride - 1 + kw], activation applied,
 // zeros outside the map (out-of-range buffer offsets); `yoff`: element offset of (item, channel 0, ho, w) in out / dy
 __device__ __forceinline__ void t2_inputs_at(const T2Args& a, rsrc_t rx, bool live, int b, int ho, int w, float (&xv)[kNK],
                                              unsigned& yoff) {
-  const int hw = a.Ho * a.W;
-  yoff = live ? (unsigned)(b * kM * hw + ho * a.W + w) * 4u : kOob;
+  const int hw = a.Ho * a.Wo;
+  yoff = live ? (unsigned)(b * kM * hw + ho * a.Wo + w) * 4u : kOob;
 #pragma unroll
   for (int ci = 0; ci < kCr; ++ci)
 #pragma unroll
@@ -58,7 +60,7 @@ __device__ __forceinline__ void t2_inputs_at(const T2Args& a, rsrc_t rx, bool li
       const unsigned rb = (unsigned)(((b * kCr + ci) * a.H + row) * a.W);
 #pragma unroll
       for (int kw = 0; kw < kKW; ++kw) {
-        const int col = w - 1 + kw;
+        const int col = w * a.w_stride - 1 + kw;
         const float v = t2_load(rx, (rok && (unsigned)col < (unsigned)a.W) ? (rb + (unsigned)col) * 4u : kOob);
         xv[(ci * kKH + kh) * kKW + kw] = v > 0.f ? v : v * a.pre_slope;
       }
@@ -66,9 +68,9 @@ __device__ __forceinline__ void t2_inputs_at(const T2Args& a, rsrc_t rx, bool li
 }
 
 __device__ __forceinline__ void t2_inputs(const T2Args& a, rsrc_t rx, int p, float (&xv)[kNK], unsigned& yoff) {
-  const int hw = a.Ho * a.W;
+  const int hw = a.Ho * a.Wo;
   const int b = p / hw, r = p - b * hw;
-  const int ho = r / a.W, w = r - ho * a.W;
+  const int ho = r / a.Wo, w = r - ho * a.Wo;
   t2_inputs_at(a, rx, p < a.n_pos, b, ho, w, xv, yoff);
 }
 
@@ -92,7 +94,7 @@ __global__ __launch_bounds__(kThreads) void cin2_fwd_kernel(const T2Args a) {
   t2_inputs(a, rx, p0, xa, oa);
   t2_inputs(a, rx, p0 + kThreads, xb, ob);
   __syncthreads();
-  const unsigned chb = (unsigned)(a.Ho * a.W) * 4u;                     // bytes per output channel plane
+  const unsigned chb = (unsigned)(a.Ho * a.Wo) * 4u;                    // bytes per output channel plane
 #pragma unroll
   for (int g = 0; g < kM / 4; ++g) {
     float va[4], vb[4];
@@ -129,7 +131,7 @@ __global__ __launch_bounds__(kThreads) void cin2_wgrad_kernel(const T2Args a) {
   const int per = (a.n_pos + a.splits - 1) / a.splits;
   const int p_lo = (int)blockIdx.x * per;
   const int p_hi = p_lo + per < a.n_pos ? p_lo + per : a.n_pos;
-  const unsigned chb = (unsigned)(a.Ho * a.W) * 4u;
+  const unsigned chb = (unsigned)(a.Ho * a.Wo) * 4u;
   float acc[8][kNK], bacc[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -141,20 +143,20 @@ __global__ __launch_bounds__(kThreads) void cin2_wgrad_kernel(const T2Args a) {
   // conditional subtractions)
   int pb, pho, pw;
   {
-    const int p = p_lo + lane, hw = a.Ho * a.W;
+    const int p = p_lo + lane, hw = a.Ho * a.Wo;
     pb = p / hw;
     const int r = p - pb * hw;
-    pho = r / a.W;
-    pw = r - pho * a.W;
+    pho = r / a.Wo;
+    pw = r - pho * a.Wo;
   }
-  const int wq = 64 / a.W, wr = 64 - wq * a.W;                           // 64 positions = wq rows + wr columns
+  const int wq = 64 / a.Wo, wr = 64 - wq * a.Wo;                         // 64 positions = wq rows + wr columns
   for (int p = p_lo + lane; p < p_hi; p += 64) {
     float xv[kNK], gy[8];
     unsigned yo;
     t2_inputs_at(a, rx, true, pb, pho, pw, xv, yo);
     pw += wr;
-    pho += wq + (pw >= a.W ? 1 : 0);
-    pw -= pw >= a.W ? a.W : 0;
+    pho += wq + (pw >= a.Wo ? 1 : 0);
+    pw -= pw >= a.Wo ? a.Wo : 0;
     while (pho >= a.Ho) {                                               // (one item at most, except on maps of a few rows)
       pho -= a.Ho;
       ++pb;
@@ -259,25 +261,88 @@ __global__ __launch_bounds__(kThreads) void cin2_dgrad_kernel(const T2Args a) {
   }
 }
 
+// backward-data of the layer run along the frequency axis (WNConv wt: stride (1, 2) on the [items, 2, frames, F] map): thread =
+// (item, row r, column pair g); column 2g receives kernel column 1 of output column g, column 2g + 1 kernel columns 2 and 0 of
+// output columns g and g + 1, from the output rows r + 1 - kr of the three kernel rows — six dy values per output channel as
+// three 8-byte loads, consecutive threads consecutive pairs.  dy is [items, 32, H, Wo], the result [items, 2, H, W].
+__global__ __launch_bounds__(kThreads) void cin2_dgrad_cols_kernel(const T2Args a) {
+  __shared__ __attribute__((aligned(16))) float wl[kM * 20];          // [co][kernel row][kernel column][ci], padded to 20 floats
+  // weights from the packed polyphase backward image [row tile 0][chunk][tap 2][channel quad][kk][row]: rows = (ci, phase),
+  // channels = (kernel row, co); kernel column jj = phase + (1 - tap) * 2
+  const int KK = 64 / a.tile_m;
+  for (int e = threadIdx.x; e < kM * 18; e += kThreads) {
+    const int co = e / 18, r = e - co * 18;
+    const int kr = r / 6, kc = (r - kr * 6) >> 1, ci = r & 1;
+    const int ph = kc & 1, tap = 1 - (kc >> 1);
+    const int c = kr * kM + co, cc = c / RTG_CK, c16 = c - cc * RTG_CK;
+    wl[co * 20 + r] = a.wp[(cc * 2 + tap) * (RTG_CK * a.tile_m) + (c16 / KK) * 64 + (c16 % KK) * a.tile_m + ci * 2 + ph];
+  }
+  const rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.y_bytes, 0x00020000);
+  const int G = (a.W + 1) >> 1;
+  const int n_thr = a.items * a.H * G;
+  const int p = (int)blockIdx.x * kThreads + (int)threadIdx.x;
+  const bool live = p < n_thr;
+  const int hg = a.H * G;
+  const int b = p / hg, rem = p - b * hg;
+  const int r = rem / G, g = rem - r * G;
+  const int hw = a.H * a.Wo;                                            // (output rows = input rows: row stride 1, "same")
+  const bool c0 = live && g < a.Wo, c1 = live && g + 1 < a.Wo;
+  __syncthreads();
+  float a00 = 0.f, a01 = 0.f, a10 = 0.f, a11 = 0.f;                    // [column 2g / 2g + 1][ci]
+#pragma unroll 4
+  for (int co = 0; co < kM; ++co) {
+    const float* wc = wl + co * 20;                                    // [kr][kc][ci]
+#pragma unroll
+    for (int kr = 0; kr < 3; ++kr) {
+      const int ro = r + 1 - kr;
+      const bool rok = (unsigned)ro < (unsigned)a.H;
+      const unsigned e = (unsigned)((b * kM + co) * hw + ro * a.Wo + g);
+      const float u0 = t2_load(rd, (rok && c0) ? e * 4u : kOob), u1 = t2_load(rd, (rok && c1) ? (e + 1u) * 4u : kOob);
+      a00 = __builtin_fmaf(wc[kr * 6 + 2], u0, a00);                   // kernel column 1, output column g -> column 2g
+      a01 = __builtin_fmaf(wc[kr * 6 + 3], u0, a01);
+      a10 = __builtin_fmaf(wc[kr * 6 + 4], u0, a10);                   // kernel column 2, output column g -> column 2g + 1
+      a11 = __builtin_fmaf(wc[kr * 6 + 5], u0, a11);
+      a10 = __builtin_fmaf(wc[kr * 6 + 0], u1, a10);                   // kernel column 0, output column g + 1 -> column 2g + 1
+      a11 = __builtin_fmaf(wc[kr * 6 + 1], u1, a11);
+    }
+  }
+  if (!live) return;
+  const float res[2][2] = {{a00, a01}, {a10, a11}};
+#pragma unroll
+  for (int cc = 0; cc < 2; ++cc) {
+    const int w = 2 * g + cc;
+    if (w >= a.W) continue;
+#pragma unroll
+    for (int ci = 0; ci < kCr; ++ci) {
+      const size_t o = ((size_t)(b * kCr + ci) * a.H + r) * a.W + w;
+      float val = res[cc][ci];
+      if (a.mask) val *= a.mask[o] > 0.f ? 1.f : a.mask_slope;
+      if (a.res) val += a.res[o];
+      a.out[o] = val * a.out_scale;
+    }
+  }
+}
+
 template <class D>
 bool t2_shape_ok(const D* d) {
   if (d->groups != 1 || d->C2 != 0 || d->h_k != kKH || d->K != kKW || d->C1 != kCr * kKH || d->Cg != d->C1 || d->Mg != kM) return false;
-  if (d->stride != 1 || d->dil != 1 || d->pad != 1 || d->h_pad != 1 || d->h_stride < 1 || d->h_stride > 2) return false;
-  if (d->h_in < 1 || d->h_n < 1 || d->B % d->h_n != 0 || d->Q != d->L_in) return false;
+  if (d->stride < 1 || d->stride > 2 || d->dil != 1 || d->pad != 1 || d->h_pad != 1 || d->h_stride < 1 || d->h_stride > 2) return false;
+  if (d->h_in < 1 || d->h_n < 1 || d->B % d->h_n != 0 || d->Q != (d->L_in + 2 - kKW) / d->stride + 1) return false;
   if (d->h_n != (d->h_in + 2 - kKH) / d->h_stride + 1) return false;
   if (d->pre_mode != RTG_PRE_NONE && d->pre_mode != RTG_PRE_LRELU) return false;
   const long long items = d->B / d->h_n;
-  if (items * kCr * d->h_in * d->L_in * 4 >= (1ll << 31) || items * kM * d->h_n * d->L_in * 4 >= (1ll << 31)) return false;
+  if (items * kCr * d->h_in * d->L_in * 4 >= (1ll << 31) || items * kM * d->h_n * (long long)d->Q * 4 >= (1ll << 31)) return false;
   return true;
 }
 
 template <class D>
 void t2_fill(const D* d, T2Args* a) {
   a->items = d->B / d->h_n; a->H = d->h_in; a->W = d->L_in; a->Ho = d->h_n; a->h_stride = d->h_stride;
+  a->Wo = d->Q; a->w_stride = d->stride;
   a->pre_slope = d->pre_mode == RTG_PRE_LRELU ? d->pre_slope : 1.f;
-  a->n_pos = a->items * a->Ho * a->W;
+  a->n_pos = a->items * a->Ho * a->Wo;
   a->x_bytes = a->items * kCr * a->H * a->W * 4;
-  a->y_bytes = a->items * kM * a->Ho * a->W * 4;
+  a->y_bytes = a->items * kM * a->Ho * a->Wo * 4;
 }
 
 }  // namespace
@@ -300,8 +365,23 @@ int rtg_thin2d_fwd_launch(const RtgConv1dDesc* d, const float* x, const float* w
   return rtg_launch_status();
 }
 
+// ... of the layer along the frequency axis: the 2-tap polyphase operator of its column stride 2 (rows = (ci, phase), shuffle
+// store), row stride 1
+static bool t2_dgrad_cols_ok(const RtgConv1dDesc* d) {
+  if (d->h_mode != 1 || d->groups != 1 || d->C2 != 0 || d->Mg != kCr * 2 || d->C1 != kM * kKH || d->Cg != d->C1) return false;
+  if (d->h_k != kKH || d->K != 2 || d->stride != 1 || d->dil != 1 || d->pad != 1 || d->shuf_S != 2 || d->shuf_P != 1) return false;
+  if (d->h_pad != 1 || d->h_stride != 1 || d->h_in < 1 || d->h_n != d->h_in || d->B % d->h_n != 0 || d->out_C != kCr) return false;
+  if (d->out_L < 1 || d->L_in != (d->out_L + 2 - kKW) / 2 + 1) return false;
+  if (d->bf16 || d->io_bf16 || d->tap_major || d->out_split != 0 || d->accumulate || d->act != RTG_ACT_NONE) return false;
+  if (d->pre_mode != RTG_PRE_NONE || (d->tile_m != 16 && d->tile_m != 32)) return false;
+  const long long items = d->B / d->h_n;
+  if (items * kM * d->h_in * d->L_in * 4 >= (1ll << 31) || items * kCr * d->h_n * (long long)d->out_L * 4 >= (1ll << 31)) return false;
+  return true;
+}
+
 // backward-data descriptor of the same layer (Conv2dFn.backward): clips = (item, input row), channels = (kernel row, co)
 bool rtg_thin2d_dgrad_ok(const RtgConv1dDesc* d) {
+  if (t2_dgrad_cols_ok(d)) return !RTG_ENV_SET("RTG_THIN2D_OFF");
   if (d->h_mode != 1 || d->groups != 1 || d->C2 != 0 || d->Mg != kCr || d->C1 != kM * kKH || d->Cg != d->C1) return false;
   if (d->h_k != kKH || d->K != kKW || d->stride != 1 || d->dil != 1 || d->pad != 1 || d->h_pad != 1 || d->h_stride != 2) return false;
   if (d->h_in < 1 || d->h_n < 1 || d->B % d->h_n != 0 || d->Q != d->L_in || d->out_L != d->Q || d->out_C != kCr) return false;
@@ -317,6 +397,16 @@ int rtg_thin2d_dgrad_launch(const RtgConv1dDesc* d, const float* dy, const float
                             float* out, hipStream_t s) {
   if (!rtg_thin2d_dgrad_ok(d)) return RTG_EINVAL;
   if (!dy || !wp || !out) return RTG_ENULL;
+  if (t2_dgrad_cols_ok(d)) {
+    T2Args c = {};
+    c.items = d->B / d->h_n; c.H = d->h_n; c.W = d->out_L; c.Wo = d->L_in; c.Ho = d->h_in; c.tile_m = d->tile_m;
+    c.dy = dy; c.wp = wp; c.mask = mask; c.res = res; c.out = out;
+    c.mask_slope = d->mask_slope; c.out_scale = d->out_scale;
+    c.y_bytes = c.items * kM * c.H * c.Wo * 4;
+    const long long n = (long long)c.items * c.H * ((c.W + 1) / 2);
+    RTG_KLAUNCH(cin2_dgrad_cols_kernel, dim3((unsigned)rtg_ceil_div(n, kThreads)), dim3(kThreads), 0, s, c);
+    return rtg_launch_status();
+  }
   T2Args a = {};
   a.items = d->B / d->h_n; a.H = d->h_n; a.W = d->L_in; a.Ho = d->h_in; a.h_stride = 2; a.tile_m = d->tile_m;
   a.dy = dy; a.wp = wp; a.mask = mask; a.res = res; a.out = out;

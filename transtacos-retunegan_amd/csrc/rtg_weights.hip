@@ -27,6 +27,15 @@ __global__ __launch_bounds__(RTG_THREADS) void wn_scales_kernel(const RtgNormJob
   }
 }
 
+// RtgPackJob.src_T: index of the operator's element (ci, kernel row r, tap t) — `sin` in the operator's order [ci][KH][src_K]
+// — in the source tensor, whose kernel axes are the other way round: [ci][src_K][KH]
+__device__ __forceinline__ int pack_src_index(const RtgPackJob& j, int sin) {
+  if (!j.src_T) return sin;
+  const int cr = sin / j.src_K, t = sin - cr * j.src_K;
+  const int ci = cr / j.KH, r = cr - ci * j.KH;
+  return (ci * j.src_K + t) * j.KH + r;
+}
+
 // the effective weight g*v/||v|| that packed row `row` (of group g) applies to packed channel c at packed tap `tap`
 __device__ __forceinline__ float pack_logical(const RtgPackJob& j, const float* params, const float* scales, int g,
                                             int row, int c, int tap) {
@@ -64,7 +73,7 @@ __device__ __forceinline__ float pack_logical(const RtgPackJob& j, const float* 
         }
       }
     }
-    if (srow >= 0) val = params[j.v_off + srow * inner + sin] * scales[j.scale_off + srow];
+    if (srow >= 0) val = params[j.v_off + srow * inner + pack_src_index(j, (int)sin)] * scales[j.scale_off + srow];
   }
   return val;
 }
@@ -88,7 +97,8 @@ __host__ __device__ inline PackGeom pack_geom(const RtgPackJob& j) {
   const int chs = (j.mode == RTG_PACK_DGRAD_POLY || j.mode == RTG_PACK_CONVT_POLY) ? (p.RT - 1) / S + 2 : 0;
   p.run = j.mode == RTG_PACK_FWD ? RTG_CK * j.src_K : (j.mode == RTG_PACK_DGRAD_S1 ? p.RT * j.src_K : chs * j.src_K);
   p.nrow = j.mode == RTG_PACK_FWD ? p.RT : RTG_CK;
-  p.staged = !j.bf16 && !j.tap_major && j.mode != RTG_PACK_DGRAD_2D && j.mode < RTG_PACK_GCONV_FWD && p.nrow * (p.run + 1) <= kPackSlab;
+  p.staged = !j.bf16 && !j.tap_major && !j.src_T && j.mode != RTG_PACK_DGRAD_2D && j.mode < RTG_PACK_GCONV_FWD &&
+             p.nrow * (p.run + 1) <= kPackSlab;
   return p;
 }
 
@@ -359,7 +369,7 @@ __global__ __launch_bounds__(RTG_THREADS) void pack_kernel(const RtgPackJob* job
             }
           }
         }
-        if (srow >= 0) val = params[j.v_off + (long long)srow * inner + sin] * scales[j.scale_off + srow];
+        if (srow >= 0) val = params[j.v_off + (long long)srow * inner + pack_src_index(j, sin)] * scales[j.scale_off + srow];
       }
       dst[in] = val;
     }
@@ -377,6 +387,14 @@ __global__ __launch_bounds__(RTG_THREADS) void wn_bwd_kernel(const RtgWnBwdJob* 
   extern __shared__ float dw[];            // [inner] the reduced row
   __shared__ float red[4];
   const RtgWnBwdJob j = jobs[blockIdx.y];
+  // element i of the tensor's row [ci][taps][rows] -> its column in the partials [ci][rows][taps] (t_rows > 0: a layer packed
+  // with RtgPackJob.src_T), else i itself
+  auto pcol = [&](int i) __attribute__((always_inline)) {
+    if (j.t_rows <= 0) return i;
+    const int ct = i / j.t_rows, rr = i - ct * j.t_rows;
+    const int ci = ct / j.t_taps, t = ct - ci * j.t_taps;
+    return (ci * j.t_rows + rr) * j.t_taps + t;
+  };
   for (int r = blockIdx.x; r < j.rows; r += gridDim.x) {
     const float* v = params + j.v_off + (size_t)r * j.inner;
     const float* p0 = partials + j.part_off + (size_t)r * j.inner;
@@ -398,7 +416,8 @@ __global__ __launch_bounds__(RTG_THREADS) void wn_bwd_kernel(const RtgWnBwdJob* 
       }
     }
     // (rows of fewer than 1024 elements keep one element per thread: more splits in flight per row)
-    const bool vec = j.inner >= 4 * RTG_THREADS && (j.inner & 3) == 0 && (j.part_off & 3) == 0 && (j.part_stride & 3) == 0;
+    const bool vec = j.inner >= 4 * RTG_THREADS && (j.inner & 3) == 0 && (j.part_off & 3) == 0 && (j.part_stride & 3) == 0 &&
+                     j.t_rows <= 0;
     if (vec) {
       // 16-byte loads of the partials (the bulk of the traffic: splits x the row), four consecutive elements per thread,
       // 8 splits in flight; every element still sums its splits in ascending order (the same bits as the scalar path)
@@ -428,7 +447,7 @@ __global__ __launch_bounds__(RTG_THREADS) void wn_bwd_kernel(const RtgWnBwdJob* 
     } else if (j.inner <= RTG_THREADS) {
       const int i = threadIdx.x;
       if (i < j.inner) {
-        const float* pa = p0 + i;
+        const float* pa = p0 + pcol(i);
         float sa = 0.f;
         for (int sp = 0; sp < j.splits; sp += 32) {
           float ta[32];
@@ -446,8 +465,8 @@ __global__ __launch_bounds__(RTG_THREADS) void wn_bwd_kernel(const RtgWnBwdJob* 
     } else {
       for (int i = threadIdx.x; i < j.inner; i += 2 * RTG_THREADS) {
         const bool two = i + RTG_THREADS < j.inner;
-        const float* pa = p0 + i;
-        const float* pb = p0 + (two ? i + RTG_THREADS : i);
+        const float* pa = p0 + pcol(i);
+        const float* pb = p0 + pcol(two ? i + RTG_THREADS : i);
         float sa = 0.f, sb = 0.f;
         for (int sp = 0; sp < j.splits; sp += 16) {
           float ta[16], tb[16];

@@ -122,6 +122,14 @@ class DiscriminatorP(nn.Module):
         return lg, views
 
 
+class _Prepared:
+    """a sub-discriminator input that already is in the layout its layers run on (StftDiscriminator.pre)"""
+
+    def __init__(self, t):
+        self.t = t
+        self.shape = t.shape
+
+
 def _split(t, B):
     """[2B, ...] batch of (real, fake) -> two halves that remember their contiguous kernel-side storage."""
     base = getattr(t, '_rtg_base', None)
@@ -177,7 +185,7 @@ def _sub_runner(d, tok, inp, frozen):
             lg, fg = d.run(tok, inp[1])
             return lr, lg, fr, fg
         B = inp[0].shape[0] // 2
-        l2, f2 = d.run(tok, inp[0])
+        l2, f2 = d.run(tok, inp[0].t, prepared=True) if isinstance(inp[0], _Prepared) else d.run(tok, inp[0])
         lr, lg = _split(l2, B)
         fs = [_split(f, B) for f in f2]
         return lr, lg, [a for a, _ in fs], [b for _, b in fs]
@@ -296,6 +304,13 @@ class MultiPeriodDiscriminator(_MultiBase):
         return [_sub_runner(d, tok, inp, frozen) for d, inp in zip(self.discriminators, self.sub_inputs(y, y_hat, frozen))]
 
 
+# The spectrogram discriminators run along the FREQUENCY axis (round 5): their maps live in HBM as [B, C, frames, F] — rows of
+# 1025 .. 8 bins instead of 137 .. 5 frames for the kernels to walk — and the layers are built with WNConv(wt=True): same
+# parameters, shapes and state-dict keys, the kernel axes swapped when the weights are packed.  What goes in and comes out
+# keeps the reference's [B, C, F, frames] shape (transposed views; logits in the reference's order).
+MTD_ALONG_FREQ = True
+
+
 class StftDiscriminator(nn.Module):
     """discrminator.py:247-308: five strided Conv2d layers + conv_post over [log|D|, phase/PI] ([B,2,F,frames])."""
 
@@ -303,14 +318,27 @@ class StftDiscriminator(nn.Module):
         super().__init__()
         spec = [(ch, 32, (3, 3), (2, 1), (1, 1)), (32, 64, (3, 3), (2, 2), (1, 1)), (64, 256, (5, 3), (3, 2), (2, 1)),
                 (256, 512, (5, 3), (3, 2), (2, 1)), (512, 512, (3, 3), (1, 1), (1, 1))]
-        self.convs = nn.ModuleList([WNConv('conv2d', ci, co, k, stride=s, pad=p) for ci, co, k, s, p in spec])
-        self.conv_post = WNConv('conv2d', 512, 1, (3, 3), stride=(1, 1), pad=(1, 1))
+        self.wt = MTD_ALONG_FREQ
+        self.convs = nn.ModuleList([WNConv('conv2d', ci, co, k, stride=s, pad=p, wt=self.wt) for ci, co, k, s, p in spec])
+        self.conv_post = WNConv('conv2d', 512, 1, (3, 3), stride=(1, 1), pad=(1, 1), wt=self.wt)
         for c in [*self.convs, self.conv_post]:
             c.burn_init_rng()       # self.convs.apply(init_weights); self.conv_post.apply(init_weights) (:264-265)
 
-    def run(self, tok, x):
-        logit, fmap = _run_stack(tok, self.convs, self.conv_post, x)
-        return torch.flatten(logit, 1, -1), fmap
+    def pre(self, x):
+        """[B,2,F,frames] map -> the tensor the layers run on: [B,2,frames,F], frequency contiguous (a view of what
+        audio.stft_mel_spec made; anything else is copied)"""
+        return x.transpose(2, 3).contiguous() if self.wt else x
+
+    def run(self, tok, x, prepared=False):
+        logit, fmap = _run_stack(tok, self.convs, self.conv_post, x if prepared else self.pre(x))
+        if not self.wt:
+            return torch.flatten(logit, 1, -1), fmap
+        views = []
+        for f in fmap:
+            v = f.transpose(2, 3)
+            v._rtg_base = f
+            views.append(v)
+        return torch.flatten(logit.transpose(2, 3), 1, -1), views
 
 
 class MultiStftDiscriminator(_MultiBase):
@@ -325,5 +353,7 @@ class MultiStftDiscriminator(_MultiBase):
     def branches(self, phs, ph_hats):
         tok = self.token()
         frozen = _frozen(self) and not phs[0].requires_grad
-        inputs = [[ph, ph_hat] if frozen else [torch.cat([ph, ph_hat], dim=0)] for ph, ph_hat in zip(phs, ph_hats)]
+        # (the real / generated pair is concatenated in the layout the layers run on: a coalesced copy)
+        inputs = [[ph, ph_hat] if frozen else [_Prepared(torch.cat([d.pre(ph), d.pre(ph_hat)], dim=0))]
+                  for d, ph, ph_hat in zip(self.discriminators, phs, ph_hats)]
         return [_sub_runner(d, tok, inp, frozen) for d, inp in zip(self.discriminators, inputs)]

@@ -19,9 +19,14 @@ class WNConv(nn.Module):
     kind 'convT' : ConvTranspose1d (dim 0 of v is the INPUT channel axis, as in the reference's ups.N.weight_g)
     kind 'conv2d': Conv2d with (rows, cols) kernel / stride / padding pairs (StftDiscriminator, discrminator.py:255-262)."""
 
-    def __init__(self, kind, cin, cout, k, stride=1, pad=0, dil=1, groups=1, out_pad=0, kdims=1):
+    def __init__(self, kind, cin, cout, k, stride=1, pad=0, dil=1, groups=1, out_pad=0, kdims=1, wt=False):
         super().__init__()
         self.kind, self.cin, self.cout, self.k = kind, cin, cout, k
+        # wt ('conv2d' only): the layer is run on tensors whose last two axes are swapped — [B, C, W, H] for the reference's
+        # [B, C, H, W] — so that the LONG axis (frequency, for the spectrogram discriminators) is the contiguous one the
+        # kernels walk; k / stride / pad and the parameter shapes stay the reference's (rows, cols) = (H, W) pairs
+        self.wt = bool(wt)
+        assert not wt or kind == 'conv2d'
         self.stride, self.pad, self.dil, self.groups, self.out_pad = stride, pad, dil, groups, out_pad
         if kind == 'conv2d':                                   # k, stride, pad are (rows, cols) pairs
             assert groups == 1 and dil == 1

@@ -78,9 +78,16 @@ class ConvLayer:
         self.kind, self.cin, self.cout, self.k = m.kind, m.cin, m.cout, m.k
         self.stride, self.pad, self.dil, self.groups, self.out_pad = m.stride, m.pad, m.dil, m.groups, m.out_pad
         self.kh = 1
+        self.wt = 0
         if self.kind == 'conv2d':
             # runs as the 1-D operator along the last axis: channels = (c, kernel row), clips = (item, output row)
             (self.kh, self.k), (self.sh, self.stride), (self.ph, self.pad) = m.k, m.stride, m.pad
+            if getattr(m, 'wt', False):
+                # ... of tensors with the last two axes swapped: the operator's taps / stride / padding are the reference's ROW
+                # ones, its kernel rows the reference's columns; the weight tensor keeps its [C_out][C_in][kh][kw] order
+                # (RtgPackJob.src_T, RtgWnBwdJob.t_rows / t_taps)
+                self.wt = 1
+                (self.k, self.kh), (self.stride, self.sh), (self.pad, self.ph) = m.k, m.stride, m.pad
             self.rows, self.inner_c = self.cout, self.cin * self.kh
         elif self.kind == 'convT':
             assert self.groups == 1 and self.dil == 1
@@ -150,13 +157,14 @@ class ConvLayer:
                 if self.kind == 'conv2d':
                     # StftDiscriminator (3 taps along the last axis): forward and backward-data
                     if fwd:
-                        return int(k == 3 and self.stride in (1, 2))
+                        # (5 taps at stride 3: the (5, 3) / (3, 2) layers run along the frequency axis, WNConv wt)
+                        return int((k == 3 and self.stride in (1, 2)) or (k == 5 and self.stride == 3))
                     if mode != L.PACK_DGRAD_2D:
                         return 0
                     if s == 1 and self.sh == 1:
                         return int(k == 3)
                     # row-strided layers: class-ordered clips, 2 taps of the polyphase walk, whole chunks per kernel row
-                    return int(k == 2 and s == 2 and 2 <= self.sh <= 4 and self.cout % ckc == 0)
+                    return int(k == 2 and s in (2, 3) and 2 <= self.sh <= 4 and self.cout % ckc == 0)
                 if self.kind == 'conv':
                     if fwd and k == 5 and self.stride in (1, 3):
                         return 1
@@ -352,12 +360,12 @@ class WeightBank:
                 if not ly.std_on[side]:
                     continue                 # (lean_pack: every launch of this layer reads the fragment image)
                 pack.append(L.PackJob(ly.v_off, ly.scale_off, off, size, mode, g, mg, cg, k, ly.k, ly.inner_c, s, tm,
-                                      ly.kh, tap, bf, 0))
+                                      ly.kh, tap, bf, 0, src_T=ly.wt))
             for (mode, g, mg, cg, k, s), off, size in ((ly.fwd_op, ly.fwd_off + ly.fwd_size, ly.fwd16_size),
                                                         (ly.bwd_op, ly.bwd_off + ly.bwd_size, ly.bwd16_size)):
                 if size:
                     pack.append(L.PackJob(ly.v_off, ly.scale_off, off, size, mode, g, mg, cg, k, ly.k, ly.inner_c, s, 16,
-                                          ly.kh, 0, ly.frag_bf, 1))
+                                          ly.kh, 0, ly.frag_bf, 1, src_T=ly.wt))
             if ly.gconv_off is not None:
                 for mode, off in ((L.PACK_GCONV_FWD, ly.gconv_off[0]), (L.PACK_GCONV_BWD, ly.gconv_off[1])):
                     pack.append(L.PackJob(ly.v_off, ly.scale_off, off, ly.gconv_size, mode, ly.groups, ly.cout // ly.groups,
@@ -420,7 +428,8 @@ class WeightBank:
         op, off, size, tm, tap, bf = ((ly.fwd_op, ly.fwd_off, ly.fwd_size, ly.fwd_tm, ly.fwd_tap, ly.fwd_bf),
                                       (ly.bwd_op, ly.bwd_off, ly.bwd_size, ly.bwd_tm, ly.bwd_tap, ly.bwd_bf))[side]
         mode, g, mg, cg, k, s = op
-        job = [L.PackJob(ly.v_off, ly.scale_off, off, size, mode, g, mg, cg, k, ly.k, ly.inner_c, s, tm, ly.kh, tap, bf, 0)]
+        job = [L.PackJob(ly.v_off, ly.scale_off, off, size, mode, g, mg, cg, k, ly.k, ly.inner_c, s, tm, ly.kh, tap, bf, 0,
+                         src_T=ly.wt)]
         blocks, lds = L.assign_pack_blocks(job)
         tab = _table(job, self.device)
         self._keep.append(tab)
@@ -513,7 +522,8 @@ class WeightBank:
         stride = ly.rows * (ly.inner + 1)
         has_bias = with_bias and ly.kind != 'convT'
         return L.WnBwdJob(ly.g_off, ly.v_off, ly.b_off if has_bias else -1, ly.scale_off,
-                          (part.data_ptr() - base_ptr) // 4, stride, splits, ly.rows, ly.inner)
+                          (part.data_ptr() - base_ptr) // 4, stride, splits, ly.rows, ly.inner,
+                          ly.kh if ly.wt else 0, ly.k if ly.wt else 0)
 
     def flush_one(self, ly, part, splits):
         tab = _table([self._job(ly, part, splits, self.flat.data_ptr())], self.device)

@@ -58,7 +58,7 @@ class PackJob(C.Structure):
     _fields_ = [('v_off', C.c_longlong), ('scale_off', C.c_longlong), ('dst_off', C.c_longlong),
                 ('dst_size', C.c_longlong)] + \
                [(n, C.c_int) for n in ('mode', 'groups', 'Mg', 'Cg', 'K', 'src_K', 'src_inner_c', 'S', 'tile_m', 'KH', 'tap_major', 'bf16',
-                                       'frag16', 'first_block', 'n_blocks')]
+                                       'frag16', 'first_block', 'n_blocks', 'src_T')]
 
 
 MAX_SCALAR_TERMS = 16
@@ -71,7 +71,7 @@ class ScalarTerms(C.Structure):
 class WnBwdJob(C.Structure):
     _fields_ = [('g_off', C.c_longlong), ('v_off', C.c_longlong), ('b_off', C.c_longlong), ('scale_off', C.c_longlong),
                 ('part_off', C.c_longlong), ('part_stride', C.c_longlong), ('splits', C.c_int), ('rows', C.c_int),
-                ('inner', C.c_int)]
+                ('inner', C.c_int), ('t_rows', C.c_int), ('t_taps', C.c_int)]
 
 
 class LossJob(C.Structure):
@@ -88,7 +88,7 @@ PtrArray6 = C.c_void_p * 6
 
 
 class StftDesc(C.Structure):
-    _fields_ = [(n, C.c_int) for n in ('B', 'T', 'n_fft', 'win', 'hop', 'frames', 'n_mel')]
+    _fields_ = [(n, C.c_int) for n in ('B', 'T', 'n_fft', 'win', 'hop', 'frames', 'n_mel', 'spec_T')]
 
 
 PRE_NONE, PRE_LRELU, PRE_MUL_DLRELU, PRE_MUL_DTANH = 0, 1, 2, 3

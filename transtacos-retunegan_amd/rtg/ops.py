@@ -1443,8 +1443,12 @@ class StripMirrorFn(torch.autograd.Function):
 # ---------------------------------------------------------------------------------------------------------------
 # STFT
 # ---------------------------------------------------------------------------------------------------------------
+SPEC_FREQ_MAJOR = True     # the spectrogram maps are kept [B, 2, frames, F] in HBM (StftFn hands out the transposed view)
+
+
 class StftFn(torch.autograd.Function):
-    """y [B,T] -> (mel [B,n_mel,frames], spec [B,2,F,frames] or None) for one resolution (see rtg_stft_forward)."""
+    """y [B,T] -> (mel [B,n_mel,frames], spec or None) for one resolution (see rtg_stft_forward).  spec: [B,2,F,frames], or with
+    SPEC_FREQ_MAJOR the tensor [B,2,frames,F] whose transposed view is that map (audio.stft_mel_spec hands the view out)."""
 
     @staticmethod
     def forward(ctx, y, plan, want_spec):
@@ -1457,15 +1461,16 @@ class StftFn(torch.autograd.Function):
         t = plan.tensors(dev)
         need_bwd = ctx.needs_input_grad[0]
         mel = torch.empty(B, plan.n_mel, frames, device=dev)
-        spec = torch.empty(B, 2, F, frames, device=dev) if want_spec else None
+        spec_t = int(SPEC_FREQ_MAJOR)
+        spec = (torch.empty(B, 2, frames, F, device=dev) if spec_t else torch.empty(B, 2, F, frames, device=dev)) if want_spec else None
         re = torch.empty(B, frames, F, device=dev) if need_bwd else None
         im = torch.empty(B, frames, F, device=dev) if need_bwd else None
-        d = L.StftDesc(B, T, plan.n_fft, plan.win, plan.hop, frames, plan.n_mel)
+        d = L.StftDesc(B, T, plan.n_fft, plan.win, plan.hop, frames, plan.n_mel, spec_t)
         nbytes = 4 * (y.numel() + mel.numel() + (spec.numel() if want_spec else 0) + (2 * re.numel() if need_bwd else 0))
         check(timed_bw('stft_fwd', nbytes, lambda: lib.rtg_stft_forward(
             C.byref(d), _p(y), _p(t['window']), _p(t['twiddle']), _p(t['mel_lo']), _p(t['mel_len']), _p(t['mel_woff']),
             _p(t['mel_w']), _p(mel), _p(spec), _p(re), _p(im), _stream()), f'n_fft {plan.n_fft} B{B} T{T}'), 'stft fwd')
-        ctx.plan, ctx.shape = plan, (B, T, frames)
+        ctx.plan, ctx.shape, ctx.spec_t = plan, (B, T, frames), spec_t
         ctx.save_for_backward(re, im)
         ctx.set_materialize_grads(False)
         return mel, spec
@@ -1481,7 +1486,7 @@ class StftFn(torch.autograd.Function):
         t = plan.tensors(dev)
         dy = torch.zeros(B, T, device=dev)
         ws = torch.empty(B * frames * plan.win, device=dev)
-        d = L.StftDesc(B, T, plan.n_fft, plan.win, plan.hop, frames, plan.n_mel)
+        d = L.StftDesc(B, T, plan.n_fft, plan.win, plan.hop, frames, plan.n_mel, ctx.spec_t)
         dmel_c, dspec_c = _c(dmel), _c(dspec)
         nbytes = 4 * (2 * re.numel() + (dmel_c.numel() if dmel_c is not None else 0) +
                       (dspec_c.numel() if dspec_c is not None else 0) + dy.numel())
