@@ -200,6 +200,10 @@ def test_feature_loss_over_bf16_maps(bf16_mode):
     ref = sum(F.l1_loss(a, b) for a, b in zip(rr, gg))
     ref.backward()
     np.testing.assert_allclose(loss.item(), ref.item(), rtol=2e-6)
+    # a lone pair of one encoded and one decoded map (what the scale discriminators hand over: the real half of convs.5's
+    # output still bf16, the generated half decoded for conv_post)
+    one = feature_loss([[r[0]]], [[dec_ref(g[0].detach())]])
+    np.testing.assert_allclose(one.item(), F.l1_loss(rr[0], gg[0]).item(), rtol=2e-6)
     for a, b in zip(g, gg):
         if a.dtype == torch.bfloat16:
             assert a.grad.dtype == torch.bfloat16

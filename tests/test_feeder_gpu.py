@@ -81,3 +81,45 @@ def test_pinned_feeder_close_without_next_and_with_unconsumed_batches():
     time.sleep(0.05)                                        # the producer has filled the ready queue and blocks on it
     f2.close()
     assert not f2._thread.is_alive()
+
+
+def test_config5_finetune_feed_drives_the_graphed_step():
+    """BASELINE configs[4] the way it is stated: Griffin-Lim reference waves on the host -> pinned double-buffered async H2D
+    (data.PinnedFeeder, exactly bench.py's `finetune_feeder`) -> Trainer.train_step_graphed on the full stack at 16 clips x
+    22016 samples (86 frames), 12 steps.  The device batches the step consumed equal the host batches the producer made (in
+    order), the losses stay finite, the generator moves."""
+    import bench
+    import data as D
+    from train import Trainer
+    torch.manual_seed(11)
+    host = []
+    feeder = bench.finetune_feeder(16, 22016, 5, 'cuda:0', pool=6)
+    make = feeder.make_batch
+
+    def recording(step):
+        b = make(step)
+        host.append(tuple(t.clone() for t in b))
+        return b
+    feeder.make_batch = recording
+    tr = Trainer(use_mpd=True, use_mtd=True, d_train_times=2, dev='cuda:0')
+    before = tr.generator.bank().flat.clone()
+    seen, losses = [], []
+    try:
+        for step in range(12):
+            x, y_tmpl, y = feeder.next()
+            assert x.shape == (16, 80, 86) and y_tmpl.shape == (16, 1, 22016) and y.shape == (16, 1, 22016)
+            seen.append((x.clone(), y_tmpl.clone(), y.clone()))
+            dl, gl = tr.train_step_graphed(x, y_tmpl, y)
+            losses.append((dl['disc_all'].clone(), gl['gen_all'].clone()))     # (static scalars: overwritten by the next replay)
+        torch.cuda.synchronize()
+    finally:
+        feeder.close()
+    assert tr._graphs is not None                                             # the steps were graph replays
+    for step, got in enumerate(seen):
+        for g_, h_ in zip(got, host[step]):
+            assert torch.equal(g_.cpu(), h_), step
+    vals = np.array([[a.item(), b.item()] for a, b in losses])
+    assert np.isfinite(vals).all(), vals
+    assert np.abs(np.diff(vals[:, 1])).max() > 0                              # different batches, different losses
+    moved = (tr.generator.bank().flat - before).abs().max().item()
+    assert 0 < moved < 12 * 4 * 1.8e-4 and torch.isfinite(tr.generator.bank().flat).all()

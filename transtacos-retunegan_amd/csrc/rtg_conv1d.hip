@@ -188,8 +188,8 @@ static bool sconv_code_ok(const RtgConv1dDesc* d) {
   return false;
 }
 static bool dconv_code_ok(const RtgConv1dDesc* d) {
-  int codes[16];
-  const int n = rtg_dconv_candidates(d, codes, 16);
+  int codes[24];
+  const int n = rtg_dconv_candidates(d, codes, 24);
   for (int i = 0; i < n; ++i)
     if (codes[i] == d->tile_cfg) return true;
   return false;
@@ -224,7 +224,7 @@ extern "C" int rtg_conv1d_tile_candidates(const RtgConv1dDesc* d, int* cfgs, int
     return RTG_EINVAL;
   if (d->io_bf16 != 0) {
     // bf16 tensors (ABI 9): only the dense-layer kernel reads / writes them — its shapes or nothing (the caller converts)
-    return rtg_dconv_candidates(d, cfgs, max < 8 ? max : 8);
+    return rtg_dconv_candidates(d, cfgs, max < 10 ? max : 10);
   }
   if (rtg_thin_kind(d)) {       // served by a bandwidth kernel: nothing to choose (0 = the library's default)
     cfgs[0] = 0;
@@ -247,7 +247,7 @@ extern "C" int rtg_conv1d_tile_candidates(const RtgConv1dDesc* d, int* cfgs, int
   for (int nt = 2; nt >= 1; --nt)
     if ((rv & (1 << (nt - 1))) && cnt < max) cfgs[cnt++] = RTG_RESCONV_CODE + nt;
   // the dense-layer kernel's best-scored shapes (all of them would double the tuning step's work on these layers)
-  if (cnt < max) cnt += rtg_dconv_candidates(d, cfgs + cnt, max - cnt < 8 ? max - cnt : 8);
+  if (cnt < max) cnt += rtg_dconv_candidates(d, cfgs + cnt, max - cnt < 10 ? max - cnt : 10);
   if (cnt < max) cnt += rtg_sconv_candidates(d, cfgs + cnt, max - cnt);
   return cnt;
 }

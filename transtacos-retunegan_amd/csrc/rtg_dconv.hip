@@ -83,17 +83,18 @@ int rtg_dconv_candidates(const RtgConv1dDesc* d, int* codes, int max) {
   struct Cand {
     int code;
     double score;
-  } c[16];
+  } c[24];
   int n = 0;
-  for (int si = 0; si < 4; ++si) {
+  for (int si = 0; si < kNumShapes; ++si) {
     const int mb16 = kShapes[si].rw16 * kShapes[si].wb;
-    if (si == 3 && n_mt16 % mb16 != 0) continue;                     // 256-row blocks only where they divide the rows
+    if (si >= 3 && n_mt16 % mb16 != 0) continue;                     // 256-row blocks only where they divide the rows
+    if (kShapes[si].rw16 == 4 && !d->bf16) continue;                 // (64 rows per wave: the bf16 instances only)
     const int n_mb = rtg_ceil_div(n_mt16, mb16);
     for (int ni = 0; ni < 4; ++ni) {
       const int BN = kNT[ni] * 16;
       // instances that need more than 256 registers at two waves per SIMD (they spill): 32 rows per wave with >= 6
       // column tiles; 8 column tiles with a strided walk in the 4-wave blocks (twice the staging registers per wave)
-      if (kShapes[si].rw16 == 2 && kNT[ni] >= 6) continue;
+      if (kShapes[si].rw16 >= 2 && kNT[ni] >= 6) continue;
       const bool two_d = d->h_k > 1 || d->h_n > 1;
       if (kNT[ni] == 8 && (d->stride > 1 || (two_d && kShapes[si].wb == 4))) continue;
       // bf16 (8 staged channels per position, two register sets): 16 rows per wave with 8 column tiles, or with 7 on a
@@ -113,7 +114,7 @@ int rtg_dconv_candidates(const RtgConv1dDesc* d, int* codes, int max) {
       const double rows_eff = (double)n_mt16 / (double)(n_mb * mb16);
       const double cols_eff = (double)n_cols / (double)(((n_cols + BN - 1) / BN) * BN);
       c[n].code = RTG_DCONV_CODE + 100 * (si + 1) + kNT[ni];
-      c[n].score = eff * rows_eff * cols_eff * (kShapes[si].rw16 == 2 ? 1.0 : 0.95);
+      c[n].score = eff * rows_eff * cols_eff * (kShapes[si].rw16 >= 2 ? 1.0 : 0.95);
       ++n;
     }
   }
@@ -135,7 +136,7 @@ int rtg_dconv_launch(const RtgConv1dDesc* d, int code, const float* x, const flo
   if (!x || !wp || !out) return RTG_ENULL;
   if ((reinterpret_cast<uintptr_t>(wp) & 15) != 0) return RTG_EINVAL;
   const int si = (code - RTG_DCONV_CODE) / 100 - 1, nt16 = (code - RTG_DCONV_CODE) % 100;
-  if (si < 0 || si > 3) return RTG_EINVAL;
+  if (si < 0 || si >= kNumShapes) return RTG_EINVAL;
   const int rw16 = kShapes[si].rw16, wb = kShapes[si].wb, BN = nt16 * 16;
   DArgs a;
   // the 16-byte-fragment image follows the standard image of the layer (RtgConv1dDesc.wp16)

@@ -736,7 +736,12 @@ __global__ __launch_bounds__(WB * 64, 2) void dconv_kernel(const DArgs a) {
 struct DShape {
   int rw16, wb;
 };
-constexpr DShape kShapes[] = {{2, 4}, {1, 8}, {1, 4}, {2, 8}};       // code digit 1..4: rows per block 128, 128, 64, 256
+// code digit 1..5: rows per block 128, 128, 64, 256, 256.  Shape 5 (bf16 only, round 5): 64 rows per wave — at bf16 matrix
+// rates the kernel lives on operand delivery (a 16x16x32 instruction eats 1 KB of weights from L1 and 1 KB of patch from LDS
+// every 16 cycles: at 32 rows x 64 columns per wave that is 64 B/clk/CU of L1 and 128 B/clk/CU of LDS at full rate — both
+// their limits); 64 rows per wave halve the LDS side
+constexpr DShape kShapes[] = {{2, 4}, {1, 8}, {1, 4}, {2, 8}, {4, 4}};
+constexpr int kNumShapes = 5;
 constexpr int kNT[] = {4, 6, 7, 8};
 
 // dynamic LDS of an instance: two patch buffers; bf16 input: + a transposition scratch per wave and a dump slot per lane
@@ -785,6 +790,9 @@ int launch_shape(const DArgs& a, int si, int nt16, int S, int K, bool two_d, uns
   RTG_DC(1, 4) RTG_DC(4, 4)
   RTG_DC(2, 4) RTG_DC(2, 6) RTG_DC(2, 7) RTG_DC(2, 8)
   RTG_DC(3, 4) RTG_DC(3, 6) RTG_DC(3, 7) RTG_DC(3, 8)
+  if constexpr (BF) {
+    RTG_DC(5, 4)
+  }
 #undef RTG_DC
   return RTG_EINVAL;
 }

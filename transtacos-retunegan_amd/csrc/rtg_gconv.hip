@@ -723,7 +723,6 @@ extern "C" int rtg_gconv_forward(const RtgGconvDesc* d, const float* x, const fl
 
 // ---- hooks of rtg_wgrad.hip (shape code 9 of RtgWgradDesc.shape_cfg)
 int rtg_gconv_wgrad_ok(const RtgWgradDesc* d) {
-  if (RTG_ENV_INT("RTG_GCONV", 1) == 0) return 0;        // A/B knob, as in rtg/ops.py: 0 = matrix cores only
   return gconv_wgrad_kind(d) > 0 ? 1 : 0;
 }
 

@@ -520,7 +520,6 @@ int gmfma_wgrad_kind(const RtgWgradDesc* d) {
 }  // namespace
 
 int rtg_gmfma_wgrad_ok(const RtgWgradDesc* d) {
-  if (RTG_ENV_INT("RTG_GMFMA", 1) == 0) return 0;         // A/B knob, as in rtg/ops.py
   return gmfma_wgrad_kind(d) > 0 ? 1 : 0;
 }
 
@@ -528,12 +527,12 @@ int rtg_gmfma_wgrad_ok(const RtgWgradDesc* d) {
 // there are four or more (the waves of a block then share a group and reduce in LDS)
 static int gmfma_wgrad_waves(const RtgWgradDesc* d) {
   const int n_blocks = d->B * rtg_ceil_div(d->Q, 64);
-  int w = rtg_ceil_div(RTG_ENV_INT("RTG_GMFMA_WAVES", 2048), d->groups);
+  int w = rtg_ceil_div(2048, d->groups);
   const int w_max = n_blocks / 4 > 0 ? n_blocks / 4 : 1;
   if (w > w_max) w = w_max;
-  if (w > RTG_ENV_INT("RTG_GMFMA_WMAX", 512)) w = RTG_ENV_INT("RTG_GMFMA_WMAX", 512);
+  if (w > 512) w = 512;
   if (w < 1) w = 1;
-  if (w >= 4 && RTG_ENV_INT("RTG_GMFMA_RED", 1)) w &= ~3;
+  if (w >= 4) w &= ~3;
   return w;
 }
 
@@ -542,7 +541,7 @@ static int gmfma_wgrad_waves(const RtgWgradDesc* d) {
 int rtg_gmfma_wgrad_splits(const RtgWgradDesc* d) {
   if (!gmfma_wgrad_kind(d)) return RTG_EINVAL;
   const int w = gmfma_wgrad_waves(d);
-  return (w % 4 == 0 && RTG_ENV_INT("RTG_GMFMA_RED", 1)) ? w / 4 : w;
+  return w % 4 == 0 ? w / 4 : w;
 }
 
 int rtg_gmfma_wgrad_launch(const RtgWgradDesc* d, const float* x, const float* dy, float* part, hipStream_t s) {

@@ -186,7 +186,6 @@ template <int CIN, int KT, int NT>
 int launch(ResArgs a, int n_mt, size_t lds_bytes, hipStream_t s) {
   // as many blocks as fill the chip at the kernel's occupancy, each a run of tiles
   int gx = 256 * kResconvOcc<CIN, KT, NT> / n_mt;
-  if (RTG_ENV_SET("RTG_RC_GX")) gx = RTG_ENV_INT("RTG_RC_GX", 0) / n_mt;
   if (gx > a.total) gx = a.total;
   gx = rtg_ceil_div(a.total, rtg_ceil_div(a.total, gx));
   static std::atomic<unsigned> optin{0};              // (> 64 KB of dynamic LDS: opt-in per kernel and device)
@@ -237,7 +236,7 @@ int rtg_resconv_launch(const RtgConv1dDesc* d, int nt, const float* x, const flo
   const int n_mt = d->Mg / 32;
   const size_t lds_bytes = ((size_t)2 * d->Cg * a.Wp + 4 * 32 * 32 * nt) * sizeof(float);   // 2 windows + transposes
   if (lds_bytes > 160 * 1024) return RTG_ERANGE;
-  a.dbg = RTG_ENV_INT("RTG_RC_DBG", 0);
+  a.dbg = 0;
 #define RTG_RC(c, k, n) \
   if (d->Cg == c && d->K == k && nt == n) return launch<c, k, n>(a, n_mt, lds_bytes, s);
   RTG_RC(32, 3, 1) RTG_RC(32, 5, 1) RTG_RC(32, 7, 1) RTG_RC(32, 3, 2) RTG_RC(32, 5, 2) RTG_RC(32, 7, 2)

@@ -215,7 +215,7 @@ constexpr size_t kSconvLdsMax = 150 * 1024;
 #define RTG_SCONV_CODE 9000
 
 int rtg_sconv_candidates(const RtgConv1dDesc* d, int* codes, int max) {
-  const int kind = RTG_ENV_INT("RTG_SCONV", 1) == 0 ? 0 : sconv_kind(d);
+  const int kind = sconv_kind(d);
   if (!kind) return 0;
   int cnt = 0;
   const int n_cc = d->Cg / 16;

@@ -793,6 +793,8 @@ int rtg_thin2d_dgrad_launch(const RtgConv1dDesc* d, const float* dy, const float
 // 0: not a thin shape (use the MFMA kernel), 1: one input channel, 2: one output channel, 3: one output channel 3 x 3,
 // 4 / 5: two input channels 3 x 3, forward / backward-data (rtg_thin2d.hip)
 int rtg_thin_kind(const RtgConv1dDesc* d) {
+  // (the two-channel layer along the frequency axis: its backward-data is a polyphase operator, shuf_S = 2)
+  if (d->groups == 1 && d->C2 == 0 && d->shuf_S == 2 && (d->h_k > 1 || d->h_n > 1) && rtg_thin2d_dgrad_ok(d)) return 5;
   if (d->groups != 1 || d->C2 != 0 || d->shuf_S != 1 || d->out_split != 0 || d->accumulate) return 0;
   if (d->h_k > 1 || d->h_n > 1) {
     if (rtg_thin2d_fwd_ok(d)) return 4;
@@ -802,7 +804,7 @@ int rtg_thin_kind(const RtgConv1dDesc* d) {
         d->pad == 1 && d->h_pad == 1 && d->h_n == d->h_in && d->Q == d->L_in && d->out_L == d->Q && d->h_n > 0 &&
         d->B % d->h_n == 0 && d->Cg % 3 == 0 && (d->Cg / 3) % (8 * 8) == 0 && d->Cg / 3 <= 512 && !d->bf16 &&
         d->pre_mode < RTG_PRE_MUL_DLRELU && (long long)d->B * d->Cg / 3 * d->L_in * 4 < (1ll << 31) &&
-        !RTG_ENV_SET("RTG_THIN_NOK3"))
+        true)
       return 3;
     return 0;
   }
@@ -886,7 +888,7 @@ int rtg_thin_launch(int kind, const RtgConv1dDesc* d, const float* x, const floa
   a.mask_slope = d->mask_slope; a.out_scale = d->out_scale; a.act = d->act; a.act_slope = d->act_slope;
   a.tile_m = d->tile_m; a.tap_major = d->tap_major ? 1 : 0;
   a.n_pos = (long long)d->B * d->Q;
-  const bool legacy = RTG_ENV_SET("RTG_THIN_LEGACY");       // A/B knob: the round-1 kernels
+  const bool legacy = false;                                // (true: the round-1 kernels, kept as the general fallback)
   TileGeo g = {};
   if (kind == 4) return rtg_thin2d_fwd_launch(d, x, wp, bias, mask, res, out, s);
   if (kind == 5) return rtg_thin2d_dgrad_launch(d, x, wp, mask, res, out, s);
@@ -900,7 +902,7 @@ int rtg_thin_launch(int kind, const RtgConv1dDesc* d, const float* x, const floa
     const long long wq = (long long)(d->Q - 1) * d->stride + (long long)(d->K - 1) * d->dil + 1;
     const bool vec_io = d->out_L % 4 == 0 && aligned16(out) && (!mask || aligned16(mask)) && (!res || aligned16(res));
     // (unaligned rows from 192 positions: a quarter-filled tile still beats cin1_flat_kernel's whole-row staging — period 11)
-    if ((vec_io && d->Q >= 256) || (!vec_io && d->Q >= 192 && RTG_ENV_INT("RTG_THIN_ROWS1", 1))) {
+    if ((vec_io && d->Q >= 256) || (!vec_io && d->Q >= 192)) {
       g.tiles = rtg_ceil_div(d->Q, kRowTile);
       g.W = (kRowTile - 1) * d->stride + (d->K - 1) * d->dil + 1;
       const long long bx = (long long)d->B * g.tiles;
@@ -933,7 +935,7 @@ int rtg_thin_launch(int kind, const RtgConv1dDesc* d, const float* x, const floa
     // two passes per block (2048 outputs): conv_post backward-data (512 rows of 10-128 positions per clip) is a chain of
     // dependent mask loads and stores per thread — 4 x more blocks hide it better than 8 passes in one (measured in the
     // step, 14 launches: 0.44 -> 0.27 ms; one pass: the same)
-    const int passes = RTG_ENV_INT("RTG_FLAT_PASSES", 2);
+    const int passes = 2;
     const int kFlatChunk = passes * 4 * RTG_THREADS;
     int rows_max = kFlatChunk / d->Q + 2;              // output rows a chunk can touch
     if (rows_max > d->Mg) rows_max = d->Mg;
@@ -956,8 +958,8 @@ int rtg_thin_launch(int kind, const RtgConv1dDesc* d, const float* x, const floa
   }
   if (kind == 2 && !legacy && !a.aux && d->K == 3 && d->stride == 1 && d->dil == 1 && d->pad == 1 && d->Q == d->L_in &&
       d->Q == d->out_L && d->Cg % (8 * 16) == 0 && d->Cg <= 1024 && (long long)d->B * d->Cg * d->L_in * 4 < (1ll << 31) &&
-      !RTG_ENV_SET("RTG_THIN_NOK3")) {
-    if (d->L_in <= 64 && d->L_in >= 4 && !RTG_ENV_SET("RTG_THIN_NOK3ROWS")) {
+      true) {
+    if (d->L_in <= 64 && d->L_in >= 4) {
       RTG_KLAUNCH(cout1_k3_rows_kernel, dim3((unsigned)d->B), dim3(64 * kK3Waves), 0, s, a);
       return rtg_launch_status();
     }

@@ -351,7 +351,7 @@ bool rtg_thin2d_fwd_ok(const RtgConv1dDesc* d) {
   if (!t2_shape_ok(d) || d->h_mode != 0 || d->bf16 || d->tap_major || d->shuf_S != 1 || d->out_split != 0 || d->accumulate) return false;
   if (d->out_C != kM || d->out_L != d->Q || d->act != RTG_ACT_NONE || d->out_scale != 1.f) return false;
   if (d->tile_m != 32 && d->tile_m != 16) return false;
-  return !RTG_ENV_SET("RTG_THIN2D_OFF");
+  return true;
 }
 
 int rtg_thin2d_fwd_launch(const RtgConv1dDesc* d, const float* x, const float* wp, const float* bias, const float* mask,
@@ -381,7 +381,7 @@ static bool t2_dgrad_cols_ok(const RtgConv1dDesc* d) {
 
 // backward-data descriptor of the same layer (Conv2dFn.backward): clips = (item, input row), channels = (kernel row, co)
 bool rtg_thin2d_dgrad_ok(const RtgConv1dDesc* d) {
-  if (t2_dgrad_cols_ok(d)) return !RTG_ENV_SET("RTG_THIN2D_OFF");
+  if (t2_dgrad_cols_ok(d)) return true;
   if (d->h_mode != 1 || d->groups != 1 || d->C2 != 0 || d->Mg != kCr || d->C1 != kM * kKH || d->Cg != d->C1) return false;
   if (d->h_k != kKH || d->K != kKW || d->stride != 1 || d->dil != 1 || d->pad != 1 || d->h_pad != 1 || d->h_stride != 2) return false;
   if (d->h_in < 1 || d->h_n < 1 || d->B % d->h_n != 0 || d->Q != d->L_in || d->out_L != d->Q || d->out_C != kCr) return false;
@@ -390,7 +390,7 @@ bool rtg_thin2d_dgrad_ok(const RtgConv1dDesc* d) {
   if (d->pre_mode != RTG_PRE_NONE || (d->tile_m != 16 && d->tile_m != 32)) return false;
   const long long items = d->B / d->h_n;
   if (items * kM * d->h_in * d->L_in * 4 >= (1ll << 31) || items * kCr * d->h_n * d->L_in * 4 >= (1ll << 31)) return false;
-  return !RTG_ENV_SET("RTG_THIN2D_OFF");
+  return true;
 }
 
 int rtg_thin2d_dgrad_launch(const RtgConv1dDesc* d, const float* dy, const float* wp, const float* mask, const float* res,
@@ -419,7 +419,7 @@ int rtg_thin2d_dgrad_launch(const RtgConv1dDesc* d, const float* dy, const float
 
 bool rtg_thin2d_wgrad_ok(const RtgWgradDesc* d) {
   if (!t2_shape_ok(d) || d->gy_mode != RTG_PRE_NONE || d->dy_L != d->Q) return false;
-  return !RTG_ENV_SET("RTG_THIN2D_OFF");
+  return true;
 }
 
 // one block per split; a lane should see a few dozen positions (the wave reduction at the end is ~150 values)

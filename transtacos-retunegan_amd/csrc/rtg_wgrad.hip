@@ -121,7 +121,6 @@ int geometry(const RtgWgradDesc* d, WgGeom* o) {
   if ((long long)d->B * Lseg * d->stride + RTG_PW_MAX >= (1ll << 24)) return RTG_ERANGE;   // float-reciprocal division
   const int per_clip = rtg_ceil_div(d->Q, TT);
   o->cont = ((double)d->Q / Lseg > 1.08 * (double)d->Q / ((double)per_clip * TT) && d->B >= 2) ? 1 : 0;
-  if (RTG_ENV_SET("RTG_DEV_WGRAD_CONT")) o->cont = (RTG_ENV_INT("RTG_DEV_WGRAD_CONT", 0) == 1 && d->B >= 2) ? 1 : 0;   // tuning aid
   if (o->cont) {
     o->n_ttiles = 1;
     o->n_tiles_total = rtg_ceil_div((long long)d->B * Lseg, TT);
@@ -189,12 +188,6 @@ extern "C" int rtg_wgrad_splits(const RtgWgradDesc* d_in) {
   if (st) return st;
   const long long base = (long long)d->groups * g.m_blocks * g.n_cchunk;
   const long long total = g.n_tiles_total;
-  if (RTG_ENV_SET("RTG_DEV_SPLIT_OLD")) {   // tuning aid: the former "aim at 640 blocks" rule
-    long long s = (640 + base - 1) / base;
-    if (s > total) s = total;
-    if (s > 512) s = 512;
-    return (int)(s < 1 ? 1 : s);
-  }
   // Cost model in microseconds: the matrix pipe of a CU is shared by its resident blocks, so the launch lasts about
   // (blocks per CU, rounded up) x (tiles per block, rounded up) tile times, plus a fixed cost per block and the
   // write + fixed-order read-back of one partial per split.

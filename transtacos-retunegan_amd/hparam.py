@@ -98,7 +98,7 @@ compute_dtype = 'fp32'
 # bf16, stored activated — bf16(leaky_relu(x, 0.15)), what every consumer inside the stacks applies to them anyway; fp32
 # accumulators, losses, weight norm and optimizer.  The fmaps the discriminators return are then such bf16 tensors
 # (feature_loss reads them; rtg.ops.decode gives the fp32 feature map).  False: fp32 tensors in HBM, bf16 operands only.
-bf16_maps = True
+bf16_maps = False
 # resume schedule: False = the installed torch's ExponentialLR (2.x: the constructor leaves the loaded lr untouched);
 # True = torch 1.8's (the reference's README.md:15): one more factor of lr_decay per resume.  See train.ExponentialLR.
 legacy_resume_lr = False

@@ -38,10 +38,10 @@ def _run_stack(tok, convs, conv_post, x):
     return conv(tok, conv_post, h, pre_slope=LRELU_SLOPE), fmap
 
 
-# RTG_GROUP=1: sibling sub-discriminators run layer by layer in grouped launches (rtg_conv1d_group) instead of on forked
+# GROUPED: sibling sub-discriminators run layer by layer in grouped launches (rtg_conv1d_group) instead of on forked
 # streams.  Measured on MI355X (config 2, batch 32): a grouped launch beats its members run back to back by 11-34 %, but
-# the forked streams already overlap them as well — 42.7 ms/step grouped vs 42.3 forked — so forking stays the default.
-GROUPED = os.environ.get('RTG_GROUP', '0') == '1'
+# the forked streams already overlap them as well — 42.7 ms/step grouped vs 42.3 forked — so forking it is (tests flip it).
+GROUPED = False
 
 
 def _groupable(c):
@@ -144,8 +144,8 @@ def _split(t, B):
 
 
 # Generator step (D frozen): real and generated clips of a sub-discriminator run as ONE 2B-clip launch per layer
-# (ops.PairConvFn), the backward-data only over the generated half.  RTG_PAIR=0: two separate passes (A/B knob).
-PAIRED = os.environ.get('RTG_PAIR', '1') == '1'
+# (ops.PairConvFn), the backward-data only over the generated half (False: two separate passes; 38.8 -> 38.4 ms in round 1).
+PAIRED = True
 
 
 def _pairable(d):
@@ -163,6 +163,10 @@ def _run_pair(d, tok, x_real, x_fake):
     # every feature map has two readers, the next layer and the feature-matching loss: the loss reads the copy the next
     # layer hands through (`tap`), so the two gradients meet in that layer's backward-data epilogue
     for c in list(d.convs[1:]) + [d.conv_post]:
+        if ops._is_bf(hg) and not c._layer.maps_bf:
+            # a bf16 (encoded) feature map in front of a layer without a bf16 input path (conv_post): ONE decode of the
+            # 2B-clip buffer serves the layer and the feature-matching loss
+            hr, hg = ops.PairDecodeFn.apply(hr, hg)
         nr, ng, tap = ops.pair_conv(tok, c._layer, hr, hg, pre_slope=LRELU_SLOPE, tap=True)
         fr.append(hr)
         fg.append(tap)
@@ -238,8 +242,6 @@ def run_stacks(calls):
     """calls: [(stack, a, b)] -> [(logits_r, logits_g, fmaps_r, fmaps_g)] per stack.  A stack whose sub-discriminators
     share an architecture of 1-D convs (MSD, MPD) runs layer by layer in grouped launches (one branch of the fork); the
     sub-discriminators of the others (MTD) are forked side by side — one flat fork in all."""
-    if os.environ.get('RTG_FLAT_FORK', '1') == '0':          # A/B knob: a fork per stack around the stacks' own forks
-        return fork_join([(lambda st=stack, a=a, b=b: st(a, b)) for stack, a, b in calls])
     brs, spans = [], []
     for stack, a, b in calls:
         if GROUPED and getattr(stack, 'groupable', False):
@@ -308,7 +310,7 @@ class MultiPeriodDiscriminator(_MultiBase):
 # 1025 .. 8 bins instead of 137 .. 5 frames for the kernels to walk — and the layers are built with WNConv(wt=True): same
 # parameters, shapes and state-dict keys, the kernel axes swapped when the weights are packed.  What goes in and comes out
 # keeps the reference's [B, C, F, frames] shape (transposed views; logits in the reference's order).
-MTD_ALONG_FREQ = True
+MTD_ALONG_FREQ = True        # (False: the reference's layout [B, C, F, frames]; same-box A/B in DESIGN.md: equal step time)
 
 
 class StftDiscriminator(nn.Module):

@@ -108,7 +108,7 @@ class BankedModel(nn.Module):
 import os
 
 _FORK_STREAMS = {}
-_FORK_MAX = int(os.environ.get('RTG_FORK_MAX', '0'))
+_FORK_MAX = 0                 # (> 0: that many forked streams at most, branches share them round robin; round 1: uncapped is best)
 _FORK_PATH = [()]
 if hasattr(torch.autograd.graph, 'set_warn_on_accumulate_grad_stream_mismatch'):
     # leaves are accumulated on the stream of their first use while forked branches run elsewhere: intended
@@ -139,7 +139,7 @@ def fork_join(fns):
     main = torch.cuda.current_stream()
     path = _FORK_PATH[0]
     pool = _FORK_STREAMS.setdefault((main.device, path), [])
-    n_str = len(fns) if _FORK_MAX <= 0 else min(len(fns), _FORK_MAX)   # RTG_FORK_MAX: branches share streams round-robin
+    n_str = len(fns) if _FORK_MAX <= 0 else min(len(fns), _FORK_MAX)
     while len(pool) < n_str:
         pool.append(new_stream(device=main.device))      # (never a pooled torch stream: rtg/lib.py:new_stream)
     outs = []

@@ -120,11 +120,12 @@ def feature_loss(fmap_r, fmap_g):
     rs = [_base(r) for dr in fmap_r for r in dr]
     gs = [_base(g) for dg in fmap_g for g in dg]
     # bf16 feature maps (hparam.bf16_maps) are stored leaky-relu encoded: their pairs go through the decoding loss kind
+    if any((r.dtype == torch.bfloat16) != (g.dtype == torch.bfloat16) for r, g in zip(rs, gs)):
+        # (a pair of one encoded and one plain map — e.g. the real half still encoded, the generated one already decoded for
+        # conv_post: everything through the fp32 feature maps)
+        rs, gs = [ops.decode(r) for r in rs], [ops.decode(g) for g in gs]
     enc = [i for i, (r, g) in enumerate(zip(rs, gs)) if r.dtype == torch.bfloat16 and g.dtype == torch.bfloat16]
     if not enc:
-        return ops.multi_loss(LOSS_L1, rs, gs)
-    if any((r.dtype == torch.bfloat16) != (g.dtype == torch.bfloat16) for r, g in zip(rs, gs)):
-        rs, gs = [ops.decode(r) for r in rs], [ops.decode(g) for g in gs]
         return ops.multi_loss(LOSS_L1, rs, gs)
     plain = [i for i in range(len(rs)) if i not in set(enc)]
     terms = [ops.multi_loss(LOSS_L1_ENC, [rs[i] for i in enc], [gs[i] for i in enc], target=ops.ENC_SLOPE)]

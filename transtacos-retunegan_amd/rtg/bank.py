@@ -23,8 +23,9 @@ from .lib import lib, check
 from .lib import current_stream_ptr as _lib_stream_ptr
 
 
-# RTG_GCONV=0 (rtg/ops.py): the thin-group layers never leave the matrix cores, no vector-ALU weight images either
-GCONV_IMAGES = os.environ.get('RTG_GCONV', '1') == '1' and os.environ.get('RTG_GCONV_PACK', '1') == '1'
+# the thin-group layers' vector-ALU / exact-fit weight images are part of the pack launch (round 4: 72 prepare launches per
+# step folded into it; False: rtg_gconv_prepare per layer and pass)
+GCONV_IMAGES = True
 # debug aid (tests/conftest.py turns it on): WeightBank.lean_pack() fills every image it drops with NaN, so a launch that
 # still reads one without reporting it (note_std_use) fails loudly instead of training on the weights of an earlier step
 LEAN_POISON = False
@@ -115,7 +116,7 @@ class ConvLayer:
             self.bwd_op = (L.PACK_FWD, 1, self.cin, self.cout, self.k, 1)
         self.fwd_tm = 32 if self.fwd_op[2] >= 32 else 16
         self.bwd_tm = 32 if self.bwd_op[2] >= 32 else 16
-        if os.environ.get('RTG_TM16_ODD', '1') == '1' and self.bwd_op[2] >= 32 and self.bwd_op[2] % 32 == 16 and \
+        if self.bwd_op[2] >= 32 and self.bwd_op[2] % 32 == 16 and \
                 self.bwd_op[2] < 256 and self.groups == 1 and self.kind == 'conv' and self.stride == 1:
             # 48 or 208 rows: 16-row tiles cover them exactly, 32-row tiles pad 25 % / 7 % (backward-data of the UNet-G
             # merge / fuse convs, whose row count is the concatenated input's channel count)
@@ -128,10 +129,10 @@ class ConvLayer:
         # order, not the 1-channel shapes of the bandwidth kernels, not the class-pure strided 2-D backward-data
         import hparam as hp
         want_bf = getattr(hp, 'compute_dtype', 'fp32') == 'bf16'
-        if want_bf and os.environ.get('RTG_BF16_NOTAP', '1') == '1':
+        if want_bf:
             # at bf16 matrix rates padding 8 channels per group to a 16-channel chunk costs less than staying on the
             # fp32 tap-major path: the grouped MSD layers run channel-major in bf16
-            min_c = int(os.environ.get('RTG_BF16_NOTAP_MINC', '8'))
+            min_c = 8
             if self.fwd_tap and self.fwd_op[3] >= min_c:
                 self.fwd_tap = 0
             if self.bwd_tap and self.bwd_op[3] >= min_c:
@@ -146,14 +147,14 @@ class ConvLayer:
         # the dense-layer kernel (rtg_dconv.hip, block-shape codes 8xxx) reads 16-byte operand fragments: layers it can serve
         # (>= 32 input channels, >= 64 output rows, dilation 1; 1-D: k5 at stride 1 / 3 forward, the k5 stride-1 or 2-tap
         # polyphase backward-data operator; Conv2d of the spectrogram discriminators: forward, stride-1 backward-data) carry a second image of their weights behind the standard one (RtgPackJob.frag16,
-        # RtgConv1dDesc.wp16); the tuner then times both kernels per problem.  RTG_DCONV=0: never (A/B knob).
+        # RtgConv1dDesc.wp16); the tuner then times both kernels per problem.
         def dense(op, fwd):
             """0: no fragment image; 1: the image, for the dense kernel (rtg_dconv.hip); 2: the image, for the dense kernel AND
             the split-K kernel (rtg_sconv.hip: another summation order, so only layers the dense-kernel rules do not name —
             the generator's — offer it; RtgConv1dDesc.wp16 carries the value)"""
             mode, g, mg, cg, k, s = op
             ckc = 32 if want_bf else L.CK         # bf16: 32-channel chunks (8 bf16 per 16-byte fragment)
-            if os.environ.get('RTG_DCONV', '1') != '0' and self.dil == 1 and g == 1 and cg % ckc == 0 and cg >= 32 and mg >= 64:
+            if self.dil == 1 and g == 1 and cg % ckc == 0 and cg >= 32 and mg >= 64:
                 if self.kind == 'conv2d':
                     # StftDiscriminator (3 taps along the last axis): forward and backward-data
                     if fwd:
@@ -170,19 +171,19 @@ class ConvLayer:
                         return 1
                     if not fwd and ((mode == L.PACK_DGRAD_S1 and k == 5) or (mode == L.PACK_DGRAD_POLY and k == 2 and s == 3)):
                         return 1
-            if self.kind == 'conv2d' or want_bf or os.environ.get('RTG_SCONV', '1') == '0':
+            if self.kind == 'conv2d' or want_bf:
                 return 0
             # (round 4) the same fragment image serves rtg_sconv.hip: the stride-1 convs of >= 128 channels at the bottom of
             # the UNet (conv_fuse, the 128-channel ResidualStack / ResBlock3 layers; any dilation, up to 8 taps), which have
-            # 1024 columns at batch 32 and want split-K over the waves of a block; fp32 only.  RTG_SCONV=0: never.
+            # 1024 columns at batch 32 and want split-K over the waves of a block; fp32 only.
             if self.kind == 'conv' and self.stride == 1 and g == 1 and cg % L.CK == 0 and mg % 16 == 0 and cg >= 128 and \
                     mg >= 128 and k <= 8 and mode in (L.PACK_FWD, L.PACK_DGRAD_S1):
                 return 2
             # ... and the strided / transposed convs next to them (downs.2: 64 -> 128, k15, stride 8 and ups.0: 256 -> 128):
             # the strided walk forward / backward-data of the transposed conv, the polyphase operator (2 taps, rows =
             # (channel, phase), shuffle store) the other way.  The split-K kernel takes rows of <= 64 columns only; further up
-            # the UNet the dense kernel's 2-tap instance serves the polyphase operators.  RTG_SCONV_STRIDED=0: never.
-            if os.environ.get('RTG_SCONV_STRIDED', '1') != '0' and self.kind in ('conv', 'convT') and 1 < self.stride <= 8 and \
+            # the UNet the dense kernel's 2-tap instance serves the polyphase operators.
+            if self.kind in ('conv', 'convT') and 1 < self.stride <= 8 and \
                     self.dil == 1 and g == 1 and cg % L.CK == 0 and mg % 16 == 0 and cg >= 64 and mg >= 128 and k <= 16 and \
                     mode in (L.PACK_FWD, L.PACK_DGRAD_POLY, L.PACK_CONVT_POLY):
                 return 2
@@ -481,7 +482,7 @@ class WeightBank:
 
     def gmfma_weights(self, ly, gd):
         """the layer's forward image for rtg_gmfma_forward ([group][oc][ci][44], part of this pass's pack launch); None: the
-        layer has none (RTG_GCONV_PACK=0)"""
+        layer has none (GCONV_IMAGES off)"""
         if getattr(ly, 'gconv_off', None) is None:
             return None
         if lib.rtg_gmfma_workspace(C.byref(gd)) != ly.gmfma_size:

@@ -186,9 +186,8 @@ class _Lib:
                 try:
                     fn = getattr(dll, name)      # AttributeError if the symbol is not exported
                 except AttributeError:
-                    if os.environ.get('RTG_DEV_PARTIAL_LIB') == '1':   # bring-up only: kernels under construction
-                        continue
-                    raise
+                    raise RtgError(f'{LIB_PATH} does not export {name}: stale build — run '
+                                   '`python transtacos-retunegan_amd/build.py`') from None
                 fn.restype, fn.argtypes = res, args
             if hasattr(dll, 'rtg_abi_version') and dll.rtg_abi_version() != ABI_VERSION:
                 raise RtgError(f'{LIB_PATH} has ABI version {dll.rtg_abi_version()}, these bindings are for '

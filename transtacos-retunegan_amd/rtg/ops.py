@@ -272,8 +272,8 @@ def _run_wgrad(wd, ptrs, st, bank, ly, tok_id, flop, label, what):
 # is one serial chain) the weight-gradient launches go to a side stream: they overlap the following backward-data
 # launches instead of delaying them.  The bank's flush waits for every stream that ran weight gradients
 # (note_backward_stream).  Not under the tuner or the per-launch profile (both time launches in isolation).
-# RTG_WGRAD_SIDE=0 turns it off (A/B knob).
-WGRAD_SIDE = _os.environ.get('RTG_WGRAD_SIDE', '1') == '1'
+# (Rounds 2-4 A/B, DESIGN.md 3: neutral eager, +1.2 % under graph replay: settled on.)
+WGRAD_SIDE = True
 _SIDE_STREAMS = {}
 
 
@@ -307,8 +307,8 @@ class wgrad_side:
         return False
 
 
-# RTG_WGRAD_GROUP=0: every weight gradient as its own launch (A/B knob)
-WGRAD_GROUP = _os.environ.get('RTG_WGRAD_GROUP', '1') == '1'
+# (False: every weight gradient as its own launch; settled on in round 2: 0.5 ms per step)
+WGRAD_GROUP = True
 
 
 def _run_wgrad_group(items, st, bank, tok_id, label):
@@ -416,14 +416,14 @@ def _desc(**kw):
     return L.Conv1dDesc(**base)
 
 
-# RTG_GCONV=0: the thin-group MSD layers on the matrix cores only (A/B knob)
-GCONV = _os.environ.get('RTG_GCONV', '1') == '1'
-# RTG_GMFMA=0: without the exact-fit matrix-core forward of rtg_gmfma.hip (A/B knob)
-GMFMA = _os.environ.get('RTG_GMFMA', '1') == '1'
+# the thin-group MSD layers: vector-ALU kernels (rtg_gconv.hip) and the exact-fit matrix-core forward (rtg_gmfma.hip) as
+# alternatives the tuner times against the general kernel (False: the general kernel only; tests flip GCONV)
+GCONV = True
+GMFMA = True
 # bf16 operands (hparam.compute_dtype, BASELINE configs[2]): the thin-group layers' fp32 kernels (vector ALUs, exact-fit
 # matrix-core tiles) stay candidates next to the bf16 general kernel, whose tiles are mostly padding for 8 channels per
-# group — fp32 arithmetic where it is FASTER than bf16 is no loss of precision.  0: bf16 layers take the bf16 kernel only
-BF16_FP32_THIN = _os.environ.get('RTG_BF16_FP32_THIN', '1') == '1'
+# group — fp32 arithmetic where it is FASTER than bf16 is no loss of precision (round 4: config 3 51.3 -> 49.3 ms/step)
+BF16_FP32_THIN = True
 
 
 def _gconv_forward(ly, bank, tok_id, d, args, x_ptr, B, L_in, out, pre_slope, flop, label):
@@ -637,10 +637,10 @@ class ConvFn(torch.autograd.Function):
 # ---------------------------------------------------------------------------------------------------------------
 # ResidualStack in one launch per direction (rtg_resstack.hip)
 # ---------------------------------------------------------------------------------------------------------------
-RESSTACK = _os.environ.get('RTG_RESSTACK', '1') == '1'          # A/B knob: 0 = six conv launches per direction
+RESSTACK = True                                                  # (False: six conv launches per direction)
 # bit mask of the fused-stack instances used (rtg_resstack_ok's instance numbers): only (128 channels, 32 samples) beat six
 # launches of the general kernel inside the train step; the 64- and 32-channel instances are built and tested, not served
-RESSTACK_KINDS = int(_os.environ.get('RTG_RESSTACK_KINDS', '1'))
+RESSTACK_KINDS = 1
 
 
 def _stack_desc(lys, B, Lx, pre_slope, final_act_slope, reverse=False):
@@ -1077,11 +1077,11 @@ def group_conv(token, lys, xs, pre_slope=1.0, res_self=False):
     return list(GroupConvFn.apply(token, tuple(lys), float(pre_slope), bool(res_self), *xs))
 
 
-# RTG_MRF_GROUP: the parallel ResBlock branches of a UNet-G decoder stage (kernel sizes 3 / 5 / 7 on the same input) as
-# grouped launches, conv by conv.  1 (default): stages of >= 64 channels, where a branch alone is 256-1024 workgroups of
+# MRF_GROUP: the parallel ResBlock branches of a UNet-G decoder stage (kernel sizes 3 / 5 / 7 on the same input) as
+# grouped launches, conv by conv.  1: stages of >= 64 channels, where a branch alone is 256-1024 workgroups of
 # 25-50 us and three of them share one launch's fixed cost; the 32-channel stage is HBM-bound and keeps its
 # weights-in-registers kernel (rtg_resconv) per branch.  0: never (forked streams), 2: every stage.
-MRF_GROUP = int(_os.environ.get('RTG_MRF_GROUP', '1'))
+MRF_GROUP = 1
 
 
 _GROUP_OK = {}
@@ -1250,6 +1250,9 @@ class MultiLossFn(torch.autograd.Function):
         a_list = [_c(t) for t in tensors[:n]]
         b_list = [_c(t) if t is not None else None for t in tensors[n:]]
         _need_cuda(*a_list)
+        want = _BF if kind == L.LOSS_L1_ENC else torch.float32
+        if any(t.dtype != want for t in a_list) or any(t is not None and t.dtype != want for t in b_list):
+            raise L.RtgError(f'multi_loss kind {kind}: expects {want} tensors (bf16 feature maps go through LOSS_L1_ENC or ops.decode)')
         dev = a_list[0].device
         loss = torch.zeros(1, device=dev)
         ws = torch.empty(64 * L.MAX_LOSS_JOBS, device=dev)

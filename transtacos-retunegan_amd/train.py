@@ -34,7 +34,7 @@ from rtg.lib import lib, check, RtgError, new_stream, current_stream_ptr as _lib
 
 device = 'cuda' if torch.cuda.is_available() else 'cpu'
 CAPTURE_ERROR_MODE = os.environ.get('RTG_CAPTURE_MODE', 'thread_local')
-LEAN_PACK = os.environ.get('RTG_LEAN_PACK', '1') == '1'
+LEAN_PACK = True              # (Trainer.lean_pack_enabled: tests build trainers without it)
 
 
 EXCHANGE_POLICIES = ('update', 'disc')
@@ -229,8 +229,6 @@ class DataParallel:
         """all-reduce `flat_grad` on the communication stream once the kernels already queued on the current stream
         (which produce it) have finished; returns immediately."""
         if not self.enabled:
-            return
-        if os.environ.get('RTG_DP_DRY') == '1':          # dev: everything but the collective itself (cost attribution)
             return
         if flat_grad.is_cuda and self.exchange == 'update':
             # stream-ordered on the compute stream: after the kernels that produced the gradients, before the optimizer
@@ -462,7 +460,7 @@ class Trainer:
         tune.ACTIVE = tuning and (not self.dp.enabled or dist.get_rank(self.dp.group) == 0)
         tune.MISSED = False
         # the first step that runs entirely on settled block shapes is watched: standard weight images no launch of it read
-        # leave the pack launches (rtg/bank.py: lean_pack; RTG_LEAN_PACK=0 keeps everything)
+        # leave the pack launches (rtg/bank.py: lean_pack; Trainer.lean_pack_enabled = False keeps everything)
         observe = self._lean_pending and not tuning and self.lean_pack_enabled
         if observe:
             for m in (self.generator, *self.discs):
@@ -646,8 +644,6 @@ class Trainer:
                         if self._capture_hook is not None:      # (tests hold a capture open: tests/test_zz_dp_gpu.py)
                             self._capture_hook()
                     graphs.append((g, after if self.dp.enabled else None))
-                    if os.environ.get('RTG_GRAPH_DEBUG'):
-                        print(f'captured graph segment {len(graphs)} of {len(segs)}', flush=True)
         except BaseException:
             # leave no stream in a (possibly invalidated) capture: every later allocation would fail, the eager step too
             lib.rtg_stream_end_capture(C.c_void_p(cap.cuda_stream))
