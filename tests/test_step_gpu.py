@@ -512,27 +512,37 @@ def test_config5_full_stack_step_at_16x22016(oracle):
     _finite_step(tr, x, y_tmpl, y)
 
 
-def test_config3_full_stack_bf16_step_at_32x16384(oracle):
+@pytest.mark.parametrize('maps', [False, True], ids=['fp32-maps', 'bf16-maps'])
+def test_config3_full_stack_bf16_step_at_32x16384(oracle, maps):
     """BASELINE configs[2]: full stack, 32 clips x 16384 samples, bf16 operands with fp32 accumulation and fp32 losses.
-    bf16 rounds the operands per element, independent of the batch: the same properties hold at bf16 summation noise."""
+    bf16 rounds the operands per element, independent of the batch: the same properties hold at bf16 summation noise —
+    also with the dense layers' feature maps and gradients stored as bf16 (hparam.bf16_maps: a stored value is rounded per
+    element as well)."""
     import hparam as hp
     hp.compute_dtype = 'bf16'
+    old_maps, hp.bf16_maps = hp.bf16_maps, maps
     try:
         tr, x, y_tmpl, y = _full_stack_trainer(oracle, 32, 16384, 43)
         assert any(ly.fwd_bf for ly in tr.generator.bank().layers) and any(ly.fwd_bf for ly in tr.mtd.bank().layers)
+        assert any(ly.maps_bf for ly in tr.mtd.bank().layers) == maps
         _pairs_property(tr, x, y_tmpl, y, tol_out=2e-2, tol_d=(2e-3, 2e-2), tol_dy=2e-2, tol_g=2e-2)
         _finite_step(tr, x, y_tmpl, y)
     finally:
         hp.compute_dtype = 'fp32'
+        hp.bf16_maps = old_maps
 
 
-def test_bf16_two_steps_against_the_bf16_rounding_oracle(oracle):
+@pytest.mark.parametrize('maps', [False, True], ids=['fp32-maps', 'bf16-maps'])
+def test_bf16_two_steps_against_the_bf16_rounding_oracle(oracle, maps):
     """cfg2-shaped run (G + MSD + MPD, d_train_times 2, two steps) in bf16 against the oracle with bf16-rounded operands
     in exactly the layers the product runs in bf16: losses within 1 % (bf16 keeps 8 significant bits; the rounding
-    decisions of two evaluations diverge after a few layers), and closer to the bf16 oracle than the fp32 oracle is."""
+    decisions of two evaluations diverge after a few layers), and closer to the bf16 oracle than the fp32 oracle is.
+    maps: with hparam.bf16_maps the feature maps between the dense discriminator layers (and their gradients) are stored as
+    bf16; the oracle rounds the stored maps where the product does (store_bf16)."""
     import hparam as hp
     from train import Trainer
     hp.compute_dtype = 'bf16'
+    old_maps, hp.bf16_maps = hp.bf16_maps, maps
     try:
         torch.manual_seed(3)
         tr = Trainer(use_mpd=True, use_mtd=False, d_train_times=2, dev='cuda:0')
@@ -563,3 +573,4 @@ def test_bf16_two_steps_against_the_bf16_rounding_oracle(oracle):
         assert np.abs(hip - b16).max() <= np.abs(b16 - f32).max() + 1e-3 * np.abs(f32).max()
     finally:
         hp.compute_dtype = 'fp32'
+        hp.bf16_maps = old_maps
