@@ -364,6 +364,7 @@ def main():
     import hparam as hp
     import train as train_mod
     from train import Trainer
+    from rtg import config as rtg_config
     t_start = time.perf_counter()
 
     def note(msg):
@@ -543,6 +544,7 @@ def main():
                                                  + ('' if mode.startswith('hip-graph') else ' (eager step)')),
                                         'chosen_by': ('RTG_DP_CUT' if exchange_trials is None else '5 timed steps per policy in set-up (MAX over ranks)'),
                                         'trial_ms_per_step': exchange_trials}} if per_rank else {})},
+            'knobs': rtg_config.non_default(),       # environment switches set to a non-default value (rtg/config.py)
             'roofline': roof, 'cpu_baseline': cpu,
             'final_losses': {'gen_all': round(loss_g, 4), 'disc_all': round(loss_d, 4)},
         }

@@ -1,13 +1,19 @@
 // rtg_stft.hip — framed rFFT of get_stft_torch (retunegan/audio.py:150-170) with the |.|, log, angle/PI and mel
 // epilogues of multi_stft_loss (retunegan/models/loss.py:32-52) fused, and its backward.
 //
-// One workgroup (256 threads) per (clip, frame): the win = n_fft/2 windowed samples are gathered (reflect indexing,
-// no padded copy of the signal) into an LDS buffer of n_fft complex points, transformed by a radix-2 Stockham
-// autosort FFT that ping-pongs between two LDS buffers (twiddles from an fp64-rounded table, L2 resident), and the
-// epilogue runs on the n_fft/2+1 bins straight from LDS.  HBM traffic per frame = win floats in, (mel | spec | re,im)
-// out: the kernel is output-write bound, the FFT itself never leaves the CU.
-// Backward = the same FFT applied to the conjugated cotangent half-spectrum (the adjoint of a real-input DFT),
-// windowed into a per-frame workspace, then a gather-form overlap-add that also folds the reflect padding back.
+// Round 5.  A frame is n_fft REAL samples (only the win = n_fft/2 in the middle are non-zero), so its spectrum comes from a
+// complex FFT of HALF the length: z[m] = x[2m] + i x[2m+1], Z = FFT_M(z) with M = n_fft/2, then
+//     X[k] = (Z[k] + conj Z[M-k]) / 2  +  W_N^k (Z[k] - conj Z[M-k]) / (2i),   k = 0 .. M.
+// FFT_M is a radix-4 Stockham autosort in LDS (one radix-2 pass where M is not a power of 4): 5 passes for n_fft 2048 where
+// the radix-2 transform of n_fft complex points took 11, each with a barrier and an LDS round trip — what the kernel's time
+// was made of.  M/4 threads own a frame (one radix-4 butterfly per thread and pass), a 256-thread block takes 1 / 2 / 4
+// frames (n_fft 2048 / 1024 / 512).  Twiddles from the fp64-rounded table (L2 resident).  The epilogue runs on the M + 1
+// bins straight from LDS; DC and Nyquist come out exactly real, like an r2c FFT's.  HBM traffic per frame = win floats in,
+// (mel | spec | re, im) out; with RtgStftDesc.spec_T the spectrum stores are coalesced.
+// Backward = the adjoint of a real-input DFT: y[n] = Re sum_f conj(G_f) W^(fn) is the DFT of the Hermitian extension of
+// c_f conj(G_f) (c = 1/2 inside, 1 at DC / Nyquist) and real, so it is one FFT_M too: Z'[k] = (H[k] + H[k+M]) +
+// i (H[k] - H[k+M]) W_N^k, FFT_M(Z')[m] = y[2m] + i y[2m+1]; windowed into a per-frame workspace, then a gather-form
+// overlap-add that also folds the reflect padding back.
 #include "rtg_common.h"
 
 namespace {
@@ -18,91 +24,138 @@ struct cpx {
   float x, y;
 };
 
-// In-place-in-LDS radix-2 Stockham FFT of n points.  Returns the buffer that holds the result.
-__device__ __forceinline__ cpx* fft_stockham(cpx* a, cpx* b, int n, const float* __restrict__ tw_cos,
-                                              const float* __restrict__ tw_sin) {
-  const int half = n >> 1;
+// exp(-2 pi i j / N) for 0 <= j < N from the table of N/2 (cos, sin) pairs of the angles 2 pi k / N
+__device__ __forceinline__ cpx tw_at(const float* __restrict__ tw, int N, int j) {
+  const int h = N >> 1;
+  const bool up = j >= h;
+  const int k = up ? j - h : j;
+  const float c = tw[k], s = tw[h + k];
+  return up ? cpx{-c, s} : cpx{c, -s};
+}
+__device__ __forceinline__ cpx cmul(cpx a, cpx b) { return cpx{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+
+// FFT of M complex points in LDS (radix-4 Stockham autosort, decimation in frequency, forward sign), by the TPF = M/4
+// threads t = 0 .. TPF-1 of one frame; every pass ends in a block barrier (all frames of the block walk the same passes).
+// N = 2M: the twiddle table's length.  Returns the buffer that holds the result.
+__device__ __forceinline__ cpx* fft_half(cpx* a, cpx* b, int M, int t, const float* __restrict__ tw) {
+  const int N = 2 * M, q4 = M >> 2;
   cpx *src = a, *dst = b;
-  for (int s = 1; s < n; s <<= 1) {          // s = stride, current sub-length = n / s
-    // butterfly idx = q + s * p (q < s) takes src[idx] and src[idx + n / 2] to dst[q + 2 s p] and dst[q + 2 s p + s] with
-    // the twiddle exp(-2 pi i p / (n / s)) = table[s p]: s p = idx with its low log2(s) bits cleared — masks, no division
-    // (measured: the same 23 us per launch as with the divisions, and as with the twiddle table staged in LDS — the passes'
-    // barriers and LDS round trips set the time, not their arithmetic)
-    const int hi = ~(s - 1);
-#pragma unroll 4
-    for (int idx = threadIdx.x; idx < half; idx += RTG_THREADS) {
-      const int k = idx & hi;
-      const cpx u = src[idx], v = src[idx + half];
-      const float c = tw_cos[k], sn = tw_sin[k];
-      const float dx = u.x - v.x, dy = u.y - v.y;
-      cpx o0, o1;
-      o0.x = u.x + v.x; o0.y = u.y + v.y;
-      o1.x = dx * c + dy * sn;                // (dx + i dy) * (c - i sn)
-      o1.y = dy * c - dx * sn;
-      dst[idx + k] = o0;
-      dst[idx + k + s] = o1;
+  int s = 1;
+  for (; 4 * s <= M; s <<= 2) {
+    // butterfly idx = q + s p (q < s): inputs idx + j M/4, outputs q + s (4p + j) = idx + 3 s p + s j, twiddles
+    // exp(-2 pi i j (s p) / M) = table[2 j s p]
+    const int k = t & ~(s - 1);
+    const cpx x0 = src[t], x1 = src[t + q4], x2 = src[t + 2 * q4], x3 = src[t + 3 * q4];
+    const cpx apc{x0.x + x2.x, x0.y + x2.y}, amc{x0.x - x2.x, x0.y - x2.y};
+    const cpx bpd{x1.x + x3.x, x1.y + x3.y}, bmd{x1.x - x3.x, x1.y - x3.y};
+    const cpx y0{apc.x + bpd.x, apc.y + bpd.y};
+    const cpx y1{amc.x + bmd.y, amc.y - bmd.x};               // amc - i (b - d)
+    const cpx y2{apc.x - bpd.x, apc.y - bpd.y};
+    const cpx y3{amc.x - bmd.y, amc.y + bmd.x};               // amc + i (b - d)
+    cpx* o = dst + t + 3 * k;
+    o[0] = y0;
+    if (k == 0) {
+      o[s] = y1; o[2 * s] = y2; o[3 * s] = y3;
+    } else {
+      o[s] = cmul(y1, tw_at(tw, N, 2 * k));
+      o[2 * s] = cmul(y2, tw_at(tw, N, 4 * k));
+      o[3 * s] = cmul(y3, tw_at(tw, N, 6 * k));
     }
     __syncthreads();
-    cpx* t = src; src = dst; dst = t;
+    cpx* tmp = src; src = dst; dst = tmp;
+  }
+  if (s < M) {                                                // M = 2 * 4^n: one radix-2 pass, s = M/2 (twiddle 1)
+    const int half = M >> 1;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int idx = t + u * q4;                             // M/2 butterflies, two per thread
+      const int k = idx & ~(s - 1);                           // (= 0: idx < s)
+      const cpx p = src[idx], r = src[idx + half];
+      dst[idx + k] = cpx{p.x + r.x, p.y + r.y};
+      dst[idx + k + s] = cpx{p.x - r.x, p.y - r.y};
+    }
+    __syncthreads();
+    cpx* tmp = src; src = dst; dst = tmp;
   }
   return src;
 }
 
-__global__ __launch_bounds__(RTG_THREADS) void stft_fwd_kernel(RtgStftDesc d, const float* __restrict__ y,
-                                                               const float* __restrict__ window,
-                                                               const float* __restrict__ twiddle,
-                                                               const int* __restrict__ mel_lo,
-                                                               const int* __restrict__ mel_len,
-                                                               const int* __restrict__ mel_woff,
-                                                               const float* __restrict__ mel_w, float* mel, float* spec,
-                                                               float* re_out, float* im_out) {
+constexpr int kStftThreads = 256;
+
+__global__ __launch_bounds__(kStftThreads) void stft_fwd_kernel(RtgStftDesc d, const float* __restrict__ y,
+                                                                const float* __restrict__ window,
+                                                                const float* __restrict__ twiddle,
+                                                                const int* __restrict__ mel_lo,
+                                                                const int* __restrict__ mel_len,
+                                                                const int* __restrict__ mel_woff,
+                                                                const float* __restrict__ mel_w, float* mel, float* spec,
+                                                                float* re_out, float* im_out) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int N = d.n_fft, F = N / 2 + 1;
-  cpx* A = reinterpret_cast<cpx*>(smem);
-  cpx* Bf = A + N;
-  float* S = reinterpret_cast<float*>(Bf + N);          // F magnitudes
-  const int frame = blockIdx.x, b = blockIdx.y;
+  const int N = d.n_fft, M = N >> 1, F = M + 1;
+  const int TPF = M >> 2, FPB = kStftThreads / TPF;          // threads per frame, frames per block
+  const int fl = threadIdx.x / TPF, t = threadIdx.x - fl * TPF;
+  const int frame = blockIdx.x * FPB + fl, b = blockIdx.y;
+  const bool live = frame < d.frames;
+  float* base = smem + (size_t)fl * (4 * M + F + 3);         // per frame: two buffers of M complex points, F magnitudes
+  cpx* A = reinterpret_cast<cpx*>(base);
+  cpx* Bf = A + M;
+  float* S = reinterpret_cast<float*>(Bf + M);
   const int lpad = (N - d.win) / 2;
   const float* yb = y + (size_t)b * d.T;
 
-  for (int i = threadIdx.x; i < N; i += RTG_THREADS) {
-    float v = 0.f;
-    const int n = i - lpad;
-    if (n >= 0 && n < d.win) {
-      int t = frame * d.hop + i - N / 2;                 // centre=True: padded index - n_fft/2
-      if (t < 0) t = -t;
-      if (t >= d.T) t = 2 * (d.T - 1) - t;
-      v = yb[t] * window[n];
+  for (int m = t; m < M; m += TPF) {
+    float v[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int i = 2 * m + h, n = i - lpad;
+      v[h] = 0.f;
+      if (live && n >= 0 && n < d.win) {
+        int tt = frame * d.hop + i - N / 2;                  // centre=True: padded index - n_fft/2
+        if (tt < 0) tt = -tt;
+        if (tt >= d.T) tt = 2 * (d.T - 1) - tt;
+        v[h] = yb[tt] * window[n];
+      }
     }
-    A[i].x = v;
-    A[i].y = 0.f;
+    A[m] = cpx{v[0], v[1]};
   }
   __syncthreads();
-  const cpx* X = fft_stockham(A, Bf, N, twiddle, twiddle + N / 2);
+  const cpx* Z = fft_half(A, Bf, M, t, twiddle);
 
-  const size_t fo = ((size_t)b * d.frames + frame) * F;  // [B][frames][F] scratch layout for the backward
-  for (int f = threadIdx.x; f < F; f += RTG_THREADS) {
-    // DC and Nyquist of a real-input transform are exactly real: a real-to-complex FFT (torch.stft / pocketfft) returns
-    // imag = +0.0 there, so angle() is exactly 0 or +pi; rounding noise of a complex FFT would flip it to -pi at random
-    const float re = X[f].x, im = (f == 0 || f == N / 2) ? 0.f : X[f].y;
+  const size_t fo = ((size_t)b * d.frames + frame) * F;     // [B][frames][F] scratch layout for the backward
+  for (int f = t; f < F; f += TPF) {
+    // X[f] = (Z[f] + conj Z[M-f]) / 2 + W^f (Z[f] - conj Z[M-f]) / (2i); DC and Nyquist (f = 0, M) are exactly real:
+    // a real-to-complex FFT (torch.stft / pocketfft) returns imag = +0.0 there, so angle() is exactly 0 or +pi
+    float re, im;
+    if (f == 0 || f == M) {
+      re = f == 0 ? Z[0].x + Z[0].y : Z[0].x - Z[0].y;
+      im = 0.f;
+    } else {
+      const cpx p = Z[f], r = Z[M - f];
+      const float ex = 0.5f * (p.x + r.x), ey = 0.5f * (p.y - r.y);        // even part
+      const float ox = 0.5f * (p.y + r.y), oy = -0.5f * (p.x - r.x);       // odd part (Z[f] - conj Z[M-f]) / (2i)
+      const cpx w = tw_at(twiddle, N, f);
+      re = ex + w.x * ox - w.y * oy;
+      im = ey + w.x * oy + w.y * ox;
+    }
     const float rr = re + 1e-9f;
     const float mag = sqrtf(rr * rr + im * im);
     S[f] = mag;
+    if (!live) continue;
     if (re_out) {
       re_out[fo + f] = re;
       im_out[fo + f] = im;
     }
     if (spec) {
       // [B][2][F][frames] (the reference's stack, loss.py:36-44: lanes 4 bytes x `frames` apart) or, spec_T, [B][2][frames][F]:
-      // a frame's bins are consecutive — coalesced stores, and the layout the spectrogram discriminators walk (round 5)
+      // a frame's bins are consecutive — coalesced stores, and the layout the spectrogram discriminators walk
       const size_t so = d.spec_T ? (((size_t)b * 2) * d.frames + frame) * F + f : (((size_t)b * 2) * F + f) * d.frames + frame;
       spec[so] = logf(mag);
       spec[so + (size_t)F * d.frames] = atan2f(im, re) / RTG_PI_REF;
     }
   }
   __syncthreads();
-  if (mel) {
-    for (int m = threadIdx.x; m < d.n_mel; m += RTG_THREADS) {
+  if (mel && live) {
+    for (int m = t; m < d.n_mel; m += TPF) {
       const int lo = mel_lo[m], len = mel_len[m];
       const float* w = mel_w + mel_woff[m];
       float acc = 0.f;
@@ -112,31 +165,36 @@ __global__ __launch_bounds__(RTG_THREADS) void stft_fwd_kernel(RtgStftDesc d, co
   }
 }
 
-__global__ __launch_bounds__(RTG_THREADS) void stft_bwd_frame_kernel(RtgStftDesc d, const float* __restrict__ re_in,
-                                                                     const float* __restrict__ im_in,
-                                                                     const float* __restrict__ dmel,
-                                                                     const float* __restrict__ dspec,
-                                                                     const float* __restrict__ window,
-                                                                     const float* __restrict__ twiddle,
-                                                                     const int* __restrict__ binmel_idx,
-                                                                     const float* __restrict__ binmel_w,
-                                                                     float* __restrict__ frame_ws) {
+__global__ __launch_bounds__(kStftThreads) void stft_bwd_frame_kernel(RtgStftDesc d, const float* __restrict__ re_in,
+                                                                      const float* __restrict__ im_in,
+                                                                      const float* __restrict__ dmel,
+                                                                      const float* __restrict__ dspec,
+                                                                      const float* __restrict__ window,
+                                                                      const float* __restrict__ twiddle,
+                                                                      const int* __restrict__ binmel_idx,
+                                                                      const float* __restrict__ binmel_w,
+                                                                      float* __restrict__ frame_ws) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int N = d.n_fft, F = N / 2 + 1;
-  cpx* A = reinterpret_cast<cpx*>(smem);
-  cpx* Bf = A + N;
-  float* dm = reinterpret_cast<float*>(Bf + N);          // n_mel cotangents of this frame
-  const int frame = blockIdx.x, b = blockIdx.y;
+  const int N = d.n_fft, M = N >> 1, F = M + 1;
+  const int TPF = M >> 2, FPB = kStftThreads / TPF;
+  const int fl = threadIdx.x / TPF, t = threadIdx.x - fl * TPF;
+  const int frame = blockIdx.x * FPB + fl, b = blockIdx.y;
+  const bool live = frame < d.frames;
+  // per frame: two buffers of M complex points, the F cotangents conj-weighted H[f] (2 F floats), n_mel mel cotangents
+  float* base = smem + (size_t)fl * (4 * M + 2 * F + 256 + 2);
+  cpx* A = reinterpret_cast<cpx*>(base);
+  cpx* Bf = A + M;
+  cpx* H = Bf + M;                                           // H[f] = c_f conj(G_f), f = 0 .. M
+  float* dm = reinterpret_cast<float*>(H + F);               // n_mel cotangents of this frame
   const int lpad = (N - d.win) / 2;
 
   if (dmel)
-    for (int m = threadIdx.x; m < d.n_mel; m += RTG_THREADS)
-      dm[m] = dmel[((size_t)b * d.n_mel + m) * d.frames + frame];
+    for (int m = t; m < d.n_mel; m += TPF) dm[m] = live ? dmel[((size_t)b * d.n_mel + m) * d.frames + frame] : 0.f;
   __syncthreads();
   const size_t fo = ((size_t)b * d.frames + frame) * F;
-  for (int f = threadIdx.x; f < N; f += RTG_THREADS) {
+  for (int f = t; f < F; f += TPF) {
     float gr = 0.f, gi = 0.f;
-    if (f < F) {
+    if (live) {
       const float re = re_in[fo + f], im = im_in[fo + f];
       const float rr = re + 1e-9f;
       const float mag = sqrtf(rr * rr + im * im);
@@ -161,15 +219,29 @@ __global__ __launch_bounds__(RTG_THREADS) void stft_bwd_frame_kernel(RtgStftDesc
         gr += dP * (-im / r2);
         gi += dP * (re / r2);
       }
-      if (f == 0 || f == N / 2) gi = 0.f;                 // structurally-zero imaginary parts carry no gradient
+      if (f == 0 || f == M) gi = 0.f;                     // structurally-zero imaginary parts carry no gradient
     }
-    A[f].x = gr;                                          // conj(G): adjoint of the forward DFT = Re FFT(conj G)
-    A[f].y = -gi;
+    const float c = (f == 0 || f == M) ? 1.f : 0.5f;      // Hermitian extension: Re z = (z + conj z) / 2
+    H[f] = cpx{c * gr, -c * gi};
   }
   __syncthreads();
-  const cpx* Z = fft_stockham(A, Bf, N, twiddle, twiddle + N / 2);
+  // Z'[k] = (H[k] + H[k+M]) + i (H[k] - H[k+M]) W_N^k with H[k+M] = conj H[M-k]
+  for (int k = t; k < M; k += TPF) {
+    const cpx h0 = H[k], hm = H[M - k];
+    const cpx sum{h0.x + hm.x, h0.y - hm.y}, dif{h0.x - hm.x, h0.y + hm.y};
+    const cpx w = tw_at(twiddle, N, k);
+    const cpx dw = cmul(dif, w);
+    A[k] = cpx{sum.x - dw.y, sum.y + dw.x};               // sum + i * dw
+  }
+  __syncthreads();
+  const cpx* Z = fft_half(A, Bf, M, t, twiddle);          // Z[m] = y[2m] + i y[2m+1]
+  if (!live) return;
   float* out = frame_ws + ((size_t)b * d.frames + frame) * d.win;
-  for (int n = threadIdx.x; n < d.win; n += RTG_THREADS) out[n] = Z[lpad + n].x * window[n];
+  for (int n = t; n < d.win; n += TPF) {
+    const int i = lpad + n;
+    const cpx z = Z[i >> 1];
+    out[n] = ((i & 1) ? z.y : z.x) * window[n];
+  }
 }
 
 // dy[b,t] += sum over the (<= 3) padded positions that alias to t of the frames covering them.
@@ -202,7 +274,7 @@ __global__ __launch_bounds__(RTG_THREADS) void stft_ola_kernel(RtgStftDesc d, co
 
 int validate(const RtgStftDesc* d) {
   if (d->B < 1 || d->T < 2 || d->hop < 1 || d->n_mel < 1 || d->n_mel > 256) return RTG_EINVAL;
-  if (d->n_fft != 512 && d->n_fft != 1024 && d->n_fft != 2048 && d->n_fft != 256 && d->n_fft != 4096) return RTG_ERANGE;
+  if (d->n_fft != 512 && d->n_fft != 1024 && d->n_fft != 2048) return RTG_ERANGE;      // (n_fft / 8 threads own a frame)
   if (d->win < 1 || d->win > d->n_fft) return RTG_EINVAL;
   if (d->frames != 1 + d->T / d->hop) return RTG_EINVAL;
   if (d->n_fft / 2 >= d->T) return RTG_ERANGE;            // reflect padding needs pad < T
@@ -220,11 +292,10 @@ extern "C" int rtg_stft_forward(const RtgStftDesc* d, const float* y, const floa
   if (st) return st;
   if (mel && (!mel_lo || !mel_len || !mel_woff || !mel_w)) return RTG_ENULL;
   if ((re == nullptr) != (im == nullptr)) return RTG_EINVAL;
-  const size_t lds = (size_t)d->n_fft * 2 * sizeof(cpx) + (size_t)(d->n_fft / 2 + 1) * sizeof(float);
-  if (lds > 64 * 1024)
-    hipFuncSetAttribute((const void*)stft_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  RTG_KLAUNCH(stft_fwd_kernel, dim3(d->frames, d->B), dim3(RTG_THREADS), lds, (hipStream_t)stream, *d, y, window,
-                     twiddle, mel_lo, mel_len, mel_woff, mel_w, mel, spec, re, im);
+  const int M = d->n_fft / 2, fpb = kStftThreads / (M / 4);
+  const size_t lds = (size_t)fpb * (4 * M + M + 1 + 3) * sizeof(float);              // <= 20.5 KB
+  RTG_KLAUNCH(stft_fwd_kernel, dim3(rtg_ceil_div(d->frames, fpb), d->B), dim3(kStftThreads), lds, (hipStream_t)stream, *d, y,
+              window, twiddle, mel_lo, mel_len, mel_woff, mel_w, mel, spec, re, im);
   return rtg_launch_status();
 }
 
@@ -235,11 +306,10 @@ extern "C" int rtg_stft_backward(const RtgStftDesc* d, const float* re, const fl
   int st = validate(d);
   if (st) return st;
   if (dmel && (!binmel_idx || !binmel_w)) return RTG_ENULL;
-  const size_t lds = (size_t)d->n_fft * 2 * sizeof(cpx) + 256 * sizeof(float);
-  if (lds > 64 * 1024)
-    hipFuncSetAttribute((const void*)stft_bwd_frame_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  RTG_KLAUNCH(stft_bwd_frame_kernel, dim3(d->frames, d->B), dim3(RTG_THREADS), lds, (hipStream_t)stream, *d, re,
-                     im, dmel, dspec, window, twiddle, binmel_idx, binmel_w, frame_ws);
+  const int M = d->n_fft / 2, fpb = kStftThreads / (M / 4);
+  const size_t lds = (size_t)fpb * (4 * M + 2 * (M + 1) + 256 + 2) * sizeof(float);
+  RTG_KLAUNCH(stft_bwd_frame_kernel, dim3(rtg_ceil_div(d->frames, fpb), d->B), dim3(kStftThreads), lds, (hipStream_t)stream, *d,
+              re, im, dmel, dspec, window, twiddle, binmel_idx, binmel_w, frame_ws);
   int e = rtg_launch_status();
   if (e) return e;
   RTG_KLAUNCH(stft_ola_kernel, dim3(rtg_ceil_div(d->T, RTG_THREADS), d->B), dim3(RTG_THREADS), 0,

@@ -7,7 +7,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from rtg import ops, tune
+from rtg import ops, tune, config
 from rtg.bank import WeightBank
 from rtg.lib import ACT_NONE, ACT_LRELU, ACT_TANH, RtgError, new_stream  # noqa: F401
 
@@ -134,7 +134,7 @@ def fork_join(fns):
     discriminator stacks forked by the trainer, their sub-discriminators forked inside) get streams of their own per
     branch: a stream never carries work of two different parents, which keeps the fork tree a tree (no false ordering
     between e.g. MSD scale 0 and MPD period 0, and a shape HIP graph capture accepts).  RTG_STREAMS=0 disables."""
-    if len(fns) < 2 or os.environ.get('RTG_STREAMS', '1') == '0' or ops.PROFILE is not None or tune.ACTIVE:
+    if len(fns) < 2 or config.get('RTG_STREAMS') == '0' or ops.PROFILE is not None or tune.ACTIVE:
         return [f() for f in fns]
     main = torch.cuda.current_stream()
     path = _FORK_PATH[0]

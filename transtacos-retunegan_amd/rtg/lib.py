@@ -7,7 +7,7 @@ import torch  # noqa: F401  FIRST: librtg.so must bind to the HIP runtime PyTorc
 #                     hipErrorNoDevice once torch has set the device up through its own copy)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get('RTG_DEV_LIB') or os.path.join(os.path.dirname(_HERE), 'librtg.so')   # RTG_DEV_LIB: tuning builds
+LIB_PATH = os.environ.get('RTG_DEV_LIB') or os.path.join(os.path.dirname(_HERE), 'librtg.so')   # (rtg/config.py: development builds)
 
 
 class RtgError(RuntimeError):

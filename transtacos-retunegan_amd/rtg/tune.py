@@ -15,9 +15,10 @@ import os
 
 import torch
 
+from . import config
 from .lib import lib
 
-ENABLED = os.environ.get('RTG_TUNE', '1') != '0'
+ENABLED = config.get('RTG_TUNE') != '0'
 ACTIVE = False
 MISSED = False
 REPS = 3

@@ -29,11 +29,11 @@ from models import (multi_stft_loss, dynamic_loss, discriminator_loss, generator
 from models.layers import BankedModel, fork_join  # noqa: F401
 from models.discrminator import run_stacks
 from models.loss import stft_cache
-from rtg import ops, tune
+from rtg import ops, tune, config
 from rtg.lib import lib, check, RtgError, new_stream, current_stream_ptr as _lib_stream_ptr
 
 device = 'cuda' if torch.cuda.is_available() else 'cpu'
-CAPTURE_ERROR_MODE = os.environ.get('RTG_CAPTURE_MODE', 'thread_local')
+CAPTURE_ERROR_MODE = config.get('RTG_CAPTURE_MODE')
 LEAN_PACK = True              # (Trainer.lean_pack_enabled: tests build trainers without it)
 
 
@@ -48,7 +48,7 @@ def default_exchange():
     cross-stream hops and the serialised discriminator backward passes cost more than they hide when the exchange moves no
     bytes over xGMI.  A 1-rank measurement cannot decide the N > 1 case: bench.py times both policies on the job's ranks
     and keeps the faster (config.exchange in its record)."""
-    v = os.environ.get('RTG_DP_CUT', 'update')
+    v = config.get('RTG_DP_CUT')
     if v not in EXCHANGE_POLICIES:
         raise RtgError(f'RTG_DP_CUT={v!r}: expected one of {EXCHANGE_POLICIES}')
     return v
@@ -211,7 +211,7 @@ class DataParallel:
         # RTG_DP_FORCE=1: keep the whole data-parallel machinery (flush hooks, communication stream, collectives between
         # graph segments) on in a group of ONE rank — how tests/test_zz_dp_gpu.py runs RCCL itself on a one-GPU box
         self.enabled = dist.is_available() and dist.is_initialized() and (
-            dist.get_world_size(process_group) > 1 or os.environ.get('RTG_DP_FORCE') == '1')
+            dist.get_world_size(process_group) > 1 or config.get('RTG_DP_FORCE') == '1')
         self.group = process_group
         self.world = dist.get_world_size(process_group) if self.enabled else 1
         self.models = [m for m in models if m is not None]
@@ -639,7 +639,7 @@ class Trainer:
                     # GPUTEST_r03); the autograd thread that launches the backward is not policed either way
                     with torch.cuda.graph(g, pool=pool, stream=cap, capture_error_mode=CAPTURE_ERROR_MODE):
                         body()
-                        if os.environ.get('RTG_TEST_FAIL_CAPTURE') == '1':      # (bench.py's fallback, exercised on the GPU box)
+                        if config.get('RTG_TEST_FAIL_CAPTURE') == '1':          # (bench.py's fallback, exercised on the GPU box)
                             torch.zeros(4).to(sx.device)                        # a synchronous copy: illegal under capture
                         if self._capture_hook is not None:      # (tests hold a capture open: tests/test_zz_dp_gpu.py)
                             self._capture_hook()
