@@ -531,6 +531,30 @@ __global__ __launch_bounds__(WB * 64, 2) void dconv_kernel(const DArgs a) {
     for (int j = 0; j < NT16; ++j) f.b[j] = *reinterpret_cast<const f32x4*>(bsrc + bcol[j]);
 #endif
   };
+  // bf16 (round 5): the weight fragments of a WHOLE chunk are requested CD chunks ahead into a register ring.  At bf16 rates a
+  // tap is 8-16 matrix instructions of 16 cycles: fragments requested one tap ahead (the fp32 scheme: a tap is 32
+  // instructions of 32 cycles there) arrive from L2 long after the tap before them has finished — the wave sat waiting for
+  // its weights.  CD = 1 chunk ahead for 5 taps, 2 for the 2- / 3-tap instances; slot (chunk % CD, tap) is refilled right
+  // after the instructions that read it were issued.
+  constexpr int CD = (K >= 5 || RW16 >= 4) ? 1 : 2;
+  constexpr bool ARING = BF && CD * RW16 * K <= 12;      // (the ring is CD x K x RW16 fragments of 4 registers: 48 at most)
+  [[maybe_unused]] f32x4 ar[ARING ? CD : 1][ARING ? K : 1][RW16];
+  auto fetch_a = [&](int slot, int t, int s) __attribute__((always_inline)) {
+    const int sc = s < n_steps ? s : n_steps - 1;
+#pragma unroll
+    for (int i = 0; i < RW16; ++i) ar[slot][t][i] = aptr[i][(size_t)sc * 64];
+  };
+  auto fetch_b = [&](Frag& f, const float* bsrc) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < NT16; ++j) f.b[j] = *reinterpret_cast<const f32x4*>(bsrc + bcol[j]);
+  };
+  auto mma_ring = [&](int slot, int t, const Frag& f) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < RW16; ++i)
+#pragma unroll
+      for (int j = 0; j < NT16; ++j)
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(ar[slot][t][i]), "v"(f.b[j]));
+  };
   auto mma = [&](const Frag& f) __attribute__((always_inline)) {
 #ifdef RTG_EXP_DC_NOMMA
     return;
@@ -573,12 +597,23 @@ __global__ __launch_bounds__(WB * 64, 2) void dconv_kernel(const DArgs a) {
   for (int i = 0; i < RW16; ++i) f0.a[i] = f1.a[i] = f32x4{1.f, 1.f, 1.f, 1.f};
   for (int j = 0; j < NT16; ++j) f0.b[j] = f1.b[j] = f32x4{1.f, 1.f, 1.f, 1.f};
 #endif
-  fetch(f0, rc0.rc * K, lds);
+  if constexpr (ARING) {
+#pragma unroll
+    for (int t = 0; t < K; ++t) fetch_a(0, t, rc0.rc * K + t);
+    if constexpr (CD == 2) {
+#pragma unroll
+      for (int t = 0; t < K; ++t) fetch_a(1, t, rc1.rc * K + t);
+    }
+    fetch_b(f0, lds);
+  } else {
+    fetch(f0, rc0.rc * K, lds);
+  }
 
   // one chunk (virtual index v): K taps; `cur` holds the fragments of tap 0 on entry, and of the next chunk's tap 0 on
   // exit (in `cur` again when K is even, in `oth` when K is odd: the caller alternates)
   // `nset`: the register set that holds the next chunk's patch (and takes the request issued at the end of this chunk)
-  auto chunk = [&](int v, Frag& cur, Frag& oth, auto nset) __attribute__((always_inline)) {
+  auto chunk = [&](int v, Frag& cur, Frag& oth, auto nset, auto slot_tag) __attribute__((always_inline)) {
+    constexpr int SLOT = decltype(slot_tag)::value;
     const float* bufc = lds + (v & 1) * bufF;
     float* bufn = lds + ((v + 1) & 1) * bufF;
 #pragma unroll
@@ -587,11 +622,22 @@ __global__ __launch_bounds__(WB * 64, 2) void dconv_kernel(const DArgs a) {
       Frag& fn = (t & 1) ? cur : oth;
       // request the next step's fragments, THEN (last tap) the patch of the chunk after the next: the wait for the
       // fragments one step later does not include the patch loads (vmcnt retires in order)
-      if (t + 1 < K) fetch(fn, rc0.rc * K + t + 1, bufc + (t + 1) * 4);
-      else fetch(fn, rc1.rc * K, bufn);
+      if constexpr (ARING) {
+        if (t + 1 < K) fetch_b(fn, bufc + (t + 1) * 4);
+        else fetch_b(fn, bufn);
+      } else {
+        if (t + 1 < K) fetch(fn, rc0.rc * K + t + 1, bufc + (t + 1) * 4);
+        else fetch(fn, rc1.rc * K, bufn);
+      }
       if (t == K - 1) stage_issue(NSET == 2 ? rc3 : rc2, nset);
       __builtin_amdgcn_sched_barrier(0);
-      mma(fc);
+      if constexpr (ARING) {
+        mma_ring(SLOT, t, fc);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch_a(SLOT, t, (CD == 1 ? rc1.rc : rc2.rc) * K + t);       // this slot again CD chunks on
+      } else {
+        mma(fc);
+      }
       __builtin_amdgcn_sched_barrier(0);
       if (t == TW) {
         // publish the next chunk's patch: its buffer was last read by fragment fetches that completed before the
@@ -613,14 +659,16 @@ __global__ __launch_bounds__(WB * 64, 2) void dconv_kernel(const DArgs a) {
   // all accumulators and fragments at the loop header and waited for every load in flight there
   int cc = 0;
   if constexpr ((K & 1) || NSET == 2) {
+    using Slot0 = std::integral_constant<int, 0>;
+    using Slot1 = std::integral_constant<int, (ARING && CD == 2) ? 1 : 0>;
     do {                                    // (n_vp >= 2)
-      chunk(cc, f0, f1, Set1{});
-      if constexpr (K & 1) chunk(cc + 1, f1, f0, Set0{});
-      else chunk(cc + 1, f0, f1, Set0{});
+      chunk(cc, f0, f1, Set1{}, Slot0{});
+      if constexpr (K & 1) chunk(cc + 1, f1, f0, Set0{}, Slot1{});
+      else chunk(cc + 1, f0, f1, Set0{}, Slot1{});
       cc += 2;
     } while (cc < n_vp);
   } else {
-    for (; cc < n_v; ++cc) chunk(cc, f0, f1, Set0{});
+    for (; cc < n_v; ++cc) chunk(cc, f0, f1, Set0{}, Set0{});
   }
 
   // (the matrix instructions are inline asm: the compiler does not know their results are still in flight)
