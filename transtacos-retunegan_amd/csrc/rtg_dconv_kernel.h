@@ -541,14 +541,24 @@ __global__ __launch_bounds__(WB * 64, 2) void dconv_kernel(const DArgs a) {
   [[maybe_unused]] f32x4 ar[ARING ? CD : 1][ARING ? K : 1][RW16];
   auto fetch_a = [&](int slot, int t, int s) __attribute__((always_inline)) {
     const int sc = s < n_steps ? s : n_steps - 1;
+#ifndef RTG_EXP_DC_NOA
 #pragma unroll
     for (int i = 0; i < RW16; ++i) ar[slot][t][i] = aptr[i][(size_t)sc * 64];
+#else
+#pragma unroll
+    for (int i = 0; i < RW16; ++i) ar[slot][t][i] = f32x4{1.f, 1.f, 1.f, 1.f};
+#endif
   };
   auto fetch_b = [&](Frag& f, const float* bsrc) __attribute__((always_inline)) {
+#ifndef RTG_EXP_DC_NOB
 #pragma unroll
     for (int j = 0; j < NT16; ++j) f.b[j] = *reinterpret_cast<const f32x4*>(bsrc + bcol[j]);
+#endif
   };
   auto mma_ring = [&](int slot, int t, const Frag& f) __attribute__((always_inline)) {
+#ifdef RTG_EXP_DC_NOMMA
+    return;
+#endif
 #pragma unroll
     for (int i = 0; i < RW16; ++i)
 #pragma unroll
