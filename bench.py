@@ -39,7 +39,7 @@ def parse():
     ap.add_argument('--workload', default='config2', choices=['config1', 'config2', 'config3', 'config4', 'config5'])
     ap.add_argument('--dtype', default=None, choices=['fp32', 'bf16'], help='conv arithmetic (default: the workload\'s)')
     ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (default: the workload\'s)')
-    ap.add_argument('--fp32-maps', action='store_true', help='bf16 workloads: keep the feature maps in HBM fp32 (hparam.bf16_maps = False)')
+    ap.add_argument('--bf16-maps', action='store_true', help='bf16 workloads: the dense discriminator layers keep their feature maps in HBM as bf16 (hparam.bf16_maps = True; measured slower than fp32 maps, DESIGN.md section 3)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     return ap.parse_args()
@@ -376,7 +376,7 @@ def main():
         batch = a.batch
     dtype = a.dtype or ('bf16' if a.workload == 'config3' else 'fp32')
     hp.compute_dtype = dtype                # read when the weight banks are built
-    hp.bf16_maps = not a.fp32_maps
+    hp.bf16_maps = bool(a.bf16_maps) and dtype == 'bf16'
     torch.manual_seed(hp.randseed)          # identical initial weights on every rank (and broadcast from rank 0)
     tr = Trainer(use_mpd=use_mpd, use_mtd=use_mtd, d_train_times=d_times, dev=device)
     feeder = None
@@ -532,7 +532,7 @@ def main():
             'metric': 'G+D train-step audio-seconds/sec', 'value': round(value, 2), 'unit': 'audio-s/s',
             'n_gpus': dist.get_world_size() if multi else 1, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(ms, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32' if dtype == 'fp32' else ('bf16 operands, f32 accumulate' + ('' if hp.bf16_maps else ' (fp32 feature maps in HBM)')), 'data': 'synthetic' if feeder is None else 'synthetic, fed from pinned host memory every step',
+            'dtype': 'f32' if dtype == 'fp32' else ('bf16 operands, f32 accumulate' + (' (bf16 feature maps in HBM)' if hp.bf16_maps else '')), 'data': 'synthetic' if feeder is None else 'synthetic, fed from pinned host memory every step',
             'config': {'workload': f'{a.workload}: {desc}', 'per_gpu_batch': batch, 'clip_samples': T,
                        'global_batch': world * batch, 'd_train_times': d_times,
                        'parallelism': f'dp{world}' if world > 1 else ('single (1-rank RCCL group, data-parallel path forced)' if forced else 'single'), 'launch': mode,
