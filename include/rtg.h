@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define RTG_ABI_VERSION 9
+#define RTG_ABI_VERSION 10
 
 #define RTG_OK 0
 #define RTG_EINVAL (-1)   /* inconsistent descriptor               */
@@ -84,6 +84,10 @@ typedef struct RtgConv1dDesc {
    * L_in = W.  The patch row of clip (item, r) and channel (c, kh) is input row
    *     h_mode 0 (forward / weight gradient):  r * h_stride - h_pad + kh
    *     h_mode 1 (backward-data over dy):      (r + h_pad - kh) / h_stride   when divisible, else a zero row
+   *     h_mode 2 (ABI 10: the forward again, with the channels ordered (kernel row kh, c) — channel index kh * C + c, the
+   *              weight image packed with RtgPackJob.kh_major; served by the dense-layer block shapes only, C a multiple of
+   *              the chunk (16; 32 with bf16 operands): rtg_conv1d_tile_candidates lists them or returns 0.  Same sums in
+   *              another order: results differ from h_mode 0 by summation-order rounding)
    * of the [items, C, h_in, W] tensor; rows outside [0, h_in) are zero padding.  The output tensor is
    * [items, out_C, h_n, out_L].  Requires groups == 1, C2 == 0, out_split == 0. */
   int h_in, h_k, h_stride, h_pad, h_n, h_mode;
@@ -288,6 +292,8 @@ typedef struct RtgPackJob {      /* one per packed layout of a layer            
                                     along the frequency axis): the operator's kernel rows are the source tensor's LAST kernel
                                     axis and its taps the one before — the source [C_out][C_in][src_K][KH] is read where the
                                     operator means [C_out][C_in][KH][src_K]                                              */
+  int kh_major;                  /* (ABI 10; RTG_PACK_FWD with KH > 1, Cg = C_in * KH) 1: packed channel kh * C_in + ci instead
+                                    of ci * KH + kh — the image RtgConv1dDesc.h_mode 2 reads                               */
 } RtgPackJob;
 
 typedef struct RtgWnBwdJob {     /* one per weight-normed tensor                                               */

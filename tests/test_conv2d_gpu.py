@@ -102,6 +102,60 @@ def test_conv2d_layer_forward_backward(case, force, wt, monkeypatch):
         assert used == [7], used                  # the two-channel bandwidth kernel really ran
 
 
+@pytest.mark.parametrize('wt', [False, True])
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+def test_conv2d_forward_over_the_kernel_row_major_image(wt, dtype, monkeypatch):
+    """Round 5: the dense Conv2d layers' forward reads a fragment image whose channels are ordered (kernel row, channel)
+    (RtgConv1dDesc.h_mode 2, RtgPackJob.kh_major; rtg/bank.py: FWD_KH_MAJOR).  Checked: the h_mode-2 instances really run
+    for every dense layer shape of StftDiscriminator; the same layer built with the (channel, kernel row) image
+    (FWD_KH_MAJOR off: h_mode 0) gives the same output up to summation order (fp32: 1e-5 of the output's scale; bf16
+    operands: identical products, fp32 sums in another order)."""
+    import ctypes as C
+    import hparam as hp
+    from models.layers import WNConv, BankedModel, conv
+    from rtg import bank, ops
+    from rtg.lib import lib
+    monkeypatch.setattr(hp, 'compute_dtype', dtype)
+    monkeypatch.setattr(hp, 'bf16_maps', False)
+    seen = []
+    run0 = ops._run_conv
+
+    def spy(d, args, flop, label, what):
+        run0(d, args, flop, label, what)
+        seen.append((d.h_mode, lib.rtg_conv1d_variant(C.byref(d))))
+    monkeypatch.setattr(ops, '_run_conv', spy)
+    for case in CASES[3:7]:
+        B, Cin, Cout, H, W, k, s, p = case
+
+        class Net(BankedModel):
+            def __init__(self):
+                super().__init__()
+                self.c = WNConv('conv2d', Cin, Cout, k, stride=s, pad=p, wt=wt)
+
+            def forward(self, x):
+                return conv(self.token(), self.c, x, pre_slope=0.15)
+
+        outs = []
+        for khc in (True, False):
+            monkeypatch.setattr(bank, 'FWD_KH_MAJOR', khc)
+            torch.manual_seed(5)
+            net = Net().to(DEV)
+            x = torch.randn(B, Cin, H, W, device=DEV)
+            if wt:
+                x = x.transpose(2, 3).contiguous()
+            del seen[:]
+            with torch.no_grad():
+                outs.append(net(x).float())
+            torch.cuda.synchronize()
+            assert net.bank().layers[0].fwd_khc == int(khc)
+            assert seen and seen[-1][0] == (2 if khc else 0), seen
+            if khc:
+                assert seen[-1][1] > 8000, seen                  # a dense-layer block shape
+        scale = outs[1].abs().max().item()
+        err = (outs[0] - outs[1]).abs().max().item()
+        assert err <= (1e-5 if dtype == 'fp32' else 2e-5) * scale, (case, err, scale)
+
+
 def _stats(t):
     t = t.detach().double().cpu()
     return np.array([t.sum().item(), t.abs().mean().item()])

@@ -81,9 +81,10 @@ def bench_wgrad(B, Cin, Cout, L, s):
     print(line, flush=True)
 
 
-def bench_2d(B, Cin, Cout, H, W, kh, sh, sw):
-    """StftDiscriminator layer forward: (kh, 3) kernel, stride (sh, sw), 'same'-style padding"""
-    kw, ph, pw = 3, kh // 2, 1
+def bench_2d(B, Cin, Cout, H, W, kh, sh, sw, kw=3):
+    """StftDiscriminator layer forward: (kh, kw) kernel, stride (sh, sw), 'same'-style padding; h_mode 0 on the (channel,
+    kernel row) images against h_mode 2 on a kernel-row-major fragment image (timing only: same image bytes)"""
+    ph, pw = kh // 2, kw // 2
     Ho, Wo = (H + 2 * ph - kh) // sh + 1, (W + 2 * pw - kw) // sw + 1
     w = (np.random.RandomState(1).randn(Cout, Cin, kh, kw) / np.sqrt(Cin * kh * kw)).astype(np.float32)
     Wl = w.reshape(1, Cout, Cin * kh, kw)
@@ -111,10 +112,21 @@ def bench_2d(B, Cin, Cout, H, W, kh, sh, sw):
         res.append((c, ms, same))
     gen = min((r for r in res if r[0] < 8000), key=lambda r: r[1])
     dc = [r for r in res if r[0] > 8000]
-    line = f'fwd2d B{B} {Cin}->{Cout} {H}x{W} k({kh},3) s({sh},{sw}): general best {gen[0]} {gen[1] * 1e3:7.1f} us {flop / gen[1] / 1e9:6.1f} TF/s'
+    line = f'fwd2d B{B} {Cin}->{Cout} {H}x{W} k({kh},{kw}) s({sh},{sw}): general best {gen[0]} {gen[1] * 1e3:7.1f} us {flop / gen[1] / 1e9:6.1f} TF/s'
     if dc:
         bd = min(dc, key=lambda r: r[1])
         line += f' | dconv best {bd[0]} {bd[1] * 1e3:7.1f} us {flop / bd[1] / 1e9:6.1f} TF/s  x{gen[1] / bd[1]:.2f}'
+    d.h_mode, d.tile_cfg = 2, 0
+    n2 = lib.rtg_conv1d_tile_candidates(C.byref(d), cands, 48)
+    r2 = []
+    for c in list(cands[:max(n2, 0)]):
+        d.tile_cfg = c
+        if lib.rtg_conv1d(C.byref(d), P(x), None, None, P(wp), None, None, None, P(out), None, st):
+            continue
+        r2.append((c, timeit(lambda: lib.rtg_conv1d(C.byref(d), P(x), None, None, P(wp), None, None, None, P(out), None, st))))
+    if r2:
+        b2 = min(r2, key=lambda r: r[1])
+        line += f' | h_mode 2 best {b2[0]} {b2[1] * 1e3:7.1f} us {flop / b2[1] / 1e9:6.1f} TF/s'
     bad = [r[0] for r in res if not r[2]]
     print(line + (f'  MISMATCH {bad}' if bad else ''), flush=True)
 
@@ -196,8 +208,8 @@ SHAPES = [
     ('wgrad', 704, 32, 128, 249, 3), ('wgrad', 192, 32, 128, 911, 3),
 ]
 
-def bench_wgrad_2d(B, Cin, Cout, H, W, kh, sh, sw):
-    kw, ph, pw = 3, kh // 2, 1
+def bench_wgrad_2d(B, Cin, Cout, H, W, kh, sh, sw, kw=3):
+    ph, pw = kh // 2, kw // 2
     Ho, Wo = (H + 2 * ph - kh) // sh + 1, (W + 2 * pw - kw) // sw + 1
     x = torch.randn(B, Cin, H, W, device='cuda')
     dy = torch.randn(B, Cout, Ho, Wo, device='cuda')
@@ -230,7 +242,7 @@ def bench_wgrad_2d(B, Cin, Cout, H, W, kh, sh, sw):
         ms = timeit(lambda: lib.rtg_conv1d_wgrad(C.byref(wd), P(x), None, P(dy), None, P(part), st))
         res.append((c, ms, splits, err))
     gen = min((r for r in res if r[0] < 10), key=lambda r: r[1])
-    line = f'wgrad2d B{B} {Cin}->{Cout} {H}x{W} k({kh},3) s({sh},{sw}): general best s{gen[0]} x{gen[2]:3d} {gen[1] * 1e3:7.1f} us {flop / gen[1] / 1e9:6.1f} TF/s'
+    line = f'wgrad2d B{B} {Cin}->{Cout} {H}x{W} k({kh},{kw}) s({sh},{sw}): general best s{gen[0]} x{gen[2]:3d} {gen[1] * 1e3:7.1f} us {flop / gen[1] / 1e9:6.1f} TF/s'
     for d in (r for r in res if r[0] >= 10):
         line += f' | s{d[0]} x{d[2]:3d} {d[1] * 1e3:7.1f} us {flop / d[1] / 1e9:6.1f} TF/s  x{gen[1] / d[1]:.2f} err {d[3]:.0e}'
     print(line, flush=True)
@@ -240,6 +252,15 @@ MTD = [  # B = 64 (real + generated clips), resolution 0 (1025 x 35) and 2 (257 
     (64, 64, 256, 257, 18, 5, 3, 2), (64, 256, 512, 86, 9, 5, 3, 2), (64, 512, 512, 29, 5, 3, 1, 1), (64, 32, 64, 513, 35, 3, 2, 2),
     (64, 64, 256, 65, 69, 5, 3, 2), (64, 256, 512, 22, 35, 5, 3, 2), (64, 512, 512, 8, 18, 3, 1, 1),
 ]
+
+# the same layers as the product runs them (spectrogram discriminators along the frequency axis: rows = frames, the operator
+# walks the frequency bins): (B, Cin, Cout, frames, bins, kh, sh, sw, kw); BD_WT=1 selects this list
+MTD_WT = [
+    (64, 64, 256, 18, 257, 3, 2, 3, 5), (64, 256, 512, 9, 86, 3, 2, 3, 5), (64, 512, 512, 5, 29, 3, 1, 1, 3), (64, 32, 64, 35, 513, 3, 2, 2, 3),
+    (64, 64, 256, 69, 65, 3, 2, 3, 5), (64, 256, 512, 35, 22, 3, 2, 3, 5), (64, 512, 512, 18, 8, 3, 1, 1, 3),
+]
+if os.environ.get('BD_WT'):
+    MTD = MTD_WT
 
 if __name__ == '__main__':
     if os.environ.get('BD_PICK'):           # e.g. BD_PICK=0,4: only those entries of the lists

@@ -187,6 +187,11 @@ static bool sconv_code_ok(const RtgConv1dDesc* d) {
     if (codes[i] == d->tile_cfg) return true;
   return false;
 }
+// descriptors only the dense-layer kernel serves: bf16 tensors (io_bf16), the 2-D forward over a kernel-row-major image (h_mode 2)
+static bool dense_only(const RtgConv1dDesc* d) {
+  return d->io_bf16 != 0 || ((d->h_k > 1 || d->h_n > 1) && d->h_mode == 2);
+}
+
 static bool dconv_code_ok(const RtgConv1dDesc* d) {
   int codes[24];
   const int n = rtg_dconv_candidates(d, codes, 24);
@@ -197,7 +202,7 @@ static bool dconv_code_ok(const RtgConv1dDesc* d) {
 
 extern "C" int rtg_conv1d_variant(const RtgConv1dDesc* d) {
   if (!d) return RTG_ENULL;
-  if (d->io_bf16 != 0) {
+  if (dense_only(d)) {
     int code = d->tile_cfg;
     if (code == 0 && rtg_dconv_candidates(d, &code, 1) < 1) return RTG_ERANGE;
     return (code > RTG_DCONV_CODE && code < RTG_SCONV_CODE) ? code : RTG_EINVAL;
@@ -222,7 +227,7 @@ extern "C" int rtg_conv1d_tile_candidates(const RtgConv1dDesc* d, int* cfgs, int
   if ((d->tile_m != 32 && d->tile_m != 16) || d->Mg < 1 || d->Q < 1 || d->B < 1 || d->groups < 1 || d->stride < 1 ||
       d->K < 1 || d->dil < 1 || max < 1)
     return RTG_EINVAL;
-  if (d->io_bf16 != 0) {
+  if (dense_only(d)) {
     // bf16 tensors (ABI 9): only the dense-layer kernel reads / writes them — its shapes or nothing (the caller converts)
     return rtg_dconv_candidates(d, cfgs, max < 10 ? max : 10);
   }
@@ -294,7 +299,7 @@ struct ConvPlan {
 static int conv_plan(const RtgConv1dDesc* d, const float* x1, const float* x2, const float* aux, const float* wp,
                      const float* bias, const float* mask, const float* res, float* out, float* out2, ConvPlan* pl) {
   if (!d || !x1 || !wp) return RTG_ENULL;
-  if (d->io_bf16 != 0) return RTG_EINVAL;                  // (bf16 tensors: the dense-layer kernel only, rtg_conv1d routes them)
+  if (dense_only(d)) return RTG_EINVAL;                    // (the dense-layer kernel only, rtg_conv1d routes them)
   if (d->out_split == 0 ? !out : (!out && !out2)) return RTG_ENULL;
   if (d->out_split < 0 || d->out_split >= d->out_C) return RTG_EINVAL;
   if (d->out_split > 0 && (mask || res)) return RTG_EINVAL;
@@ -402,7 +407,7 @@ extern "C" int rtg_conv1d(const RtgConv1dDesc* d, const float* x1, const float* 
                           const float* bias, const float* mask, const float* res, float* out, float* out2,
                           void* stream) {
   if (!d) return RTG_ENULL;
-  if (d->io_bf16 != 0) {
+  if (dense_only(d)) {
     // bf16 tensors: the dense-layer kernel or nothing.  tile_cfg 0 (the library's heuristic) = its best-scored shape
     int code = d->tile_cfg;
     if (code == 0 && rtg_dconv_candidates(d, &code, 1) < 1) return RTG_ERANGE;

@@ -48,12 +48,12 @@ bool dconv_eligible(const RtgConv1dDesc* d) {
     // forward of the Conv2d layers, backward-data of the row-stride-1 ones; 3 taps along the last axis
     // ... and of the row-strided ones (class-ordered clips, 2 taps of the polyphase walk along the last axis)
     if (d->h_in < 1 || d->h_k < 1 || d->h_n < 1 || d->h_pad < 0 || d->C1 % d->h_k != 0 || d->B % d->h_n != 0) return false;
-    if (d->dil != 1 || d->h_stride < 1 || (d->h_mode != 0 && d->h_mode != 1)) return false;
-    if (d->h_mode == 1 && (d->C1 / d->h_k) % ckc != 0) return false;      // whole chunks per kernel row
+    if (d->dil != 1 || d->h_stride < 1 || d->h_mode < 0 || d->h_mode > 2) return false;
+    if (d->h_mode != 0 && (d->C1 / d->h_k) % ckc != 0) return false;      // whole chunks per kernel row
     if (d->h_mode == 1 && d->h_stride > 1) {
       if (d->K != 2 || d->stride != 1 || d->h_stride > 4) return false;
     } else {
-      const bool k3 = d->K == 3 && (d->stride == 1 || d->stride == 2), k5 = d->K == 5 && d->stride == 3 && d->h_mode == 0;
+      const bool k3 = d->K == 3 && (d->stride == 1 || d->stride == 2), k5 = d->K == 5 && d->stride == 3 && d->h_mode != 1;
       if (!(k3 || k5) || d->shuf_S != 1) return false;
       if (d->h_mode == 1 && d->stride != 1) return false;
     }

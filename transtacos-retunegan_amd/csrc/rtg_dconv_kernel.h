@@ -76,9 +76,15 @@ constexpr int window_positions(int cols, int Q, int S, int K) {
 // kernel's with one matrix instruction per fragment pair instead of four; a wave stages 8 channels per position (fp32
 // tensors in HBM, activation applied in fp32, rounded to nearest even when the 16 bytes are written to LDS).
 using bf16x8 = __bf16 __attribute__((ext_vector_type(8)));
-// HB: 2-D backward-data (RtgConv1dDesc.h_mode 1) — a template parameter although it only selects address arithmetic: with
-// both forms in one loop the compiler's wait-count bookkeeping merged their pending loads at every join and waited for the
-// staging loads (and the fragment loads behind them) a chunk early
+// HB: the reduction walks (kernel row, channel) with whole chunks per kernel row — 2-D backward-data (RtgConv1dDesc.h_mode 1)
+// and, round 5, the forward on a kernel-row-major weight image (h_mode 2: row = r * h_stride - h_pad + kh, else the same
+// code).  One kernel row per chunk makes the row test and the row offset of a staged position a per-chunk quantity and the
+// channel a scalar offset of the load; the forward in (channel, kernel row) order (h_mode 0, !HB) pays ~4 vector instructions
+// per LOAD for them — measured on the bf16 512 -> 512 3 x 3 layer: 97.7 us, 83.5 with coalesced dummy loads and the address
+// arithmetic kept, 58.6 with the arithmetic dropped as well (profiles/r05_dconv_addr_ablations.txt).
+// A template parameter although it only selects address arithmetic: with both forms in one loop the compiler's wait-count
+// bookkeeping merged their pending loads at every join and waited for the staging loads (and the fragment loads behind
+// them) a chunk early
 //
 // IO (RtgConv1dDesc.io_bf16, round 5: bf16 feature maps in HBM).  Bit 0, x is bf16 NCW and already activated (the producer
 // stored bf16(leaky_relu(.)), or x is a gradient): the staging walks UNITS — 8 consecutive positions of one clip row — with
@@ -103,7 +109,7 @@ constexpr int kXbScrF = 8 * 144 / 4;                 // floats of one wave's tra
 template <int RW16, int WB, int NT16, int S, int K, bool TWO_D, bool CLS, bool BF, bool HB, int IO = 0>
 __global__ __launch_bounds__(WB * 64, 2) void dconv_kernel(const DArgs a) {
   static_assert(!CLS || TWO_D, "class-ordered clips belong to the 2-D backward-data");
-  static_assert((!CLS || HB) && (!HB || TWO_D), "h_mode 1 is 2-D; class-ordered clips are backward-data");
+  static_assert((!CLS || HB) && (!HB || TWO_D), "h_mode 1 / 2 is 2-D; class-ordered clips are backward-data");
   static_assert(IO == 0 || BF, "bf16 tensors go with bf16 operands");
   constexpr bool XB = (IO & 1) != 0, OB = (IO & 2) != 0;
   constexpr int CKC = BF ? 32 : RTG_CK;              // channels per chunk
@@ -118,6 +124,7 @@ __global__ __launch_bounds__(WB * 64, 2) void dconv_kernel(const DArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  [[maybe_unused]] const bool fwd2 = HB && !CLS && a.h_mode == 2;      // forward over the kernel-row-major image
   // block -> work item: blocks b and b + 8 share an XCD, each XCD walks a contiguous range of items, the row blocks of
   // one column tile next to each other (they read the same input window: L2 hits)
   const int item = (int)(blockIdx.x & 7u) * a.per_xcd + (int)(blockIdx.x >> 3);
@@ -160,7 +167,7 @@ __global__ __launch_bounds__(WB * 64, 2) void dconv_kernel(const DArgs a) {
     if constexpr (TWO_D) {
       int item, ho, cls;
       decode(clip, item, ho, cls);
-      srow[it] = !HB ? ho * a.h_stride - a.h_pad : ho + a.h_pad;
+      srow[it] = (!HB || fwd2) ? ho * a.h_stride - a.h_pad : ho + a.h_pad;
       if constexpr (CLS) {
         // rows of class cls take kernel rows cls, cls + h_stride, ...: kernel row cls + m * h_stride reads row srow - m
         srow[it] = (ho + a.h_pad - cls) / a.h_stride;
@@ -234,7 +241,7 @@ __global__ __launch_bounds__(WB * 64, 2) void dconv_kernel(const DArgs a) {
         }
       } else {
         // one kernel row per chunk: the rows (and, class-ordered, whether the row's class takes this kernel row) once
-        const int dr = is_past ? (1 << 24) : (CLS ? -w.khq : -w.kh);
+        const int dr = is_past ? (1 << 24) : (CLS ? -w.khq : (fwd2 ? w.kh : -w.kh));
         unsigned voff[MAXIT];
 #pragma unroll
         for (int it = 0; it < MAXIT; ++it) {
@@ -251,6 +258,9 @@ __global__ __launch_bounds__(WB * 64, 2) void dconv_kernel(const DArgs a) {
         }
       }
     } else {
+      // (the channel as part of the vector offset — add + and + or per load.  Round 5 tried it as the load's SCALAR offset, no
+      // vector arithmetic per load: 2-3 % slower on the 512 -> 512 k5 layers in fp32 and bf16 (157.0 -> 160.1 us, 32.7 -> 33.9);
+      // and written as selects on the uniform `is_past` the compiler branched around the loads and waited at every join)
       const unsigned past = is_past ? DC_OOB : 0u;
 #pragma unroll
       for (int i = 0; i < NSI; ++i) {
@@ -265,6 +275,13 @@ __global__ __launch_bounds__(WB * 64, 2) void dconv_kernel(const DArgs a) {
   auto stage_write_f = [&](float* buf, auto set_tag) __attribute__((always_inline)) {
     constexpr int SET = decltype(set_tag)::value;
 #ifdef RTG_EXP_DC_NOSTWRITE
+    return;
+#endif
+#ifdef RTG_EXP_DC_WAITONLY                              // ablation: the loads are waited for, nothing is converted or written
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it)
+#pragma unroll
+      for (int i = 0; i < NSI; ++i) asm volatile("" ::"v"(st[SET][i][it]));
     return;
 #endif
 #pragma unroll
@@ -354,7 +371,7 @@ __global__ __launch_bounds__(WB * 64, 2) void dconv_kernel(const DArgs a) {
       if constexpr (TWO_D) {
         int item, ho, cls;
         decode(uok ? clip : 0, item, ho, cls);
-        xl_row[it] = !HB ? ho * a.h_stride - a.h_pad : ho + a.h_pad;
+        xl_row[it] = (!HB || fwd2) ? ho * a.h_stride - a.h_pad : ho + a.h_pad;
         if constexpr (CLS) {
           xl_row[it] = (ho + a.h_pad - cls) / a.h_stride;
           xl_cls[it] = cls;
@@ -392,7 +409,7 @@ __global__ __launch_bounds__(WB * 64, 2) void dconv_kernel(const DArgs a) {
         xc[it] += wrap ? q32 + 1 : q32;
       }
     } else if constexpr (TWO_D) {
-      const int dr = is_past ? (1 << 24) : (CLS ? -w.khq : -w.kh);
+      const int dr = is_past ? (1 << 24) : (CLS ? -w.khq : (fwd2 ? w.kh : -w.kh));
       const unsigned cb = is_past ? 0u : (unsigned)(w.cw * 32 * a.h_in) * chb2;
 #pragma unroll
       for (int it = 0; it < MAXT; ++it) {
@@ -825,6 +842,12 @@ int launch(const DArgs& a, unsigned blocks, size_t lds_bytes, hipStream_t s) {
 template <int RW16, int WB, int NT16, bool BF, int IO = 0>
 int launch_sk(const DArgs& a, int S, int K, bool two_d, unsigned blocks, size_t lds_bytes, hipStream_t s) {
   if (two_d) {
+    if (a.h_mode == 2) {        // forward, channels ordered (kernel row, channel): the HB instances
+      if (S == 1 && K == 3) return launch<RW16, WB, NT16, 1, 3, true, false, BF, true, IO>(a, blocks, lds_bytes, s);
+      if (S == 2 && K == 3) return launch<RW16, WB, NT16, 2, 3, true, false, BF, true, IO>(a, blocks, lds_bytes, s);
+      if (S == 3 && K == 5) return launch<RW16, WB, NT16, 3, 5, true, false, BF, true, IO>(a, blocks, lds_bytes, s);
+      return RTG_EINVAL;
+    }
     if (a.h_mode == 1 && a.h_stride > 1) return launch<RW16, WB, NT16, 1, 2, true, true, BF, true, IO>(a, blocks, lds_bytes, s);
     if (S == 1 && K == 3 && a.h_mode == 1) return launch<RW16, WB, NT16, 1, 3, true, false, BF, true, IO>(a, blocks, lds_bytes, s);
     if (S == 1 && K == 3) return launch<RW16, WB, NT16, 1, 3, true, false, BF, false, IO>(a, blocks, lds_bytes, s);

@@ -46,6 +46,11 @@ __device__ __forceinline__ float pack_logical(const RtgPackJob& j, const float* 
     if (j.mode == RTG_PACK_FWD) {
       srow = (long long)g * j.Mg + row;
       sin = (long long)c * j.src_K + tap;
+      if (j.kh_major) {        // packed channel (kernel row, ci) <- the operator's [ci][KH][src_K]
+        const int n_ci = j.Cg / j.KH;
+        const int kh = c / n_ci, ci = c - kh * n_ci;
+        sin = ((long long)ci * j.KH + kh) * j.src_K + tap;
+      }
     } else if (j.mode == RTG_PACK_DGRAD_S1) {
       srow = (long long)g * j.Cg + c;
       sin = (long long)row * j.src_K + (j.src_K - 1 - tap);
@@ -97,7 +102,7 @@ __host__ __device__ inline PackGeom pack_geom(const RtgPackJob& j) {
   const int chs = (j.mode == RTG_PACK_DGRAD_POLY || j.mode == RTG_PACK_CONVT_POLY) ? (p.RT - 1) / S + 2 : 0;
   p.run = j.mode == RTG_PACK_FWD ? RTG_CK * j.src_K : (j.mode == RTG_PACK_DGRAD_S1 ? p.RT * j.src_K : chs * j.src_K);
   p.nrow = j.mode == RTG_PACK_FWD ? p.RT : RTG_CK;
-  p.staged = !j.bf16 && !j.tap_major && !j.src_T && j.mode != RTG_PACK_DGRAD_2D && j.mode < RTG_PACK_GCONV_FWD &&
+  p.staged = !j.bf16 && !j.tap_major && !j.src_T && !j.kh_major && j.mode != RTG_PACK_DGRAD_2D && j.mode < RTG_PACK_GCONV_FWD &&
              p.nrow * (p.run + 1) <= kPackSlab;
   return p;
 }
@@ -343,6 +348,13 @@ __global__ __launch_bounds__(RTG_THREADS) void pack_kernel(const RtgPackJob* job
         if (j.mode == RTG_PACK_FWD) {
           srow = g * j.Mg + m;
           sin = c * j.src_K + tp;
+          if (j.kh_major) {
+            int kh = (int)((float)c * inv_nco);
+            int ci = c - kh * n_co;
+            if (ci < 0) { --kh; ci += n_co; }
+            else if (ci >= n_co) { ++kh; ci -= n_co; }
+            sin = (ci * j.KH + kh) * j.src_K + tp;
+          }
         } else if (j.mode == RTG_PACK_DGRAD_S1) {
           srow = g * j.Cg + c;
           sin = m * j.src_K + (j.src_K - 1 - tp);

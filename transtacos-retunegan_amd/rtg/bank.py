@@ -29,6 +29,8 @@ GCONV_IMAGES = True
 # debug aid (tests/conftest.py turns it on): WeightBank.lean_pack() fills every image it drops with NaN, so a launch that
 # still reads one without reporting it (note_std_use) fails loudly instead of training on the weights of an earlier step
 LEAN_POISON = False
+# the Conv2d layers' forward fragment images in kernel-row-major channel order (ConvLayer.fwd_khc; measured: DESIGN.md 3, round 5)
+FWD_KH_MAJOR = True
 
 
 def _stream():
@@ -190,6 +192,10 @@ class ConvLayer:
             return 0
         self.fwd16 = dense(self.fwd_op, True) if not self.fwd_tap else 0
         self.bwd16 = dense(self.bwd_op, False) if not self.bwd_tap else 0
+        # Conv2d forward over a kernel-row-major fragment image (RtgConv1dDesc.h_mode 2, RtgPackJob.kh_major): whole chunks
+        # per kernel row make the staged rows' validity and offsets per-chunk quantities in the dense kernel
+        self.fwd_khc = int(FWD_KH_MAJOR and self.kind == 'conv2d' and self.fwd16 == 1 and self.kh > 1 and
+                           self.cin % (32 if want_bf else L.CK) == 0)
         # bf16 feature maps in HBM (hparam.bf16_maps with compute_dtype 'bf16'): a layer whose forward the dense kernel serves
         # stores bf16(leaky_relu(out, LRELU_SLOPE)) and reads such tensors natively (rtg/ops.py); only the discriminators'
         # dense layers qualify (fwd16 == 1: k5 1-D / 3-tap 2-D, dilation 1, >= 32 input and >= 64 output channels)
@@ -362,11 +368,11 @@ class WeightBank:
                     continue                 # (lean_pack: every launch of this layer reads the fragment image)
                 pack.append(L.PackJob(ly.v_off, ly.scale_off, off, size, mode, g, mg, cg, k, ly.k, ly.inner_c, s, tm,
                                       ly.kh, tap, bf, 0, src_T=ly.wt))
-            for (mode, g, mg, cg, k, s), off, size in ((ly.fwd_op, ly.fwd_off + ly.fwd_size, ly.fwd16_size),
-                                                        (ly.bwd_op, ly.bwd_off + ly.bwd_size, ly.bwd16_size)):
+            for (mode, g, mg, cg, k, s), off, size, khc in ((ly.fwd_op, ly.fwd_off + ly.fwd_size, ly.fwd16_size, ly.fwd_khc),
+                                                             (ly.bwd_op, ly.bwd_off + ly.bwd_size, ly.bwd16_size, 0)):
                 if size:
                     pack.append(L.PackJob(ly.v_off, ly.scale_off, off, size, mode, g, mg, cg, k, ly.k, ly.inner_c, s, 16,
-                                          ly.kh, 0, ly.frag_bf, 1, src_T=ly.wt))
+                                          ly.kh, 0, ly.frag_bf, 1, src_T=ly.wt, kh_major=khc))
             if ly.gconv_off is not None:
                 for mode, off in ((L.PACK_GCONV_FWD, ly.gconv_off[0]), (L.PACK_GCONV_BWD, ly.gconv_off[1])):
                     pack.append(L.PackJob(ly.v_off, ly.scale_off, off, ly.gconv_size, mode, ly.groups, ly.cout // ly.groups,

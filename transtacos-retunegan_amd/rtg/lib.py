@@ -58,7 +58,7 @@ class PackJob(C.Structure):
     _fields_ = [('v_off', C.c_longlong), ('scale_off', C.c_longlong), ('dst_off', C.c_longlong),
                 ('dst_size', C.c_longlong)] + \
                [(n, C.c_int) for n in ('mode', 'groups', 'Mg', 'Cg', 'K', 'src_K', 'src_inner_c', 'S', 'tile_m', 'KH', 'tap_major', 'bf16',
-                                       'frag16', 'first_block', 'n_blocks', 'src_T')]
+                                       'frag16', 'first_block', 'n_blocks', 'src_T', 'kh_major')]
 
 
 MAX_SCALAR_TERMS = 16
@@ -99,7 +99,7 @@ CK = 16
 LOSS_L1, LOSS_L1_L1LOG, LOSS_MSE_TARGET, LOSS_MSE_REL, LOSS_L1_ENC = 0, 1, 2, 3, 4
 MAX_LOSS_JOBS = 48
 
-ABI_VERSION = 9            # RTG_ABI_VERSION of include/rtg.h these struct layouts / prototypes were written for
+ABI_VERSION = 10           # RTG_ABI_VERSION of include/rtg.h these struct layouts / prototypes were written for
 _P = C.c_void_p
 _I, _F, _D, _LL, _ULL = C.c_int, C.c_float, C.c_double, C.c_longlong, C.c_ulonglong
 

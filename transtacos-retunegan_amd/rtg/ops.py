@@ -807,6 +807,12 @@ class Conv2dFn(torch.autograd.Function):
         d = _desc(B=B * Ho, C1=Cin * ly.kh, L_in=W, groups=1, Cg=Cin * ly.kh, Mg=ly.cout, K=ly.k, stride=ly.stride,
                   pad=ly.pad, Q=Wo, out_C=ly.cout, out_L=Wo, pre_mode=pre_mode, pre_slope=pre_slope, tile_m=ly.fwd_tm,
                   h_in=H, h_k=ly.kh, h_stride=ly.sh, h_pad=ly.ph, h_n=Ho, h_mode=0, bf16=ly.fwd_bf, wp16=ly.fwd16)
+        if ly.fwd_khc:
+            # the fragment image is kernel-row major (RtgPackJob.kh_major): the dense kernel's h_mode-2 instances read it; a
+            # shape they do not serve runs on the standard image (the fragment image is not offered to h_mode 0 then)
+            d.h_mode = 2
+            if not _conv_native(d):
+                d.h_mode, d.wp16 = 0, 0
         flop = 2.0 * B * Ho * Wo * ly.cout * Cin * ly.kh * ly.k
         _run_conv_t(d, x, bank.fwd_ptr(ly), bank.bias_ptr(ly), None, None, out, flop, f'fwd2d {ly.name} B{B} {H}x{W}',
                     f'conv2d fwd {ly.name}', x_slope=ENC_SLOPE, out_slope=ENC_SLOPE)
