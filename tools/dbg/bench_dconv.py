@@ -208,6 +208,47 @@ SHAPES = [
     ('wgrad', 704, 32, 128, 249, 3), ('wgrad', 192, 32, 128, 911, 3),
 ]
 
+def bench_dgrad_2d(B, Cin, Cout, H, W, kh, sh, sw, kw=3):
+    """StftDiscriminator layer backward-data (h_mode 1): the stride-1 3-tap operator, or — column stride > 1 — the 2-tap
+    polyphase operator with rows (ci, phase) and the interleaving store; row stride > 1: class-ordered clips.  Timing only
+    (arbitrary weights of the packed operator's shape)."""
+    ph, pw = kh // 2, kw // 2
+    Ho, Wo = (H + 2 * ph - kh) // sh + 1, (W + 2 * pw - kw) // sw + 1
+    nt = -(-kw // sw)
+    mg, cg, k = Cin * sw, Cout * kh, (kw if sw == 1 else nt)
+    Wl = (np.random.RandomState(1).randn(1, mg, cg, k) / np.sqrt(cg * k)).astype(np.float32)
+    wp = images(Wl)
+    dy = torch.randn(B, Cout, Ho, Wo, device='cuda')
+    xm = torch.randn(B, Cin, H, W, device='cuda')
+    dx = torch.empty(B, Cin, H, W, device='cuda')
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    common = dict(B=B * H, C1=Cout * kh, C2=0, L_in=Wo, groups=1, Cg=cg, Mg=mg, K=k, dil=1, out_C=Cin, out_L=W, pre_mode=0,
+                  pre_slope=1.0, mask_slope=0.15, out_scale=1.0, act=0, act_slope=1.0, accumulate=0, tile_m=32, out_split=0,
+                  wp16=1, h_in=Ho, h_k=kh, h_stride=sh, h_pad=ph, h_n=H, h_mode=1, bf16=int(BF))
+    if sw == 1:
+        d = Conv1dDesc(stride=1, pad=(kw - 1) - pw, Q=W, shuf_S=1, shuf_P=0, **common)
+    else:
+        d = Conv1dDesc(stride=1, pad=k - 1, Q=(W - 1 + pw) // sw + 1, shuf_S=sw, shuf_P=pw, **common)
+    flop = 2.0 * B * Ho * Wo * Cout * Cin * kh * kw
+    cands = (C.c_int * 48)()
+    n = lib.rtg_conv1d_tile_candidates(C.byref(d), cands, 48)
+    res = []
+    for c in list(cands[:max(n, 0)]):
+        d.tile_cfg = c
+        if lib.rtg_conv1d(C.byref(d), P(dy), None, None, P(wp), None, P(xm), None, P(dx), None, st):
+            continue
+        torch.cuda.synchronize()
+        res.append((c, timeit(lambda: lib.rtg_conv1d(C.byref(d), P(dy), None, None, P(wp), None, P(xm), None, P(dx), None, st))))
+    gen = [r for r in res if r[0] < 8000]
+    dc = sorted((r for r in res if r[0] > 8000), key=lambda r: r[1])
+    line = f'dgrad2d B{B} {Cin}->{Cout} {H}x{W} k({kh},{kw}) s({sh},{sw}):'
+    if gen:
+        g = min(gen, key=lambda r: r[1])
+        line += f' general best {g[0]} {g[1] * 1e3:7.1f} us {flop / g[1] / 1e9:6.1f} TF/s |'
+    line += ' dconv ' + '  '.join(f'{r[0]} {r[1] * 1e3:6.1f} us {flop / r[1] / 1e9:5.1f} TF/s' for r in dc[:3])
+    print(line, flush=True)
+
+
 def bench_wgrad_2d(B, Cin, Cout, H, W, kh, sh, sw, kw=3):
     ph, pw = kh // 2, kw // 2
     Ho, Wo = (H + 2 * ph - kh) // sh + 1, (W + 2 * pw - kw) // sw + 1
@@ -272,6 +313,10 @@ if __name__ == '__main__':
             bench_2d(*sh)
         for sh in MTD:
             bench_wgrad_2d(*sh)
+        sys.exit(0)
+    if sys.argv[1:] == ['dgrad2d']:
+        for sh in MTD:
+            bench_dgrad_2d(*sh)
         sys.exit(0)
     kinds = sys.argv[1:]
     for sh in SHAPES:

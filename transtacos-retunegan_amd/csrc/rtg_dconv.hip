@@ -171,7 +171,6 @@ int rtg_dconv_launch(const RtgConv1dDesc* d, int code, const float* x, const flo
   const long long total = (long long)a.n_mb * rtg_ceil_div(a.n_cols, BN);
   if (total > (1ll << 28)) return RTG_ERANGE;
   a.total = (int)total;
-  a.per_xcd = rtg_ceil_div(total, 8);
   a.PW = window_positions(a.n_cols < BN ? a.n_cols : BN, d->Q, d->stride, d->K);
   // (bf16 x: + the 16 readable bytes the caller guarantees behind the tensor — a 16-byte load that starts at its last elements
   // runs past the end, and the range check drops whole dwords: clipped at the end it would lose the last element)
@@ -186,7 +185,63 @@ int rtg_dconv_launch(const RtgConv1dDesc* d, int code, const float* x, const flo
   a.xb_j0 = a.xb_n0 = a.xb_units = 0;                             // (per block: computed in the kernel)
   const size_t lds_bytes = lds_bytes_for(a.PW, d->stride, wb, xb ? xb_max_tasks(BN, min_q(d->K, two_d), d->stride, d->K, wb) : 0);
   if (lds_bytes > 158 * 1024) return RTG_ERANGE;
-  const unsigned blocks = (unsigned)(8 * a.per_xcd);
+  // ---- the XCDs' item ranges: equal work.  Items are (column tile, row block) with the row block fastest; a column tile's
+  // work is the chunks it walks: all of them, or — class-ordered clips, the tile inside one residue class — that class's
+  // kernel rows.  The classes are contiguous column ranges, so the cumulative work is piecewise linear: a few segments.
+  {
+    const int n_tiles = (int)(total / a.n_mb);
+    struct Seg { int tiles; long long work; } seg[16];
+    int ns = 0;
+    const bool cls = two_d && a.h_mode == 1 && a.h_stride > 1;
+    // work of a tile in matrix-pipe cycles of one wave: its chunks' matrix instructions plus a fixed part (prologue, epilogue:
+    // memory time, which does not scale with the kernel rows — the bf16 instances and the thin first layers are mostly that)
+    const long long chunk_cyc = (long long)rw16 * nt16 * d->K * (d->bf16 ? 16 : 4 * 32);
+    // (measured, same box: fixed part 0 / 6000 / 20000 / equal counts: config 4 56.97 / 56.73 / 56.89 / 58.13 ms, config 3
+    // 48.82 / 47.57 / 47.72 / 48.14)
+    const long long fixed_cyc = 6000;
+    auto tile_work = [&](int chunks) { return chunks * chunk_cyc + fixed_cyc; };
+    if (!cls) {
+      seg[ns++] = {n_tiles, 1};
+    } else {
+      int t = 0;                                                   // tiles accounted for
+      for (int c = 0; c < a.h_stride && c < 4; ++c) {
+        const long long lo = (long long)a.cls_base[c] * a.Q;
+        const long long hi = c + 1 < a.h_stride && c + 1 < 4 ? (long long)a.cls_base[c + 1] * a.Q : (long long)a.n_cols;
+        if (hi <= lo) continue;
+        const int t_lo = (int)((lo + BN - 1) / BN);               // first tile that starts inside the class
+        int t_hi = (int)(hi / BN);                                 // tiles [t_lo, t_hi) end inside it
+        if (hi == (long long)a.n_cols) t_hi = n_tiles;             // (the partial last tile)
+        if (t_lo > t) { seg[ns++] = {t_lo - t, tile_work(a.n_cc)}; t = t_lo; }   // straddling tiles before it: every chunk
+        if (t_hi > t) {
+          const int rows = c < a.h_k ? (a.h_k - c + a.h_stride - 1) / a.h_stride : 0;
+          seg[ns++] = {t_hi - t, tile_work(rows * a.cpk)};
+          t = t_hi;
+        }
+      }
+      if (t < n_tiles) seg[ns++] = {n_tiles - t, tile_work(a.n_cc)};
+    }
+    long long work = 0;
+    for (int i = 0; i < ns; ++i) work += (long long)seg[i].tiles * seg[i].work;
+    a.xcd_first[0] = 0;
+    int si2 = 0, t_done = 0;                                       // segment cursor: tiles before it, work before it
+    long long w_done = 0;
+    for (int x = 1; x < 8; ++x) {
+      const long long target = (work * x + 7) / 8;
+      while (si2 < ns && w_done + (long long)seg[si2].tiles * seg[si2].work < target) {
+        w_done += (long long)seg[si2].tiles * seg[si2].work;
+        t_done += seg[si2].tiles;
+        ++si2;
+      }
+      int tile = n_tiles;
+      if (si2 < ns) tile = t_done + (int)((target - w_done + seg[si2].work - 1) / seg[si2].work);
+      if (tile > n_tiles) tile = n_tiles;
+      a.xcd_first[x] = tile * a.n_mb;
+    }
+    a.xcd_first[8] = a.total;
+  }
+  int per_max = 0;
+  for (int x = 0; x < 8; ++x) per_max = a.xcd_first[x + 1] - a.xcd_first[x] > per_max ? a.xcd_first[x + 1] - a.xcd_first[x] : per_max;
+  const unsigned blocks = (unsigned)(8 * per_max);
   if (d->io_bf16 & 3) {
     const int io = d->io_bf16 & 3;
     return io == 1 ? rtg_dconv_launch_io1(a, si, nt16, d->stride, d->K, two_d, blocks, lds_bytes, s)

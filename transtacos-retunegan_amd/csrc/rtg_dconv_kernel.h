@@ -24,7 +24,11 @@ struct DArgs {
   float pre_slope, mask_slope, out_scale, act_slope;
   int seg_pw;                 // virtual positions per clip: (Q - 1) * S + K
   int n_cols;                 // B * Q
-  int n_mb, total, per_xcd;   // row blocks, work items, work items per XCD
+  int n_mb, total;            // row blocks, work items
+  // XCD x walks the items [xcd_first[x], xcd_first[x + 1]): contiguous ranges of equal WORK — equal counts except for the
+  // class-ordered clips, where a tile of residue class c walks only that class's kernel rows (round 5: with equal counts the
+  // XCDs that held the classes with more kernel rows ran 4/3 as long as the average and set the launch's duration)
+  int xcd_first[9];
   int PW;                     // staged positions per buffer
   int x_bytes, out_bytes;
   // second dimension (RtgConv1dDesc.h_*): a clip is an (item, output row) pair, a channel a (channel, kernel row) pair
@@ -127,8 +131,9 @@ __global__ __launch_bounds__(WB * 64, 2) void dconv_kernel(const DArgs a) {
   [[maybe_unused]] const bool fwd2 = HB && !CLS && a.h_mode == 2;      // forward over the kernel-row-major image
   // block -> work item: blocks b and b + 8 share an XCD, each XCD walks a contiguous range of items, the row blocks of
   // one column tile next to each other (they read the same input window: L2 hits)
-  const int item = (int)(blockIdx.x & 7u) * a.per_xcd + (int)(blockIdx.x >> 3);
-  if (item >= a.total) return;
+  const int xcd = (int)(blockIdx.x & 7u);
+  const int item = a.xcd_first[xcd] + (int)(blockIdx.x >> 3);
+  if (item >= a.xcd_first[xcd + 1]) return;
   const int mb = item % a.n_mb, nt = item / a.n_mb;
   const int n0 = nt * BN;
   const int clip0 = n0 / a.Q, q0 = n0 - clip0 * a.Q;
