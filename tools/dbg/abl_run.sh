@@ -1,12 +1,11 @@
 set -e
 cd $GRAFT_REPO_ROOT
-for F in 1000000000 0 6000 20000; do
-  echo "== RTG_DEV_XCDF=$F"
-  export RTG_DEV_XCDF=$F
-  for bf in 1 ""; do
+for v in base late; do
+  echo "== $v"
+  if [ $v = base ]; then unset RTG_DEV_LIB; else export RTG_DEV_LIB=$PWD/transtacos-retunegan_amd/librtg_dev_$v.so; fi
+  for bf in "" 1; do
     echo "-- BD_BF=$bf"
-    BD_WT=1 BD_BF=$bf BD_PICK=0,1,3,4,5 timeout -k 10 200 python tools/dbg/bench_dconv.py dgrad2d 2>&1 | grep "2d" | cut -c1-150 || true
+    BD_BF=$bf BD_PICK=23,24,27,29,31 timeout -k 10 200 python tools/dbg/bench_dconv.py wgrad 2>&1 | grep "^wgrad" | cut -c1-260 || true
+    BD_WT=1 BD_BF=$bf BD_PICK=0,1,2,3 timeout -k 10 200 python tools/dbg/bench_dconv.py 2d 2>&1 | grep "^wgrad2d" | cut -c1-330 || true
   done
-  bash tools/dbg/ab_cfg.sh c3_$F --workload config3
-  bash tools/dbg/ab_cfg.sh c4_$F --workload config4
 done

@@ -127,7 +127,20 @@ __global__ __launch_bounds__(kWB * 64, 2) void dwgrad_kernel(const WArgs a) {
       return (unsigned)clip * (unsigned)a.Mg * (unsigned)a.dy_L * YES;
     }
   };
+  // (ablation hooks, tools/dbg/abl_dwgrad.sh: RTG_EXP_DW_NOLOAD no global loads, _NOWRITE no column-image writes, _NOFETCH no
+  // LDS fragment reads, _NOMMA no matrix instructions, _NOEPI no partial stores — wrong results by design.  Round 5,
+  // profiles/r05_dwgrad_ablations.txt: fp32 512 -> 512 k5 194 us; matrix instructions alone 135; 156 without the loads; 168
+  // without the image writes; 35 without matrix instructions.  Spreading the image writes of the next tile over the second
+  // half of the tile's matrix instructions was built on that and measured: neutral where it fits the registers (351 vs 356
+  // us, bf16 110.7 vs 110.8), twice as slow where it spills (the fp32 2-chunk and 4-chunk shapes sit at 249-253 registers).)
   auto a_load = [&](int tile) __attribute__((always_inline)) {
+#ifdef RTG_EXP_DW_NOLOAD
+    for (int g = 0; g < NAG; ++g) {
+      arem[g] = aval[g] = AEL;
+      for (int i = 0; i < RW; ++i) l1[i][g] = l2[i][g] = f32x4{1.f, 1.f, 1.f, 1.f};
+    }
+    return;
+#endif
 #pragma unroll
     for (int g = 0; g < NAG; ++g) {
       // this lane's four consecutive reductions of group g (bf16: halves g & 1 of the 8 reductions of k-group g >> 1); bf16
@@ -185,6 +198,15 @@ __global__ __launch_bounds__(kWB * 64, 2) void dwgrad_kernel(const WArgs a) {
   int ssh[NSH];
   unsigned stv = 0;                                  // bit t: tap t of this lane's reduction lies inside the row
   auto b_load = [&](int tile) __attribute__((always_inline)) {
+#ifdef RTG_EXP_DW_NOLOAD
+    stv = 31u;
+    for (int j = 0; j < NSH; ++j) ssh[j] = 0;
+    for (int j = 0; j < CPW; ++j) {
+      sbv[j] = f32x4{1.f, 1.f, 1.f, 1.f};
+      if constexpr (kK == 5 && !XB) sb4[j] = 1.f;
+    }
+    return;
+#endif
     const int n = tile * kTT + lane;
     int q;
     const int clip = divq(n, q);
@@ -261,6 +283,9 @@ __global__ __launch_bounds__(kWB * 64, 2) void dwgrad_kernel(const WArgs a) {
     return (unsigned short)((stv >> t) & 1u ? v : 0u);
   };
   auto b_write = [&](int buf) __attribute__((always_inline)) {
+#ifdef RTG_EXP_DW_NOWRITE
+    return;
+#endif
     // channel c = wave + kWB * j of the block's NCH * 16: chunk c / 16, column (c % 16) * K + t
     if constexpr (BF) {
       // reduction n = lane: k-group n / 32, plane (n / 8) % 4, element n % 8 of the column's 16 bytes
@@ -346,6 +371,9 @@ __global__ __launch_bounds__(kWB * 64, 2) void dwgrad_kernel(const WArgs a) {
       b_load(nxt);
       const float* pb = lds + cur * (NCH * kBF) + boff;
       auto fetch = [&](Frag& f, int g) __attribute__((always_inline)) {
+#ifdef RTG_EXP_DW_NOFETCH
+        return;
+#endif
 #pragma unroll
         for (int h = 0; h < NCH; ++h)
 #pragma unroll
@@ -353,6 +381,9 @@ __global__ __launch_bounds__(kWB * 64, 2) void dwgrad_kernel(const WArgs a) {
             f.b[h][j] = *reinterpret_cast<const f32x4*>(pb + h * kBF + g * kGS + j * 64);
       };
       auto mma = [&](const Frag& f, int g) __attribute__((always_inline)) {
+#ifdef RTG_EXP_DW_NOMMA
+        return;
+#endif
         if constexpr (BF) {
 #pragma unroll
           for (int i = 0; i < RW; ++i) {
@@ -425,6 +456,9 @@ __global__ __launch_bounds__(kWB * 64, 2) void dwgrad_kernel(const WArgs a) {
   // ---- this split's partial: [rows][Cg * K] then the bias partials (gy_scale applied here: the sums are linear in gy)
   float* wpart = a.part + (size_t)split * a.part_stride;
   const int ck = a.Cg * kK;                       // (2-D: Cg = channels x kernel rows)
+#ifdef RTG_EXP_DW_NOEPI
+  if (acc[0][0][0][0] != 12345.f) return;
+#endif
 #pragma unroll
   for (int i = 0; i < RW; ++i)
 #pragma unroll
