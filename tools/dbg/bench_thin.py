@@ -1,4 +1,4 @@
-"""dev: time the thin-shape launches of the train step through the C ABI (new tile-staged vs RTG_THIN_LEGACY=1)"""
+"""dev: time the thin-shape launches of the train step through the C ABI"""
 import os, sys, ctypes as C
 REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(REPO, 'transtacos-retunegan_amd')); sys.path.insert(0, os.path.join(REPO, 'tests'))
