@@ -558,8 +558,20 @@ __global__ __launch_bounds__(WB * 64, 2) void dconv_kernel(const DArgs a) {
   // instructions of 32 cycles there) arrive from L2 long after the tap before them has finished — the wave sat waiting for
   // its weights.  CD = 1 chunk ahead for 5 taps, 2 for the 2- / 3-tap instances; slot (chunk % CD, tap) is refilled right
   // after the instructions that read it were issued.
-  constexpr int CD = (K >= 5 || RW16 >= 4) ? 1 : 2;
-  constexpr bool ARING = BF && CD * RW16 * K <= 12;      // (the ring is CD x K x RW16 fragments of 4 registers: 48 at most)
+  // fp32 (later in round 5): one chunk ahead as well, where the K x RW16 extra fragments cost no occupancy — the 2- / 3-tap
+  // instances and the 8-wave blocks (two waves per SIMD whatever they use); measured per family, same box, best block shape:
+  // -1 .. -5 % (class-ordered 2-tap 396.7 -> 381.8 us, polyphase 112.8 -> 107.3, 512 -> 512 k5 152.1 -> 147.2), but +10 % on
+  // the 5-tap 2-D forward in 4-wave blocks (118 -> 138 registers: three waves per SIMD instead of four), which keeps the
+  // one-tap-ahead scheme.  In the train step: config 4 56.95 / 56.76 -> 56.08 / 55.81 ms (two rounds, one box), config 2
+  // 26.28 / 26.25 -> 26.43 / 26.31 — the 1-D instances keep the old scheme as well (TWO_D only).  Results are bit-identical
+  // either way.
+  constexpr int CD = (K >= 5 || RW16 >= 4 || !BF) ? 1 : 2;
+#ifdef RTG_EXP_DC_NORING32                               // (A/B: the fp32 instances one tap ahead, as before)
+  constexpr bool ARING = BF && CD * RW16 * K <= 12;
+#else
+  constexpr bool ARING = BF ? CD * RW16 * K <= 12        // (the ring is CD x K x RW16 fragments of 4 registers: 48 at most)
+                            : TWO_D && RW16 * K <= 10 && (K <= 3 || WB == 8);
+#endif
   [[maybe_unused]] f32x4 ar[ARING ? CD : 1][ARING ? K : 1][RW16];
   auto fetch_a = [&](int slot, int t, int s) __attribute__((always_inline)) {
     const int sc = s < n_steps ? s : n_steps - 1;
@@ -581,11 +593,23 @@ __global__ __launch_bounds__(WB * 64, 2) void dconv_kernel(const DArgs a) {
 #ifdef RTG_EXP_DC_NOMMA
     return;
 #endif
+    if constexpr (BF) {
 #pragma unroll
-    for (int i = 0; i < RW16; ++i)
+      for (int i = 0; i < RW16; ++i)
 #pragma unroll
-      for (int j = 0; j < NT16; ++j)
-        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(ar[slot][t][i]), "v"(f.b[j]));
+        for (int j = 0; j < NT16; ++j)
+          asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(ar[slot][t][i]), "v"(f.b[j]));
+    } else {
+#pragma unroll
+      for (int kq = 0; kq < 4; ++kq)
+#pragma unroll
+        for (int i = 0; i < RW16; ++i)
+#pragma unroll
+          for (int j = 0; j < NT16; ++j) {
+            const float av = ar[slot][t][i][kq], bv = f.b[j][kq];
+            asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(av), "v"(bv));
+          }
+    }
   };
   auto mma = [&](const Frag& f) __attribute__((always_inline)) {
 #ifdef RTG_EXP_DC_NOMMA
