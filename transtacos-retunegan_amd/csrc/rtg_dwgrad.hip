@@ -132,7 +132,11 @@ __global__ __launch_bounds__(kWB * 64, 2) void dwgrad_kernel(const WArgs a) {
   // profiles/r05_dwgrad_ablations.txt: fp32 512 -> 512 k5 194 us; matrix instructions alone 135; 156 without the loads; 168
   // without the image writes; 35 without matrix instructions.  Spreading the image writes of the next tile over the second
   // half of the tile's matrix instructions was built on that and measured: neutral where it fits the registers (351 vs 356
-  // us, bf16 110.7 vs 110.8), twice as slow where it spills (the fp32 2-chunk and 4-chunk shapes sit at 249-253 registers).)
+  // us, bf16 110.7 vs 110.8), twice as slow where it spills (the fp32 2-chunk and 4-chunk shapes sit at 249-253 registers).
+  // So was a phase shift between the two waves of a SIMD (the upper four waves request their input rows two tiles ahead and
+  // write them right behind the barrier, the lower four as now): fp32 271 / 414 / 516 us against 268 / 407 / 515 — the write
+  // phases meeting is not what the 60 us over the matrix-only loop are; the ~16 load issues per wave and tile at the top of
+  // the iteration are the next suspect (156 us without them).)
   auto a_load = [&](int tile) __attribute__((always_inline)) {
 #ifdef RTG_EXP_DW_NOLOAD
     for (int g = 0; g < NAG; ++g) {
