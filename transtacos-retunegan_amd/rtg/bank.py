@@ -29,6 +29,10 @@ GCONV_IMAGES = True
 # debug aid (tests/conftest.py turns it on): WeightBank.lean_pack() fills every image it drops with NaN, so a launch that
 # still reads one without reporting it (note_std_use) fails loudly instead of training on the weights of an earlier step
 LEAN_POISON = False
+# bf16 feature maps (hparam.bf16_maps): layers with fewer output channels keep fp32 maps.  Measured at the end of round 5
+# (config 3, ms per step, fp32 maps / bf16 maps with the threshold at 0 / 128 / 256 / 512): 47.96 / 48.27 / 48.49 / 47.60 / -
+# on one box, 48.35-48.50 / - / - / 48.52-48.72 / 48.24-48.55 on another — parity at best, whatever the threshold
+MAPS_BF_MIN_COUT = 0
 # the Conv2d layers' forward fragment images in kernel-row-major channel order (ConvLayer.fwd_khc; measured: DESIGN.md 3, round 5)
 FWD_KH_MAJOR = True
 
@@ -199,7 +203,8 @@ class ConvLayer:
         # bf16 feature maps in HBM (hparam.bf16_maps with compute_dtype 'bf16'): a layer whose forward the dense kernel serves
         # stores bf16(leaky_relu(out, LRELU_SLOPE)) and reads such tensors natively (rtg/ops.py); only the discriminators'
         # dense layers qualify (fwd16 == 1: k5 1-D / 3-tap 2-D, dilation 1, >= 32 input and >= 64 output channels)
-        self.maps_bf = bool(want_bf and getattr(hp, 'bf16_maps', True) and self.fwd16 == 1 and self.kind in ('conv', 'conv2d'))
+        self.maps_bf = bool(want_bf and getattr(hp, 'bf16_maps', True) and self.fwd16 == 1 and self.kind in ('conv', 'conv2d') and
+                            self.cout >= MAPS_BF_MIN_COUT)
         self.frag_bf = int(want_bf)           # the fragment images are bf16 with the layer
         self.fwd_bf = int(ok(self.fwd_op, self.fwd_tap))
         self.wgrad_bf = int(want_bf and not thin2d)   # the weight-gradient kernel has one K order: every layer
