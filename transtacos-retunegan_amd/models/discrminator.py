@@ -150,7 +150,7 @@ PAIRED = True
 
 def _pairable(d):
     return (hasattr(d, 'pre') and hasattr(d, 'post') and
-            all(c._layer is not None and c._layer.kind == 'conv' for c in list(d.convs) + [d.conv_post]))
+            all(c._layer is not None and c._layer.kind in ('conv', 'conv2d') for c in list(d.convs) + [d.conv_post]))
 
 
 def _run_pair(d, tok, x_real, x_fake):
@@ -333,6 +333,10 @@ class StftDiscriminator(nn.Module):
 
     def run(self, tok, x, prepared=False):
         logit, fmap = _run_stack(tok, self.convs, self.conv_post, x if prepared else self.pre(x))
+        return self.post(logit, fmap, logit.shape[0])
+
+    def post(self, logit, fmap, B):
+        """kernel-side logits / feature maps -> what the reference returns (its layout, as views)"""
         if not self.wt:
             return torch.flatten(logit, 1, -1), fmap
         views = []

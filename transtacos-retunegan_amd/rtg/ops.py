@@ -789,6 +789,35 @@ def conv(token, ly, x1, x2=None, res=None, pre_slope=1.0, act=L.ACT_NONE, act_sl
                         res_is_input)
 
 
+def _fwd2d_desc(ly, B, H, W, pre_slope):
+    """descriptor of a Conv2d layer's forward on [B, C_in, H, W] -> (desc, Ho, Wo)"""
+    Cin = ly.cin
+    Ho = (H + 2 * ly.ph - ly.kh) // ly.sh + 1
+    Wo = (W + 2 * ly.pad - ly.k) // ly.stride + 1
+    pre_mode = L.PRE_LRELU if pre_slope != 1.0 else L.PRE_NONE
+    d = _desc(B=B * Ho, C1=Cin * ly.kh, L_in=W, groups=1, Cg=Cin * ly.kh, Mg=ly.cout, K=ly.k, stride=ly.stride,
+              pad=ly.pad, Q=Wo, out_C=ly.cout, out_L=Wo, pre_mode=pre_mode, pre_slope=pre_slope, tile_m=ly.fwd_tm,
+              h_in=H, h_k=ly.kh, h_stride=ly.sh, h_pad=ly.ph, h_n=Ho, h_mode=0, bf16=ly.fwd_bf, wp16=ly.fwd16)
+    if ly.fwd_khc:
+        # the fragment image is kernel-row major (RtgPackJob.kh_major): the dense kernel's h_mode-2 instances read it; a
+        # shape they do not serve runs on the standard image (the fragment image is not offered to h_mode 0 then)
+        d.h_mode = 2
+        if not _conv_native(d):
+            d.h_mode, d.wp16 = 0, 0
+    return d, Ho, Wo
+
+
+def _dgrad2d_desc(ly, B, H, W, Ho, Wo, pre_slope):
+    """... and of its backward-data: dy [B, C_out, Ho, Wo] -> dx [B, C_in, H, W]"""
+    mode, g, mg, cg, k, s = ly.bwd_op
+    common = dict(B=B * H, C1=ly.cout * ly.kh, L_in=Wo, groups=1, Cg=cg, Mg=mg, K=k, out_C=ly.cin, out_L=W,
+                  mask_slope=pre_slope, tile_m=ly.bwd_tm, h_in=Ho, h_k=ly.kh, h_stride=ly.sh, h_pad=ly.ph,
+                  h_n=H, h_mode=1, bf16=ly.bwd_bf, wp16=ly.bwd16)
+    if ly.stride == 1:
+        return _desc(stride=1, pad=(ly.k - 1) - ly.pad, Q=W, **common)
+    return _desc(stride=1, pad=k - 1, Q=(W - 1 + ly.pad) // ly.stride + 1, shuf_S=ly.stride, shuf_P=ly.pad, **common)
+
+
 class Conv2dFn(torch.autograd.Function):
     """out = conv2d(leaky_relu(x, pre_slope)) + bias for the StftDiscriminator layers (discrminator.py:255-262),
     executed by the 1-D MFMA kernels along the last axis: clips = (item, output row), channels = (c, kernel row)."""
@@ -800,19 +829,8 @@ class Conv2dFn(torch.autograd.Function):
         x = _c(x)
         B, Cin, H, W = x.shape
         assert Cin == ly.cin
-        Ho = (H + 2 * ly.ph - ly.kh) // ly.sh + 1
-        Wo = (W + 2 * ly.pad - ly.k) // ly.stride + 1
+        d, Ho, Wo = _fwd2d_desc(ly, B, H, W, pre_slope)
         out = empty_bf((B, ly.cout, Ho, Wo), x.device) if ly.maps_bf else torch.empty(B, ly.cout, Ho, Wo, device=x.device)
-        pre_mode = L.PRE_LRELU if pre_slope != 1.0 else L.PRE_NONE
-        d = _desc(B=B * Ho, C1=Cin * ly.kh, L_in=W, groups=1, Cg=Cin * ly.kh, Mg=ly.cout, K=ly.k, stride=ly.stride,
-                  pad=ly.pad, Q=Wo, out_C=ly.cout, out_L=Wo, pre_mode=pre_mode, pre_slope=pre_slope, tile_m=ly.fwd_tm,
-                  h_in=H, h_k=ly.kh, h_stride=ly.sh, h_pad=ly.ph, h_n=Ho, h_mode=0, bf16=ly.fwd_bf, wp16=ly.fwd16)
-        if ly.fwd_khc:
-            # the fragment image is kernel-row major (RtgPackJob.kh_major): the dense kernel's h_mode-2 instances read it; a
-            # shape they do not serve runs on the standard image (the fragment image is not offered to h_mode 0 then)
-            d.h_mode = 2
-            if not _conv_native(d):
-                d.h_mode, d.wp16 = 0, 0
         flop = 2.0 * B * Ho * Wo * ly.cout * Cin * ly.kh * ly.k
         _run_conv_t(d, x, bank.fwd_ptr(ly), bank.bias_ptr(ly), None, None, out, flop, f'fwd2d {ly.name} B{B} {H}x{W}',
                     f'conv2d fwd {ly.name}', x_slope=ENC_SLOPE, out_slope=ENC_SLOPE)
@@ -835,16 +853,8 @@ class Conv2dFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[1]:
             dx = empty_bf(x.shape, x.device) if _is_bf(x) else torch.empty_like(x)
-            mode, g, mg, cg, k, s = ly.bwd_op
             mask = x if pre_slope != 1.0 else None
-            common = dict(B=B * H, C1=ly.cout * ly.kh, L_in=Wo, groups=1, Cg=cg, Mg=mg, K=k, out_C=Cin, out_L=W,
-                          mask_slope=pre_slope, tile_m=ly.bwd_tm, h_in=Ho, h_k=ly.kh, h_stride=ly.sh, h_pad=ly.ph,
-                          h_n=H, h_mode=1, bf16=ly.bwd_bf, wp16=ly.bwd16)
-            if ly.stride == 1:
-                d = _desc(stride=1, pad=(ly.k - 1) - ly.pad, Q=W, **common)
-            else:
-                d = _desc(stride=1, pad=k - 1, Q=(W - 1 + ly.pad) // ly.stride + 1, shuf_S=ly.stride, shuf_P=ly.pad,
-                          **common)
+            d = _dgrad2d_desc(ly, B, H, W, Ho, Wo, pre_slope)
             _run_conv_t(d, dy, bank.bwd_ptr(ly), None, mask, None, dx, flop, f'dgrad2d {ly.name} B{B} {H}x{W}',
                         f'conv2d bwd-data {ly.name}')
         if ctx.needs_input_grad[0]:
@@ -996,6 +1006,55 @@ class PairConvFn(torch.autograd.Function):
         return None, None, None, None, None, dx
 
 
+class PairConv2dFn(torch.autograd.Function):
+    """PairConvFn for the Conv2d layers of StftDiscriminator (round 5: the generator step ran the spectrogram discriminators
+    on the real and on the generated maps in two half-batch launches per layer)."""
+
+    @staticmethod
+    def forward(ctx, token, ly, pre_slope, tap, x_c, x_g):
+        _need_cuda(x_c, x_g)
+        assert _adjacent(x_c, x_g), 'PairConv2dFn needs the halves of one buffer (PairEntryFn)'
+        assert ly.kind == 'conv2d'
+        bank = token._rtg_bank
+        B, Cin, H, W = x_c.shape
+        assert Cin == ly.cin
+        d, Ho, Wo = _fwd2d_desc(ly, 2 * B, H, W, pre_slope)
+        out = empty_bf((2 * B, ly.cout, Ho, Wo), x_c.device) if ly.maps_bf else torch.empty(2 * B, ly.cout, Ho, Wo, device=x_c.device)
+        whole = torch.as_strided(x_c, (2 * B, Cin, H, W), x_c.stride())
+        flop = 2.0 * 2 * B * Ho * Wo * ly.cout * Cin * ly.kh * ly.k
+        _run_conv_t(d, whole, bank.fwd_ptr(ly), bank.bias_ptr(ly), None, None, out, flop, f'fwd2d {ly.name} B{2 * B} {H}x{W}',
+                    f'conv2d fwd {ly.name}', x_slope=ENC_SLOPE, out_slope=ENC_SLOPE)
+        o_c, o_g = out[:B], out[B:]
+        ctx.ly, ctx.bank, ctx.pre_slope = ly, bank, pre_slope
+        ctx.save_for_backward(x_g)
+        ctx.mark_non_differentiable(o_c)
+        ctx.set_materialize_grads(False)
+        if tap:
+            return o_c, o_g, x_g.view_as(x_g)          # (see PairConvFn.forward)
+        return o_c, o_g
+
+    @staticmethod
+    def backward(ctx, d_c, d_g, d_tap=None):
+        if ctx.needs_input_grad[0]:
+            raise L.RtgError('PairConv2dFn is for frozen stacks: no weight gradient path')
+        if not ctx.needs_input_grad[5] or (d_g is None and d_tap is None):
+            return None, None, None, None, None, None
+        if d_g is None:
+            return None, None, None, None, None, d_tap
+        ly, bank, pre_slope = ctx.ly, ctx.bank, ctx.pre_slope
+        x_g, = ctx.saved_tensors
+        d_g = _c(d_g)
+        B, Cin, H, W = x_g.shape
+        _, _, Ho, Wo = d_g.shape
+        dx = empty_bf(x_g.shape, x_g.device) if _is_bf(x_g) else torch.empty_like(x_g)
+        d = _dgrad2d_desc(ly, B, H, W, Ho, Wo, pre_slope)
+        res = _c(d_tap) if d_tap is not None else None            # dx = lrelu'(x) * convT(d_g) + d_tap
+        flop = 2.0 * B * Ho * Wo * ly.cout * Cin * ly.kh * ly.k
+        _run_conv_t(d, d_g, bank.bwd_ptr(ly), None, x_g if pre_slope != 1.0 else None, res, dx, flop,
+                    f'dgrad2d {ly.name} B{B} {H}x{W}', f'conv2d bwd-data {ly.name}')
+        return None, None, None, None, None, dx
+
+
 def pair_entry(x_const, x_grad):
     return PairEntryFn.apply(x_const, x_grad)
 
@@ -1004,7 +1063,8 @@ def pair_conv(token, ly, x_c, x_g, pre_slope=1.0, tap=False):
     """-> (out_const, out_grad) and, with tap, the input x_g passed through as a third output (see PairConvFn.forward)"""
     if _is_bf(x_g) and not ly.maps_bf:
         x_c, x_g = PairDecodeFn.apply(x_c, x_g)      # (a layer without a bf16 input path, e.g. conv_post)
-    return PairConvFn.apply(token, ly, float(pre_slope), bool(tap), x_c, x_g)
+    fn = PairConv2dFn if ly.kind == 'conv2d' else PairConvFn
+    return fn.apply(token, ly, float(pre_slope), bool(tap), x_c, x_g)
 
 
 class GroupConvFn(torch.autograd.Function):
