@@ -256,7 +256,11 @@ def test_conv2d_dgrad_stride1_codes(case):
 
 
 @pytest.mark.parametrize('case', [(2, 64, 256, 40, 18, (5, 3), (3, 2), (2, 1)), (3, 256, 512, 22, 9, (5, 3), (3, 2), (2, 1)),
-                                  (2, 32, 64, 33, 35, (3, 3), (2, 2), (1, 1)), (1, 128, 96, 17, 20, (5, 3), (3, 2), (2, 1))])
+                                  (2, 32, 64, 33, 35, (3, 3), (2, 2), (1, 1)), (1, 128, 96, 17, 20, (5, 3), (3, 2), (2, 1)),
+                                  # (round 5: the XCDs' item ranges are cut by work — residue classes with 2 / 1 / 1 / 1 kernel rows,
+                                  # a class WITHOUT kernel rows (3 rows at stride 4), enough tiles for every XCD to get a range)
+                                  (2, 64, 128, 35, 22, (5, 3), (4, 2), (2, 1)), (2, 64, 128, 33, 18, (3, 3), (4, 2), (1, 1)),
+                                  (6, 64, 128, 48, 70, (3, 3), (2, 2), (1, 1))])
 def test_conv2d_dgrad_strided_codes(case):
     """backward-data of the row-strided Conv2d layers: clips in residue-class order of their rows (a tile inside one class
     walks only that class's kernel rows), polyphase walk and interleaving store along the last axis"""
