@@ -206,6 +206,8 @@ __global__ __launch_bounds__(WB * 64, 2) void dconv_kernel(const DArgs a) {
     int kh, khq, khr, cw;     // backward-data: kernel row, kh / h_stride, kh % h_stride, chunk within the kernel row
   };
   [[maybe_unused]] int m0c[NSI], m0r[NSI], m0q = 0, m0rem = 0;
+  [[maybe_unused]] unsigned hb_voff[(TWO_D && HB) ? MAXIT : 1];     // (h_mode 1 / 2: per staged position, for the walk's kernel row)
+  [[maybe_unused]] int hb_key = -2;                                   // ... which is this one (-1: past the end)
   if constexpr (TWO_D && !HB) {
     {
       m0q = CKC / a.h_k;
@@ -245,21 +247,26 @@ __global__ __launch_bounds__(WB * 64, 2) void dconv_kernel(const DArgs a) {
           }
         }
       } else {
-        // one kernel row per chunk: the rows (and, class-ordered, whether the row's class takes this kernel row) once
-        const int dr = is_past ? (1 << 24) : (CLS ? -w.khq : (fwd2 ? w.kh : -w.kh));
-        unsigned voff[MAXIT];
+        // one kernel row per chunk: the rows (and, class-ordered, whether the row's class takes this kernel row) depend on the
+        // KERNEL ROW only — computed when the walk enters a kernel row (a uniform branch around vector arithmetic, no memory
+        // access inside: the wait counts stay exact), kept for its C / 16 (or 32) chunks
+        const int key = is_past ? -1 : w.kh;
+        if (key != hb_key) {
+          hb_key = key;
+          const int dr = is_past ? (1 << 24) : (CLS ? -w.khq : (fwd2 ? w.kh : -w.kh));
 #pragma unroll
-        for (int it = 0; it < MAXIT; ++it) {
-          bool ok = (unsigned)(srow[it] + dr) < (unsigned)a.h_in;
-          if constexpr (CLS) ok = ok && scls[it] == w.khr;       // a kernel row of another residue class: zeros
-          voff[it] = ok ? soff[it] + (unsigned)dr * chb : DC_OOB;
+          for (int it = 0; it < MAXIT; ++it) {
+            bool ok = (unsigned)(srow[it] + dr) < (unsigned)a.h_in;
+            if constexpr (CLS) ok = ok && scls[it] == w.khr;     // a kernel row of another residue class: zeros
+            hb_voff[it] = ok ? soff[it] + (unsigned)dr * chb : DC_OOB;
+          }
         }
 #pragma unroll
         for (int i = 0; i < NSI; ++i) {
           const int c = w.cw * CKC + (BF ? 8 * skgrp + i : skgrp + 4 * i);
           const unsigned cb = is_past ? 0u : (unsigned)(c * a.h_in) * chb;
 #pragma unroll
-          for (int it = 0; it < MAXIT; ++it) st[SET][i][it] = dc_load(rx, voff[it], cb);
+          for (int it = 0; it < MAXIT; ++it) st[SET][i][it] = dc_load(rx, hb_voff[it], cb);
         }
       }
     } else {
@@ -329,6 +336,8 @@ __global__ __launch_bounds__(WB * 64, 2) void dconv_kernel(const DArgs a) {
   [[maybe_unused]] float* const xscr = lds + 2 * bufF + wave * MAXT * kXbScrF;
   [[maybe_unused]] float* const xdump = lds + 2 * bufF + WB * MAXT * kXbScrF + tid * 4;
   [[maybe_unused]] int xb_cnt = 0;                    // task slots of this wave that hold units (wave-uniform)
+  [[maybe_unused]] unsigned xb_voff[(XB && TWO_D && HB) ? MAXT : 1];
+  [[maybe_unused]] int xb_key = -2;
   [[maybe_unused]] const unsigned chb2 = (unsigned)a.L_in * 2u;
   // scratch addresses: the load side parks 16 bytes at [channel lane & 7][unit slot lane >> 3]; the transposing read of lane
   // 16 g + 4 q + p names row q, columns 16 g + 4 p .. + 3 and hands lane 16 g + i column 16 g + i (rows q = 0..3 as 4 x bf16)
@@ -414,14 +423,20 @@ __global__ __launch_bounds__(WB * 64, 2) void dconv_kernel(const DArgs a) {
         xc[it] += wrap ? q32 + 1 : q32;
       }
     } else if constexpr (TWO_D) {
-      const int dr = is_past ? (1 << 24) : (CLS ? -w.khq : (fwd2 ? w.kh : -w.kh));
       const unsigned cb = is_past ? 0u : (unsigned)(w.cw * 32 * a.h_in) * chb2;
+      const int key = is_past ? -1 : w.kh;                 // (per kernel row, as in stage_issue_f)
+      if (key != xb_key) {
+        xb_key = key;
+        const int dr = is_past ? (1 << 24) : (CLS ? -w.khq : (fwd2 ? w.kh : -w.kh));
 #pragma unroll
-      for (int it = 0; it < MAXT; ++it) {
-        bool ok = (unsigned)(xl_row[it] + dr) < (unsigned)a.h_in;
-        if constexpr (CLS) ok = ok && xl_cls[it] == w.khr;
-        xst[SET][it] = xb_load(ok ? xl_off[it] + (unsigned)(xl_row[it] + dr) * chb2 : DC_OOB, cb);
+        for (int it = 0; it < MAXT; ++it) {
+          bool ok = (unsigned)(xl_row[it] + dr) < (unsigned)a.h_in;
+          if constexpr (CLS) ok = ok && xl_cls[it] == w.khr;
+          xb_voff[it] = ok ? xl_off[it] + (unsigned)(xl_row[it] + dr) * chb2 : DC_OOB;
+        }
       }
+#pragma unroll
+      for (int it = 0; it < MAXT; ++it) xst[SET][it] = xb_load(xb_voff[it], cb);
     } else {
       const unsigned past = is_past ? DC_OOB : 0u;
       const unsigned cb = is_past ? 0u : (unsigned)(w.rc * 32) * chb2;
