@@ -1,11 +1,6 @@
-set -e
 cd $GRAFT_REPO_ROOT
-for v in base vcache; do
-  echo "== $v"
-  if [ $v = base ]; then unset RTG_DEV_LIB; else export RTG_DEV_LIB=$PWD/transtacos-retunegan_amd/librtg_abl_$v.so; fi
-  for bf in "" 1; do
-  echo "-- BD_BF=$bf"
-  BD_BF=$bf BD_WT=1 BD_PICK=0,1,2,3 timeout -k 10 200 python tools/dbg/bench_dconv.py dgrad2d 2>&1 | grep "2d" | cut -c1-170 || true
-  BD_BF=$bf BD_WT=1 BD_PICK=0,1,2,3 timeout -k 10 200 python tools/dbg/bench_dconv.py 2d 2>&1 | grep "^fwd2d" | cut -c1-250 || true
-  done
+timeout -k 10 500 python -m pytest tests/test_bf16_maps_gpu.py tests/test_dconv_bf16_gpu.py tests/test_bf16_gpu.py tests/test_dconv_gpu.py tests/test_conv2d_gpu.py -x -q 2>&1 | tail -2
+for r in 1 2 3; do
+bash tools/dbg/ab_cfg.sh c3 --workload config3
+bash tools/dbg/ab_cfg.sh c3bf --workload config3 --bf16-maps
 done

@@ -218,13 +218,22 @@ def bench_dgrad_2d(B, Cin, Cout, H, W, kh, sh, sw, kw=3):
     mg, cg, k = Cin * sw, Cout * kh, (kw if sw == 1 else nt)
     Wl = (np.random.RandomState(1).randn(1, mg, cg, k) / np.sqrt(cg * k)).astype(np.float32)
     wp = images(Wl)
-    dy = torch.randn(B, Cout, Ho, Wo, device='cuda')
-    xm = torch.randn(B, Cin, H, W, device='cuda')
-    dx = torch.empty(B, Cin, H, W, device='cuda')
+    # BD_IO (with BD_BF=1): RTG_IO_* bits — 1 dy bf16, 2 dx bf16, 4 mask bf16 (bf16 tensors carry 16 readable bytes of slack)
+    io = int(os.environ.get('BD_IO', '0')) if BF else 0
+
+    def tensor(shape, b16):
+        n = int(np.prod(shape))
+        if not b16:
+            return torch.randn(*shape, device='cuda')
+        buf = torch.randn(n + 8, device='cuda').bfloat16()
+        return buf[:n].view(*shape)
+    dy = tensor((B, Cout, Ho, Wo), io & 1)
+    xm = tensor((B, Cin, H, W), io & 4)
+    dx = tensor((B, Cin, H, W), io & 2)
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     common = dict(B=B * H, C1=Cout * kh, C2=0, L_in=Wo, groups=1, Cg=cg, Mg=mg, K=k, dil=1, out_C=Cin, out_L=W, pre_mode=0,
                   pre_slope=1.0, mask_slope=0.15, out_scale=1.0, act=0, act_slope=1.0, accumulate=0, tile_m=32, out_split=0,
-                  wp16=1, h_in=Ho, h_k=kh, h_stride=sh, h_pad=ph, h_n=H, h_mode=1, bf16=int(BF))
+                  wp16=1, h_in=Ho, h_k=kh, h_stride=sh, h_pad=ph, h_n=H, h_mode=1, bf16=int(BF), io_bf16=io, enc_slope=1.0)
     if sw == 1:
         d = Conv1dDesc(stride=1, pad=(kw - 1) - pw, Q=W, shuf_S=1, shuf_P=0, **common)
     else:
@@ -241,7 +250,7 @@ def bench_dgrad_2d(B, Cin, Cout, H, W, kh, sh, sw, kw=3):
         res.append((c, timeit(lambda: lib.rtg_conv1d(C.byref(d), P(dy), None, None, P(wp), None, P(xm), None, P(dx), None, st))))
     gen = [r for r in res if r[0] < 8000]
     dc = sorted((r for r in res if r[0] > 8000), key=lambda r: r[1])
-    line = f'dgrad2d B{B} {Cin}->{Cout} {H}x{W} k({kh},{kw}) s({sh},{sw}):'
+    line = f'dgrad2d io{io} B{B} {Cin}->{Cout} {H}x{W} k({kh},{kw}) s({sh},{sw}):'
     if gen:
         g = min(gen, key=lambda r: r[1])
         line += f' general best {g[0]} {g[1] * 1e3:7.1f} us {flop / g[1] / 1e9:6.1f} TF/s |'

@@ -71,6 +71,12 @@ bool dconv_eligible(const RtgConv1dDesc* d) {
   return true;
 }
 
+// bf16 x: the shortest row the launch's instance is built for — 32 for the 2-D kernel-row walks (h_mode 1 / 2) on rows of at
+// least 32 positions (dconv_kernel's XQ), else the shape's min_q
+int xb_row_class(const RtgConv1dDesc* d, bool two_d) {
+  return (two_d && d->h_mode != 0 && d->Q >= 32) ? 32 : min_q(d->K, two_d);
+}
+
 }  // namespace
 
 #define RTG_DCONV_CODE 8000
@@ -104,7 +110,7 @@ int rtg_dconv_candidates(const RtgConv1dDesc* d, int* codes, int max) {
            (kShapes[si].wb == 4 && (kNT[ni] == 7 || (kNT[ni] == 6 && d->stride > 1)))))
         continue;
       const int pw = window_positions((int)(n_cols < BN ? n_cols : BN), d->Q, d->stride, d->K);
-      const int xbt = (d->io_bf16 & RTG_IO_X_BF16) ? xb_max_tasks(BN, min_q(d->K, two_d), d->stride, d->K, kShapes[si].wb) : 0;
+      const int xbt = (d->io_bf16 & RTG_IO_X_BF16) ? xb_max_tasks(BN, xb_row_class(d, two_d), d->stride, d->K, kShapes[si].wb) : 0;
       if (lds_bytes_for(pw, d->stride, kShapes[si].wb, xbt) > 158 * 1024) continue;
       const long long blocks = (long long)n_mb * ((n_cols + BN - 1) / BN);
       // rounds of the chip at one block per CU (two for the 4-wave shapes): the tail round's idle CUs are the loss
@@ -183,7 +189,8 @@ int rtg_dconv_launch(const RtgConv1dDesc* d, int code, const float* x, const flo
   if (a.xb_Lv < 1) a.xb_Lv = 1;
   a.xb_ups = (a.xb_Lv + 7) / 8;
   a.xb_j0 = a.xb_n0 = a.xb_units = 0;                             // (per block: computed in the kernel)
-  const size_t lds_bytes = lds_bytes_for(a.PW, d->stride, wb, xb ? xb_max_tasks(BN, min_q(d->K, two_d), d->stride, d->K, wb) : 0);
+  a.xq = (xb && xb_row_class(d, two_d) == 32) ? 32 : 0;
+  const size_t lds_bytes = lds_bytes_for(a.PW, d->stride, wb, xb ? xb_max_tasks(BN, xb_row_class(d, two_d), d->stride, d->K, wb) : 0);
   if (lds_bytes > 158 * 1024) return RTG_ERANGE;
   // ---- the XCDs' item ranges: equal work.  Items are (column tile, row block) with the row block fastest; a column tile's
   // work is the chunks it walks: all of them, or — class-ordered clips, the tile inside one residue class — that class's

@@ -44,6 +44,7 @@ struct DArgs {
   // xb_n0 units, xb_units in all.  mask / res may be bf16 whatever the instance (epilogue loads are per element).
   int xb_ups, xb_Lv, xb_j0, xb_n0, xb_units;
   int mask_b16, res_b16, mask_bytes, res_bytes;
+  int xq;                     // bf16 x, 2-D: 0, or 32 = the instance built for rows of >= 32 positions serves this launch
   float enc_slope;            // bf16 output: out = bf16(leaky_relu(v, enc_slope)) — the consumer's activation, applied once
 };
 
@@ -110,7 +111,14 @@ constexpr int xb_max_units(int cols, int minq, int S, int K) {
 constexpr int xb_max_tasks(int cols, int minq, int S, int K, int WB) { return (4 * ((xb_max_units(cols, minq, S, K) + 7) / 8) + WB - 1) / WB; }
 constexpr int kXbScrF = 8 * 144 / 4;                 // floats of one wave's transposition scratch
 
-template <int RW16, int WB, int NT16, int S, int K, bool TWO_D, bool CLS, bool BF, bool HB, int IO = 0>
+// XQ (bf16 x, 2-D, end of round 5): 0, or the shortest row the instance serves.  The task slots of a wave are sized for the
+// widest window of the shape, and a window over rows of min_q = 4 positions touches two partial units per row: 9 slots per
+// wave for the 96-column 2-tap instance, 150 registers of staging state, spills, two waves per SIMD — where the product's
+// rows (the spectrogram discriminators run along the frequency axis: 22-513 positions) need 3.  XQ = 32: 3 slots, 158
+// registers, no spills: the class-ordered 64 -> 256 backward-data on bf16 dy 163 -> 108 us (fp32 dy: 131), 32 -> 64 268 -> 156
+// (167).  The time of these instances follows the slot count (every slot is a load issue, an LDS round trip and a patch
+// write per chunk, against 130-260 matrix cycles): XQ = 16 (4 slots, serves the rows of 22-30 too) measured 115 / 183 us.
+template <int RW16, int WB, int NT16, int S, int K, bool TWO_D, bool CLS, bool BF, bool HB, int IO = 0, int XQ = 0>
 __global__ __launch_bounds__(WB * 64, 2) void dconv_kernel(const DArgs a) {
   static_assert(!CLS || TWO_D, "class-ordered clips belong to the 2-D backward-data");
   static_assert((!CLS || HB) && (!HB || TWO_D), "h_mode 1 / 2 is 2-D; class-ordered clips are backward-data");
@@ -324,7 +332,7 @@ __global__ __launch_bounds__(WB * 64, 2) void dconv_kernel(const DArgs a) {
   };
 
   // ---- x in bf16 (IO bit 0): units of 8 positions, wave tasks of 8 units x 8 channels (see the kernel's header comment)
-  constexpr int MAXT = XB ? xb_max_tasks(BN, min_q(K, TWO_D), S, K, WB) : 1;
+  constexpr int MAXT = XB ? xb_max_tasks(BN, XQ ? XQ : min_q(K, TWO_D), S, K, WB) : 1;
   [[maybe_unused]] u32x4 xst[NSET][MAXT];
   [[maybe_unused]] unsigned xl_off[MAXT];            // load side: byte offset of this lane's (unit, channel of the plane), or out of range
   [[maybe_unused]] int xl_row[TWO_D ? MAXT : 1];      // 2-D: the unit's clip's input row for kernel row 0
@@ -869,13 +877,14 @@ inline size_t lds_bytes_for(int PW, int S, int WB, int xb_tasks) {
          (xb_tasks ? (size_t)WB * xb_tasks * kXbScrF * 4 + (size_t)WB * 64 * 16 : 0);
 }
 
-template <int RW16, int WB, int NT16, int S, int K, bool TWO_D, bool CLS, bool BF, bool HB = CLS, int IO = 0>
+template <int RW16, int WB, int NT16, int S, int K, bool TWO_D, bool CLS, bool BF, bool HB = CLS, int IO = 0, int XQ = 0>
 int launch(const DArgs& a, unsigned blocks, size_t lds_bytes, hipStream_t s) {
-  auto k = dconv_kernel<RW16, WB, NT16, S, K, TWO_D, CLS, BF, HB, IO>;
+  auto k = dconv_kernel<RW16, WB, NT16, S, K, TWO_D, CLS, BF, HB, IO, XQ>;
   if constexpr ((IO & 1) != 0) {
     // every unit of the widest window of this problem must find a task slot (a unit left out would be a patch of zeros)
     const int nseg = (a.PW + a.seg_pw - 2) / a.seg_pw + 1;
-    if (a.PW / 8 + 2 * nseg + 1 > 2 * WB * xb_max_tasks(NT16 * 16, min_q(K, TWO_D), S, K, WB)) return RTG_ERANGE;
+    if (a.PW / 8 + 2 * nseg + 1 > 2 * WB * xb_max_tasks(NT16 * 16, XQ ? XQ : min_q(K, TWO_D), S, K, WB)) return RTG_ERANGE;
+    if (XQ != 0 && a.Q < XQ) return RTG_ERANGE;
   }
   static std::atomic<unsigned> optin{0};              // (> 64 KB of dynamic LDS: opt-in per kernel and device)
   if (lds_bytes > 64 * 1024 && rtg_lds_optin((const void*)k, optin) != RTG_OK) return RTG_ERANGE;
@@ -883,17 +892,29 @@ int launch(const DArgs& a, unsigned blocks, size_t lds_bytes, hipStream_t s) {
   return rtg_launch_status();
 }
 
+// the 2-D instances that walk (kernel row, channel): backward-data, and the forward over the kernel-row-major image
+template <int RW16, int WB, int NT16, bool BF, int IO, int XQ>
+int launch_hb(const DArgs& a, int S, int K, unsigned blocks, size_t lds_bytes, hipStream_t s) {
+  if (a.h_mode == 2) {
+    if (S == 1 && K == 3) return launch<RW16, WB, NT16, 1, 3, true, false, BF, true, IO, XQ>(a, blocks, lds_bytes, s);
+    if (S == 2 && K == 3) return launch<RW16, WB, NT16, 2, 3, true, false, BF, true, IO, XQ>(a, blocks, lds_bytes, s);
+    if (S == 3 && K == 5) return launch<RW16, WB, NT16, 3, 5, true, false, BF, true, IO, XQ>(a, blocks, lds_bytes, s);
+    return RTG_EINVAL;
+  }
+  if (a.h_mode == 1 && a.h_stride > 1) return launch<RW16, WB, NT16, 1, 2, true, true, BF, true, IO, XQ>(a, blocks, lds_bytes, s);
+  if (S == 1 && K == 3 && a.h_mode == 1) return launch<RW16, WB, NT16, 1, 3, true, false, BF, true, IO, XQ>(a, blocks, lds_bytes, s);
+  return RTG_EINVAL;
+}
+
 template <int RW16, int WB, int NT16, bool BF, int IO = 0>
 int launch_sk(const DArgs& a, int S, int K, bool two_d, unsigned blocks, size_t lds_bytes, hipStream_t s) {
   if (two_d) {
-    if (a.h_mode == 2) {        // forward, channels ordered (kernel row, channel): the HB instances
-      if (S == 1 && K == 3) return launch<RW16, WB, NT16, 1, 3, true, false, BF, true, IO>(a, blocks, lds_bytes, s);
-      if (S == 2 && K == 3) return launch<RW16, WB, NT16, 2, 3, true, false, BF, true, IO>(a, blocks, lds_bytes, s);
-      if (S == 3 && K == 5) return launch<RW16, WB, NT16, 3, 5, true, false, BF, true, IO>(a, blocks, lds_bytes, s);
-      return RTG_EINVAL;
+    if (a.h_mode == 2 || a.h_mode == 1) {
+      if constexpr ((IO & 1) != 0) {
+        if (a.xq == 32) return launch_hb<RW16, WB, NT16, BF, IO, 32>(a, S, K, blocks, lds_bytes, s);
+      }
+      return launch_hb<RW16, WB, NT16, BF, IO, 0>(a, S, K, blocks, lds_bytes, s);
     }
-    if (a.h_mode == 1 && a.h_stride > 1) return launch<RW16, WB, NT16, 1, 2, true, true, BF, true, IO>(a, blocks, lds_bytes, s);
-    if (S == 1 && K == 3 && a.h_mode == 1) return launch<RW16, WB, NT16, 1, 3, true, false, BF, true, IO>(a, blocks, lds_bytes, s);
     if (S == 1 && K == 3) return launch<RW16, WB, NT16, 1, 3, true, false, BF, false, IO>(a, blocks, lds_bytes, s);
     if (S == 2 && K == 3 && a.h_mode == 0) return launch<RW16, WB, NT16, 2, 3, true, false, BF, false, IO>(a, blocks, lds_bytes, s);
     // (round 5: StftDiscriminator along the frequency axis — its (5, 3) kernels with stride (3, 2) walk 5 taps at stride 3)
