@@ -331,6 +331,8 @@ int rtg_weightnorm_backward(const RtgWnBwdJob* jobs_dev, int n_jobs, int max_row
  * Backward: given dmel [B,n_mel,frames] (may be NULL) and dspec [B,2,F,frames] (may be NULL) -> dy [B,T] (+=).
  * melW is passed as CSR-like band tables: for filter m the non-zero bins are [lo[m], lo[m]+len[m]) with weights
  * at wts + woff[m].  twiddle: [n_fft/2] cos then [n_fft/2] sin of 2*pi*k/n_fft (fp64-rounded).  window: [win].
+ * Sizes: n_fft a power of two in 128 .. 4096 (RTG_ERANGE otherwise; the reference's multi_stft_params use 2048 / 1024 /
+ * 512, torch.stft itself takes any size), 1 <= win <= n_fft, n_fft/2 < T (reflect padding), n_mel <= 256.
  * ------------------------------------------------------------------------------------------------------------ */
 typedef struct RtgStftDesc {
   int B, T, n_fft, win, hop, frames, n_mel;

@@ -244,6 +244,40 @@ def test_stft_backward_through_log_magnitude_and_phase(oracle, gold):
         assert err < 5e-3, (n_fft, err)      # fp32 vs float64: d angle / dD ~ 1/|D| amplifies rounding at weak bins
 
 
+@pytest.mark.parametrize('n_fft,win,hop', [(128, 64, 16), (256, 128, 30), (4096, 2048, 480), (4096, 4096, 1024)])
+def test_stft_sizes_outside_the_reference_defaults(oracle, gold, n_fft, win, hop):
+    """multi_stft_params is user-editable (hparam.py:78-80) and torch.stft takes any size: the kernel serves every power of
+    two in 128 .. 4096 (8 frames per block .. two butterflies per thread) — magnitudes, phases, mel and d/dy against float64."""
+    from audio import stft_mel_spec
+    yd = torch.from_numpy(gold['y_hat']).squeeze(1)
+    gen = torch.Generator().manual_seed(n_fft)
+    yh = yd.clone().to(DEV).requires_grad_(True)
+    mel, spec = stft_mel_spec(yh, n_fft, win, hop, True)
+    y64 = yd.double().requires_grad_(True)
+    S, M, P = oracle.stft_mag_mel_phase(y64, n_fft, win, hop)
+    assert tuple(spec.shape) == (yd.shape[0], 2, n_fft // 2 + 1, 1 + yd.shape[1] // hop)
+    big = S > 1e-2
+    np.testing.assert_allclose(spec[:, 0].detach().cpu().double()[big].numpy(), torch.log(S)[big].detach().numpy(), rtol=0, atol=2e-4)
+    d = (spec[:, 1].detach().cpu().double() - P.detach() / oracle.PI).abs()
+    d = torch.minimum(d, 2 - d)
+    assert d[big].max().item() < 2e-3
+    np.testing.assert_allclose(mel.detach().cpu().numpy(), M.detach().numpy(), rtol=2e-4, atol=2e-6)
+    cs = torch.randn(spec.shape, generator=gen)
+    cm = torch.randn(mel.shape, generator=gen)
+    ((spec * cs.to(DEV)).sum() + (mel * cm.to(DEV)).sum()).backward()
+    o = torch.stack([torch.log(S), P / oracle.PI], dim=1)
+    ((o * cs.double()).sum() + (M * cm.double()).sum()).backward()
+    err = (yh.grad.cpu().double() - y64.grad).norm().item() / y64.grad.norm().item()
+    assert err < 5e-3, (n_fft, err)
+
+
+def test_stft_size_that_is_not_served_fails_loudly():
+    from audio import stft_mel_spec
+    from rtg.lib import RtgError
+    with pytest.raises(RtgError):
+        stft_mel_spec(torch.zeros(1, 8192, device=DEV), 768, 384, 96, True)
+
+
 @pytest.mark.parametrize('case', [CASES[1], CASES[3], CASES[4], (2, 32, 64, 9, 65, (3, 9), (1, 1), (1, 4))])
 def test_conv2d_every_block_shape(case, monkeypatch):
     """2-D layers through every block shape the library lists for their forward and backward-data problems (whole-clip

@@ -205,7 +205,10 @@ extern "C" int rtg_conv1d_variant(const RtgConv1dDesc* d) {
   if (dense_only(d)) {
     int code = d->tile_cfg;
     if (code == 0 && rtg_dconv_candidates(d, &code, 1) < 1) return RTG_ERANGE;
-    return (code > RTG_DCONV_CODE && code < RTG_SCONV_CODE) ? code : RTG_EINVAL;
+    // (a caller-fixed shape must be one the candidate list holds: the list leaves out what must not run — instances that
+    // spill, 256-row blocks that do not divide the rows, 64-row waves without bf16 — and a stale tuner table must not get past it)
+    if (d->tile_cfg != 0 && !dconv_code_ok(d)) return RTG_EINVAL;
+    return (code > RTG_DCONV_CODE && code <= RTG_SCONV_CODE) ? code : RTG_EINVAL;
   }
   if (d->tile_cfg > RTG_SCONV_CODE) return sconv_code_ok(d) ? d->tile_cfg : RTG_EINVAL;
   if (d->tile_cfg > RTG_DCONV_CODE) return dconv_code_ok(d) ? d->tile_cfg : RTG_EINVAL;
@@ -412,6 +415,7 @@ extern "C" int rtg_conv1d(const RtgConv1dDesc* d, const float* x1, const float* 
     int code = d->tile_cfg;
     if (code == 0 && rtg_dconv_candidates(d, &code, 1) < 1) return RTG_ERANGE;
     if (code <= RTG_DCONV_CODE || code > RTG_SCONV_CODE || x2 || aux || out2) return RTG_EINVAL;
+    if (d->tile_cfg != 0 && !dconv_code_ok(d)) return RTG_EINVAL;
     return rtg_dconv_launch(d, code, x1, wp, bias, mask, res, out, (hipStream_t)stream);
   }
   if (d->tile_cfg == 0 && x1 && wp) {

@@ -49,6 +49,7 @@ bool dconv_eligible(const RtgConv1dDesc* d) {
     // ... and of the row-strided ones (class-ordered clips, 2 taps of the polyphase walk along the last axis)
     if (d->h_in < 1 || d->h_k < 1 || d->h_n < 1 || d->h_pad < 0 || d->C1 % d->h_k != 0 || d->B % d->h_n != 0) return false;
     if (d->dil != 1 || d->h_stride < 1 || d->h_mode < 0 || d->h_mode > 2) return false;
+    if ((d->io_bf16 & 3) != 0 && d->h_mode == 0) return false;            // (bf16 tensors: kernel-row walks only, dc_built)
     if (d->h_mode != 0 && (d->C1 / d->h_k) % ckc != 0) return false;      // whole chunks per kernel row
     if (d->h_mode == 1 && d->h_stride > 1) {
       if (d->K != 2 || d->stride != 1 || d->h_stride > 4) return false;
@@ -94,21 +95,13 @@ int rtg_dconv_candidates(const RtgConv1dDesc* d, int* codes, int max) {
   for (int si = 0; si < kNumShapes; ++si) {
     const int mb16 = kShapes[si].rw16 * kShapes[si].wb;
     if (si >= 3 && n_mt16 % mb16 != 0) continue;                     // 256-row blocks only where they divide the rows
-    if (kShapes[si].rw16 == 4 && !d->bf16) continue;                 // (64 rows per wave: the bf16 instances only)
     const int n_mb = rtg_ceil_div(n_mt16, mb16);
     for (int ni = 0; ni < 4; ++ni) {
       const int BN = kNT[ni] * 16;
-      // instances that need more than 256 registers at two waves per SIMD (they spill): 32 rows per wave with >= 6
-      // column tiles; 8 column tiles with a strided walk in the 4-wave blocks (twice the staging registers per wave)
-      if (kShapes[si].rw16 >= 2 && kNT[ni] >= 6) continue;
       const bool two_d = d->h_k > 1 || d->h_n > 1;
-      if (kNT[ni] == 8 && (d->stride > 1 || (two_d && kShapes[si].wb == 4))) continue;
-      // bf16 (8 staged channels per position, two register sets): 16 rows per wave with 8 column tiles, or with 7 on a
-      // strided walk, or with 7 (6 on a strided walk) in the 4-wave blocks
-      if (d->bf16 && kShapes[si].rw16 == 1 &&
-          (kNT[ni] == 8 || (kNT[ni] == 7 && d->stride > 1) ||
-           (kShapes[si].wb == 4 && (kNT[ni] == 7 || (kNT[ni] == 6 && d->stride > 1)))))
-        continue;
+      // the instances that exist (rtg_dconv_kernel.h: dc_built — the ones that do not spill, and for bf16 tensors the ones
+      // the tuner ever picked)
+      if (!dc_built(kShapes[si].rw16, kShapes[si].wb, kNT[ni], d->stride, two_d, d->h_mode != 0, d->bf16 != 0, d->io_bf16 & 3)) continue;
       const int pw = window_positions((int)(n_cols < BN ? n_cols : BN), d->Q, d->stride, d->K);
       const int xbt = (d->io_bf16 & RTG_IO_X_BF16) ? xb_max_tasks(BN, xb_row_class(d, two_d), d->stride, d->K, kShapes[si].wb) : 0;
       if (lds_bytes_for(pw, d->stride, kShapes[si].wb, xbt) > 158 * 1024) continue;
@@ -255,7 +248,7 @@ int rtg_dconv_launch(const RtgConv1dDesc* d, int code, const float* x, const flo
          : io == 2 ? rtg_dconv_launch_io2(a, si, nt16, d->stride, d->K, two_d, blocks, lds_bytes, s)
                    : rtg_dconv_launch_io3(a, si, nt16, d->stride, d->K, two_d, blocks, lds_bytes, s);
   }
-  return d->bf16 ? launch_shape<true, 0>(a, si, nt16, d->stride, d->K, two_d, blocks, lds_bytes, s)
+  return d->bf16 ? rtg_dconv_launch_bf(a, si, nt16, d->stride, d->K, two_d, blocks, lds_bytes, s)
                  : launch_shape<false, 0>(a, si, nt16, d->stride, d->K, two_d, blocks, lds_bytes, s);
 }
 

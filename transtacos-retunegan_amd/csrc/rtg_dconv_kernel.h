@@ -871,6 +871,27 @@ constexpr DShape kShapes[] = {{2, 4}, {1, 8}, {1, 4}, {2, 8}, {4, 4}};
 constexpr int kNumShapes = 5;
 constexpr int kNT[] = {4, 6, 7, 8};
 
+// Which (block shape, column tiles, geometry, arithmetic, tensor types) instances EXIST.  One rule for the candidate list
+// (rtg_dconv_candidates) and for the dispatch below: a shape the list does not hold is not compiled, and rtg_conv1d refuses a
+// caller-fixed code that is not on the list (round 6; rounds 3-5 built every combination — 672 instances, 70 of them
+// with scratch, for the 68 a step launches).  Left out:
+//   * 32 / 64 rows per wave with 6 or more column tiles, and 8 column tiles with a strided walk or in the 4-wave 2-D blocks:
+//     more than 256 registers at two waves per SIMD (they spill);
+//   * 64 rows per wave in fp32 (the shape exists for the bf16 operand-delivery limit, section "launch" below);
+//   * bf16 operands, 16 rows per wave (8 staged channels per position, two register sets): 8 column tiles, 7 on a strided
+//     walk, 7 (6 on a strided walk) in the 4-wave blocks;
+//   * bf16 TENSORS (IO != 0): 64-column tiles and 16 / 32 rows per wave only (what the tuner picked in every measured step,
+//     profiles/r05a_*; the strided 2-D walks at 64 rows per wave spill 1-2 registers), and no 2-D walk over the channel-major image (h_mode 0: the forward runs over the kernel-row-major one, rtg/bank.py FWD_KH_MAJOR;
+//     a shape without native instance goes through fp32 copies, rtg/ops.py).
+constexpr bool dc_built(int rw16, int wb, int nt16, int S, bool two_d, bool hb, bool bf, int io) {
+  if (rw16 >= 2 && nt16 >= 6) return false;
+  if (rw16 == 4 && !bf) return false;
+  if (nt16 == 8 && (S > 1 || (two_d && wb == 4))) return false;
+  if (bf && rw16 == 1 && (nt16 == 8 || (nt16 == 7 && S > 1) || (wb == 4 && (nt16 == 7 || (nt16 == 6 && S > 1))))) return false;
+  if (io != 0 && (nt16 != 4 || rw16 == 4 || (two_d && !hb))) return false;
+  return true;
+}
+
 // dynamic LDS of an instance: two patch buffers; bf16 input: + a transposition scratch per wave and a dump slot per lane
 inline size_t lds_bytes_for(int PW, int S, int WB, int xb_tasks) {
   return (size_t)2 * 4 * plane_floats(PW, S) * sizeof(float) +
@@ -892,17 +913,23 @@ int launch(const DArgs& a, unsigned blocks, size_t lds_bytes, hipStream_t s) {
   return rtg_launch_status();
 }
 
+template <int RW16, int WB, int NT16, int S, int K, bool TWO_D, bool CLS, bool BF, bool HB = CLS, int IO = 0, int XQ = 0>
+int launch_if_built(const DArgs& a, unsigned blocks, size_t lds_bytes, hipStream_t s) {
+  if constexpr (dc_built(RW16, WB, NT16, S, TWO_D, HB, BF, IO)) return launch<RW16, WB, NT16, S, K, TWO_D, CLS, BF, HB, IO, XQ>(a, blocks, lds_bytes, s);
+  else return RTG_EINVAL;
+}
+
 // the 2-D instances that walk (kernel row, channel): backward-data, and the forward over the kernel-row-major image
 template <int RW16, int WB, int NT16, bool BF, int IO, int XQ>
 int launch_hb(const DArgs& a, int S, int K, unsigned blocks, size_t lds_bytes, hipStream_t s) {
   if (a.h_mode == 2) {
-    if (S == 1 && K == 3) return launch<RW16, WB, NT16, 1, 3, true, false, BF, true, IO, XQ>(a, blocks, lds_bytes, s);
-    if (S == 2 && K == 3) return launch<RW16, WB, NT16, 2, 3, true, false, BF, true, IO, XQ>(a, blocks, lds_bytes, s);
-    if (S == 3 && K == 5) return launch<RW16, WB, NT16, 3, 5, true, false, BF, true, IO, XQ>(a, blocks, lds_bytes, s);
+    if (S == 1 && K == 3) return launch_if_built<RW16, WB, NT16, 1, 3, true, false, BF, true, IO, XQ>(a, blocks, lds_bytes, s);
+    if (S == 2 && K == 3) return launch_if_built<RW16, WB, NT16, 2, 3, true, false, BF, true, IO, XQ>(a, blocks, lds_bytes, s);
+    if (S == 3 && K == 5) return launch_if_built<RW16, WB, NT16, 3, 5, true, false, BF, true, IO, XQ>(a, blocks, lds_bytes, s);
     return RTG_EINVAL;
   }
-  if (a.h_mode == 1 && a.h_stride > 1) return launch<RW16, WB, NT16, 1, 2, true, true, BF, true, IO, XQ>(a, blocks, lds_bytes, s);
-  if (S == 1 && K == 3 && a.h_mode == 1) return launch<RW16, WB, NT16, 1, 3, true, false, BF, true, IO, XQ>(a, blocks, lds_bytes, s);
+  if (a.h_mode == 1 && a.h_stride > 1) return launch_if_built<RW16, WB, NT16, 1, 2, true, true, BF, true, IO, XQ>(a, blocks, lds_bytes, s);
+  if (S == 1 && K == 3 && a.h_mode == 1) return launch_if_built<RW16, WB, NT16, 1, 3, true, false, BF, true, IO, XQ>(a, blocks, lds_bytes, s);
   return RTG_EINVAL;
 }
 
@@ -915,15 +942,15 @@ int launch_sk(const DArgs& a, int S, int K, bool two_d, unsigned blocks, size_t 
       }
       return launch_hb<RW16, WB, NT16, BF, IO, 0>(a, S, K, blocks, lds_bytes, s);
     }
-    if (S == 1 && K == 3) return launch<RW16, WB, NT16, 1, 3, true, false, BF, false, IO>(a, blocks, lds_bytes, s);
-    if (S == 2 && K == 3 && a.h_mode == 0) return launch<RW16, WB, NT16, 2, 3, true, false, BF, false, IO>(a, blocks, lds_bytes, s);
+    if (S == 1 && K == 3) return launch_if_built<RW16, WB, NT16, 1, 3, true, false, BF, false, IO>(a, blocks, lds_bytes, s);
+    if (S == 2 && K == 3 && a.h_mode == 0) return launch_if_built<RW16, WB, NT16, 2, 3, true, false, BF, false, IO>(a, blocks, lds_bytes, s);
     // (round 5: StftDiscriminator along the frequency axis — its (5, 3) kernels with stride (3, 2) walk 5 taps at stride 3)
-    if (S == 3 && K == 5 && a.h_mode == 0) return launch<RW16, WB, NT16, 3, 5, true, false, BF, false, IO>(a, blocks, lds_bytes, s);
+    if (S == 3 && K == 5 && a.h_mode == 0) return launch_if_built<RW16, WB, NT16, 3, 5, true, false, BF, false, IO>(a, blocks, lds_bytes, s);
     return RTG_EINVAL;
   }
-  if (S == 1 && K == 5) return launch<RW16, WB, NT16, 1, 5, false, false, BF, false, IO>(a, blocks, lds_bytes, s);
-  if (S == 3 && K == 5) return launch<RW16, WB, NT16, 3, 5, false, false, BF, false, IO>(a, blocks, lds_bytes, s);
-  if (S == 1 && K == 2) return launch<RW16, WB, NT16, 1, 2, false, false, BF, false, IO>(a, blocks, lds_bytes, s);
+  if (S == 1 && K == 5) return launch_if_built<RW16, WB, NT16, 1, 5, false, false, BF, false, IO>(a, blocks, lds_bytes, s);
+  if (S == 3 && K == 5) return launch_if_built<RW16, WB, NT16, 3, 5, false, false, BF, false, IO>(a, blocks, lds_bytes, s);
+  if (S == 1 && K == 2) return launch_if_built<RW16, WB, NT16, 1, 2, false, false, BF, false, IO>(a, blocks, lds_bytes, s);
   return RTG_EINVAL;
 }
 
@@ -945,7 +972,9 @@ int launch_shape(const DArgs& a, int si, int nt16, int S, int K, bool two_d, uns
 
 }  // namespace rtg_dc
 
-// the bf16-tensor instances live in translation units of their own (rtg_dconv_io{1,2,3}.hip: IO = the file's number)
+// the bf16-operand instances on fp32 tensors (rtg_dconv_bf.hip) and the bf16-tensor instances (rtg_dconv_io{1,2,3}.hip: IO = the
+// file's number) live in translation units of their own
+int rtg_dconv_launch_bf(const rtg_dc::DArgs& a, int si, int nt16, int S, int K, bool two_d, unsigned blocks, size_t lds_bytes, hipStream_t s);
 int rtg_dconv_launch_io1(const rtg_dc::DArgs& a, int si, int nt16, int S, int K, bool two_d, unsigned blocks, size_t lds_bytes, hipStream_t s);
 int rtg_dconv_launch_io2(const rtg_dc::DArgs& a, int si, int nt16, int S, int K, bool two_d, unsigned blocks, size_t lds_bytes, hipStream_t s);
 int rtg_dconv_launch_io3(const rtg_dc::DArgs& a, int si, int nt16, int S, int K, bool two_d, unsigned blocks, size_t lds_bytes, hipStream_t s);

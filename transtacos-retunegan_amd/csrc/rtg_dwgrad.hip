@@ -427,8 +427,9 @@ __global__ __launch_bounds__(kWB * 64, 2) void dwgrad_kernel(const WArgs a) {
         }
       };
       // the column fragments of 16-reduction group g + 1 are requested before group g is multiplied (two register sets;
-      // one set where twelve fragments are already 48 registers: the 4-chunk shape)
-      if constexpr (NCH * kNCT <= 10) {
+      // one set where twelve fragments are already 48 registers: the 4-chunk shape — and where ten of them sit next to the
+      // fp32 row fragments of the bf16-operand instances on fp32 tensors: two sets there are 257 registers, one spilled)
+      if constexpr (NCH * kNCT <= 10 && !(BF && !YB && NCH * kNCT == 10)) {
         Frag f0, f1;
         fetch(f0, 0);
 #pragma unroll

@@ -37,13 +37,14 @@ __device__ __forceinline__ cpx cmul(cpx a, cpx b) { return cpx{a.x * b.x - a.y *
 // FFT of M complex points in LDS (radix-4 Stockham autosort, decimation in frequency, forward sign), by the TPF = M/4
 // threads t = 0 .. TPF-1 of one frame; every pass ends in a block barrier (all frames of the block walk the same passes).
 // N = 2M: the twiddle table's length.  Returns the buffer that holds the result.
-__device__ __forceinline__ cpx* fft_half(cpx* a, cpx* b, int M, int t, const float* __restrict__ tw) {
+__device__ __forceinline__ cpx* fft_half(cpx* a, cpx* b, int M, int t0, int TPF, const float* __restrict__ tw) {
   const int N = 2 * M, q4 = M >> 2;
   cpx *src = a, *dst = b;
   int s = 1;
   for (; 4 * s <= M; s <<= 2) {
     // butterfly idx = q + s p (q < s): inputs idx + j M/4, outputs q + s (4p + j) = idx + 3 s p + s j, twiddles
     // exp(-2 pi i j (s p) / M) = table[2 j s p]
+   for (int t = t0; t < q4; t += TPF) {                       // (one butterfly per thread up to n_fft 2048, two at 4096)
     const int k = t & ~(s - 1);
     const cpx x0 = src[t], x1 = src[t + q4], x2 = src[t + 2 * q4], x3 = src[t + 3 * q4];
     const cpx apc{x0.x + x2.x, x0.y + x2.y}, amc{x0.x - x2.x, x0.y - x2.y};
@@ -61,14 +62,16 @@ __device__ __forceinline__ cpx* fft_half(cpx* a, cpx* b, int M, int t, const flo
       o[2 * s] = cmul(y2, tw_at(tw, N, 4 * k));
       o[3 * s] = cmul(y3, tw_at(tw, N, 6 * k));
     }
+   }
     __syncthreads();
     cpx* tmp = src; src = dst; dst = tmp;
   }
   if (s < M) {                                                // M = 2 * 4^n: one radix-2 pass, s = M/2 (twiddle 1)
     const int half = M >> 1;
+    for (int t = t0; t < q4; t += TPF)
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const int idx = t + u * q4;                             // M/2 butterflies, two per thread
+      const int idx = t + u * q4;                             // M/2 butterflies, two per thread and round
       const int k = idx & ~(s - 1);                           // (= 0: idx < s)
       const cpx p = src[idx], r = src[idx + half];
       dst[idx + k] = cpx{p.x + r.x, p.y + r.y};
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(kStftThreads) void stft_fwd_kernel(RtgStftDesc d, c
                                                                 float* re_out, float* im_out) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int N = d.n_fft, M = N >> 1, F = M + 1;
-  const int TPF = M >> 2, FPB = kStftThreads / TPF;          // threads per frame, frames per block
+  const int TPF = min(M >> 2, kStftThreads), FPB = kStftThreads / TPF;   // threads per frame, frames per block
   const int fl = threadIdx.x / TPF, t = threadIdx.x - fl * TPF;
   const int frame = blockIdx.x * FPB + fl, b = blockIdx.y;
   const bool live = frame < d.frames;
@@ -119,7 +122,7 @@ __global__ __launch_bounds__(kStftThreads) void stft_fwd_kernel(RtgStftDesc d, c
     A[m] = cpx{v[0], v[1]};
   }
   __syncthreads();
-  const cpx* Z = fft_half(A, Bf, M, t, twiddle);
+  const cpx* Z = fft_half(A, Bf, M, t, TPF, twiddle);
 
   const size_t fo = ((size_t)b * d.frames + frame) * F;     // [B][frames][F] scratch layout for the backward
   for (int f = t; f < F; f += TPF) {
@@ -176,7 +179,7 @@ __global__ __launch_bounds__(kStftThreads) void stft_bwd_frame_kernel(RtgStftDes
                                                                       float* __restrict__ frame_ws) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int N = d.n_fft, M = N >> 1, F = M + 1;
-  const int TPF = M >> 2, FPB = kStftThreads / TPF;
+  const int TPF = min(M >> 2, kStftThreads), FPB = kStftThreads / TPF;
   const int fl = threadIdx.x / TPF, t = threadIdx.x - fl * TPF;
   const int frame = blockIdx.x * FPB + fl, b = blockIdx.y;
   const bool live = frame < d.frames;
@@ -234,7 +237,7 @@ __global__ __launch_bounds__(kStftThreads) void stft_bwd_frame_kernel(RtgStftDes
     A[k] = cpx{sum.x - dw.y, sum.y + dw.x};               // sum + i * dw
   }
   __syncthreads();
-  const cpx* Z = fft_half(A, Bf, M, t, twiddle);          // Z[m] = y[2m] + i y[2m+1]
+  const cpx* Z = fft_half(A, Bf, M, t, TPF, twiddle);          // Z[m] = y[2m] + i y[2m+1]
   if (!live) return;
   float* out = frame_ws + ((size_t)b * d.frames + frame) * d.win;
   for (int n = t; n < d.win; n += TPF) {
@@ -274,7 +277,9 @@ __global__ __launch_bounds__(RTG_THREADS) void stft_ola_kernel(RtgStftDesc d, co
 
 int validate(const RtgStftDesc* d) {
   if (d->B < 1 || d->T < 2 || d->hop < 1 || d->n_mel < 1 || d->n_mel > 256) return RTG_EINVAL;
-  if (d->n_fft != 512 && d->n_fft != 1024 && d->n_fft != 2048) return RTG_ERANGE;      // (n_fft / 8 threads own a frame)
+  // n_fft = 2 M with M a power of two: min(M / 4, 256) threads own a frame, 8 .. 1 frames per block (torch.stft takes any size;
+  // the reference's multi_stft_params, hparam.py:78-80, are 2048 / 1024 / 512)
+  if (d->n_fft < 128 || d->n_fft > 4096 || (d->n_fft & (d->n_fft - 1))) return RTG_ERANGE;
   if (d->win < 1 || d->win > d->n_fft) return RTG_EINVAL;
   if (d->frames != 1 + d->T / d->hop) return RTG_EINVAL;
   if (d->n_fft / 2 >= d->T) return RTG_ERANGE;            // reflect padding needs pad < T
@@ -292,7 +297,7 @@ extern "C" int rtg_stft_forward(const RtgStftDesc* d, const float* y, const floa
   if (st) return st;
   if (mel && (!mel_lo || !mel_len || !mel_woff || !mel_w)) return RTG_ENULL;
   if ((re == nullptr) != (im == nullptr)) return RTG_EINVAL;
-  const int M = d->n_fft / 2, fpb = kStftThreads / (M / 4);
+  const int M = d->n_fft / 2, fpb = kStftThreads / (M / 4 < kStftThreads ? M / 4 : kStftThreads);
   const size_t lds = (size_t)fpb * (4 * M + M + 1 + 3) * sizeof(float);              // <= 20.5 KB
   RTG_KLAUNCH(stft_fwd_kernel, dim3(rtg_ceil_div(d->frames, fpb), d->B), dim3(kStftThreads), lds, (hipStream_t)stream, *d, y,
               window, twiddle, mel_lo, mel_len, mel_woff, mel_w, mel, spec, re, im);
@@ -306,7 +311,7 @@ extern "C" int rtg_stft_backward(const RtgStftDesc* d, const float* re, const fl
   int st = validate(d);
   if (st) return st;
   if (dmel && (!binmel_idx || !binmel_w)) return RTG_ENULL;
-  const int M = d->n_fft / 2, fpb = kStftThreads / (M / 4);
+  const int M = d->n_fft / 2, fpb = kStftThreads / (M / 4 < kStftThreads ? M / 4 : kStftThreads);
   const size_t lds = (size_t)fpb * (4 * M + 2 * (M + 1) + 256 + 2) * sizeof(float);
   RTG_KLAUNCH(stft_bwd_frame_kernel, dim3(rtg_ceil_div(d->frames, fpb), d->B), dim3(kStftThreads), lds, (hipStream_t)stream, *d,
               re, im, dmel, dspec, window, twiddle, binmel_idx, binmel_w, frame_ws);

@@ -487,7 +487,8 @@ __global__ __launch_bounds__(RTG_THREADS) void wgrad_group_kernel(const WgGroupA
 template <int TM, int MTW, int NTW, int WM, int MODE>
 int launch_group(const WgGroupArgs& ga, size_t lds_bytes, hipStream_t s) {
   auto k = wgrad_group_kernel<TM, MTW, NTW, WM, 2, MODE>;          // staging width of the members: PW <= 128 (host check)
-  if (lds_bytes > 64 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  static std::atomic<unsigned> optin{0};              // (> 64 KB of dynamic LDS: opt-in per kernel and device)
+  if (lds_bytes > 64 * 1024 && rtg_lds_optin((const void*)k, optin) != RTG_OK) return RTG_ERANGE;
   RTG_KLAUNCH(k, dim3(ga.blk_end[ga.n - 1]), dim3(RTG_THREADS), lds_bytes, s, ga);
   return rtg_launch_status();
 }
@@ -507,7 +508,8 @@ int launch_group_mode(int shape, const WgGroupArgs& ga, size_t lds_bytes, hipStr
 template <int TM, int MTW, int NTW, int WM, int MAXIT, int MODE>
 int launch(const WgArgs& a, dim3 grid, size_t lds_bytes, hipStream_t s) {
   auto k = wgrad_kernel<TM, MTW, NTW, WM, MAXIT, MODE>;
-  if (lds_bytes > 64 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  static std::atomic<unsigned> optin{0};              // (> 64 KB of dynamic LDS: opt-in per kernel and device)
+  if (lds_bytes > 64 * 1024 && rtg_lds_optin((const void*)k, optin) != RTG_OK) return RTG_ERANGE;
   RTG_KLAUNCH(k, grid, dim3(RTG_THREADS), lds_bytes, s, a);
   return rtg_launch_status();
 }

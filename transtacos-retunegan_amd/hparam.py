@@ -52,7 +52,7 @@ resblock_dilation_sizes = [[1, 2], [2, 6], [3, 12]]
 msd_layers = 3
 mpd_periods = [3, 5, 7, 11]
 multi_stft_params = [
-    # (n_fft, win_length, hop_length)
+    # (n_fft, win_length, hop_length); the STFT kernel takes n_fft = a power of two in 128 .. 4096 (RtgError otherwise)
     (2048, 1024, 240),
     (1024, 512, 120),
     (512, 256, 60),

@@ -203,7 +203,7 @@ class ConvLayer:
         # bf16 feature maps in HBM (hparam.bf16_maps with compute_dtype 'bf16'): a layer whose forward the dense kernel serves
         # stores bf16(leaky_relu(out, LRELU_SLOPE)) and reads such tensors natively (rtg/ops.py); only the discriminators'
         # dense layers qualify (fwd16 == 1: k5 1-D / 3-tap 2-D, dilation 1, >= 32 input and >= 64 output channels)
-        self.maps_bf = bool(want_bf and getattr(hp, 'bf16_maps', True) and self.fwd16 == 1 and self.kind in ('conv', 'conv2d') and
+        self.maps_bf = bool(want_bf and getattr(hp, 'bf16_maps', False) and self.fwd16 == 1 and self.kind in ('conv', 'conv2d') and
                             self.cout >= MAPS_BF_MIN_COUT)
         self.frag_bf = int(want_bf)           # the fragment images are bf16 with the layer
         self.fwd_bf = int(ok(self.fwd_op, self.fwd_tap))

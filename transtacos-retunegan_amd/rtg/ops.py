@@ -199,14 +199,16 @@ def _run_conv_t(d, x1, wp, bias, mask, res, out, flop, label, what, x_slope=1.0,
          (L.IO_MASK_BF16 if _is_bf(mask) else 0) | (L.IO_RES_BF16 if _is_bf(res) else 0)
     if io:
         x1 = _slacked(x1)
-        if _is_bf(x1) and d.pre_mode == L.PRE_LRELU and abs(d.pre_slope - x_slope) > 1e-6:
+        if _is_bf(x1) and abs(x_slope - 1.0) > 1e-6 and (d.pre_mode != L.PRE_LRELU or abs(d.pre_slope - x_slope) > 1e-6):
+            # (an encoded tensor holds leaky_relu(x, x_slope): only a layer that applies exactly that activation may read
+            # it as if it were x; a layer without pre-activation would silently convolve the activated values)
             raise L.RtgError(f'{label}: a bf16 activation tensor encoded with slope {x_slope} feeds a layer with pre-activation '
-                             f'slope {d.pre_slope}')
+                             f'{"none" if d.pre_mode != L.PRE_LRELU else d.pre_slope}')
         d.io_bf16, d.enc_slope = io, float(out_slope)
         if not _conv_native(d):
             # no native kernel at this shape: fp32 copies around the fp32 launch
             d.io_bf16, d.enc_slope = 0, 1.0
-            x32 = bf16_decode(x1, x_slope if d.pre_mode == L.PRE_LRELU else 1.0) if _is_bf(x1) else x1
+            x32 = bf16_decode(x1, x_slope) if _is_bf(x1) else x1
             m32 = bf16_decode(mask, 1.0) if _is_bf(mask) else mask
             r32 = bf16_decode(res, 1.0) if _is_bf(res) else res
             o32 = torch.empty(out.shape, device=out.device, dtype=torch.float32) if _is_bf(out) else out
@@ -229,18 +231,22 @@ def _run_conv(d, args, flop, label, what):
                  lambda: lib.rtg_conv1d(C.byref(d), *args), label, _conv_bytes(d, args) if PROFILE is not None else 0), what)
 
 
-def _wgrad_io(wd, ly, a1, gyt):
-    """bf16 operands of a weight gradient (x = a bf16 activation tensor and / or dy = a bf16 gradient): native where the
-    dense-layer kernel serves the shape (RtgWgradDesc.io_bf16), else fp32 copies.  -> (x, dy) to launch on"""
+def _wgrad_io(wd, ly, a1, gyt, x_encoded=True):
+    """bf16 operands of a weight gradient (x = a bf16 activation tensor, ENCODED with ENC_SLOPE unless `x_encoded` is False,
+    and / or dy = a plain bf16 gradient): native where the dense-layer kernel serves the shape (RtgWgradDesc.io_bf16), else
+    fp32 copies.  -> (x, dy) to launch on"""
     io = (L.IO_X_BF16 if _is_bf(a1) else 0) | (L.IO_OUT_BF16 if _is_bf(gyt) else 0)
     wd.io_bf16 = 0
     if io:
+        if _is_bf(a1) and x_encoded and (wd.pre_mode != L.PRE_LRELU or abs(wd.pre_slope - ENC_SLOPE) > 1e-6):
+            raise L.RtgError(f'wgrad {ly.name}: a bf16 activation tensor encoded with slope {ENC_SLOPE} feeds a layer with '
+                             f'pre-activation {"none" if wd.pre_mode != L.PRE_LRELU else wd.pre_slope}')
         a1, gyt = _slacked(a1), _slacked(gyt)
         wd.bf16, wd.io_bf16 = int(getattr(ly, 'wgrad_bf', 0)), io
         if not (wd.bf16 and _wgrad_native(wd)):
             wd.io_bf16 = 0
             if _is_bf(a1):
-                a1 = bf16_decode(a1, ENC_SLOPE if wd.pre_mode == L.PRE_LRELU else 1.0)
+                a1 = bf16_decode(a1, ENC_SLOPE if x_encoded else 1.0)
             if _is_bf(gyt):
                 gyt = bf16_decode(gyt, 1.0)
     return a1, gyt
@@ -621,7 +627,7 @@ class ConvFn(torch.autograd.Function):
             lc = L_out if ly.kind == 'conv' else L_in
             with wgrad_side(bank, (a1, a2, gyt, aux, dy)):
                 st = _stream()
-                a1, gyt = _wgrad_io(wd, ly, a1, gyt)
+                a1, gyt = _wgrad_io(wd, ly, a1, gyt, x_encoded=(ly.kind == 'conv'))
                 part, splits, immediate = _run_wgrad(wd, (_p(a1), _p(a2), _p(gyt), _p(aux)), st, bank, ly, ctx.tok_id,
                                                      _conv_flop(ly, B, lc), f'wgrad {ly.name} B{B} L{L_in}',
                                                      f'conv1d wgrad {ly.name}')
