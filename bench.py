@@ -151,11 +151,12 @@ def _src_digest():
     return h.hexdigest()[:16]
 
 
-def _pmc_for(prefix, workload='config2'):
+def _pmc_for(prefix, workload='config2', bf16_maps=False):
     """launch-weighted HBM bytes and matrix-pipe busy fraction of the kernels whose name starts with `prefix`, from the
-    newest profiles/*_bench_<workload>_pmc.json (None without a pass of this workload)"""
+    newest profiles/*_bench_<workload>[_bf16maps]_pmc.json (None without a pass of this workload AND this kind of feature
+    maps: a pass of the fp32-map build says nothing about the bytes the bf16-map kernels move)"""
     import glob
-    files = sorted(glob.glob(os.path.join(REPO, 'profiles', f'*_bench_{workload}_pmc.json')))
+    files = sorted(glob.glob(os.path.join(REPO, 'profiles', f'*_bench_{workload}{"_bf16maps" if bf16_maps else ""}_pmc.json')))
     if not files:
         return None
     doc = json.load(open(files[-1]))
@@ -177,7 +178,7 @@ def _pmc_for(prefix, workload='config2'):
             'source': 'profiles/' + os.path.basename(files[-1]), 'stale': bool(stale)}
 
 
-def roofline(trainer, batch, bf16=False, workload='config2'):
+def roofline(trainer, batch, bf16=False, workload='config2', bf16_maps=False):
     """Live per-kernel timing of extra (eager) steps: every conv launch bracketed by HIP events on its launch stream."""
     from rtg import ops
     # an eager step first (the timed steps were graph replays: allocator blocks and caches of the eager path are cold), then
@@ -230,10 +231,10 @@ def roofline(trainer, batch, bf16=False, workload='config2'):
     # HBM traffic and matrix-pipe occupancy of that kernel from the committed PMC passes (rocprofv3 --pmc cannot run inside
     # this process): profiles/*_pmc.json, written by tools/pmc_pass.sh + tools/pmc_summary.py from this same command
     if kernel == 'dconv':
-        pmc = _pmc_for('dconv_kernel<', workload)
+        pmc = _pmc_for('dconv_kernel<', workload, bf16_maps)
     else:
         pmc = _pmc_for(f'conv1d_mfma_group_kernel<{variant // 100}, {variant // 10 % 10}, {variant % 10},' if kernel == 'conv1d'
-                       else f'wgrad_kernel<{variant},', workload)
+                       else f'wgrad_kernel<{variant},', workload, bf16_maps)
     if pmc:                                  # (a pass of this workload: its instances and arithmetic type)
         out['traffic'] = pmc['traffic']
         out['traffic_unit'] = 'bytes/launch (HBM read + write, PMC FETCH_SIZE x2 + WRITE_SIZE)'
@@ -324,6 +325,8 @@ def main():
     a = parse()
     if a.gpus < 1:
         raise SystemExit('bench.py: --gpus must be >= 1')
+    if a.steps < 1 or a.warmup < 0:
+        raise SystemExit('bench.py: --steps must be >= 1 and --warmup >= 0')
     if 'WORLD_SIZE' not in os.environ and a.gpus > 1:
         return self_launch(a)
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -476,18 +479,29 @@ def main():
             el_ = t_.item()
         return el_, mine_, out_
 
-    # Exchange policy (data parallel only): both are set up and timed over 5 steps HERE, on the job's own ranks and links
-    # — round 4 picked 'update' from a 1-rank RCCL group, where an all-reduce moves no bytes — and the faster one (MAX over
-    # ranks, so every rank picks the same) runs the warm-up and the timed steps.  RTG_DP_CUT set: that policy, no trial.
-    exchange_trials = None
+    # Exchange policy (data parallel only): both are set up and timed HERE, on the job's own ranks and links — round 4 picked
+    # 'update' from a 1-rank RCCL group, where an all-reduce moves no bytes — each after `TRIAL_WARM` untimed steps, in two
+    # blocks of `TRIAL_STEPS` steps whose two readings are the trial's own spread (MAX over ranks, so every rank sees the same
+    # numbers).  The faster one by its better block runs the warm-up and the timed steps — unless the two are closer than the
+    # larger spread (box noise is 1-2 %): then the first policy of train.EXCHANGE_POLICIES, the compute-stream all-reduce with
+    # one graph segment per optimizer update.  RTG_DP_CUT set: that policy, no trial.
+    TRIAL_WARM, TRIAL_STEPS = 3, 8
+    exchange_trials = exchange_blocks = None
     if multi and 'RTG_DP_CUT' not in os.environ:
-        exchange_trials = {}
+        exchange_trials, exchange_blocks = {}, {}
         for pol in train_mod.EXCHANGE_POLICIES:
             step, mode = setup_step(pol)
-            step(*next_batch())
-            exchange_trials[pol] = round(timed(step, 5)[0] / 5 * 1e3, 3)
-            note(f'exchange {pol!r}: {exchange_trials[pol]} ms/step over 5 steps ({mode})')
+            for _ in range(TRIAL_WARM):
+                step(*next_batch())
+            blocks = [round(timed(step, TRIAL_STEPS)[0] / TRIAL_STEPS * 1e3, 3) for _ in range(2)]
+            exchange_blocks[pol] = blocks
+            exchange_trials[pol] = min(blocks)
+            note(f'exchange {pol!r}: {blocks} ms/step over 2 x {TRIAL_STEPS} steps ({mode})')
+        first = train_mod.EXCHANGE_POLICIES[0]
         best = min(train_mod.EXCHANGE_POLICIES, key=lambda p_: exchange_trials[p_])
+        spread = max(abs(b[0] - b[1]) for b in exchange_blocks.values())
+        if best != first and exchange_trials[first] - exchange_trials[best] <= spread:
+            best = first                                    # (within the trial's own noise: the simpler policy)
         if best != tr.dp.exchange:
             step, mode = setup_step(best)
     else:
@@ -518,7 +532,7 @@ def main():
     if not a.no_roofline:
         # every rank runs the instrumented steps (they are train steps: under data parallelism their gradient all-reduces
         # need all ranks), rank 0 reports its own launches
-        roof = roofline(tr, data, bf16=dtype == 'bf16', workload=a.workload)
+        roof = roofline(tr, data, bf16=dtype == 'bf16', workload=a.workload, bf16_maps=bool(hp.bf16_maps))
     if multi:
         dist.barrier()
     cpu = None
@@ -542,10 +556,14 @@ def main():
                                                  + ('on the compute stream, graphs cut per optimizer update' if tr.dp.exchange == 'update'
                                                     else 'on a high-priority communication stream from the banks\' flush hooks, graphs cut per discriminator')
                                                  + ('' if mode.startswith('hip-graph') else ' (eager step)')),
-                                        'chosen_by': ('RTG_DP_CUT' if exchange_trials is None else '5 timed steps per policy in set-up (MAX over ranks)'),
-                                        'trial_ms_per_step': exchange_trials}} if per_rank else {})},
+                                        'chosen_by': ('RTG_DP_CUT' if exchange_trials is None else
+                                                      f'{TRIAL_WARM} untimed + 2 x {TRIAL_STEPS} timed steps per policy in set-up (MAX over ranks); the '
+                                                      f'better block decides, a difference inside the blocks\' spread keeps {train_mod.EXCHANGE_POLICIES[0]!r}'),
+                                        'trial_ms_per_step': exchange_trials, 'trial_blocks_ms_per_step': exchange_blocks}} if per_rank else {})},
             'knobs': rtg_config.non_default(),       # environment switches set to a non-default value (rtg/config.py)
             'roofline': roof, 'cpu_baseline': cpu,
+            **({'cpu_baseline_ref': 'timed on rank 0 at N = 1 only (the --gpus 1 line of the same sources carries it): the host cores are '
+                                    'busy with the other ranks here'} if world > 1 else {}),
             'final_losses': {'gen_all': round(loss_g, 4), 'disc_all': round(loss_d, 4)},
         }
         print(json.dumps(out), flush=True)

@@ -263,6 +263,7 @@ def test_stft_sizes_outside_the_reference_defaults(oracle, gold, n_fft, win, hop
     assert d[big].max().item() < 2e-3
     np.testing.assert_allclose(mel.detach().cpu().numpy(), M.detach().numpy(), rtol=2e-4, atol=2e-6)
     cs = torch.randn(spec.shape, generator=gen)
+    cs[:, 1] *= big.float()       # (d angle / dD ~ 1 / |D|: a phase cotangent at a weak bin measures fp32 rounding, not the kernel)
     cm = torch.randn(mel.shape, generator=gen)
     ((spec * cs.to(DEV)).sum() + (mel * cm.to(DEV)).sum()).backward()
     o = torch.stack([torch.log(S), P / oracle.PI], dim=1)
