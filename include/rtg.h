@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define RTG_ABI_VERSION 10
+#define RTG_ABI_VERSION 11
 
 #define RTG_OK 0
 #define RTG_EINVAL (-1)   /* inconsistent descriptor               */
@@ -349,6 +349,30 @@ int rtg_stft_backward(const RtgStftDesc* d, const float* re, const float* im, co
                       const int* binmel_idx, const float* binmel_w,   /* per bin: 2 (filter, weight) pairs          */
                       float* frame_ws,                                 /* workspace [B*frames*win]                   */
                       float* dy, void* stream);
+
+/* (ABI 11) Several (resolution, signal) jobs in ONE launch per kernel: multi_stft_loss (retunegan/models/loss.py:30-52) runs
+ * hparam.multi_stft_params' three resolutions on the real and on the generated wave — six calls of get_stft_torch
+ * (retunegan/audio.py:150-170), launch-shaped rather than byte-shaped on the GPU.  A job = the descriptor and the operands
+ * of rtg_stft_forward / rtg_stft_backward.  The `jobs` array is HOST memory (copied into the launch's arguments).
+ * rtg_stft_backward_multi: the jobs are the resolutions of ONE wave [B, T] (equal B, T or RTG_EINVAL); dy[b,t] =
+ * (accumulate ? dy[b,t] : 0) + the jobs' contributions in job order — no zero-filled dy needed, no atomics. */
+#define RTG_STFT_MAX_JOBS 8
+typedef struct RtgStftFwdJob {
+  RtgStftDesc d;
+  const float *y, *window, *twiddle;
+  const int *mel_lo, *mel_len, *mel_woff;
+  const float* mel_w;
+  float *mel, *spec, *re, *im;       /* mel, spec, (re, im) may be NULL as in rtg_stft_forward */
+} RtgStftFwdJob;
+typedef struct RtgStftBwdJob {
+  RtgStftDesc d;
+  const float *re, *im, *dmel, *dspec, *window, *twiddle;     /* dmel, dspec may be NULL */
+  const int* binmel_idx;
+  const float* binmel_w;
+  float* frame_ws;                   /* [B * frames * win] scratch of this job */
+} RtgStftBwdJob;
+int rtg_stft_forward_multi(int n, const RtgStftFwdJob* jobs, void* stream);
+int rtg_stft_backward_multi(int n, const RtgStftBwdJob* jobs, float* dy, int accumulate, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Small fused element-wise / reduction kernels of the path

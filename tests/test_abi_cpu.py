@@ -82,7 +82,7 @@ def test_integration_md_binding_stub_is_the_real_struct():
 def test_abi_version_and_host_side_queries(built):
     from rtg.lib import lib, Conv1dDesc, WgradDesc
     from rtg.lib import ABI_VERSION
-    assert lib.rtg_abi_version() == ABI_VERSION == 10
+    assert lib.rtg_abi_version() == ABI_VERSION == 11
     assert b'gfx950' in lib.rtg_build_info()
     # packed sizes: [groups][m-tiles][c-chunks][taps][16 channels][tile_m rows]
     assert lib.rtg_packed_size(1, 32, 32, 7, 32) == 1 * 1 * 2 * 7 * 16 * 32

@@ -272,6 +272,52 @@ def test_stft_sizes_outside_the_reference_defaults(oracle, gold, n_fft, win, hop
     assert err < 5e-3, (n_fft, err)
 
 
+@pytest.mark.parametrize('want_spec', [False, True])
+def test_all_resolutions_in_one_launch_equal_one_launch_each(gold, want_spec):
+    """audio.multi_stft_mel_spec (rtg_stft_forward_multi / rtg_stft_backward_multi: the three resolutions of multi_stft_loss on the
+    generated and the real wave in one launch, one frame launch + one overlap-add backward) against stft_mel_spec per
+    resolution: the same bits forward and per resolution backward."""
+    import hparam as hp
+    from audio import stft_mel_spec, multi_stft_mel_spec
+    yd = torch.from_numpy(gold['y_hat']).squeeze(1).to(DEV)
+    yr = torch.flip(yd, dims=[1]).contiguous()
+    gen = torch.Generator().manual_seed(5)
+    y1 = yd.clone().requires_grad_(True)
+    y2 = yd.clone().requires_grad_(True)
+    (mels, specs), (mels_r, specs_r) = multi_stft_mel_spec(y1, hp.multi_stft_params, want_spec, y_real=yr)
+    assert all(not t.requires_grad for t in mels_r) and all(t.requires_grad for t in mels)
+    tot1 = tot2 = 0
+    for i, (n_fft, win, hop) in enumerate(hp.multi_stft_params):
+        m, sp = stft_mel_spec(y2, n_fft, win, hop, want_spec)
+        with torch.no_grad():
+            mr, spr = stft_mel_spec(yr, n_fft, win, hop, want_spec)
+        assert torch.equal(m, mels[i]) and torch.equal(mr, mels_r[i])
+        cm = torch.randn(m.shape, generator=gen).to(DEV)
+        tot1 = tot1 + (mels[i] * cm).sum()
+        tot2 = tot2 + (m * cm).sum()
+        if want_spec:
+            assert specs[i].shape == sp.shape and torch.equal(sp, specs[i]) and torch.equal(spr, specs_r[i])
+            cs = torch.randn(sp.shape, generator=gen).to(DEV)
+            tot1 = tot1 + (specs[i] * cs).sum()
+            tot2 = tot2 + (sp * cs).sum()
+        else:
+            assert specs[i] is None and specs_r[i] is None
+    tot1.backward()
+    tot2.backward()
+    # (one launch adds a sample's three contributions in resolution order, autograd adds the three launches' tensors in its own:
+    # equal up to the rounding of two additions)
+    np.testing.assert_allclose(y1.grad.cpu().numpy(), y2.grad.cpu().numpy(), rtol=1e-5, atol=1e-5 * y2.grad.abs().max().item())
+    # a subset of the resolutions carrying a gradient, and the generated wave alone (the real one's spectra cached)
+    y3 = yd.clone().requires_grad_(True)
+    y4 = yd.clone().requires_grad_(True)
+    mels3, _ = multi_stft_mel_spec(y3, hp.multi_stft_params, want_spec)
+    n_fft, win, hop = hp.multi_stft_params[1]
+    m4, _ = stft_mel_spec(y4, n_fft, win, hop, want_spec)
+    mels3[1].sum().backward()
+    m4.sum().backward()
+    assert torch.equal(y3.grad, y4.grad)
+
+
 def test_stft_size_that_is_not_served_fails_loudly():
     from audio import stft_mel_spec
     from rtg.lib import RtgError

@@ -101,6 +101,21 @@ def stft_mel_spec(y, n_fft, win_length, hop_length, want_spec=False):
     return mel, spec
 
 
+def multi_stft_mel_spec(y, params, want_spec=False, y_real=None):
+    """every (n_fft, win_length, hop_length) of `params` on y [B,T] — and on the constant y_real, if given — in one launch
+    (ops.MultiStftFn).  -> (mels, specs) of y, or ((mels, specs), (mels_real, specs_real)); entries as stft_mel_spec's."""
+    plans = [get_plan(*p) for p in params]
+    n = len(plans)
+    out = ops.MultiStftFn.apply(y, y_real, want_spec, *plans)
+
+    def view(s):
+        return s.transpose(2, 3) if (s is not None and ops.SPEC_FREQ_MAJOR) else s
+    mine = (list(out[:n]), [view(s) for s in out[n:2 * n]])
+    if y_real is None:
+        return mine
+    return mine, (list(out[2 * n:3 * n]), [view(s) for s in out[3 * n:4 * n]])
+
+
 def get_stft_torch(y, n_fft, win_length, hop_length):
     """audio.py:150-170: returns (S, M, P) = (|D + 1e-9|, mel_basis @ S, angle(D)).  API-compatibility wrapper;
     the train step consumes `stft_mel_spec` directly (log-magnitude / phase-over-PI straight from the kernel)."""

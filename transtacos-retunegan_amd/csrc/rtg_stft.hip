@@ -85,19 +85,16 @@ __device__ __forceinline__ cpx* fft_half(cpx* a, cpx* b, int M, int t0, int TPF,
 
 constexpr int kStftThreads = 256;
 
-__global__ __launch_bounds__(kStftThreads) void stft_fwd_kernel(RtgStftDesc d, const float* __restrict__ y,
-                                                                const float* __restrict__ window,
-                                                                const float* __restrict__ twiddle,
-                                                                const int* __restrict__ mel_lo,
-                                                                const int* __restrict__ mel_len,
-                                                                const int* __restrict__ mel_woff,
-                                                                const float* __restrict__ mel_w, float* mel, float* spec,
-                                                                float* re_out, float* im_out) {
+__device__ __forceinline__ void stft_fwd_body(const RtgStftDesc& d, const float* __restrict__ y,
+                                              const float* __restrict__ window, const float* __restrict__ twiddle,
+                                              const int* __restrict__ mel_lo, const int* __restrict__ mel_len,
+                                              const int* __restrict__ mel_woff, const float* __restrict__ mel_w,
+                                              float* mel, float* spec, float* re_out, float* im_out, int fblock, int b) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int N = d.n_fft, M = N >> 1, F = M + 1;
   const int TPF = min(M >> 2, kStftThreads), FPB = kStftThreads / TPF;   // threads per frame, frames per block
   const int fl = threadIdx.x / TPF, t = threadIdx.x - fl * TPF;
-  const int frame = blockIdx.x * FPB + fl, b = blockIdx.y;
+  const int frame = fblock * FPB + fl;
   const bool live = frame < d.frames;
   float* base = smem + (size_t)fl * (4 * M + F + 3);         // per frame: two buffers of M complex points, F magnitudes
   cpx* A = reinterpret_cast<cpx*>(base);
@@ -168,20 +165,49 @@ __global__ __launch_bounds__(kStftThreads) void stft_fwd_kernel(RtgStftDesc d, c
   }
 }
 
-__global__ __launch_bounds__(kStftThreads) void stft_bwd_frame_kernel(RtgStftDesc d, const float* __restrict__ re_in,
-                                                                      const float* __restrict__ im_in,
-                                                                      const float* __restrict__ dmel,
-                                                                      const float* __restrict__ dspec,
-                                                                      const float* __restrict__ window,
-                                                                      const float* __restrict__ twiddle,
-                                                                      const int* __restrict__ binmel_idx,
-                                                                      const float* __restrict__ binmel_w,
-                                                                      float* __restrict__ frame_ws) {
+// Several (resolution, signal) jobs in ONE launch (round 6): multi_stft_loss runs three resolutions on the real and the
+// generated wave — six forward launches of 14-17 us that move 6 MB each (launch-shaped, not byte-shaped), three backward
+// frame launches and three overlap-adds on the generator's serial chain.  grid.x enumerates the jobs' frame blocks one job
+// after the other (blk_end = running sums), grid.y the clips; a block whose clip index is past its job's batch returns.
+constexpr int kStftMaxJobs = RTG_STFT_MAX_JOBS;
+using StftFwdJob = RtgStftFwdJob;          // (include/rtg.h: descriptor + the operands of rtg_stft_forward)
+struct StftFwdJobs {
+  int n;
+  int blk_end[kStftMaxJobs];
+  StftFwdJob j[kStftMaxJobs];
+};
+
+__global__ __launch_bounds__(kStftThreads) void stft_fwd_kernel(RtgStftDesc d, const float* __restrict__ y,
+                                                                const float* __restrict__ window,
+                                                                const float* __restrict__ twiddle,
+                                                                const int* __restrict__ mel_lo,
+                                                                const int* __restrict__ mel_len,
+                                                                const int* __restrict__ mel_woff,
+                                                                const float* __restrict__ mel_w, float* mel, float* spec,
+                                                                float* re_out, float* im_out) {
+  stft_fwd_body(d, y, window, twiddle, mel_lo, mel_len, mel_woff, mel_w, mel, spec, re_out, im_out, blockIdx.x, blockIdx.y);
+}
+
+__global__ __launch_bounds__(kStftThreads) void stft_fwd_multi_kernel(const StftFwdJobs js) {
+  int ji = 0;
+  while (ji + 1 < js.n && (int)blockIdx.x >= js.blk_end[ji]) ++ji;           // (block-uniform)
+  const StftFwdJob& q = js.j[ji];
+  if ((int)blockIdx.y >= q.d.B) return;
+  stft_fwd_body(q.d, q.y, q.window, q.twiddle, q.mel_lo, q.mel_len, q.mel_woff, q.mel_w, q.mel, q.spec, q.re, q.im,
+                (int)blockIdx.x - (ji ? js.blk_end[ji - 1] : 0), blockIdx.y);
+}
+
+__device__ __forceinline__ void stft_bwd_frame_body(const RtgStftDesc& d, const float* __restrict__ re_in,
+                                                    const float* __restrict__ im_in, const float* __restrict__ dmel,
+                                                    const float* __restrict__ dspec, const float* __restrict__ window,
+                                                    const float* __restrict__ twiddle, const int* __restrict__ binmel_idx,
+                                                    const float* __restrict__ binmel_w, float* __restrict__ frame_ws,
+                                                    int fblock, int b) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int N = d.n_fft, M = N >> 1, F = M + 1;
   const int TPF = min(M >> 2, kStftThreads), FPB = kStftThreads / TPF;
   const int fl = threadIdx.x / TPF, t = threadIdx.x - fl * TPF;
-  const int frame = blockIdx.x * FPB + fl, b = blockIdx.y;
+  const int frame = fblock * FPB + fl;
   const bool live = frame < d.frames;
   // per frame: two buffers of M complex points, the F cotangents conj-weighted H[f] (2 F floats), n_mel mel cotangents
   float* base = smem + (size_t)fl * (4 * M + 2 * F + 256 + 2);
@@ -247,12 +273,20 @@ __global__ __launch_bounds__(kStftThreads) void stft_bwd_frame_kernel(RtgStftDes
   }
 }
 
-// dy[b,t] += sum over the (<= 3) padded positions that alias to t of the frames covering them.
-__global__ __launch_bounds__(RTG_THREADS) void stft_ola_kernel(RtgStftDesc d, const float* __restrict__ frame_ws,
-                                                               float* __restrict__ dy) {
-  const int b = blockIdx.y;
-  const int t = blockIdx.x * RTG_THREADS + threadIdx.x;
-  if (t >= d.T) return;
+__global__ __launch_bounds__(kStftThreads) void stft_bwd_frame_kernel(RtgStftDesc d, const float* __restrict__ re_in,
+                                                                      const float* __restrict__ im_in,
+                                                                      const float* __restrict__ dmel,
+                                                                      const float* __restrict__ dspec,
+                                                                      const float* __restrict__ window,
+                                                                      const float* __restrict__ twiddle,
+                                                                      const int* __restrict__ binmel_idx,
+                                                                      const float* __restrict__ binmel_w,
+                                                                      float* __restrict__ frame_ws) {
+  stft_bwd_frame_body(d, re_in, im_in, dmel, dspec, window, twiddle, binmel_idx, binmel_w, frame_ws, blockIdx.x, blockIdx.y);
+}
+
+// sum over the (<= 3) padded positions that alias to sample t of clip b of the frames covering them
+__device__ __forceinline__ float stft_ola_at(const RtgStftDesc& d, const float* __restrict__ frame_ws, int b, int t) {
   const int N = d.n_fft, half = N / 2, lpad = (N - d.win) / 2;
   const float* ws = frame_ws + (size_t)b * d.frames * d.win;
   int src[3];
@@ -272,7 +306,44 @@ __global__ __launch_bounds__(RTG_THREADS) void stft_ola_kernel(RtgStftDesc d, co
     if (hi > d.frames - 1) hi = d.frames - 1;
     for (int i = lo; i <= hi; ++i) acc += ws[(size_t)i * d.win + (pi - lpad - i * d.hop)];
   }
-  dy[(size_t)b * d.T + t] += acc;
+  return acc;
+}
+
+// dy[b,t] += the overlap-add of one resolution
+__global__ __launch_bounds__(RTG_THREADS) void stft_ola_kernel(RtgStftDesc d, const float* __restrict__ frame_ws,
+                                                               float* __restrict__ dy) {
+  const int b = blockIdx.y;
+  const int t = blockIdx.x * RTG_THREADS + threadIdx.x;
+  if (t >= d.T) return;
+  dy[(size_t)b * d.T + t] += stft_ola_at(d, frame_ws, b, t);
+}
+
+using StftBwdJob = RtgStftBwdJob;          // (include/rtg.h: descriptor + the operands of rtg_stft_backward but dy)
+struct StftBwdJobs {
+  int n;
+  int blk_end[kStftMaxJobs];
+  StftBwdJob j[kStftMaxJobs];
+};
+
+__global__ __launch_bounds__(kStftThreads) void stft_bwd_frame_multi_kernel(const StftBwdJobs js) {
+  int ji = 0;
+  while (ji + 1 < js.n && (int)blockIdx.x >= js.blk_end[ji]) ++ji;
+  const StftBwdJob& q = js.j[ji];
+  if ((int)blockIdx.y >= q.d.B) return;
+  stft_bwd_frame_body(q.d, q.re, q.im, q.dmel, q.dspec, q.window, q.twiddle, q.binmel_idx, q.binmel_w, q.frame_ws,
+                      (int)blockIdx.x - (ji ? js.blk_end[ji - 1] : 0), blockIdx.y);
+}
+
+// the resolutions of ONE wave [B, T] (every job has the same B, T): dy[b,t] = (accumulate ? dy[b,t] : 0) + the jobs' overlap-adds
+// in job order — one thread owns a sample over all resolutions, so the launch needs neither a zeroed dy nor atomics
+__global__ __launch_bounds__(RTG_THREADS) void stft_ola_multi_kernel(const StftBwdJobs js, float* __restrict__ dy, int accumulate) {
+  const int b = blockIdx.y;
+  const int t = blockIdx.x * RTG_THREADS + threadIdx.x;
+  const int T = js.j[0].d.T;
+  if (t >= T) return;
+  float acc = accumulate ? dy[(size_t)b * T + t] : 0.f;
+  for (int ji = 0; ji < js.n; ++ji) acc += stft_ola_at(js.j[ji].d, js.j[ji].frame_ws, b, t);
+  dy[(size_t)b * T + t] = acc;
 }
 
 int validate(const RtgStftDesc* d) {
@@ -319,5 +390,72 @@ extern "C" int rtg_stft_backward(const RtgStftDesc* d, const float* re, const fl
   if (e) return e;
   RTG_KLAUNCH(stft_ola_kernel, dim3(rtg_ceil_div(d->T, RTG_THREADS), d->B), dim3(RTG_THREADS), 0,
                      (hipStream_t)stream, *d, frame_ws, dy);
+  return rtg_launch_status();
+}
+
+// ---- several (resolution, signal) jobs in one launch per kernel (ABI 11)
+static size_t stft_lds_fwd(const RtgStftDesc* d) {
+  const int M = d->n_fft / 2, fpb = kStftThreads / (M / 4 < kStftThreads ? M / 4 : kStftThreads);
+  return (size_t)fpb * (4 * M + M + 1 + 3) * sizeof(float);
+}
+static size_t stft_lds_bwd(const RtgStftDesc* d) {
+  const int M = d->n_fft / 2, fpb = kStftThreads / (M / 4 < kStftThreads ? M / 4 : kStftThreads);
+  return (size_t)fpb * (4 * M + 2 * (M + 1) + 256 + 2) * sizeof(float);
+}
+static int stft_fblocks(const RtgStftDesc* d) {
+  const int M = d->n_fft / 2, fpb = kStftThreads / (M / 4 < kStftThreads ? M / 4 : kStftThreads);
+  return rtg_ceil_div(d->frames, fpb);
+}
+
+extern "C" int rtg_stft_forward_multi(int n, const RtgStftFwdJob* jobs, void* stream) {
+  if (!jobs) return RTG_ENULL;
+  if (n < 1 || n > kStftMaxJobs) return RTG_EINVAL;
+  StftFwdJobs js;
+  js.n = n;
+  size_t lds = 0;
+  int end = 0, maxB = 0;
+  for (int i = 0; i < n; ++i) {
+    const RtgStftFwdJob& q = jobs[i];
+    if (!q.y || !q.window || !q.twiddle) return RTG_ENULL;
+    const int st = validate(&q.d);
+    if (st) return st;
+    if (q.mel && (!q.mel_lo || !q.mel_len || !q.mel_woff || !q.mel_w)) return RTG_ENULL;
+    if ((q.re == nullptr) != (q.im == nullptr)) return RTG_EINVAL;
+    js.j[i] = q;
+    end += stft_fblocks(&q.d);
+    js.blk_end[i] = end;
+    lds = stft_lds_fwd(&q.d) > lds ? stft_lds_fwd(&q.d) : lds;
+    maxB = q.d.B > maxB ? q.d.B : maxB;
+  }
+  for (int i = n; i < kStftMaxJobs; ++i) js.blk_end[i] = end;
+  RTG_KLAUNCH(stft_fwd_multi_kernel, dim3(end, maxB), dim3(kStftThreads), lds, (hipStream_t)stream, js);
+  return rtg_launch_status();
+}
+
+extern "C" int rtg_stft_backward_multi(int n, const RtgStftBwdJob* jobs, float* dy, int accumulate, void* stream) {
+  if (!jobs || !dy) return RTG_ENULL;
+  if (n < 1 || n > kStftMaxJobs) return RTG_EINVAL;
+  StftBwdJobs js;
+  js.n = n;
+  size_t lds = 0;
+  int end = 0;
+  for (int i = 0; i < n; ++i) {
+    const RtgStftBwdJob& q = jobs[i];
+    if (!q.re || !q.im || !q.window || !q.twiddle || !q.frame_ws) return RTG_ENULL;
+    const int st = validate(&q.d);
+    if (st) return st;
+    if (q.dmel && (!q.binmel_idx || !q.binmel_w)) return RTG_ENULL;
+    if (q.d.B != jobs[0].d.B || q.d.T != jobs[0].d.T) return RTG_EINVAL;        // the resolutions of ONE wave
+    js.j[i] = q;
+    end += stft_fblocks(&q.d);
+    js.blk_end[i] = end;
+    lds = stft_lds_bwd(&q.d) > lds ? stft_lds_bwd(&q.d) : lds;
+  }
+  for (int i = n; i < kStftMaxJobs; ++i) js.blk_end[i] = end;
+  RTG_KLAUNCH(stft_bwd_frame_multi_kernel, dim3(end, jobs[0].d.B), dim3(kStftThreads), lds, (hipStream_t)stream, js);
+  int e = rtg_launch_status();
+  if (e) return e;
+  RTG_KLAUNCH(stft_ola_multi_kernel, dim3(rtg_ceil_div(jobs[0].d.T, RTG_THREADS), jobs[0].d.B), dim3(RTG_THREADS), 0,
+              (hipStream_t)stream, js, dy, accumulate);
   return rtg_launch_status();
 }

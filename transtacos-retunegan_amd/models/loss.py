@@ -7,7 +7,7 @@ import torch.nn as nn  # noqa: F401
 import torch.nn.functional as F  # noqa: F401
 
 import hparam as hp
-from audio import get_stft_torch, stft_mel_spec  # noqa: F401
+from audio import get_stft_torch, stft_mel_spec, multi_stft_mel_spec  # noqa: F401
 from utils import PI  # noqa: F401
 from rtg import ops
 from rtg.lib import LOSS_L1, LOSS_L1_L1LOG, LOSS_L1_ENC, LOSS_MSE_TARGET, LOSS_MSE_REL, MAX_LOSS_JOBS, RtgError  # noqa: F401
@@ -28,20 +28,17 @@ class stft_cache:
         _real_cache.clear()
 
 
-def _real_specs(y, want_spec):
-    key = (y.data_ptr(), tuple(y.shape), y._version)
+def _real_key(y):
+    return (y.data_ptr(), tuple(y.shape), y._version)
+
+
+def _real_hit(y, want_spec):
+    """the cached spectra of the real wave (inside a stft_cache context), or None"""
     if _real_cache.get('on'):
-        hit = _real_cache.get(key)
+        hit = _real_cache.get(_real_key(y))
         if hit is not None and (not want_spec or hit[1][0] is not None):
             return hit
-    with torch.no_grad():
-        mels, specs = [], []
-        for n_fft, win, hop in hp.multi_stft_params:
-            m, s = stft_mel_spec(y, n_fft, win, hop, want_spec)
-            mels.append(m); specs.append(s)
-    if _real_cache.get('on'):
-        _real_cache[key] = (mels, specs)
-    return mels, specs
+    return None
 
 
 def multi_stft_loss(y, y_g, ret_loss=False, ret_specs=False):
@@ -55,11 +52,15 @@ def multi_stft_loss(y, y_g, ret_loss=False, ret_specs=False):
         y, y_g = y.squeeze(1), y_g.squeeze(1)
     if y.requires_grad:
         raise RtgError('multi_stft_loss: the real wave is treated as a constant (as in retunegan/train.py)')
-    mels_r, specs_r = _real_specs(y, ret_specs)
-    mels_g, specs_g = [], []
-    for n_fft, win, hop in hp.multi_stft_params:
-        m, s = stft_mel_spec(y_g, n_fft, win, hop, ret_specs)
-        mels_g.append(m); specs_g.append(s)
+    # every resolution of the generated wave — and of the real one unless its spectra are cached — in ONE launch
+    # (audio.multi_stft_mel_spec; rounds 1-5: a launch per resolution and wave, six of 14-17 us per loss call)
+    hit = _real_hit(y, ret_specs)
+    if hit is not None:
+        (mels_r, specs_r), (mels_g, specs_g) = hit, multi_stft_mel_spec(y_g, hp.multi_stft_params, ret_specs)
+    else:
+        (mels_g, specs_g), (mels_r, specs_r) = multi_stft_mel_spec(y_g, hp.multi_stft_params, ret_specs, y_real=y)
+        if _real_cache.get('on'):
+            _real_cache[_real_key(y)] = (mels_r, specs_r)
     loss = None
     if ret_loss:
         n = len(hp.multi_stft_params)

@@ -91,6 +91,19 @@ class StftDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in ('B', 'T', 'n_fft', 'win', 'hop', 'frames', 'n_mel', 'spec_T')]
 
 
+STFT_MAX_JOBS = 8
+
+
+class StftFwdJob(C.Structure):      # RtgStftFwdJob (ABI 11)
+    _fields_ = [('d', StftDesc)] + [(n, C.c_void_p) for n in ('y', 'window', 'twiddle', 'mel_lo', 'mel_len', 'mel_woff', 'mel_w',
+                                                               'mel', 'spec', 're', 'im')]
+
+
+class StftBwdJob(C.Structure):      # RtgStftBwdJob (ABI 11)
+    _fields_ = [('d', StftDesc)] + [(n, C.c_void_p) for n in ('re', 'im', 'dmel', 'dspec', 'window', 'twiddle', 'binmel_idx',
+                                                               'binmel_w', 'frame_ws')]
+
+
 PRE_NONE, PRE_LRELU, PRE_MUL_DLRELU, PRE_MUL_DTANH = 0, 1, 2, 3
 ACT_NONE, ACT_LRELU, ACT_TANH = 0, 1, 2
 PACK_FWD, PACK_DGRAD_S1, PACK_DGRAD_POLY, PACK_CONVT_POLY, PACK_DGRAD_2D, PACK_GCONV_FWD, PACK_GCONV_BWD, PACK_GMFMA_FWD = 0, 1, 2, 3, 4, 5, 6, 7
@@ -99,7 +112,7 @@ CK = 16
 LOSS_L1, LOSS_L1_L1LOG, LOSS_MSE_TARGET, LOSS_MSE_REL, LOSS_L1_ENC = 0, 1, 2, 3, 4
 MAX_LOSS_JOBS = 48
 
-ABI_VERSION = 10           # RTG_ABI_VERSION of include/rtg.h these struct layouts / prototypes were written for
+ABI_VERSION = 11           # RTG_ABI_VERSION of include/rtg.h these struct layouts / prototypes were written for
 _P = C.c_void_p
 _I, _F, _D, _LL, _ULL = C.c_int, C.c_float, C.c_double, C.c_longlong, C.c_ulonglong
 
@@ -135,6 +148,8 @@ PROTOTYPES = {
     'rtg_weightnorm_backward': (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P]),
     'rtg_stft_forward': (_I, [C.POINTER(StftDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'rtg_stft_backward': (_I, [C.POINTER(StftDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'rtg_stft_forward_multi': (_I, [_I, C.POINTER(StftFwdJob), _P]),
+    'rtg_stft_backward_multi': (_I, [_I, C.POINTER(StftBwdJob), _P, _I, _P]),
     'rtg_noise_lrelu_fwd': (_I, [_P, _P, _P, _P, _LL, _F, _ULL, _P, _P]),
     'rtg_noise_lrelu_bwd': (_I, [_P, _P, _P, _P, _P, _P, _I, _LL, _F, _ULL, _P, _P]),
     'rtg_noise_lrelu_bwd_acc': (_I, [_P, _P, _P, _P, _P, _P, _I, _LL, _F, _ULL, _P, _P, _P]),

@@ -1521,6 +1521,93 @@ class StripMirrorFn(torch.autograd.Function):
 SPEC_FREQ_MAJOR = True     # the spectrogram maps are kept [B, 2, frames, F] in HBM (StftFn hands out the transposed view)
 
 
+class MultiStftFn(torch.autograd.Function):
+    """The resolutions `plans` of multi_stft_loss (retunegan/models/loss.py:30-52) on the generated wave y [B,T] — and, with
+    `y_real` [B,T] (a constant), on the real wave too — in ONE forward launch (rtg_stft_forward_multi); the backward is one frame
+    launch plus one overlap-add over all resolutions (rtg_stft_backward_multi).  Returns (mel_0, .., spec_0 | None, ..) of y,
+    then the same of y_real (non-differentiable) when given.  spec as in StftFn."""
+
+    @staticmethod
+    def forward(ctx, y, y_real, want_spec, *plans):
+        _need_cuda(y)
+        y = _c(y)
+        sigs = [y] + ([_c(y_real)] if y_real is not None else [])
+        need_bwd = ctx.needs_input_grad[0]
+        n = len(plans)
+        if n * len(sigs) > L.STFT_MAX_JOBS:
+            raise L.RtgError(f'multi-STFT: {n} resolutions x {len(sigs)} waves exceed {L.STFT_MAX_JOBS} jobs per launch')
+        jobs = (L.StftFwdJob * (n * len(sigs)))()
+        outs, saved, nbytes = [], [], 0
+        spec_t = int(SPEC_FREQ_MAJOR)
+        for si, sig in enumerate(sigs):
+            B, T = sig.shape
+            dev = sig.device
+            mels, specs = [], []
+            for pi, plan in enumerate(plans):
+                frames, F = 1 + T // plan.hop, plan.n_fft // 2 + 1
+                t = plan.tensors(dev)
+                mel = torch.empty(B, plan.n_mel, frames, device=dev)
+                spec = (torch.empty(B, 2, frames, F, device=dev) if spec_t else torch.empty(B, 2, F, frames, device=dev)) if want_spec else None
+                keep = need_bwd and si == 0
+                re = torch.empty(B, frames, F, device=dev) if keep else None
+                im = torch.empty(B, frames, F, device=dev) if keep else None
+                j = jobs[si * n + pi]
+                j.d = L.StftDesc(B, T, plan.n_fft, plan.win, plan.hop, frames, plan.n_mel, spec_t)
+                j.y, j.window, j.twiddle = sig.data_ptr(), t['window'].data_ptr(), t['twiddle'].data_ptr()
+                j.mel_lo, j.mel_len, j.mel_woff, j.mel_w = (t[k].data_ptr() for k in ('mel_lo', 'mel_len', 'mel_woff', 'mel_w'))
+                j.mel, j.spec = mel.data_ptr(), (spec.data_ptr() if want_spec else None)
+                j.re, j.im = (re.data_ptr(), im.data_ptr()) if keep else (None, None)
+                nbytes += 4 * (sig.numel() + mel.numel() + (spec.numel() if want_spec else 0) + (2 * re.numel() if keep else 0))
+                mels.append(mel); specs.append(spec)
+                if keep:
+                    saved += [re, im]
+            outs.append((mels, specs))
+        B, T = y.shape
+        check(timed_bw('stft_fwd', nbytes, lambda: lib.rtg_stft_forward_multi(len(jobs), jobs, _stream()),
+                       f'{n} resolutions x {len(sigs)} waves B{B} T{T}'), 'stft fwd (multi)')
+        ctx.plans, ctx.shape, ctx.spec_t, ctx.want_spec = plans, (B, T), spec_t, want_spec
+        ctx.save_for_backward(*saved)
+        ctx.set_materialize_grads(False)
+        flat = []
+        for si, (mels, specs) in enumerate(outs):
+            flat += mels + specs
+            if si == 1:
+                ctx.mark_non_differentiable(*[t_ for t_ in mels + specs if t_ is not None])
+        return tuple(flat)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        plans, (B, T), n = ctx.plans, ctx.shape, len(ctx.plans)
+        saved = ctx.saved_tensors
+        dmels, dspecs = grads[:n], grads[n:2 * n]
+        live = [i for i in range(n) if dmels[i] is not None or dspecs[i] is not None]
+        if not live:
+            return (None,) * (3 + n)
+        dev = saved[0].device
+        jobs = (L.StftBwdJob * len(live))()
+        hold, nbytes = [], 0
+        for k, i in enumerate(live):
+            plan = plans[i]
+            frames = 1 + T // plan.hop
+            t = plan.tensors(dev)
+            re, im = saved[2 * i], saved[2 * i + 1]
+            dm, ds = _c(dmels[i]), _c(dspecs[i])
+            ws = torch.empty(B * frames * plan.win, device=dev)
+            hold += [dm, ds, ws]
+            j = jobs[k]
+            j.d = L.StftDesc(B, T, plan.n_fft, plan.win, plan.hop, frames, plan.n_mel, ctx.spec_t)
+            j.re, j.im = re.data_ptr(), im.data_ptr()
+            j.dmel, j.dspec = (dm.data_ptr() if dm is not None else None), (ds.data_ptr() if ds is not None else None)
+            j.window, j.twiddle = t['window'].data_ptr(), t['twiddle'].data_ptr()
+            j.binmel_idx, j.binmel_w, j.frame_ws = t['binmel_idx'].data_ptr(), t['binmel_w'].data_ptr(), ws.data_ptr()
+            nbytes += 4 * (2 * re.numel() + (dm.numel() if dm is not None else 0) + (ds.numel() if ds is not None else 0))
+        dy = torch.empty(B, T, device=dev)
+        nbytes += 4 * dy.numel()
+        check(timed_bw('stft_bwd', nbytes, lambda: lib.rtg_stft_backward_multi(len(live), jobs, _p(dy), 0, _stream()),
+                       f'{len(live)} resolutions B{B} T{T}'), 'stft bwd (multi)')
+        return (dy, None, None) + (None,) * n
+
+
 class StftFn(torch.autograd.Function):
     """y [B,T] -> (mel [B,n_mel,frames], spec or None) for one resolution (see rtg_stft_forward).  spec: [B,2,F,frames], or with
     SPEC_FREQ_MAJOR the tensor [B,2,frames,F] whose transposed view is that map (audio.stft_mel_spec hands the view out)."""
