@@ -42,6 +42,7 @@ def _run_stack(tok, convs, conv_post, x):
 # streams.  Measured on MI355X (config 2, batch 32): a grouped launch beats its members run back to back by 11-34 %, but
 # the forked streams already overlap them as well — 42.7 ms/step grouped vs 42.3 forked — so forking it is (tests flip it).
 GROUPED = False
+PROLOGUES_FORKED = True      # run_stacks: the stacks' weight refresh and input preparation on forked streams
 
 
 def _groupable(c):
@@ -238,21 +239,33 @@ class _MultiBase(BankedModel):
         return _collect(outs)
 
 
-def run_stacks(calls):
+def run_stacks(calls, extra=()):
     """calls: [(stack, a, b)] -> [(logits_r, logits_g, fmaps_r, fmaps_g)] per stack.  A stack whose sub-discriminators
     share an architecture of 1-D convs (MSD, MPD) runs layer by layer in grouped launches (one branch of the fork); the
-    sub-discriminators of the others (MTD) are forked side by side — one flat fork in all."""
+    sub-discriminators of the others (MTD) are forked side by side — one flat fork in all.
+    extra: thunks that depend on no stack (the generator step's spectral / dynamic losses): more branches of the same fork,
+    their results follow the stacks' in the returned list."""
     brs, spans = [], []
+    # The stacks' prologues — weight-norm scales + weight pack of the stack's bank, the input pyramid / folds / concatenations —
+    # side by side on forked streams as well (PROLOGUES_FORKED): bandwidth launches that ran one after the other on the main
+    # stream in front of the fork, with nothing else on the chip (round 6, kernel trace of the replayed step: 0.2 ms per pass;
+    # same-box A/B of the config-2 step 25.99 / 26.00 ms forked against 26.14 / 26.22).
+    plain = [c for c in calls if not (GROUPED and getattr(c[0], 'groupable', False))]
+    pre = {}
+    if PROLOGUES_FORKED and len(plain) > 1:
+        for c, bs in zip(plain, fork_join([(lambda st=st, a=a, b=b: st.branches(a, b)) for st, a, b in plain])):
+            pre[id(c[0])] = bs
     for stack, a, b in calls:
         if GROUPED and getattr(stack, 'groupable', False):
             bs = [(lambda st=stack, a=a, b=b: st.run_grouped(a, b))]
             spans.append((len(brs), None))
         else:
-            bs = stack.branches(a, b)
+            bs = pre[id(stack)] if id(stack) in pre else stack.branches(a, b)
             spans.append((len(brs), len(brs) + len(bs)))
         brs += bs
-    outs = fork_join(brs)
-    return [outs[lo] if hi is None else _collect(outs[lo:hi]) for lo, hi in spans]
+    n_br = len(brs)
+    outs = fork_join(brs + list(extra))
+    return [outs[lo] if hi is None else _collect(outs[lo:hi]) for lo, hi in spans] + outs[n_br:]
 
 
 class MultiScaleDiscriminator(_MultiBase):

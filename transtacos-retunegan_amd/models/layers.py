@@ -124,6 +124,9 @@ def _record(obj, stream):
     elif isinstance(obj, (list, tuple)):
         for o in obj:
             _record(o, stream)
+    elif isinstance(obj, dict):
+        for o in obj.values():
+            _record(o, stream)
 
 
 def fork_join(fns):

@@ -38,6 +38,9 @@ LEAN_PACK = True              # (Trainer.lean_pack_enabled: tests build trainers
 
 
 EXCHANGE_POLICIES = ('update', 'disc')
+# the generator step's wave-only loss terms (multi-resolution STFT, dynamic / envelope / strip-mirror) as a branch of the
+# discriminator stacks' fork (Trainer.g_step; round 6, same-box A/B of the config-2 step: 26.23 / 26.32 ms against 26.43 / 26.49)
+WAVE_LOSSES_FORKED = True
 
 
 def default_exchange():
@@ -406,17 +409,24 @@ class Trainer:
         """train.py:163-193."""
         self.optim_g.zero_grad()
         losses = {}
+
+        def wave_losses():
+            """the loss terms that depend on the two waves only (train.py:165-168)"""
+            out = {'env': envelope_loss(y, y_g_hat) if hp.envelope_loss else None,
+                   'dyn': dynamic_loss(y, y_g_hat) if hp.dynamic_loss else None,
+                   'sm': strip_mirror_loss(y_g_hat) if hp.strip_mirror_loss else None}
+            if self.mtd is None:
+                out['mstft'] = multi_stft_loss(y, y_g_hat, ret_loss=True)
+            return out
+        # They share nothing with the discriminators: with WAVE_LOSSES_FORKED they are one more branch of the stacks' fork — their
+        # launches (and, autograd replaying every backward on its forward's stream, their backward) run beside the stacks'
+        # instead of in front of them.  The spectrogram stack takes the spectra as its input: with it the multi-resolution STFT
+        # stays in front.
         if self.mtd is not None:
             losses['mstft'], (S, S_g_hat) = multi_stft_loss(y, y_g_hat, ret_loss=True, ret_specs=True)
-        else:
-            losses['mstft'] = multi_stft_loss(y, y_g_hat, ret_loss=True)
-        losses['env'] = envelope_loss(y, y_g_hat) if hp.envelope_loss else None          # train.py:166-168
-        losses['dyn'] = dynamic_loss(y, y_g_hat) if hp.dynamic_loss else None
-        losses['sm'] = strip_mirror_loss(y_g_hat) if hp.strip_mirror_loss else None
-        terms, weights = [losses['mstft']], [hp.w_loss_mstft]  # the total is ONE weighted sum over the terms, in this order
-        for key, w in (('env', hp.w_loss_env), ('dyn', hp.w_loss_dyn), ('sm', hp.w_loss_sm)):
-            if losses[key] is not None:
-                terms.append(losses[key]); weights.append(w)
+        forked = WAVE_LOSSES_FORKED
+        if not forked:
+            losses.update(wave_losses())
         self._freeze(True)       # the reference lets D weight gradients accumulate and discards them at the next
         try:                     # optim_d.zero_grad() (train.py:133): skipping them changes no result
             jobs = [('s', (self.msd, y, y_g_hat))]
@@ -424,7 +434,14 @@ class Trainer:
                 jobs.append(('p', (self.mpd, y, y_g_hat)))
             if self.mtd is not None:
                 jobs.append(('t', (self.mtd, S, S_g_hat)))
-            for (tag, _), (r, g, fr, fg) in zip(jobs, run_stacks([j for _, j in jobs])):
+            stack_outs = run_stacks([j for _, j in jobs], extra=[wave_losses] if forked else ())
+            if forked:
+                losses.update(stack_outs.pop())
+            terms, weights = [losses['mstft']], [hp.w_loss_mstft]  # the total is ONE weighted sum over the terms, in this order
+            for key, w in (('env', hp.w_loss_env), ('dyn', hp.w_loss_dyn), ('sm', hp.w_loss_sm)):
+                if losses[key] is not None:
+                    terms.append(losses[key]); weights.append(w)
+            for (tag, _), (r, g, fr, fg) in zip(jobs, stack_outs):
                 losses['gen_' + tag] = generator_loss(g, r)
                 losses['fm_' + tag] = feature_loss(fr, fg)
                 terms += [losses['gen_' + tag], losses['fm_' + tag]]; weights += [1.0, hp.w_loss_fm]
