@@ -246,21 +246,25 @@ def run_stacks(calls, extra=()):
     extra: thunks that depend on no stack (the generator step's spectral / dynamic losses): more branches of the same fork,
     their results follow the stacks' in the returned list."""
     brs, spans = [], []
-    # The stacks' prologues — weight-norm scales + weight pack of the stack's bank, the input pyramid / folds / concatenations —
-    # side by side on forked streams as well (PROLOGUES_FORKED): bandwidth launches that ran one after the other on the main
-    # stream in front of the fork, with nothing else on the chip (round 6, kernel trace of the replayed step: 0.2 ms per pass;
-    # same-box A/B of the config-2 step 25.99 / 26.00 ms forked against 26.14 / 26.22).
+    # The stacks' weight refresh — weight-norm scales + weight pack of each stack's bank — side by side on forked streams as
+    # well (PROLOGUES_FORKED): bandwidth launches that ran one after the other on the main stream in front of the fork, with
+    # nothing else on the chip (round 6, kernel trace of the replayed step: 0.2 ms per pass with the input preparation; same-box
+    # A/B of the config-2 step 25.99 / 26.00 ms forked against 26.14 / 26.22), and a bank's weight-norm backward runs on the
+    # stream of its pack.  ONLY the token: it writes the bank's persistent buffers.  The input preparation (concatenations, the
+    # pooling pyramid, folds) allocates tensors that the sub-discriminators' branches read on OTHER streams — allocated on a
+    # forked stream they would return to that stream's allocator pool while those readers may still run (a first version
+    # forked them too and lost bit-reproducibility of the full stack under the caching allocator's reuse).
     plain = [c for c in calls if not (GROUPED and getattr(c[0], 'groupable', False))]
-    pre = {}
+    toks = {}
     if PROLOGUES_FORKED and len(plain) > 1:
-        for c, bs in zip(plain, fork_join([(lambda st=st, a=a, b=b: st.branches(a, b)) for st, a, b in plain])):
-            pre[id(c[0])] = bs
+        for c, tok in zip(plain, fork_join([c[0].token for c in plain])):
+            toks[id(c[0])] = tok
     for stack, a, b in calls:
         if GROUPED and getattr(stack, 'groupable', False):
             bs = [(lambda st=stack, a=a, b=b: st.run_grouped(a, b))]
             spans.append((len(brs), None))
         else:
-            bs = pre[id(stack)] if id(stack) in pre else stack.branches(a, b)
+            bs = stack.branches(a, b, tok=toks.get(id(stack)))
             spans.append((len(brs), len(brs) + len(bs)))
         brs += bs
     n_br = len(brs)
@@ -278,8 +282,8 @@ class MultiScaleDiscriminator(_MultiBase):
 
     groupable = True
 
-    def branches(self, y, y_hat):
-        tok = self.token()
+    def branches(self, y, y_hat, tok=None):
+        tok = self.token() if tok is None else tok
         frozen = _frozen(self) and not y.requires_grad
         inputs = self.sub_inputs(y, y_hat, frozen)
         return [_sub_runner(d, tok, inp, frozen) for d, inp in zip(self.discriminators, inputs)]
@@ -313,8 +317,8 @@ class MultiPeriodDiscriminator(_MultiBase):
         inp = [y, y_hat] if frozen else [torch.cat([y, y_hat], dim=0)]
         return [inp for _ in self.discriminators]
 
-    def branches(self, y, y_hat):
-        tok = self.token()
+    def branches(self, y, y_hat, tok=None):
+        tok = self.token() if tok is None else tok
         frozen = _frozen(self) and not y.requires_grad
         return [_sub_runner(d, tok, inp, frozen) for d, inp in zip(self.discriminators, self.sub_inputs(y, y_hat, frozen))]
 
@@ -369,8 +373,8 @@ class MultiStftDiscriminator(_MultiBase):
 
     groupable = False      # 2-D convs: not served by the grouped launch yet
 
-    def branches(self, phs, ph_hats):
-        tok = self.token()
+    def branches(self, phs, ph_hats, tok=None):
+        tok = self.token() if tok is None else tok
         frozen = _frozen(self) and not phs[0].requires_grad
         # (the real / generated pair is concatenated in the layout the layers run on: a coalesced copy)
         inputs = [[ph, ph_hat] if frozen else [_Prepared(torch.cat([d.pre(ph), d.pre(ph_hat)], dim=0))]
