@@ -49,6 +49,18 @@ def main():
         else:
             live.discard(i)
     tot = t1 - t0
+    # idle gaps: intervals with no kernel in flight, largest first, with the launch that ended before and the one that starts after
+    order = sorted(range(len(seg)), key=lambda i: seg[i][1])
+    gaps_, end_max, last_i = [], seg[order[0]][2], order[0]
+    for i in order[1:]:
+        if seg[i][1] > end_max:
+            gaps_.append((seg[i][1] - end_max, end_max, last_i, i))
+        if seg[i][2] > end_max:
+            end_max, last_i = seg[i][2], i
+    out.append(f'idle gaps: {len(gaps_)} of {sum(g[0] for g in gaps_) / 1e6:.3f} ms in all; by size: ' +
+               ', '.join(f'>= {th} us: {sum(1 for g in gaps_ if g[0] >= th * 1e3)} ({sum(g[0] for g in gaps_ if g[0] >= th * 1e3) / 1e6:.3f} ms)' for th in (1, 2, 4, 8, 16)))
+    for g, t, a_, b_ in sorted(gaps_, reverse=True)[:12]:
+        out.append(f'  {g / 1e3:6.1f} us at {(t - t0) / 1e6:7.3f} ms  after {short(seg[a_][0])[:40]}  before {short(seg[b_][0])[:40]}')
     out.append('time by number of kernels in flight (6 = six or more):')
     for k in sorted(by_n):
         out.append(f'  {k}: {by_n[k] / 1e6:7.3f} ms  {100 * by_n[k] / tot:5.1f} %')
