@@ -61,6 +61,19 @@ def test_struct_layouts_follow_the_header():
         assert [f[0] for f in cls._fields_] == header_struct_fields(cname), cname
 
 
+def test_stft_job_structs_follow_the_header():
+    """(ABI 11) RtgStftFwdJob / RtgStftBwdJob: a descriptor followed by pointers — names in the header's order, and the size a C
+    compiler gives them (the descriptor is 8 ints, every other member a pointer)"""
+    from rtg import lib as L
+    txt = re.sub(r'/\*.*?\*/', '', open(HEADER).read(), flags=re.S)
+    for cname, cls in (('RtgStftFwdJob', L.StftFwdJob), ('RtgStftBwdJob', L.StftBwdJob)):
+        body = re.search(r'typedef struct %s \{(.*?)\} %s;' % (cname, cname), txt, flags=re.S).group(1)
+        names = [re.findall(r'[A-Za-z_][A-Za-z0-9_]*', piece)[-1] for decl in body.split(';') if decl.strip() for piece in decl.split(',')]
+        assert [f[0] for f in cls._fields_] == names, cname
+        assert C.sizeof(cls) == C.sizeof(L.StftDesc) + 8 * (len(names) - 1)
+    assert L.STFT_MAX_JOBS == int(re.search(r'#define RTG_STFT_MAX_JOBS (\d+)', txt).group(1))
+
+
 def test_integration_md_binding_stub_is_the_real_struct():
     """INTEGRATION.md section 2 shows the ctypes stub a maintainer would copy: its RtgConv1dDesc must be the header's struct
     field for field and type for type (round 3: the example was 4 ints short — rtg_conv1d would have read 16 bytes past it)"""

@@ -182,6 +182,14 @@ def _sub_runner(d, tok, inp, frozen):
     """closure running one sub-discriminator on (real, fake): separately when D is frozen (real half without autograd),
     as one 2B batch otherwise.  Returns (logit_r, logit_g, fmap_r, fmap_g)."""
     def run():
+        # The inputs may have been prepared on ANOTHER forked stream (run_stacks forks the stacks' prologues): tell the caching
+        # allocator that this branch's stream reads them, so that their memory is not handed out again — to that other stream,
+        # which never waits for this one — before the branch (and, later, its backward) is done with it.
+        cur = torch.cuda.current_stream()
+        for t in inp:
+            tt = t.t if isinstance(t, _Prepared) else t
+            if torch.is_tensor(tt) and tt.is_cuda:
+                tt.record_stream(cur)
         if frozen and PAIRED and _pairable(d):
             return _run_pair(d, tok, inp[0], inp[1])
         if frozen:
@@ -246,25 +254,24 @@ def run_stacks(calls, extra=()):
     extra: thunks that depend on no stack (the generator step's spectral / dynamic losses): more branches of the same fork,
     their results follow the stacks' in the returned list."""
     brs, spans = [], []
-    # The stacks' weight refresh — weight-norm scales + weight pack of each stack's bank — side by side on forked streams as
-    # well (PROLOGUES_FORKED): bandwidth launches that ran one after the other on the main stream in front of the fork, with
-    # nothing else on the chip (round 6, kernel trace of the replayed step: 0.2 ms per pass with the input preparation; same-box
-    # A/B of the config-2 step 25.99 / 26.00 ms forked against 26.14 / 26.22), and a bank's weight-norm backward runs on the
-    # stream of its pack.  ONLY the token: it writes the bank's persistent buffers.  The input preparation (concatenations, the
-    # pooling pyramid, folds) allocates tensors that the sub-discriminators' branches read on OTHER streams — allocated on a
-    # forked stream they would return to that stream's allocator pool while those readers may still run (a first version
-    # forked them too and lost bit-reproducibility of the full stack under the caching allocator's reuse).
+    # The stacks' prologues — weight-norm scales + weight pack of the stack's bank, the input concatenations / pooling pyramid —
+    # side by side on forked streams as well (PROLOGUES_FORKED): bandwidth launches that ran one after the other on the main
+    # stream in front of the fork, with nothing else on the chip (round 6, kernel trace of the replayed step: 0.2 ms per pass;
+    # same-box A/B of the config-2 step 25.97 / 25.79 ms forked against 26.15 / 26.19), and a bank's weight-norm backward runs on
+    # the stream of its pack.  The inputs a prologue allocates are read by the sub-discriminators' branches on OTHER streams:
+    # every branch records itself as a reader (_sub_runner) — without that they returned to the prologue stream's allocator pool
+    # while those readers could still run (the 1-rank RCCL bit-identity test of the full stack caught the first version).
     plain = [c for c in calls if not (GROUPED and getattr(c[0], 'groupable', False))]
-    toks = {}
+    pre = {}
     if PROLOGUES_FORKED and len(plain) > 1:
-        for c, tok in zip(plain, fork_join([c[0].token for c in plain])):
-            toks[id(c[0])] = tok
+        for c, bs in zip(plain, fork_join([(lambda st=st, a=a, b=b: st.branches(a, b)) for st, a, b in plain])):
+            pre[id(c[0])] = bs
     for stack, a, b in calls:
         if GROUPED and getattr(stack, 'groupable', False):
             bs = [(lambda st=stack, a=a, b=b: st.run_grouped(a, b))]
             spans.append((len(brs), None))
         else:
-            bs = stack.branches(a, b, tok=toks.get(id(stack)))
+            bs = pre[id(stack)] if id(stack) in pre else stack.branches(a, b)
             spans.append((len(brs), len(brs) + len(bs)))
         brs += bs
     n_br = len(brs)
