@@ -61,6 +61,22 @@ def test_struct_layouts_follow_the_header():
         assert [f[0] for f in cls._fields_] == header_struct_fields(cname), cname
 
 
+def test_no_kernel_of_the_build_uses_scratch_memory(built):
+    """build.py keeps the compiler's per-kernel resource remarks next to every object and refuses to link a library in which a
+    kernel spills (round 5 shipped 70 spilling instances of the dense conv kernel): the table of the build the tests run on has
+    every translation unit's kernels, none with scratch, and the dense conv kernel's instance set is the pruned one."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('rtg_build', os.path.join(REPO, 'transtacos-retunegan_amd', 'build.py'))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    rows = b.kernel_resources()
+    assert len(rows) > 500 and all('vgpr' in r and 'scratch' in r for r in rows)
+    assert [r for r in rows if r['scratch'] > 0] == []
+    b.check_no_scratch()
+    dconv = [r for r in rows if 'dconv_kernel' in r['name']]
+    assert 200 < len(dconv) <= 300, len(dconv)
+
+
 def test_stft_job_structs_follow_the_header():
     """(ABI 11) RtgStftFwdJob / RtgStftBwdJob: a descriptor followed by pointers — names in the header's order, and the size a C
     compiler gives them (the descriptor is 8 ints, every other member a pointer)"""
