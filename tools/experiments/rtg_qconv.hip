@@ -1,3 +1,9 @@
+// NOT PART OF librtg.so.  Round-6 experiment, kept with its measurements (profiles/r06_qconv_experiment.txt, DESIGN.md section 3,
+// round 6): bit-identical to the library's block shapes, a tie on the large stride-1 layers (126 vs 127-130 TFLOP/s), slower on
+// short rows and on the 2-tap / stride-3 operators (64-position column granularity).  To try it again: copy it into
+// transtacos-retunegan_amd/csrc/, declare rtg_qconv_candidates / rtg_qconv_launch in rtg_dconv.hip, put the candidates in front of
+// rtg_dconv_candidates' list and route shape digits >= 6 of rtg_dconv_launch to rtg_qconv_launch (git show cc2bb1c~3 has the hooks).
+//
 // rtg_qconv.hip — "quad-column" form of the dense-layer conv kernel (round 6): the same layers as rtg_dconv.hip in 1-D —
 //   DiscriminatorP convs.1-4 ((5,1) kernels, stride 3 / 3 / 3 / 1) and DiscriminatorS convs.5 (k5)   discrminator.py:44,155-163
 // forward (5 taps at stride 1 / 3), backward-data of the stride-1 layers (5 taps) and the polyphase backward-data of the
