@@ -21,6 +21,9 @@ import time
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(REPO, 'transtacos-retunegan_amd'))
+# HIP-runtime defaults of the package (rtg/config.py: HIP_FORCE_DEV_KERNARG) before anything here can initialise the runtime;
+# ranks started by self_launch inherit the environment
+from rtg import config as _rtg_config  # noqa: E402,F401
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402

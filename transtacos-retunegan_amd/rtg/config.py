@@ -16,7 +16,21 @@ KNOBS = {
     'RTG_TEST_FAIL_CAPTURE': ('0', 'test hook: an illegal synchronous copy inside the capture (bench.py\'s eager fallback)'),
     'RTG_DEV_LIB': ('', 'path of a development build of librtg.so to load instead of the in-tree one (ablation builds)'),
     'RTG_EXTRA_FLAGS': ('', 'build.py: extra hipcc flags (ablation defines are refused there)'),
+    # a switch of the HIP RUNTIME, not of this package: kernel arguments in device memory instead of host-coherent memory — the
+    # command processor fetches them faster, which a step of 670 launches (115 of them one dependent chain) feels: round 6,
+    # same-box A/B of the replayed config-2 step, four pairs: 26.35 / 26.43 / 26.55 / 26.42 ms with it, 26.72 / 26.65 / 26.85 /
+    # 27.20 without (profiles/r06_ab_dev_kernarg.txt).  Read when the runtime initialises: the package sets it on import
+    # (apply_runtime_env) unless the environment already says otherwise; a process that touched the GPU before is not affected.
+    'HIP_FORCE_DEV_KERNARG': ('1', 'HIP runtime: 1 = kernel arguments in device memory (set by the package on import if unset; 0 restores the runtime default)'),
 }
+
+
+def apply_runtime_env():
+    """defaults of HIP-runtime switches this package wants, for variables the caller has not set (before the runtime initialises)"""
+    os.environ.setdefault('HIP_FORCE_DEV_KERNARG', KNOBS['HIP_FORCE_DEV_KERNARG'][0])
+
+
+apply_runtime_env()
 
 
 def get(name):
